@@ -1,0 +1,232 @@
+// Per-lane dense linear algebra on 3x3 / 4x4 problems, everything in
+// registers with compile-time indices (fully unrolled): the building blocks
+// of epipole extraction, essential-matrix decomposition and DLT triangulation
+// (one lane per problem).
+#pragma once
+#include "wave.h"
+
+namespace tff {
+
+struct Mat3 { double m[3][3]; };
+
+__device__ __forceinline__ double sgn(double x) { return (x > 0.0) ? 1.0 : ((x < 0.0) ? -1.0 : 0.0); }   // MATLAB sign()
+
+__device__ __forceinline__ Mat3 mat3_mul(const Mat3& a, const Mat3& b) {
+    Mat3 c;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
+    return c;
+}
+__device__ __forceinline__ Mat3 mat3_T(const Mat3& a) {
+    Mat3 c;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c.m[i][j] = a.m[j][i];
+    return c;
+}
+__device__ __forceinline__ double mat3_det(const Mat3& a) {
+    return a.m[0][0] * (a.m[1][1] * a.m[2][2] - a.m[1][2] * a.m[2][1])
+         - a.m[0][1] * (a.m[1][0] * a.m[2][2] - a.m[1][2] * a.m[2][0])
+         + a.m[0][2] * (a.m[1][0] * a.m[2][1] - a.m[1][1] * a.m[2][0]);
+}
+// inverse by adjugate (the reference's inv() of 3x3 calibration / normalisation matrices)
+__device__ __forceinline__ Mat3 mat3_inv(const Mat3& a) {
+    Mat3 c;
+    c.m[0][0] = a.m[1][1] * a.m[2][2] - a.m[1][2] * a.m[2][1];
+    c.m[0][1] = a.m[0][2] * a.m[2][1] - a.m[0][1] * a.m[2][2];
+    c.m[0][2] = a.m[0][1] * a.m[1][2] - a.m[0][2] * a.m[1][1];
+    c.m[1][0] = a.m[1][2] * a.m[2][0] - a.m[1][0] * a.m[2][2];
+    c.m[1][1] = a.m[0][0] * a.m[2][2] - a.m[0][2] * a.m[2][0];
+    c.m[1][2] = a.m[0][2] * a.m[1][0] - a.m[0][0] * a.m[1][2];
+    c.m[2][0] = a.m[1][0] * a.m[2][1] - a.m[1][1] * a.m[2][0];
+    c.m[2][1] = a.m[0][1] * a.m[2][0] - a.m[0][0] * a.m[2][1];
+    c.m[2][2] = a.m[0][0] * a.m[1][1] - a.m[0][1] * a.m[1][0];
+    const double id = 1.0 / (a.m[0][0] * c.m[0][0] + a.m[0][1] * c.m[1][0] + a.m[0][2] * c.m[2][0]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c.m[i][j] *= id;
+    return c;
+}
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// --------------------------------------------------------------------------
+// Eigenvector of the smallest eigenvalue of a symmetric positive
+// semi-definite n x n matrix S (n = 3, 4): Cholesky of S + delta*I followed by
+// inverse iteration.  The shift only conditions the factorisation (it does not
+// change eigenvectors); the loop runs until the iterate stops moving, so the
+// result is the converged eigenvector whatever the spectral gap.
+// Replaces the reference's [~,~,V]=svd(M); V(:,end) with S = M'M
+// (triangulation3D.m:61-62, linearTFT.m:71-79, R_t_from_TFT.m:47-55).
+// Returns the number of iterations used; x has unit norm, sign free.
+// --------------------------------------------------------------------------
+template <int n>
+__device__ __forceinline__ int spd_min_eigvec(const double (&S)[n][n], double (&x)[n], int maxit = 40) {
+    double tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) tr += S[i][i];
+    const double delta = 1e-14 * tr;
+    const double pfloor = 1e-3 * delta + 1e-300;
+    double L[n][n];
+    double inv[n];
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+        double d = S[j][j] + delta;
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        d = (d > pfloor) ? d : pfloor;
+        const double rs = 1.0 / sqrt(d);
+        L[j][j] = d * rs;
+        inv[j] = rs;
+#pragma unroll
+        for (int i = j + 1; i < n; ++i) {
+            double s = S[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            L[i][j] = s * rs;
+        }
+    }
+    const double x0 = 1.0 / sqrt((double)n);
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[i] = x0;
+    double rprev2 = 1.0;
+    int it = 0;
+    for (; it < maxit;) {
+        double y[n];
+        // forward L y = x
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double s = x[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+            y[i] = s * inv[i];
+        }
+        // backward L' z = y (in place)
+#pragma unroll
+        for (int i = n - 1; i >= 0; --i) {
+            double s = y[i];
+#pragma unroll
+            for (int k = i + 1; k < n; ++k) s -= L[k][i] * y[k];
+            y[i] = s * inv[i];
+        }
+        double nn = 0.0, dot = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) { nn += y[i] * y[i]; dot += y[i] * x[i]; }
+        const double rn = 1.0 / sqrt(nn);
+        const double sg = (dot < 0.0) ? -rn : rn;
+        double r2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) { const double yi = y[i] * sg; const double d = yi - x[i]; r2 += d * d; x[i] = yi; }
+        ++it;
+        // r2 = |step|^2.  Error of the new iterate ~ rho*|step|/(1-rho), rho ~ |step|/|previous step|.
+        if (!(r2 > 1e-28)) break;                                        // also leaves on NaN
+        if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) break;
+        rprev2 = r2;
+    }
+    return it;
+}
+
+// --------------------------------------------------------------------------
+// Cyclic Jacobi eigen-decomposition of a symmetric 3x3 matrix (per lane).
+// A is overwritten by its diagonal form, V (columns) are the eigenvectors.
+// --------------------------------------------------------------------------
+__device__ __forceinline__ void jacobi3_rotate(double (&A)[3][3], double (&V)[3][3], const int p, const int q, const int r) {
+    const double apq = A[p][q];
+    if (apq == 0.0) return;
+    const double app = A[p][p], aqq = A[q][q];
+    const double tau = (aqq - app) / (2.0 * apq);
+    const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+    const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+    A[p][p] = app - t * apq;
+    A[q][q] = aqq + t * apq;
+    A[p][q] = A[q][p] = 0.0;
+    const double arp = A[r][p], arq = A[r][q];
+    A[r][p] = A[p][r] = c * arp - s * arq;
+    A[r][q] = A[q][r] = s * arp + c * arq;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double vkp = V[k][p], vkq = V[k][q];
+        V[k][p] = c * vkp - s * vkq;
+        V[k][q] = s * vkp + c * vkq;
+    }
+}
+__device__ __forceinline__ void jacobi3(double (&A)[3][3], double (&V)[3][3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 24; ++sweep) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (!(off > 1e-34 * dg)) break;
+        jacobi3_rotate(A, V, 0, 1, 2);
+        jacobi3_rotate(A, V, 0, 2, 1);
+        jacobi3_rotate(A, V, 1, 2, 0);
+    }
+}
+
+// Full SVD of a 3x3 matrix through the eigen-decomposition of E'E:
+// V from Jacobi (columns sorted by descending singular value), u1,u2 = E v / |E v|
+// (so that a rotation of (v1,v2) inside a nearly degenerate singular plane is
+// mirrored in (u1,u2) -- the product U*W*V' of recover_R_t is then stable),
+// u3 = u1 x u2.  Follows [U,~,V]=svd(E21) (R_t_from_TFT.m:85); signs free.
+__device__ __forceinline__ void svd3(const Mat3& E, Mat3& U, Mat3& V, double (&sv)[3]) {
+    double A[3][3], W[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) A[i][j] = E.m[0][i] * E.m[0][j] + E.m[1][i] * E.m[1][j] + E.m[2][i] * E.m[2][j];
+    jacobi3(A, W);
+    double ev[3] = {A[0][0], A[1][1], A[2][2]};
+    // sort indices descending (3 elements)
+    int i0 = 0, i1 = 1, i2 = 2;
+    if (ev[i0] < ev[i1]) { int t = i0; i0 = i1; i1 = t; }
+    if (ev[i1] < ev[i2]) { int t = i1; i1 = i2; i2 = t; }
+    if (ev[i0] < ev[i1]) { int t = i0; i0 = i1; i1 = t; }
+    const int ord[3] = {i0, i1, i2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        // select column ord[c] without dynamic register indexing
+#pragma unroll
+        for (int k = 0; k < 3; ++k) V.m[k][c] = (ord[c] == 0) ? W[k][0] : ((ord[c] == 1) ? W[k][1] : W[k][2]);
+        const double e = (ord[c] == 0) ? ev[0] : ((ord[c] == 1) ? ev[1] : ev[2]);
+        sv[c] = sqrt(e > 0.0 ? e : 0.0);
+    }
+    double u1[3], u2[3], u3[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        u1[k] = E.m[k][0] * V.m[0][0] + E.m[k][1] * V.m[1][0] + E.m[k][2] * V.m[2][0];
+        u2[k] = E.m[k][0] * V.m[0][1] + E.m[k][1] * V.m[1][1] + E.m[k][2] * V.m[2][1];
+    }
+    double n1 = 1.0 / sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u1[k] *= n1;
+    const double d12 = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u2[k] -= d12 * u1[k];
+    double n2 = 1.0 / sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u2[k] *= n2;
+    cross3(u1, u2, u3);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { U.m[k][0] = u1[k]; U.m[k][1] = u2[k]; U.m[k][2] = u3[k]; }
+}
+
+// right null vector of a 3x3 matrix M: smallest eigenvector of M'M
+__device__ __forceinline__ void null3(const Mat3& M, double (&x)[3]) {
+    double S[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) S[i][j] = M.m[0][i] * M.m[0][j] + M.m[1][i] * M.m[1][j] + M.m[2][i] * M.m[2][j];
+    spd_min_eigvec<3>(S, x);
+}
+
+}  // namespace tff

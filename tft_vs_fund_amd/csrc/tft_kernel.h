@@ -1,0 +1,304 @@
+// LinearTFTPoseEstimation as one fused kernel: one wavefront per triplet.
+//
+//   Normalize2Ddata x3  ->  linearTFT (moment-form Gram matrix, smallest
+//   eigenvector, epipoles, constrained re-solve in the 15-dim range of E)
+//   ->  transform_TFT  ->  R_t_from_TFT (calibrate, epipoles, E21/E31,
+//   recover_R_t with the cheirality vote, t3 scale)  ->  optional Reconst.
+//
+// Reference: TFT_methods/LinearTFTPoseEstimation.m:44-62, linearTFT.m:33-91,
+// transform_TFT.m:42-49, R_t_from_TFT.m:40-106, triangulation3D.m:51-63.
+//
+// The 4N x 27 design matrix A of linearTFT.m:36-62 is never formed.  Its rows
+// are Kronecker products h1 (x) c3 (x) c2 with h1 = (x1,y1,1),
+// c2 in {(1,0,-x2),(0,1,-y2)}, c3 likewise, so
+//     G = A'A = sum_n (h1 h1') (x) (C3'C3) (x) (C2'C2)
+// has only 6 x 4 x 4 = 96 distinct entries: products of the monomials
+//   p1 = {x1^2, x1 y1, x1, y1^2, y1, 1},  q3 = {1, x3, y3, x3^2+y3^2},  q2 likewise.
+// The wave accumulates those 96 sums (one correspondence per lane, halving
+// butterfly across lanes), expands them to the 27x27 G in LDS, and takes the
+// eigenvector of the smallest eigenvalue (== V(:,end) of svd(A), :64-67).
+//
+// Constrained re-solve (:82-91): range(E) = { T : Q2' T_i Q3 has a zero lower
+// right 2x2 block }, with Q2 = [e21 | complement], Q3 = [e31 | complement]
+// orthonormal.  An orthonormal basis Up of range(E) is therefore 15 columns of
+// I3 (x) Q3 (x) Q2; (A Up)'(A Up) = Up' G Up is a 15x15 matrix assembled from G,
+// no second pass over the data.  rank(E) = 15 always (e21, e31 are unit vectors).
+#pragma once
+#include "pose_common.h"
+
+namespace tff {
+
+struct LinearTftArgs {
+    const double* corresp;   // B x (6 x N), column-major per triplet
+    const double* calm;      // B x 27 (9x3 column-major) or 27 shared
+    long calm_stride;        // 27 or 0
+    long B;
+    int N;
+    int flags;
+    double* Rt2;             // B x 12 (3x4 column-major)
+    double* Rt3;             // B x 12
+    double* T;               // B x 27
+    double* reconst;         // B x 3N or null
+    int* iter;               // B or null
+    int* status;             // B or null
+    double* dbg;             // B x DBG_STRIDE or null
+};
+
+// sign and q-monomial index of entry (j,j') of C'C,  C = [1 0 -x; 0 1 -y]
+__device__ __forceinline__ void ctc_entry(int j, int jp, int& sign, int& idx) {
+    const int a = (j < jp) ? j : jp, b = (j < jp) ? jp : j;
+    if (b < 2) { sign = (a == b) ? 1 : 0; idx = 0; }
+    else if (a < 2) { sign = -1; idx = 1 + a; }
+    else { sign = 1; idx = 3; }
+}
+__device__ __forceinline__ int hht_index(int i, int ip) {          // index into p1 of entry (i,i') of h1 h1'
+    const int a = (i < ip) ? i : ip, b = (i < ip) ? ip : i;
+    return (a == 0) ? b : ((a == 1) ? 2 + b : 5);
+}
+
+// 96 moment sums -> w->mom.  Three passes of 32 accumulators per lane.
+__device__ inline void accumulate_moments(PoseLds* w, const double* pts, int N) {
+    const int lane = lane_id();
+    const double s1 = w->nrm[0], ox1 = w->nrm[1], oy1 = w->nrm[2];
+    const double s2 = w->nrm[3], ox2 = w->nrm[4], oy2 = w->nrm[5];
+    const double s3 = w->nrm[6], ox3 = w->nrm[7], oy3 = w->nrm[8];
+    for (int pass = 0; pass < 3; ++pass) {
+        double acc[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+        for (int i = lane; i < N; i += WAVE) {
+            const Pt6 p = load_pt(pts, i);
+            // new_points = N_matrix(1:2,:) * [points; 1]   (Normalize2Ddata.m:39)
+            const double x1 = s1 * p.v[0] + ox1, y1 = s1 * p.v[1] + oy1;
+            const double x2 = s2 * p.v[2] + ox2, y2 = s2 * p.v[3] + oy2;
+            const double x3 = s3 * p.v[4] + ox3, y3 = s3 * p.v[5] + oy3;
+            const double q2[4] = {1.0, x2, y2, x2 * x2 + y2 * y2};
+            const double q3[4] = {1.0, x3, y3, x3 * x3 + y3 * y3};
+            double pa, pb;
+            if (pass == 0) { pa = x1 * x1; pb = x1 * y1; }
+            else if (pass == 1) { pa = x1; pb = y1 * y1; }
+            else { pa = y1; pb = 1.0; }
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double wv = q3[b] * q2[c];
+                    acc[4 * b + c] += pa * wv;
+                    acc[16 + 4 * b + c] += pb * wv;
+                }
+        }
+        const double tot = wave_reduce_scatter<32>(acc);
+        if ((lane & 1) == 0) w->mom[32 * pass + reduce32_index(lane)] = tot;
+    }
+    wave_sync();
+}
+
+// expand the moments into the full 27x27 Gram matrix (ld 27)
+__device__ inline void build_gram27(PoseLds* w) {
+    const int lane = lane_id();
+    for (int e = lane; e < 729; e += WAVE) {
+        const int r = e / 27, c = e % 27;
+        const int i = r / 9, k = (r % 9) / 3, j = r % 3;
+        const int ip = c / 9, kp = (c % 9) / 3, jp = c % 3;
+        int sg2, i2, sg3, i3;
+        ctc_entry(j, jp, sg2, i2);
+        ctc_entry(k, kp, sg3, i3);
+        const int sg = sg2 * sg3;
+        const double m = w->mom[16 * hht_index(i, ip) + 4 * i3 + i2];
+        w->G[e] = (sg == 0) ? 0.0 : ((sg > 0) ? m : -m);
+    }
+    wave_sync();
+}
+
+// orthonormal frame [e | q | q'] of a unit vector e, row-major Q[3*r + c]
+__device__ __forceinline__ void frame_of(const double* e, double* Q) {
+    const double a0 = fabs(e[0]), a1 = fabs(e[1]), a2 = fabs(e[2]);
+    double ax[3] = {0.0, 0.0, 0.0};
+    if (a0 <= a1 && a0 <= a2) ax[0] = 1.0; else if (a1 <= a2) ax[1] = 1.0; else ax[2] = 1.0;
+    double q1[3], q2[3];
+    cross3(e, ax, q1);
+    const double n1 = 1.0 / sqrt(q1[0] * q1[0] + q1[1] * q1[1] + q1[2] * q1[2]);
+    q1[0] *= n1; q1[1] *= n1; q1[2] *= n1;
+    cross3(e, q1, q2);
+    const double n2 = 1.0 / sqrt(q2[0] * q2[0] + q2[1] * q2[1] + q2[2] * q2[2]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { Q[3 * r] = e[r]; Q[3 * r + 1] = q1[r]; Q[3 * r + 2] = q2[r] * n2; }
+}
+
+// eigenvector of the smallest eigenvalue of the n x n matrix at Gm (ld n),
+// workspace Lw (n*n); Gm is destroyed when the Jacobi path runs.
+__device__ inline double solve_min_eigvec(double* Gm, double* Lw, int n, int flags, int* its) {
+    int it = 0;
+    double r2 = 0.0, x;
+    bool need_jacobi = (flags & FLAG_JACOBI) != 0;
+    if (!need_jacobi) {
+        x = wave_min_eigvec(Gm, Lw, n, n, 60, &it, &r2);
+        need_jacobi = !(r2 < 1e-20);          // inverse iteration stalled (tiny spectral gap) or NaN
+    }
+    if (need_jacobi) {
+        int sw = 0;
+        x = wave_jacobi_min_eigvec(Gm, Lw, n, n, &sw);
+        it = 1000 + sw;
+    }
+    *its = it;
+    return x;
+}
+
+// linearTFT.m:33-91 on the normalised correspondences.  Leaves the constrained
+// tensor in w->t, the epipoles in w->epi and (if want_P) linearTFT's `a`
+// (P2 = [reshape(a(1:9),3,3) e21], P3 = [reshape(a(10:18),3,3) e31]) in w->pa.
+__device__ inline void linear_tft_wave(PoseLds* w, const double* pts, int N, int flags, bool want_P, double* dbg) {
+    const int lane = lane_id();
+    accumulate_moments(w, pts, N);
+    build_gram27(w);
+    int it1 = 0, it2 = 0;
+    {
+        const double x = solve_min_eigvec(w->G, w->L, 27, flags, &it1);      // :64-67
+        if (lane < 27) w->t[lane] = x;
+        wave_sync();
+        if (it1 >= 1000) build_gram27(w);                                    // Jacobi consumed G
+    }
+    if (dbg && lane < 27) dbg[lane] = w->t[lane];
+    epipoles_from_tensor(w->t, w->nullv, w->epi, false);                     // :71-79
+    if (dbg && lane < 6) dbg[27 + lane] = w->epi[lane];
+    if (lane == 0) frame_of(w->epi, w->Q);                                   // Q2 from e21
+    if (lane == 1) frame_of(w->epi + 3, w->Q + 9);                           // Q3 from e31
+    wave_sync();
+    // Gp = Up' G Up (15x15) at L[0..225); column a = (i, m): (jj,kk) = m<3 ? (0,m) : (m-2,0)
+    double* Gp = w->L;
+    double* Lp = w->L + 225;
+    for (int e = lane; e < 225; e += WAVE) {
+        const int a = e / 15, b = e % 15;
+        const int ia = a / 5, ma = a % 5, ib = b / 5, mb = b % 5;
+        const int jja = (ma < 3) ? 0 : ma - 2, kka = (ma < 3) ? ma : 0;
+        const int jjb = (mb < 3) ? 0 : mb - 2, kkb = (mb < 3) ? mb : 0;
+        double acc = 0.0;
+        for (int k = 0; k < 3; ++k)
+            for (int j = 0; j < 3; ++j) {
+                const double wa = w->Q[3 * j + jja] * w->Q[9 + 3 * k + kka];
+                const double* grow = w->G + (j + 3 * k + 9 * ia) * 27 + 9 * ib;
+                double inner = 0.0;
+                for (int kp = 0; kp < 3; ++kp)
+                    for (int jp = 0; jp < 3; ++jp) inner += grow[jp + 3 * kp] * (w->Q[3 * jp + jjb] * w->Q[9 + 3 * kp + kkb]);
+                acc += wa * inner;
+            }
+        Gp[e] = acc;
+    }
+    wave_sync();
+    {
+        const double x = solve_min_eigvec(Gp, Lp, 15, flags, &it2);          // :84
+        if (lane < 15) w->tp[lane] = x;
+        wave_sync();
+    }
+    if (lane < 27) {                                                         // t = Up * tp   (:85)
+        const int i = lane / 9, k = (lane % 9) / 3, j = lane % 3;
+        double acc = 0.0;
+        for (int m = 0; m < 5; ++m) {
+            const int jj = (m < 3) ? 0 : m - 2, kk = (m < 3) ? m : 0;
+            acc += w->Q[3 * j + jj] * w->Q[9 + 3 * k + kk] * w->tp[5 * i + m];
+        }
+        w->t[lane] = acc;
+    }
+    wave_sync();
+    if (dbg && lane < 27) dbg[33 + lane] = w->t[lane];
+    if (dbg && lane == 0) { dbg[69] = (double)it1; dbg[70] = (double)it2; }
+    if (want_P && lane < 3) {
+        // a = pinv(E) t (:86): T_i = a_i e31' - e21 b_i'; particular solution with b_i.e31 = 0, then
+        // the minimum-norm gauge  a_i += c e21, b_i += c e31,  c = -(a_i.e21 + b_i.e31)/(|e21|^2+|e31|^2)
+        const int i = lane;
+        const double* e21 = w->epi; const double* e31 = w->epi + 3;
+        double ai[3], bi[3];
+        for (int j = 0; j < 3; ++j) ai[j] = w->t[j + 9 * i] * e31[0] + w->t[j + 3 + 9 * i] * e31[1] + w->t[j + 6 + 9 * i] * e31[2];
+        const double ae = ai[0] * e21[0] + ai[1] * e21[1] + ai[2] * e21[2];
+        for (int k = 0; k < 3; ++k) {
+            const double tte = w->t[3 * k + 9 * i] * e21[0] + w->t[1 + 3 * k + 9 * i] * e21[1] + w->t[2 + 3 * k + 9 * i] * e21[2];
+            bi[k] = e31[k] * ae - tte;
+        }
+        const double be = bi[0] * e31[0] + bi[1] * e31[1] + bi[2] * e31[2];
+        const double n21 = e21[0] * e21[0] + e21[1] * e21[1] + e21[2] * e21[2];
+        const double n31 = e31[0] * e31[0] + e31[1] * e31[1] + e31[2] * e31[2];
+        const double c = -(ae + be) / (n21 + n31);
+        for (int j = 0; j < 3; ++j) { w->pa[3 * i + j] = ai[j] + c * e21[j]; w->pa[9 + 3 * i + j] = bi[j] + c * e31[j]; }
+    }
+    wave_sync();
+}
+
+// R_t_from_TFT.m:40-76 on the de-normalised tensor w->T1.
+__device__ inline int rt_from_tft_wave(PoseLds* w, const double* pts, int N, double* dbg) {
+    const int lane = lane_id();
+    const Mat3 K1 = load_K(w->calm, 0), K2 = load_K(w->calm, 1), K3 = load_K(w->calm, 2);
+    transform_tft_inverse(w->T1, w->T2, K1, K2, K3);                        // :44
+    epipoles_from_tensor(w->T2, w->nullv, w->epi, true);                     // :47-55
+    double* Ein = w->Minv;                                                   // 18 doubles of scratch
+    if (lane < 2) {
+        const double* e21 = w->epi; const double* e31 = w->epi + 3;
+        Mat3 M;                                                              // [T1*e T2*e T3*e]
+        for (int i = 0; i < 3; ++i)
+            for (int r = 0; r < 3; ++r) {
+                double acc = 0.0;
+                for (int q = 0; q < 3; ++q) {
+                    // lane 0: (T_i e31)(r) = sum_k T(r,k,i) e31(k); lane 1: (T_i' e21)(r) = sum_j T(j,r,i) e21(j)
+                    acc += (lane == 0) ? w->T2[r + 3 * q + 9 * i] * e31[q] : w->T2[q + 3 * r + 9 * i] * e21[q];
+                }
+                M.m[r][i] = acc;
+            }
+        const double* e = (lane == 0) ? e21 : e31;
+        const double sg = (lane == 0) ? 1.0 : -1.0;                          // E31 = -crossM(epi31)*[...]  (:58)
+        for (int c = 0; c < 3; ++c) {
+            Ein[9 * lane + 0 + c] = sg * (-e[2] * M.m[1][c] + e[1] * M.m[2][c]);
+            Ein[9 * lane + 3 + c] = sg * (e[2] * M.m[0][c] - e[0] * M.m[2][c]);
+            Ein[9 * lane + 6 + c] = sg * (-e[1] * M.m[0][c] + e[0] * M.m[1][c]);
+        }
+    }
+    wave_sync();
+    const int st = recover_poses(w, Ein, pts, N, dbg);                       // :61,:64
+    scale_t3(w, pts, N, dbg);                                                // :68-74
+    return st;
+}
+
+__global__ void __launch_bounds__(64) k_linear_tft_pose(const LinearTftArgs a) {
+    TFF_DYNAMIC_LDS(double, smem);
+    PoseLds* w = reinterpret_cast<PoseLds*>(smem);
+    const int lane = lane_id();
+    for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const int N = a.N;
+        double* dbg = a.dbg ? a.dbg + b * DBG_STRIDE : nullptr;
+        const double* src = a.corresp + b * 6 * (long)N;
+        const double* pts = src;
+        if (a.flags & FLAG_STAGE_LDS) {
+            double* lp = smem + ((POSE_LDS_DOUBLES + 1) & ~1);
+            wave_sync();
+            stage_points(src, lp, N);
+            pts = lp;
+        }
+        if (lane < 27) w->calm[lane] = a.calm[b * a.calm_stride + lane];
+        int status = ST_OK;
+        if (N < 7) {                                                         // experiments.m:99
+            status = ST_TOO_FEW;
+            const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+            if (lane < 12) { a.Rt2[b * 12 + lane] = qnan; a.Rt3[b * 12 + lane] = qnan; }
+            if (lane < 27) a.T[b * 27 + lane] = qnan;
+            if (a.reconst) for (int i = lane; i < 3 * N; i += WAVE) a.reconst[b * 3 * (long)N + i] = qnan;
+        } else {
+            normalise3(pts, N, w->nrm);                                      // LinearTFTPoseEstimation.m:45-47
+            if (dbg && lane < 9) dbg[71 + lane] = w->nrm[lane];
+            linear_tft_wave(w, pts, N, a.flags, false, dbg);                 // :50
+            transform_tft_inverse(w->t, w->T1, normal_matrix(w->nrm, 0), normal_matrix(w->nrm, 1), normal_matrix(w->nrm, 2));   // :53
+            status = rt_from_tft_wave(w, pts, N, dbg);                       // :56
+            write_poses(w, a.Rt2 + b * 12, a.Rt3 + b * 12);
+            if (lane < 27) a.T[b * 27 + lane] = w->T1[lane];
+            if (a.reconst) final_reconst(w, pts, N, a.reconst + b * 3 * (long)N);   // :59-60
+            // non-finite outputs -> status 2
+            double chk = (lane < 12) ? w->Rt[0][lane] : ((lane < 24) ? w->Rt[1][lane - 12] : ((lane < 51) ? w->T1[lane - 24] : 0.0));
+            const bool bad = !(fabs(chk) <= 1.79e308);
+            if (wave_any(bad) && status == ST_OK) status = ST_NONFINITE;
+        }
+        if (lane == 0) {
+            if (a.iter) a.iter[b] = 0;                                       // :62
+            if (a.status) a.status[b] = status;
+        }
+        wave_sync();
+    }
+}
+
+}  // namespace tff

@@ -1,0 +1,139 @@
+// Wavefront-level primitives for the one-wavefront-per-correspondence-set
+// kernels (gfx950: 64 lanes, LDS shared by the lanes of a wave).
+//
+// Every kernel in this directory is written against this small vocabulary:
+//   lane_id, wave_sync, wave_bcast, wave_sum / wave_max / wave_sum_i,
+//   wave_any, wave_shfl_xor, TFF_DYNAMIC_LDS.
+// The only place the build target shows through is the include below: the
+// GPU-less unit tests compile the same kernels against tests/emu/hip_emu.h
+// (a thread-per-lane emulator, test infrastructure only).
+#pragma once
+#ifdef TFF_CPU_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+
+namespace tff {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_in_block() { return (int)(threadIdx.x >> 6); }
+
+#ifdef TFF_CPU_EMU
+#define TFF_DYNAMIC_LDS(type, name) type* name = reinterpret_cast<type*>(emu::dyn_smem())
+__device__ inline void wave_sync() { emu::wave_barrier(); }
+__device__ inline double wave_shfl_xor(double v, int mask) {
+    uint64_t u; std::memcpy(&u, &v, 8);
+    u = emu::exchange(u, lane_id() ^ mask);
+    std::memcpy(&v, &u, 8); return v;
+}
+__device__ inline double wave_bcast(double v, int src) {
+    uint64_t u; std::memcpy(&u, &v, 8);
+    u = emu::exchange(u, src);
+    std::memcpy(&v, &u, 8); return v;
+}
+__device__ inline int wave_shfl_xor_i(int v, int mask) { return (int)emu::exchange((uint64_t)(uint32_t)v, lane_id() ^ mask); }
+__device__ inline int wave_bcast_i(int v, int src) { return (int)emu::exchange((uint64_t)(uint32_t)v, src); }
+#else
+#define TFF_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+// Lanes of one wavefront exchange data through LDS without a workgroup
+// barrier: DS operations of a wave execute in program order, so only the
+// compiler has to be told not to move accesses across this point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double wave_shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ int wave_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
+// src must be wave-uniform: lowers to v_readlane_b32 pairs (no LDS crossbar).
+__device__ __forceinline__ double wave_bcast(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int wave_bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+#endif
+
+// Butterfly reductions: every lane ends with the same value, summed in a
+// fixed order, so results are bit-reproducible run to run.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += wave_shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { double o = wave_shfl_xor(v, m); v = (o > v) ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += wave_shfl_xor_i(v, m);
+    return v;
+}
+__device__ __forceinline__ bool wave_any(bool p) { return wave_sum_i(p ? 1 : 0) != 0; }
+
+// Reduce K (= 32) per-lane values over the 64 lanes with a halving
+// ("transposing") butterfly: K-1+1 shuffles instead of 6K.  On return lane l
+// holds the full 64-lane sum of value index  reduce32_index(l).
+template <int K>
+__device__ __forceinline__ double wave_reduce_scatter(double (&v)[K]) {
+    static_assert(K == 32, "tuned for 32 values on a 64-lane wave");
+    const int lane = lane_id();
+    // stage xor 32: 32 -> 16 values
+    {
+        const bool up = (lane & 32) != 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double keep = up ? v[i + 16] : v[i];
+            double send = up ? v[i] : v[i + 16];
+            v[i] = keep + wave_shfl_xor(send, 32);
+        }
+    }
+    {
+        const bool up = (lane & 16) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            double keep = up ? v[i + 8] : v[i];
+            double send = up ? v[i] : v[i + 8];
+            v[i] = keep + wave_shfl_xor(send, 16);
+        }
+    }
+    {
+        const bool up = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double keep = up ? v[i + 4] : v[i];
+            double send = up ? v[i] : v[i + 4];
+            v[i] = keep + wave_shfl_xor(send, 8);
+        }
+    }
+    {
+        const bool up = (lane & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            double keep = up ? v[i + 2] : v[i];
+            double send = up ? v[i] : v[i + 2];
+            v[i] = keep + wave_shfl_xor(send, 4);
+        }
+    }
+    {
+        const bool up = (lane & 2) != 0;
+        double keep = up ? v[1] : v[0];
+        double send = up ? v[0] : v[1];
+        v[0] = keep + wave_shfl_xor(send, 2);
+    }
+    v[0] += wave_shfl_xor(v[0], 1);
+    return v[0];
+}
+// value index owned by `lane` after wave_reduce_scatter<32>
+__device__ __forceinline__ int reduce32_index(int lane) {
+    return ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+}
+
+}  // namespace tff
