@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""
+bench.py -- triplet-hypotheses/sec of the hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): a batch of 10 000 synthetic three-view
+scenes (geometry of generateSyntheticScene.m, sigma = 1 px), 200
+correspondences each; one "step" = linearTFT + R_t_from_TFT for the whole batch
+(LinearTFTPoseEstimation without the Reconst output), inputs resident in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1 is launched by the driver as `python -m torch.distributed.run ...`: one
+process per GPU, every rank owns a batch of its own (weak scaling, independent
+triplets, no collective on the data path) and the fixed-size result records are
+all-gathered over RCCL, overlapped with the next step's compute.
+
+Rank 0 prints ONE JSON line (metric, value, roofline, cpu_baseline, ...).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_triplet(N, reconst=False):
+    # in Corresp 48N + CalM 216; out T 216 + R_t_2,R_t_3 192 (+ Reconst 24N + iter,status 8)
+    return 48 * N + 216 + 216 + 192 + ((24 * N + 8) if reconst else 0)
+
+
+def cpu_baseline(C, CalM, sample):
+    """The plain-C restatement (oracle/tft_oracle_c.c, 'port') on all host cores, bounded sample."""
+    from oracle import c_oracle
+    cores = os.cpu_count() or 1
+    c_oracle.linear_tft_pose_batch(C[:max(2, min(cores, sample))], CalM, reconst=False, threads=cores)   # warm
+    t0 = time.perf_counter()
+    out = c_oracle.linear_tft_pose_batch(C[:sample], CalM, reconst=False, threads=cores)
+    dt = time.perf_counter() - t0
+    return dict(value=sample / dt, unit="triplet-hypotheses/s", cores=int(out["threads"]), kind="port",
+                sample="first %d triplets of the same batch (N=%d), %.1f s wall, C restatement of the reference "
+                       "algorithm (explicit 4Nx27 SVDs), OpenMP over triplets" % (sample, C.shape[1], dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=10000)
+    ap.add_argument("--ncorr", type=int, default=200)
+    ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tft_vs_fund_amd import api, dist as tdist
+    from tft_vs_fund_amd.build import build_library
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+
+    rank, world, local = tdist.init_from_env("cuda")
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if rank == 0:
+        build_library()
+    if world > 1:
+        dist.barrier()
+    ctx = api.Context(local)
+
+    B, N = args.batch, args.ncorr
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=1000 + rank)
+    d_C = torch.from_numpy(C).to(dev)
+    d_calm = torch.from_numpy(np.ascontiguousarray(CalM.T).reshape(27)).to(dev)
+
+    # result records, double-buffered so that the gather of step k overlaps the compute of step k+1
+    NBUF = 2
+    recs = [torch.empty(tdist.RECORD_DOUBLES * B, dtype=torch.float64, device=dev) for _ in range(NBUF)]
+    gathered = [torch.empty((world, tdist.RECORD_DOUBLES * B), dtype=torch.float64, device=dev) for _ in range(NBUF)] if world > 1 else None
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    import ctypes
+    lib = ctx.lib
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+    p = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + 8 * off)
+    pending = [None] * NBUF
+
+    def step(k, ev=None):
+        buf = k % NBUF
+        if pending[buf] is not None:
+            pending[buf].wait()
+            pending[buf] = None
+        r = recs[buf]
+        if ev is not None:
+            ev[0].record(stream)
+        rc = lib.tff_linear_tft_pose_batch_dev(ctx.handle, p(d_C), p(d_calm), 0, B, N, p(r, 0), p(r, 12 * B), p(r, 24 * B),
+                                               None, None, ctypes.c_void_p(status.data_ptr()))
+        if ev is not None:
+            ev[1].record(stream)
+        if rc != 0:
+            raise RuntimeError("tff_linear_tft_pose_batch_dev failed: %s" % lib.tff_last_error().decode())
+        if world > 1:
+            pending[buf] = dist.all_gather_into_tensor(gathered[buf].reshape(-1), r, async_op=True)
+
+    def drain():
+        for i in range(NBUF):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
+
+    for k in range(args.warmup):
+        step(k)
+    drain()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k, events[k])
+    drain()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_bad = int((status != 0).sum().item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
+
+    if rank == 0:
+        total = world * B * args.steps
+        value = total / elapsed
+        alg = algorithmic_bytes_per_triplet(N) * B
+        achieved = alg / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "triplet-hypotheses/sec (linearTFT+R,t) at N=200 corresp.",
+            "value": value, "unit": "triplet-hypotheses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: batch of %d synthetic triplets x %d correspondences, sigma=1px, "
+                                   "linearTFT + R_t_from_TFT (LinearTFTPoseEstimation without Reconst), one batch per GPU" % (B, N),
+                       "batch_per_gpu": B, "correspondences": N,
+                       "gather": "RCCL all_gather of 408-B result records, overlapped" if world > 1 else "none (1 GPU)",
+                       "failed_triplets": n_bad},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "k_linear_tft_pose", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(C, CalM, min(args.cpu_sample, B))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

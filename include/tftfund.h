@@ -1,0 +1,89 @@
+/*
+ * tftfund.h -- C ABI of the MI355X-native batched trifocal-tensor /
+ * fundamental-matrix pose estimators (libtftfund.so, built by hipcc for gfx950).
+ *
+ * This is the drop-in boundary for the hot path of LauraFJulia/TFT_vs_Fund.
+ * The reference has no FFI layer; its "operator API" is the MATLAB calling
+ * convention of the method handles
+ *     [R_t_2,R_t_3,Reconst,T,iter] = Method(Corresp,CalM)
+ * (experiments.m:51-59,108; experiments_real.m:53-61,126; example.m:32-42).
+ * Each tff_*_pose_batch entry point below replaces one such method for a batch
+ * of B independent triplets; the MEX shim in matlab/ and the ctypes binding in
+ * tft_vs_fund_amd/api.py bind exactly these symbols.
+ *
+ * Data layout (all IEEE double, MATLAB column-major, caller owns every buffer):
+ *   corresp  B x (6 x N): triplet b, correspondence n = 6 contiguous doubles
+ *            [x1 y1 x2 y2 x3 y3] at corresp[(b*N + n)*6]          (Corresp, 6xN)
+ *   calm     27 doubles per triplet = 9x3 column-major [K1;K2;K3]; calm_stride
+ *            is 27 (one per triplet) or 0 (one shared by the batch)   (CalM, 9x3)
+ *   Rt2,Rt3  B x 12: 3x4 column-major [R|t], camera 1 = [I|0], |t2| = 1
+ *   T        B x 27: T(j,k,i) at j + 3k + 9i, unit Frobenius norm, global sign free
+ *   reconst  B x (3 x N) or NULL                                   (Reconst, 3xN)
+ *   iter     B int32 or NULL  (0 for the linear methods, GH iterations otherwise)
+ *   status   B int32 or NULL  (replaces MATLAB exceptions, see TFF_ST_*)
+ *
+ * Every function returns 0 on success or a negative code (-hipError_t for HIP
+ * failures, TFF_E_* otherwise); tff_last_error() gives a thread-local message.
+ * `_dev` variants take device pointers valid on the context's device and only
+ * enqueue work on the context's stream (no allocation, no synchronisation: safe
+ * inside a hipGraph capture).  `_host` variants take host pointers and perform
+ * H2D, compute, D2H and a stream synchronisation.
+ * A context is bound to one device; calls on one context are serialised by its
+ * stream; different contexts are independent.  No global state.
+ */
+#ifndef TFTFUND_H
+#define TFTFUND_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tff_ctx tff_ctx;
+
+/* per-triplet status codes */
+#define TFF_ST_OK 0
+#define TFF_ST_TOO_FEW 1    /* N < 7 (TFT) or N < 8 (F): experiments.m:99, linearF.m:35-37 */
+#define TFF_ST_NONFINITE 2  /* NaN/Inf in the result: Gauss_Helmert.m:53-55,63-65 */
+#define TFF_ST_NO_POSE 3    /* no candidate with score >= 0: R_f unassigned in R_t_from_TFT.m:91-104 */
+
+/* error codes (besides -hipError_t) */
+#define TFF_E_INVALID (-10001)
+#define TFF_E_NOMEM (-10002)
+
+/* options for tff_ctx_set_option */
+#define TFF_OPT_SOLVER 1    /* 0: Cholesky inverse iteration with Jacobi fallback (default); 1: Jacobi sweeps only */
+#define TFF_OPT_STAGE_LDS 2 /* -1 auto (default), 0 re-read correspondences through L2, 1 stage them in LDS */
+
+#define TFF_DEBUG_STRIDE 128 /* doubles per triplet written by the *_debug_dev entry points */
+
+int tff_version(void);
+const char* tff_last_error(void);
+
+/* Context: device ordinal; owns a stream unless one is supplied. */
+int tff_ctx_create(tff_ctx** out, int device);
+void tff_ctx_destroy(tff_ctx* ctx);
+int tff_ctx_set_stream(tff_ctx* ctx, void* hip_stream); /* borrow the caller's hipStream_t (NULL: back to own stream) */
+void* tff_ctx_get_stream(tff_ctx* ctx);
+int tff_ctx_set_option(tff_ctx* ctx, int option, long value);
+int tff_ctx_synchronize(tff_ctx* ctx);
+
+/* LinearTFTPoseEstimation (TFT_methods/LinearTFTPoseEstimation.m:44-62):
+ * Normalize2Ddata x3 -> linearTFT -> transform_TFT -> R_t_from_TFT -> (Reconst). */
+int tff_linear_tft_pose_batch_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                                  int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                  int32_t* iter, int32_t* status);
+int tff_linear_tft_pose_batch_host(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                                   int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                   int32_t* iter, int32_t* status);
+/* same, additionally writing B x TFF_DEBUG_STRIDE intermediates (unconstrained tensor,
+ * epipoles, constrained tensor, cheirality votes, t3 scale, solver iterations, normalisation) */
+int tff_linear_tft_pose_batch_debug_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                                        int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                        int32_t* iter, int32_t* status, double* dbg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

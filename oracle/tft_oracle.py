@@ -44,9 +44,11 @@ def _svd(A):
 
 def _svdV(A):
     """[~,~,V] = svd(A): only V is consumed, so the thin factorisation is
-    enough (V is n x n whenever rows >= cols, which holds at every call site
-    restated here: 4N x 27 with N >= 7, 3x3, 2M x 4, 27 x 18 uses _svd)."""
-    _, _, Vh = np.linalg.svd(A, full_matrices=False)
+    enough whenever rows >= cols (V is then n x n: 4N x 27 with N >= 7, 3x3,
+    2M x 4).  With fewer rows than columns (linearF at N = 8: 8 x 9) MATLAB's
+    full svd still returns a 9 x 9 V whose last column spans the null space,
+    so the full factorisation is taken."""
+    _, _, Vh = np.linalg.svd(A, full_matrices=A.shape[0] < A.shape[1])
     assert Vh.shape[0] == A.shape[1]
     return Vh.T
 

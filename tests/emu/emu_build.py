@@ -1,0 +1,30 @@
+"""Builds tests/emu/_build/libtff_emu.so: the HIP kernels compiled by g++ against
+the lane emulator (test infrastructure only; optional ASan/UBSan build)."""
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT_DIR = os.path.join(HERE, "_build")
+
+
+def build(sanitize=False):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    out = os.path.join(OUT_DIR, "libtff_emu_san.so" if sanitize else "libtff_emu.so")
+    src = os.path.join(HERE, "emu_lib.cpp")
+    deps = [src, os.path.join(HERE, "hip_emu.h")]
+    csrc = os.path.join(ROOT, "tft_vs_fund_amd", "csrc")
+    deps += [os.path.join(csrc, f) for f in os.listdir(csrc)]
+    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    cmd = ["g++", "-std=c++20", "-O1", "-g", "-pthread", "-shared", "-fPIC", "-I" + HERE, "-o", out, src]
+    if sanitize:
+        cmd[3:3] = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+    subprocess.run(cmd, check=True)
+    return out
+
+
+def load():
+    lib = ctypes.CDLL(build())
+    return lib

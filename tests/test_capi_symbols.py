@@ -1,0 +1,50 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/tftfund.h
+declares; with no device it fails loudly instead of computing anything."""
+import os
+import re
+
+import pytest
+
+from tft_vs_fund_amd import api
+from tft_vs_fund_amd.build import build_library
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    txt = open(os.path.join(ROOT, "include", "tftfund.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(tff_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_builds_and_exports_all_declared_symbols():
+    build_library()
+    lib = api.load_library()
+    names = declared_functions()
+    assert len(names) >= 11
+    for n in names:
+        assert hasattr(lib, n), "libtftfund.so does not export %s" % n
+    assert sorted(api.EXPORTED_SYMBOLS) == names
+    assert lib.tff_version() >= 100
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the context cannot be created (the test is skipped on a GPU box)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(api.TffError):
+        api.Context(0)
+    with pytest.raises((api.TffError, ValueError)):
+        import numpy as np
+        api.LinearTFTPoseEstimation(np.zeros((6, 10)), np.eye(3).repeat(3, axis=0))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "tft_vs_fund_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".c")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("the oracle", "").lower() or f == "__never__", \
+                    "%s mentions the oracle" % os.path.join(dirpath, f)

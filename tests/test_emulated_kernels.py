@@ -1,0 +1,63 @@
+"""
+CPU coverage of the HIP kernel *logic*: the kernels of tft_vs_fund_amd/csrc are
+compiled by g++ against tests/emu/hip_emu.h (one thread per lane, barriers for
+the cross-lane primitives) and compared with the oracle.  This is test
+infrastructure -- the shipped library has no CPU path -- and the real parity
+gate is tests/test_gpu_parity.py on the MI355X.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from oracle import tft_oracle as O
+from tft_vs_fund_amd.scenes import generate_scene_batch, calm_colmajor
+from helpers import rel_err_T, rel_err
+from emu import emu_build
+
+FLAG_JACOBI = 2
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return emu_build.load()
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+def run_linear_tft(lib, C, CalM, flags=0, reconst=True):
+    B, N, _ = C.shape
+    calm = calm_colmajor(CalM)
+    Rt2 = np.zeros((B, 12)); Rt3 = np.zeros((B, 12)); T = np.zeros((B, 27))
+    Rec = np.zeros((B, N, 3)) if reconst else None
+    it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32); dbg = np.zeros((B, 128))
+    lib.emu_linear_tft_pose(_p(C), _p(calm), ctypes.c_long(0), ctypes.c_long(B), ctypes.c_int(N), ctypes.c_int(flags),
+                            _p(Rt2), _p(Rt3), _p(T), _p(Rec), _p(it), _p(st), _p(dbg))
+    return dict(R_t_2=Rt2.reshape(B, 4, 3).transpose(0, 2, 1), R_t_3=Rt3.reshape(B, 4, 3).transpose(0, 2, 1),
+                T=T.reshape(B, 3, 3, 3).transpose(0, 3, 2, 1), Reconst=None if Rec is None else Rec.transpose(0, 2, 1),
+                iter=it, status=st, debug=dbg)
+
+
+@pytest.mark.parametrize("N,sigma,flags", [(7, 1.0, 0), (12, 1.0, 0), (70, 0.0, 0), (130, 1.0, 0), (12, 1.0, FLAG_JACOBI)])
+def test_linear_tft_kernel_matches_oracle(emu, N, sigma, flags):
+    B = 2
+    C, CalM, Rt0, _ = generate_scene_batch(B, N, noise=sigma, seed=100 + N)
+    out = run_linear_tft(emu, C, CalM, flags)
+    assert np.all(out["status"] == 0) and np.all(out["iter"] == 0)
+    for b in range(B):
+        R2, R3, Rec, T, _ = O.LinearTFTPoseEstimation(C[b].T.copy(), CalM)
+        tol = 1e-9                                            # fp64; expected 1e-11 or better
+        assert rel_err_T(out["T"][b], T) < tol
+        assert rel_err(out["R_t_2"][b], R2) < tol and rel_err(out["R_t_3"][b], R3) < tol
+        assert rel_err(out["Reconst"][b], Rec) < tol
+        votes = out["debug"][b, 60:68]
+        assert sorted(np.abs(votes[0:4])) == [0, 0, 2 * N, 2 * N] or sigma > 0
+
+
+def test_too_few_points_sets_status(emu):
+    C, CalM, _, _ = generate_scene_batch(1, 6, noise=1.0, seed=1)
+    out = run_linear_tft(emu, C, CalM)
+    assert out["status"][0] == 1 and np.all(np.isnan(out["T"][0]))

@@ -1,0 +1,116 @@
+"""
+What pins the oracle (oracle/tft_oracle.py), since the MATLAB reference ships
+no tests or golden vectors and cannot run here ("parity unpinned"):
+
+  * known answers that follow from the reference's own ground truth
+    (generateSyntheticScene.m:113): noise-free scenes recover R_t0;
+  * structural facts of linearTFT (rank(E) = 15; cheirality votes are
+    {+2N, -2N, 0, 0} on clean data);
+  * deterministic EPFL inlier counts under the 1-px rule of
+    experiments_real.m:93-99 (obtained there with an
+    independent scratch restatement);
+  * the committed golden fixtures reproduce bit-for-bit-ish from the oracle
+    (guards against silent drift of the oracle or of LAPACK).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import tft_oracle as O
+from tft_vs_fund_amd.scenes import generate_scene_batch
+from helpers import rel_err_T, rel_err, golden_cases
+
+METHODS = ["LinearTFTPoseEstimation", "LinearFPoseEstimation", "ResslTFTPoseEstimation",
+           "NordbergTFTPoseEstimation", "FaugPapaTFTPoseEstimation"]
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_noise_free_scene_recovers_ground_truth(method):
+    C, CalM, Rt0, X = generate_scene_batch(2, 40, noise=0.0, seed=3)
+    for b in range(2):
+        R2, R3, Rec, T, it = getattr(O, method)(C[b].T.copy(), CalM)[:5]
+        s = np.linalg.norm(Rt0[0][:, 3])                      # reference fixes |t2| = 1
+        assert np.max(np.abs(R2[:, :3] - Rt0[0][:, :3])) < 1e-9
+        assert np.max(np.abs(R3[:, :3] - Rt0[1][:, :3])) < 1e-9
+        assert np.max(np.abs(R2[:, 3] - Rt0[0][:, 3] / s)) < 1e-9
+        assert np.max(np.abs(R3[:, 3] - Rt0[1][:, 3] / s)) < 1e-9
+        # Reconst is in camera-1 coordinates at scale 1/s
+        P = [CalM[0:3] @ np.eye(3, 4), CalM[3:6] @ R2, CalM[6:9] @ R3]
+        assert O.ReprError(P, C[b].T.copy(), Rec) < 1e-8
+
+
+def test_rank_E_is_15_and_votes_are_clean():
+    C, CalM, Rt0, X = generate_scene_batch(3, 30, noise=0.0, seed=5)
+    for b in range(3):
+        Cb = C[b].T.copy()
+        x1, N1 = O.Normalize2Ddata(Cb[0:2]); x2, N2 = O.Normalize2Ddata(Cb[2:4]); x3, N3 = O.Normalize2Ddata(Cb[4:6])
+        T, P1, P2, P3, d = O.linearTFT(x1, x2, x3, return_debug=True)
+        assert d["rankE"] == 15
+        Tn = O.transform_TFT(T, N1, N2, N3, 1)
+        _, _, dd = O.R_t_from_TFT(Tn, CalM, Cb, return_debug=True)
+        for v in (dd["votes2"], dd["votes3"]):
+            assert sorted(v) == [-60, 0, 0, 60]
+        # T is a valid trifocal tensor of the returned cameras
+        assert rel_err_T(O.TFT_from_P(P1, P2, P3), T / np.linalg.norm(T)) < 1e-9
+
+
+def test_normalize2ddata_properties():
+    rng = np.random.default_rng(0)
+    p = rng.normal(size=(2, 50)) * 300 + 700
+    q, Nm = O.Normalize2Ddata(p)
+    assert q.shape == (2, 50)                                  # quirk: 2xN, not homogeneous
+    assert np.allclose(q.mean(axis=1), 0, atol=1e-12)
+    assert abs(np.mean(np.sqrt(np.sum(q ** 2, axis=0))) - np.sqrt(2)) < 1e-12
+
+
+def test_linearF_needs_8_points():
+    C, CalM, _, _ = generate_scene_batch(1, 7, noise=1.0, seed=1)
+    with pytest.raises(ValueError):
+        O.linearF(C[0].T[0:2], C[0].T[2:4])
+
+
+EPFL_INLIERS = [1360, 1253, 1250, 85, 1222, 1037, 920, 39]
+EPFL_TOTAL = [1400, 1306, 1302, 95, 1482, 1267, 1117, 97]
+
+
+def test_epfl_inlier_counts(golden_dir):
+    g = np.load(os.path.join(golden_dir, "epfl.npz"))
+    assert int(g["count"]) == 8
+    for n in range(8):
+        pre = "t%d_" % n
+        Corresp, CalM, Rt0 = g[pre + "Corresp_all"], g[pre + "CalM"], g[pre + "Rt0"]
+        assert Corresp.shape[1] == EPFL_TOTAL[n]
+        Ps = [CalM[0:3] @ np.eye(3, 4), CalM[3:6] @ Rt0[0], CalM[6:9] @ Rt0[1]]
+        Rec0 = O.triangulation3D(Ps, Corresp)
+        Rec0 = Rec0[0:3] / Rec0[3:4]
+        resid = O.project3Dpoints(Rec0, Ps) - Corresp
+        n_in = int(np.sum(np.sum(np.abs(resid) > 1.0, axis=0) == 0))       # experiments_real.m:98
+        assert n_in == EPFL_INLIERS[n] == int(g[pre + "n_inliers"])
+
+
+def test_golden_linear_reproduces(golden_dir):
+    g = np.load(os.path.join(golden_dir, "synthetic_linear.npz"))
+    for ci, pre in golden_cases(g):
+        C, CalM = g[pre + "Corresp"], g[pre + "CalM"]
+        b = 0
+        R2, R3, Rec, T, it = O.LinearTFTPoseEstimation(C[b].T.copy(), CalM)
+        assert rel_err_T(T, g[pre + "tft_T"][b]) < 1e-10
+        assert rel_err(R2, g[pre + "tft_Rt2"][b]) < 1e-10 and rel_err(R3, g[pre + "tft_Rt3"][b]) < 1e-10
+        if C.shape[1] >= 8:
+            R2, R3, Rec, T, it = O.LinearFPoseEstimation(C[b].T.copy(), CalM)
+            assert rel_err_T(T, g[pre + "f_T"][b]) < 1e-10
+            assert rel_err(R2, g[pre + "f_Rt2"][b]) < 1e-10 and rel_err(R3, g[pre + "f_Rt3"][b]) < 1e-10
+
+
+def test_golden_epfl_linear_quality(golden_dir):
+    """On real data the linear TFT pose is within a few degrees of the EPFL ground truth."""
+    g = np.load(os.path.join(golden_dir, "epfl.npz"))
+    for n in range(8):
+        pre = "t%d_" % n
+        for m in ("tft", "f", "ressl"):
+            r2, t2 = O.AngError(g[pre + "Rt0"][0], g[pre + m + "_Rt2"])
+            r3, t3 = O.AngError(g[pre + "Rt0"][1], g[pre + m + "_Rt3"])
+            # AngError does not clamp acos: a NaN means the argument drifted above 1, i.e. ~0 degrees
+            assert np.nan_to_num(max(r2, r3)) < 1.0 and np.nan_to_num(max(t2, t3)) < 2.0
+            assert float(g[pre + m + "_repr_all"]) < 6.5

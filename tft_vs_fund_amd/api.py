@@ -1,0 +1,240 @@
+"""
+Host-side mirror of the reference's operator API on top of libtftfund.so.
+
+The reference's drop-in surface is the MATLAB calling convention
+    [R_t_2, R_t_3, Reconst, T, iter] = Method(Corresp, CalM)
+(experiments.m:51-59,108).  This module exposes
+
+  * the same names with the same argument meaning for ONE triplet
+    (`LinearTFTPoseEstimation(Corresp, CalM)` with Corresp 6xN, CalM 9x3), and
+  * `*_batch` variants for B triplets -- the form the GPU is built for --
+    on numpy arrays (host path: the library does H2D/D2H) or on torch CUDA
+    tensors (device path: only pointers and the current stream are passed; torch
+    is plumbing for device memory and streams, nothing else).
+
+There is no CPU fallback: if libtftfund.so is missing or no HIP device is
+present, every call raises.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libtftfund.so")
+
+TFF_OPT_SOLVER = 1
+TFF_OPT_STAGE_LDS = 2
+DEBUG_STRIDE = 128
+
+ST_OK, ST_TOO_FEW, ST_NONFINITE, ST_NO_POSE = 0, 1, 2, 3
+
+_c_dp = ctypes.c_void_p
+_POSE_SIG = [ctypes.c_void_p, _c_dp, _c_dp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+             _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class TffError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen libtftfund.so and declare its prototypes.  Raises if it is missing:
+    the product has no other compute path."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or _LIB_PATH
+        if not os.path.exists(p):
+            raise TffError("libtftfund.so not found at %s -- build it with `python -m tft_vs_fund_amd.build` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
+        lib = ctypes.CDLL(p)
+        lib.tff_version.restype = ctypes.c_int
+        lib.tff_last_error.restype = ctypes.c_char_p
+        lib.tff_ctx_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+        lib.tff_ctx_destroy.argtypes = [ctypes.c_void_p]
+        lib.tff_ctx_destroy.restype = None
+        lib.tff_ctx_set_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.tff_ctx_get_stream.argtypes = [ctypes.c_void_p]
+        lib.tff_ctx_get_stream.restype = ctypes.c_void_p
+        lib.tff_ctx_set_option.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_long]
+        lib.tff_ctx_synchronize.argtypes = [ctypes.c_void_p]
+        for name in POSE_METHODS.values():
+            for suffix in ("_dev", "_host"):
+                fn = getattr(lib, name + suffix, None)
+                if fn is not None:
+                    fn.argtypes = _POSE_SIG
+                    fn.restype = ctypes.c_int
+        lib.tff_linear_tft_pose_batch_debug_dev.argtypes = _POSE_SIG + [_c_dp]
+        lib.tff_linear_tft_pose_batch_debug_dev.restype = ctypes.c_int
+        if path is None:
+            _lib = lib
+        return lib
+
+
+# reference method name -> C entry point stem
+POSE_METHODS = {
+    "LinearTFTPoseEstimation": "tff_linear_tft_pose_batch",
+}
+
+# every symbol include/tftfund.h declares (checked by the CPU test-suite)
+EXPORTED_SYMBOLS = [
+    "tff_version", "tff_last_error", "tff_ctx_create", "tff_ctx_destroy", "tff_ctx_set_stream",
+    "tff_ctx_get_stream", "tff_ctx_set_option", "tff_ctx_synchronize",
+    "tff_linear_tft_pose_batch_dev", "tff_linear_tft_pose_batch_host", "tff_linear_tft_pose_batch_debug_dev",
+]
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        msg = lib.tff_last_error()
+        raise TffError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+class Context:
+    """A tff_ctx: one device, one stream.  `solver`: 'invit' (Cholesky inverse
+    iteration with Jacobi fallback) or 'jacobi'."""
+
+    def __init__(self, device=0, solver="invit", stage_lds=-1):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.tff_ctx_create(ctypes.byref(h), int(device)), "tff_ctx_create")
+        self.handle = h
+        self.device = int(device)
+        self.set_solver(solver)
+        _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_STAGE_LDS, int(stage_lds)), "set_option")
+
+    def set_solver(self, solver):
+        v = {"invit": 0, "jacobi": 1}[solver]
+        _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_SOLVER, v), "set_option")
+
+    def set_stream(self, stream_ptr):
+        _check(self.lib, self.lib.tff_ctx_set_stream(self.handle, ctypes.c_void_p(stream_ptr or 0)), "set_stream")
+
+    def synchronize(self):
+        _check(self.lib, self.lib.tff_ctx_synchronize(self.handle), "synchronize")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.tff_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- batched pose estimation ------------------------------------------
+    def pose_batch(self, method, corresp, calm, reconst=True, debug=False):
+        """corresp: (B, N, 6) float64 (== MATLAB 6 x N x B); calm: (9,3) shared or
+        (B, 9, 3).  numpy in -> numpy out (host path); torch CUDA tensors in ->
+        torch tensors out (device path, asynchronous on the current stream).
+        Returns dict(R_t_2 (B,3,4), R_t_3 (B,3,4), T (B,3,3,3) indexed [b,j,k,i],
+        Reconst (B,3,N) or None, iter (B,), status (B,))."""
+        stem = POSE_METHODS[method]
+        if isinstance(corresp, np.ndarray):
+            return self._pose_batch_host(stem, corresp, calm, reconst)
+        return self._pose_batch_dev(stem, corresp, calm, reconst, debug)
+
+    @staticmethod
+    def _calm_cm_np(calm, B):
+        calm = np.asarray(calm, dtype=np.float64)
+        if calm.shape == (9, 3):
+            return np.ascontiguousarray(calm.T).reshape(27), 0
+        if calm.shape == (B, 9, 3):
+            return np.ascontiguousarray(calm.transpose(0, 2, 1)).reshape(B * 27), 27
+        raise ValueError("CalM must be 9x3 or Bx9x3")
+
+    def _pose_batch_host(self, stem, corresp, calm, reconst):
+        corresp = np.ascontiguousarray(corresp, dtype=np.float64)
+        if corresp.ndim != 3 or corresp.shape[2] != 6:
+            raise ValueError("corresp must be (B, N, 6)")
+        B, N, _ = corresp.shape
+        calm_cm, stride = self._calm_cm_np(calm, B)
+        Rt2 = np.empty((B, 12)); Rt3 = np.empty((B, 12)); T = np.empty((B, 27))
+        rec = np.empty((B, N, 3)) if reconst else None
+        it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32)
+        fn = getattr(self.lib, stem + "_host")
+        ptr = lambda a: ctypes.c_void_p(a.ctypes.data) if a is not None else None
+        _check(self.lib, fn(self.handle, ptr(corresp), ptr(calm_cm), stride, B, N, ptr(Rt2), ptr(Rt3), ptr(T), ptr(rec),
+                            ptr(it), ptr(st)), stem + "_host")
+        return dict(R_t_2=Rt2.reshape(B, 4, 3).transpose(0, 2, 1), R_t_3=Rt3.reshape(B, 4, 3).transpose(0, 2, 1),
+                    T=T.reshape(B, 3, 3, 3).transpose(0, 3, 2, 1),
+                    Reconst=rec.transpose(0, 2, 1) if reconst else None, iter=it, status=st)
+
+    def _pose_batch_dev(self, stem, corresp, calm, reconst, debug):
+        import torch
+        if not (corresp.is_cuda and corresp.dtype == torch.float64 and corresp.is_contiguous()):
+            raise ValueError("corresp must be a contiguous float64 CUDA tensor of shape (B, N, 6)")
+        B, N, _ = corresp.shape
+        dev = corresp.device
+        if tuple(calm.shape) == (9, 3):
+            calm_cm, stride = calm.t().contiguous().reshape(27), 0
+        elif tuple(calm.shape) == (27,):
+            calm_cm, stride = calm.contiguous(), 0          # already column-major
+        else:
+            calm_cm, stride = calm.transpose(1, 2).contiguous().reshape(B * 27), 27
+        calm_cm = calm_cm.to(device=dev, dtype=torch.float64)
+        Rt2 = torch.empty((B, 12), dtype=torch.float64, device=dev)
+        Rt3 = torch.empty((B, 12), dtype=torch.float64, device=dev)
+        T = torch.empty((B, 27), dtype=torch.float64, device=dev)
+        rec = torch.empty((B, N, 3), dtype=torch.float64, device=dev) if reconst else None
+        it = torch.zeros(B, dtype=torch.int32, device=dev)
+        st = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        out = dict()
+        if debug:
+            dbg = torch.zeros((B, DEBUG_STRIDE), dtype=torch.float64, device=dev)
+            fn = getattr(self.lib, stem + "_debug_dev")
+            _check(self.lib, fn(self.handle, p(corresp), p(calm_cm), stride, B, N, p(Rt2), p(Rt3), p(T), p(rec), p(it), p(st),
+                                p(dbg)), stem + "_debug_dev")
+            out["debug"] = dbg
+        else:
+            fn = getattr(self.lib, stem + "_dev")
+            _check(self.lib, fn(self.handle, p(corresp), p(calm_cm), stride, B, N, p(Rt2), p(Rt3), p(T), p(rec), p(it), p(st)),
+                   stem + "_dev")
+        out.update(R_t_2=Rt2.reshape(B, 4, 3).transpose(1, 2), R_t_3=Rt3.reshape(B, 4, 3).transpose(1, 2),
+                   T=T.reshape(B, 3, 3, 3).permute(0, 3, 2, 1),
+                   Reconst=rec.transpose(1, 2) if reconst else None, iter=it, status=st,
+                   _raw=(Rt2, Rt3, T, rec))
+        return out
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    c = _default_ctx.get(device)
+    if c is None:
+        c = _default_ctx[device] = Context(device)
+    return c
+
+
+def _single(method, Corresp, CalM, nargout=5):
+    """One triplet with the reference's shapes: Corresp 6xN, CalM 9x3 ->
+    R_t_2 (3x4), R_t_3 (3x4), Reconst (3xN), T (3x3x3), iter."""
+    Corresp = np.asarray(Corresp, dtype=np.float64)
+    if Corresp.ndim != 2 or Corresp.shape[0] != 6:
+        raise ValueError("Corresp must be 6xN")
+    N = Corresp.shape[1]
+    out = default_context().pose_batch(method, np.ascontiguousarray(Corresp.T).reshape(1, N, 6), np.asarray(CalM),
+                                       reconst=nargout >= 3)
+    st = int(out["status"][0])
+    if st == ST_TOO_FEW:
+        raise ValueError("not enough correspondences for %s (N=%d)" % (method, N))
+    if st == ST_NO_POSE:
+        raise RuntimeError("%s: no pose candidate with non-negative cheirality score" % method)
+    rec = out["Reconst"][0] if out["Reconst"] is not None else None
+    return out["R_t_2"][0], out["R_t_3"][0], rec, out["T"][0], int(out["iter"][0])
+
+
+def LinearTFTPoseEstimation(Corresp, CalM):
+    """Drop-in for TFT_methods/LinearTFTPoseEstimation.m (same inputs/outputs)."""
+    return _single("LinearTFTPoseEstimation", Corresp, CalM)

@@ -1,0 +1,199 @@
+// C ABI of libtftfund.so (see include/tftfund.h).  gfx950 only; there is no
+// CPU path behind these entry points: without a HIP device they fail loudly.
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+#include "../../include/tftfund.h"
+#include "launch.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* what) {
+    g_err = what;
+    return code;
+}
+int hip_fail(hipError_t e, const char* where) {
+    g_err = std::string(where) + ": " + hipGetErrorString(e);
+    return -(int)e;
+}
+#define TFF_HIP(call)                                    \
+    do {                                                 \
+        hipError_t e__ = (call);                         \
+        if (e__ != hipSuccess) return hip_fail(e__, #call); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc(workspace)");
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct tff_ctx {
+    int device = 0;
+    hipStream_t own = nullptr;
+    hipStream_t stream = nullptr;
+    int solver = 0;
+    int stage = -1;
+    DevBuf in, calm, out, idx;
+};
+
+namespace {
+
+int pose_flags(const tff_ctx* c, int N, bool reconst) {
+    int flags = 0;
+    if (reconst) flags |= tff::FLAG_RECONST;
+    if (c->solver == 1) flags |= tff::FLAG_JACOBI;
+    if (c->stage < 0) flags = tff::pose_auto_flags(N, flags);
+    else if (c->stage > 0) flags |= tff::FLAG_STAGE_LDS;
+    return flags;
+}
+
+template <class K>
+int ensure_lds(K kernel, size_t bytes) {
+    if (bytes > 160 * 1024) return fail(TFF_E_INVALID, "N too large for LDS staging (set TFF_OPT_STAGE_LDS to 0)");
+    if (bytes > 64 * 1024) TFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+int check_common(const tff_ctx* c, const void* corresp, const void* calm, int64_t calm_stride, int64_t B, int32_t N) {
+    if (!c) return fail(TFF_E_INVALID, "null context");
+    if (B < 0 || N < 0) return fail(TFF_E_INVALID, "negative batch or correspondence count");
+    if (B > 0 && (!corresp || !calm)) return fail(TFF_E_INVALID, "null input pointer");
+    if (calm_stride != 0 && calm_stride != 27) return fail(TFF_E_INVALID, "calm_stride must be 0 (shared CalM) or 27");
+    return 0;
+}
+
+int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
+                      double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+    if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
+    if (B == 0) return 0;
+    if (!Rt2 || !Rt3 || !T) return fail(TFF_E_INVALID, "null output pointer");
+    TFF_HIP(hipSetDevice(c->device));
+    tff::LinearTftArgs a{corresp, calm, (long)calm_stride, (long)B, N, pose_flags(c, N, reconst != nullptr),
+                         Rt2, Rt3, T, reconst, iter, status, dbg};
+    const size_t lds = tff::pose_lds_bytes(N, a.flags);
+    if (int r = ensure_lds(tff::k_linear_tft_pose, lds)) return r;
+    hipLaunchKernelGGL(tff::k_linear_tft_pose, dim3(tff::pose_grid(B)), dim3(64), lds, c->stream, a);
+    TFF_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tff_version(void) { return 100; }
+const char* tff_last_error(void) { return g_err.c_str(); }
+
+int tff_ctx_create(tff_ctx** out, int device) {
+    if (!out) return fail(TFF_E_INVALID, "null out pointer");
+    *out = nullptr;
+    int n = 0;
+    TFF_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(TFF_E_INVALID, "no such HIP device (libtftfund has no CPU path)");
+    TFF_HIP(hipSetDevice(device));
+    tff_ctx* c = new (std::nothrow) tff_ctx();
+    if (!c) return fail(TFF_E_NOMEM, "out of host memory");
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
+    c->stream = c->own;
+    *out = c;
+    return 0;
+}
+
+void tff_ctx_destroy(tff_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->own) { (void)hipStreamSynchronize(c->own); (void)hipStreamDestroy(c->own); }
+    c->in.release(); c->calm.release(); c->out.release(); c->idx.release();
+    delete c;
+}
+
+int tff_ctx_set_stream(tff_ctx* c, void* s) {
+    if (!c) return fail(TFF_E_INVALID, "null context");
+    c->stream = s ? (hipStream_t)s : c->own;
+    return 0;
+}
+void* tff_ctx_get_stream(tff_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int tff_ctx_set_option(tff_ctx* c, int option, long value) {
+    if (!c) return fail(TFF_E_INVALID, "null context");
+    switch (option) {
+        case TFF_OPT_SOLVER: if (value != 0 && value != 1) return fail(TFF_E_INVALID, "solver must be 0 or 1"); c->solver = (int)value; return 0;
+        case TFF_OPT_STAGE_LDS: if (value < -1 || value > 1) return fail(TFF_E_INVALID, "stage_lds must be -1, 0 or 1"); c->stage = (int)value; return 0;
+        default: return fail(TFF_E_INVALID, "unknown option");
+    }
+}
+
+int tff_ctx_synchronize(tff_ctx* c) {
+    if (!c) return fail(TFF_E_INVALID, "null context");
+    TFF_HIP(hipSetDevice(c->device));
+    TFF_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tff_linear_tft_pose_batch_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                                  int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                                  int32_t* status) {
+    return launch_linear_tft(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, nullptr);
+}
+
+int tff_linear_tft_pose_batch_debug_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride,
+                                        int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                        int32_t* iter, int32_t* status, double* dbg) {
+    if (!dbg) return fail(TFF_E_INVALID, "null debug buffer");
+    return launch_linear_tft(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+}
+
+int tff_linear_tft_pose_batch_host(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                                   int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                                   int32_t* status) {
+    if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
+    if (B == 0) return 0;
+    if (!Rt2 || !Rt3 || !T) return fail(TFF_E_INVALID, "null output pointer");
+    TFF_HIP(hipSetDevice(c->device));
+    const size_t nin = (size_t)B * 6 * (size_t)N * sizeof(double);
+    const size_t ncal = (calm_stride ? (size_t)B : 1) * 27 * sizeof(double);
+    const size_t per_out = (12 + 12 + 27 + (reconst ? 3 * (size_t)N : 0)) * sizeof(double);
+    if (int r = c->in.reserve(nin ? nin : 8)) return r;
+    if (int r = c->calm.reserve(ncal)) return r;
+    if (int r = c->out.reserve((size_t)B * per_out)) return r;
+    if (int r = c->idx.reserve((size_t)B * 2 * sizeof(int32_t))) return r;
+    double* d_in = (double*)c->in.p;
+    double* d_cal = (double*)c->calm.p;
+    double* d_Rt2 = (double*)c->out.p;
+    double* d_Rt3 = d_Rt2 + (size_t)B * 12;
+    double* d_T = d_Rt3 + (size_t)B * 12;
+    double* d_rec = reconst ? d_T + (size_t)B * 27 : nullptr;
+    int32_t* d_it = (int32_t*)c->idx.p;
+    int32_t* d_st = d_it + B;
+    if (nin) TFF_HIP(hipMemcpyAsync(d_in, corresp, nin, hipMemcpyHostToDevice, c->stream));
+    TFF_HIP(hipMemcpyAsync(d_cal, calm, ncal, hipMemcpyHostToDevice, c->stream));
+    if (int r = launch_linear_tft(c, d_in, d_cal, calm_stride, B, N, d_Rt2, d_Rt3, d_T, d_rec, d_it, d_st, nullptr)) return r;
+    TFF_HIP(hipMemcpyAsync(Rt2, d_Rt2, (size_t)B * 12 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TFF_HIP(hipMemcpyAsync(Rt3, d_Rt3, (size_t)B * 12 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TFF_HIP(hipMemcpyAsync(T, d_T, (size_t)B * 27 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (reconst && N) TFF_HIP(hipMemcpyAsync(reconst, d_rec, (size_t)B * 3 * (size_t)N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (iter) TFF_HIP(hipMemcpyAsync(iter, d_it, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (status) TFF_HIP(hipMemcpyAsync(status, d_st, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    TFF_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+"""
+Multi-GPU layer: one process per GPU, independent triplets sharded as contiguous
+blocks of the batch index, no collective on the data path; a single all-gather
+of fixed-size result records (RCCL over xGMI; `nccl` backend == RCCL on ROCm)
+brings the results together.  The reference has no parallelism
+at all (experiments.m:74-144 runs its independent trials serially).
+
+The same code runs under `gloo` on CPU tensors for the world_size-2 tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+RECORD_DOUBLES = 51          # R_t_2 (12) + R_t_3 (12) + T (27)
+
+
+def shard_bounds(B, world, rank):
+    """Contiguous block [lo, hi) of the batch owned by `rank` (GPU g of G gets [g*B/G, (g+1)*B/G))."""
+    return (rank * B) // world, ((rank + 1) * B) // world
+
+
+def init_from_env(device_type=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (set by torch.distributed.run).
+    Returns (rank, world, local_rank).  Single process: (0, 1, 0) without a process group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if device_type is None:
+            device_type = "cuda" if torch.cuda.is_available() else "cpu"
+        if device_type == "cuda":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, world, local
+
+
+def pack_records(Rt2, Rt3, T):
+    """(b,12), (b,12), (b,27) -> one (51*b,) record block [all Rt2 | all Rt3 | all T]."""
+    return torch.cat([Rt2.reshape(-1), Rt3.reshape(-1), T.reshape(-1)])
+
+
+def unpack_records(block, b):
+    Rt2 = block[: 12 * b].reshape(b, 12)
+    Rt3 = block[12 * b: 24 * b].reshape(b, 12)
+    T = block[24 * b: 51 * b].reshape(b, 27)
+    return Rt2, Rt3, T
+
+
+def all_gather_records(local_block, B, async_op=False, out=None):
+    """All-gather the per-rank record blocks of a batch of B triplets sharded with
+    shard_bounds.  Shards may differ by one triplet; blocks are padded to the
+    largest shard.  Returns (gathered (world, 51*bmax) tensor, work handle or None)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    bmax = -(-B // world)
+    n = RECORD_DOUBLES * bmax
+    if local_block.numel() < n:
+        local_block = torch.cat([local_block, local_block.new_zeros(n - local_block.numel())])
+    if world == 1:
+        return local_block.reshape(1, n), None
+    if out is None:
+        out = local_block.new_empty((world, n))
+    work = dist.all_gather_into_tensor(out.reshape(-1), local_block.contiguous(), async_op=async_op)
+    return out, work
+
+
+def assemble(gathered, B):
+    """(world, 51*bmax) gathered blocks -> Rt2 (B,12), Rt3 (B,12), T (B,27) in batch order."""
+    world = gathered.shape[0]
+    bmax = -(-B // world)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_bounds(B, world, r)
+        b = hi - lo
+        blk = gathered[r]
+        # block layout uses the padded shard size only if the sender padded *after* packing its own b
+        Rt2 = blk[: 12 * b].reshape(b, 12)
+        Rt3 = blk[12 * b: 24 * b].reshape(b, 12)
+        T = blk[24 * b: 51 * b].reshape(b, 27)
+        parts.append((Rt2, Rt3, T))
+    return (torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]), torch.cat([p[2] for p in parts]))
+
+
+def all_gather_counts(local_counts, B):
+    """int32 per-hypothesis counts (config 4: inlier counts) -> all ranks, batch order."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return local_counts
+    bmax = -(-B // world)
+    pad = local_counts.new_zeros(bmax)
+    pad[: local_counts.numel()] = local_counts
+    out = local_counts.new_empty(world * bmax)
+    dist.all_gather_into_tensor(out, pad)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_bounds(B, world, r)
+        parts.append(out[r * bmax: r * bmax + (hi - lo)])
+    return torch.cat(parts)
