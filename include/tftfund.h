@@ -25,8 +25,9 @@
  * Every function returns 0 on success or a negative code (-hipError_t for HIP
  * failures, TFF_E_* otherwise); tff_last_error() gives a thread-local message.
  * `_dev` variants take device pointers valid on the context's device and only
- * enqueue work on the context's stream (no allocation, no synchronisation: safe
- * inside a hipGraph capture).  `_host` variants take host pointers and perform
+ * enqueue work on the context's stream (no synchronisation; no allocation when a
+ * status array is supplied -- then they are safe inside a hipGraph capture; with
+ * status == NULL the context grows a scratch status array on first use).  `_host` variants take host pointers and perform
  * H2D, compute, D2H and a stream synchronisation.
  * A context is bound to one device; calls on one context are serialised by its
  * stream; different contexts are independent.  No global state.
@@ -64,7 +65,8 @@ const char* tff_last_error(void);
 /* Context: device ordinal; owns a stream unless one is supplied. */
 int tff_ctx_create(tff_ctx** out, int device);
 void tff_ctx_destroy(tff_ctx* ctx);
-int tff_ctx_set_stream(tff_ctx* ctx, void* hip_stream); /* borrow the caller's hipStream_t (NULL: back to own stream) */
+int tff_ctx_set_stream(tff_ctx* ctx, void* hip_stream); /* borrow the caller's hipStream_t; NULL is the device's null stream */
+int tff_ctx_use_own_stream(tff_ctx* ctx);               /* back to the context's own non-blocking stream */
 void* tff_ctx_get_stream(tff_ctx* ctx);
 int tff_ctx_set_option(tff_ctx* ctx, int option, long value);
 int tff_ctx_synchronize(tff_ctx* ctx);

@@ -20,6 +20,11 @@ import os
 import threading
 
 import numpy as np
+# torch is plumbing here (device memory, streams, torch.distributed) -- and it must be
+# imported BEFORE libtftfund.so is dlopen'ed: the torch wheel bundles its own
+# libamdhip64.so (soname libamdhip64.so.7); loading it first makes the dynamic loader
+# bind libtftfund.so to that same HIP runtime instead of starting a second one.
+import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libtftfund.so")
@@ -60,6 +65,7 @@ def load_library(path=None):
         lib.tff_ctx_destroy.argtypes = [ctypes.c_void_p]
         lib.tff_ctx_destroy.restype = None
         lib.tff_ctx_set_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.tff_ctx_use_own_stream.argtypes = [ctypes.c_void_p]
         lib.tff_ctx_get_stream.argtypes = [ctypes.c_void_p]
         lib.tff_ctx_get_stream.restype = ctypes.c_void_p
         lib.tff_ctx_set_option.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_long]
@@ -85,7 +91,7 @@ POSE_METHODS = {
 # every symbol include/tftfund.h declares (checked by the CPU test-suite)
 EXPORTED_SYMBOLS = [
     "tff_version", "tff_last_error", "tff_ctx_create", "tff_ctx_destroy", "tff_ctx_set_stream",
-    "tff_ctx_get_stream", "tff_ctx_set_option", "tff_ctx_synchronize",
+    "tff_ctx_use_own_stream", "tff_ctx_get_stream", "tff_ctx_set_option", "tff_ctx_synchronize",
     "tff_linear_tft_pose_batch_dev", "tff_linear_tft_pose_batch_host", "tff_linear_tft_pose_batch_debug_dev",
 ]
 
@@ -100,8 +106,8 @@ class Context:
     """A tff_ctx: one device, one stream.  `solver`: 'invit' (Cholesky inverse
     iteration with Jacobi fallback) or 'jacobi'."""
 
-    def __init__(self, device=0, solver="invit", stage_lds=-1):
-        self.lib = load_library()
+    def __init__(self, device=0, solver="invit", stage_lds=-1, lib_path=None):
+        self.lib = load_library(lib_path)
         h = ctypes.c_void_p()
         _check(self.lib, self.lib.tff_ctx_create(ctypes.byref(h), int(device)), "tff_ctx_create")
         self.handle = h
@@ -114,7 +120,11 @@ class Context:
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_SOLVER, v), "set_option")
 
     def set_stream(self, stream_ptr):
+        """Enqueue on the caller's hipStream_t (0 / None = the device's null stream, torch's default)."""
         _check(self.lib, self.lib.tff_ctx_set_stream(self.handle, ctypes.c_void_p(stream_ptr or 0)), "set_stream")
+
+    def use_own_stream(self):
+        _check(self.lib, self.lib.tff_ctx_use_own_stream(self.handle), "use_own_stream")
 
     def synchronize(self):
         _check(self.lib, self.lib.tff_ctx_synchronize(self.handle), "synchronize")
@@ -169,7 +179,6 @@ class Context:
                     Reconst=rec.transpose(0, 2, 1) if reconst else None, iter=it, status=st)
 
     def _pose_batch_dev(self, stem, corresp, calm, reconst, debug):
-        import torch
         if not (corresp.is_cuda and corresp.dtype == torch.float64 and corresp.is_contiguous()):
             raise ValueError("corresp must be a contiguous float64 CUDA tensor of shape (B, N, 6)")
         B, N, _ = corresp.shape

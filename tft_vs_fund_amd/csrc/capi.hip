@@ -49,17 +49,15 @@ struct tff_ctx {
     hipStream_t stream = nullptr;
     int solver = 0;
     int stage = -1;
-    DevBuf in, calm, out, idx;
+    DevBuf in, calm, out, idx, scratch_status;
 };
 
 namespace {
 
-int pose_flags(const tff_ctx* c, int N, bool reconst) {
-    int flags = 0;
-    if (reconst) flags |= tff::FLAG_RECONST;
-    if (c->solver == 1) flags |= tff::FLAG_JACOBI;
-    if (c->stage < 0) flags = tff::pose_auto_flags(N, flags);
-    else if (c->stage > 0) flags |= tff::FLAG_STAGE_LDS;
+int base_flags(const tff_ctx* c, bool reconst) { return reconst ? tff::FLAG_RECONST : 0; }
+int staged_flags(const tff_ctx* c, int N, int flags, bool jacobi) {
+    if (c->stage < 0) return tff::pose_auto_flags(N, flags, jacobi);
+    if (c->stage > 0) return flags | tff::FLAG_STAGE_LDS;
     return flags;
 }
 
@@ -78,17 +76,35 @@ int check_common(const tff_ctx* c, const void* corresp, const void* calm, int64_
     return 0;
 }
 
+// Two launches on the context's stream: the inverse-iteration kernel for the whole
+// batch, then the Jacobi kernel over the (rare) triplets it marked ST_RETRY.
+// With TFF_OPT_SOLVER = 1 only the Jacobi kernel runs, for every triplet.
 int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     if (B == 0) return 0;
     if (!Rt2 || !Rt3 || !T) return fail(TFF_E_INVALID, "null output pointer");
     TFF_HIP(hipSetDevice(c->device));
-    tff::LinearTftArgs a{corresp, calm, (long)calm_stride, (long)B, N, pose_flags(c, N, reconst != nullptr),
+    if (!status) {                         // the kernels hand ST_RETRY over through the status array
+        if (int r = c->scratch_status.reserve((size_t)B * sizeof(int32_t))) return r;
+        status = (int32_t*)c->scratch_status.p;
+    }
+    tff::LinearTftArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr),
                          Rt2, Rt3, T, reconst, iter, status, dbg};
-    const size_t lds = tff::pose_lds_bytes(N, a.flags);
-    if (int r = ensure_lds(tff::k_linear_tft_pose, lds)) return r;
-    hipLaunchKernelGGL(tff::k_linear_tft_pose, dim3(tff::pose_grid(B)), dim3(64), lds, c->stream, a);
+    if (c->solver == 0) {
+        tff::LinearTftArgs m = a;
+        m.flags = staged_flags(c, N, a.flags, false);
+        const size_t lds = tff::pose_lds_bytes(N, m.flags, false);
+        if (int r = ensure_lds(tff::k_linear_tft_pose<false>, lds)) return r;
+        hipLaunchKernelGGL(tff::k_linear_tft_pose<false>, dim3(tff::pose_grid(B)), dim3(64), lds, c->stream, m);
+        TFF_HIP(hipGetLastError());
+        a.flags |= tff::FLAG_ONLY_RETRY;
+    }
+    a.flags = staged_flags(c, N, a.flags, true);
+    const size_t lds = tff::pose_lds_bytes(N, a.flags, true);
+    if (int r = ensure_lds(tff::k_linear_tft_pose<true>, lds)) return r;
+    const unsigned grid = (c->solver == 0) ? (unsigned)(B < 1024 ? B : 1024) : tff::pose_grid(B);
+    hipLaunchKernelGGL(tff::k_linear_tft_pose<true>, dim3(grid), dim3(64), lds, c->stream, a);
     TFF_HIP(hipGetLastError());
     return 0;
 }
@@ -121,13 +137,18 @@ void tff_ctx_destroy(tff_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own) { (void)hipStreamSynchronize(c->own); (void)hipStreamDestroy(c->own); }
-    c->in.release(); c->calm.release(); c->out.release(); c->idx.release();
+    c->in.release(); c->calm.release(); c->out.release(); c->idx.release(); c->scratch_status.release();
     delete c;
 }
 
 int tff_ctx_set_stream(tff_ctx* c, void* s) {
     if (!c) return fail(TFF_E_INVALID, "null context");
-    c->stream = s ? (hipStream_t)s : c->own;
+    c->stream = (hipStream_t)s;
+    return 0;
+}
+int tff_ctx_use_own_stream(tff_ctx* c) {
+    if (!c) return fail(TFF_E_INVALID, "null context");
+    c->stream = c->own;
     return 0;
 }
 void* tff_ctx_get_stream(tff_ctx* c) { return c ? (void*)c->stream : nullptr; }

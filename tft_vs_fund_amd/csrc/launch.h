@@ -5,16 +5,16 @@
 namespace tff {
 
 // dynamic LDS bytes of the pose kernels for N correspondences
-inline size_t pose_lds_bytes(int N, int flags) {
+inline size_t pose_lds_bytes(int N, int flags, bool jacobi) {
     size_t d = (size_t)((POSE_LDS_DOUBLES + 1) & ~1);
+    if (jacobi) d += (size_t)((JACOBI_LDS_DOUBLES + 1) & ~1);
     if (flags & FLAG_STAGE_LDS) d += 6 * (size_t)N;
     return d * sizeof(double);
 }
 // stage the correspondences in LDS when the whole workspace stays within the
-// default 64 KiB dynamic-LDS window (N <= ~1000); beyond that, points are
-// re-read through L2 instead.
-inline int pose_auto_flags(int N, int flags) {
-    if (pose_lds_bytes(N, flags | FLAG_STAGE_LDS) <= 64 * 1024) flags |= FLAG_STAGE_LDS;
+// default 64 KiB dynamic-LDS window; beyond that, points are re-read through L2.
+inline int pose_auto_flags(int N, int flags, bool jacobi) {
+    if (pose_lds_bytes(N, flags | FLAG_STAGE_LDS, jacobi) <= 64 * 1024) flags |= FLAG_STAGE_LDS;
     return flags;
 }
 inline unsigned pose_grid(long B) { return (unsigned)((B < (1L << 30)) ? (B > 0 ? B : 1) : (1L << 30)); }

@@ -13,20 +13,21 @@ namespace tff {
 constexpr int FLAG_RECONST = 1;       // also produce Reconst (3-view triangulation of every correspondence)
 constexpr int FLAG_JACOBI = 2;        // force the Jacobi eigen-solver for the Gram matrices
 constexpr int FLAG_STAGE_LDS = 4;     // correspondences are staged once in LDS (else re-read through L2)
+constexpr int FLAG_ONLY_RETRY = 8;    // fix-up pass: process only triplets whose status is ST_RETRY
 
 // ---- status codes (per triplet), mirroring the reference's failure modes --
 constexpr int ST_OK = 0;
 constexpr int ST_TOO_FEW = 1;         // N < 7 (TFT) / N < 8 (F): experiments.m:99, linearF.m:35
 constexpr int ST_NONFINITE = 2;       // NaN/Inf reached the outputs (Gauss_Helmert.m:53,63)
 constexpr int ST_NO_POSE = 3;         // no candidate with non-negative cheirality score (R_t_from_TFT.m:91-104)
+constexpr int ST_RETRY = 100;         // internal: inverse iteration did not converge; redone by the Jacobi fix-up pass
 
 constexpr int DBG_STRIDE = 128;       // doubles per triplet in the optional debug buffer
 
 // ---- per-wave LDS workspace ------------------------------------------------
 struct PoseLds {
-    double mom[96];        // 6 x 4 x 4 moment sums of the normalised correspondences
-    double G[27 * 27];     // Gram matrix A'A of the DLT system (full symmetric storage)
-    double L[27 * 27];     // Cholesky factor / Jacobi V / 15x15 and 9x9 sub-problems
+    double mom[96];        // 6 x 4 x 4 moment sums of the normalised correspondences: mom[16*h + 4*i3 + i2]
+    double Lp[378];        // packed lower Cholesky factor (27x27), reused for the 15x15 / 9x9 sub-problems
     double nrm[9];         // per view: s, ox, oy  (Normal_v = [s 0 ox; 0 s oy; 0 0 1])
     double t[27];          // tensor, vec order j + 3k + 9i  <->  T(j,k,i)   (linearTFT.m:67)
     double T1[27];         // tensor after de-normalisation (output T)
@@ -39,11 +40,18 @@ struct PoseLds {
     double Minv[18];
     double cand[2][21];    // per call: R (9, row-major), Rp (9), t (3)
     double P[4][12];       // candidate cameras K_v [R_c | t], row-major 3x4
+    double candRt[4][12];  // candidate poses [R_c | t], row-major 3x4 (same order as P)
     double Rt[2][12];      // chosen poses, row-major 3x4
     double Pfin[3][12];    // final cameras
     double pa[18];         // linearTFT's a (18) -> P2, P3 of the constrained solution
 };
+// extra workspace of the Jacobi kernel variant: full matrix + eigenvector matrix
+struct JacobiLds {
+    double A[27 * 27];
+    double V[27 * 27];
+};
 constexpr int POSE_LDS_DOUBLES = (int)(sizeof(PoseLds) / sizeof(double));
+constexpr int JACOBI_LDS_DOUBLES = (int)(sizeof(JacobiLds) / sizeof(double));
 
 __device__ __forceinline__ Mat3 load_K(const double* calm, int v) {
     Mat3 K;
@@ -122,7 +130,7 @@ __device__ __forceinline__ Mat3 normal_matrix(const double* nrm, int v) {
 // ones, lanes 0/1 then the null vector of each stacked 3x3.  epi[0..2] = e21,
 // epi[3..5] = e31.  fix_sign: multiply by sign of the own third component
 // (R_t_from_TFT.m:50,55).
-__device__ inline void epipoles_from_tensor(const double* t, double* nullv, double* epi, bool fix_sign) {
+__device__ __attribute__((noinline)) void epipoles_from_tensor(const double* t, double* nullv, double* epi, bool fix_sign) {
     const int lane = lane_id();
     if (lane < 6) {
         const int i = (lane < 3) ? lane : lane - 3;
@@ -155,28 +163,50 @@ __device__ inline void epipoles_from_tensor(const double* t, double* nullv, doub
 }
 
 // transform_TFT.m:42-49 with inverse = 1:  Tn(:,:,i) = inv(M2) (sum_j M1(j,i) To(:,:,j)) inv(M3).'
-// followed by the Frobenius normalisation.  to/tn are 27-vectors in LDS.
-__device__ inline void transform_tft_inverse(const double* to, double* tn, const Mat3& M1, const Mat3& M2, const Mat3& M3) {
+// followed by the Frobenius normalisation.  to/tn are 27-vectors in LDS; `mats`
+// is 27 doubles of LDS scratch (M1, inv(M2), inv(M3) row-major) so that the
+// lane-dependent indices address memory, not registers.
+template <class MatFn>
+__device__ inline void transform_tft_inverse(const double* to, double* tn, double* mats, MatFn matrix_of) {
     const int lane = lane_id();
-    const Mat3 M2i = mat3_inv(M2), M3i = mat3_inv(M3);
+    if (lane < 3) {
+        Mat3 M = matrix_of(lane);
+        if (lane > 0) M = mat3_inv(M);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) mats[9 * lane + 3 * r + c] = M.m[r][c];
+    }
+    wave_sync();
     double val = 0.0;
     if (lane < 27) {
         const int i = lane / 9, k = (lane % 9) / 3, j = lane % 3;           // entry T(j,k,i)
+        const double m0 = mats[i], m1 = mats[3 + i], m2 = mats[6 + i];       // M1(:,i)
+#pragma unroll
         for (int c = 0; c < 3; ++c)
+#pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const double mix = M1.m[0][i] * to[c + 3 * d] + M1.m[1][i] * to[c + 3 * d + 9] + M1.m[2][i] * to[c + 3 * d + 18];
-                val += M2i.m[j][c] * mix * M3i.m[k][d];
+                const double mix = m0 * to[c + 3 * d] + m1 * to[c + 3 * d + 9] + m2 * to[c + 3 * d + 18];
+                val += mats[9 + 3 * j + c] * mix * mats[18 + 3 * k + d];
             }
     }
     const double nn = wave_sum(val * val);
     wave_sync();
-    if (lane < 27) tn[lane] = val / sqrt(nn);
+    if (lane < 27) tn[lane] = val * rsqrt(nn);
     wave_sync();
+}
+
+// Wave-uniform operands of the per-correspondence loops (camera matrices, poses)
+// are read from LDS once per pass and pinned to scalar registers: three 3x4
+// cameras held in VGPRs would cost 72 registers and a wave per SIMD.
+__device__ __forceinline__ void load_uniform12(const double* p, double (&u)[12]) {
+#pragma unroll
+    for (int c = 0; c < 12; ++c) u[c] = wave_uniform(p[c]);
 }
 
 // 2-view / 3-view DLT triangulation of one correspondence (triangulation3D.m:51-63):
 // accumulate S = ls' * ls for the two rows [0 -1 y; 1 0 -x] * P of one view.
-__device__ __forceinline__ void tri_accum(double (&S)[4][4], const double* P, double x, double y) {
+__device__ __forceinline__ void tri_accum(double (&S)[4][4], const double (&P)[12], double x, double y) {
     double r0[4], r1[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) { r0[c] = y * P[8 + c] - P[4 + c]; r1[c] = P[c] - x * P[8 + c]; }
@@ -200,6 +230,75 @@ __device__ __forceinline__ void compose_camera(const Mat3& K, const double* R, c
         for (int c = 0; c < 3; ++c) P[4 * r + c] = K.m[r][0] * R[c] + K.m[r][1] * R[3 + c] + K.m[r][2] * R[6 + c];
         P[4 * r + 3] = K.m[r][0] * t[0] + K.m[r][1] * t[1] + K.m[r][2] * t[2];
     }
+}
+
+// P = K_v [R | t] from a row-major 3x4 pose held in LDS
+__device__ __forceinline__ void compose_camera_from_pose(const Mat3& K, const double* Rt, double* P) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) P[4 * r + c] = K.m[r][0] * Rt[c] + K.m[r][1] * Rt[4 + c] + K.m[r][2] * Rt[8 + c];
+}
+
+// One pass over the correspondences of the triplet, one lane per correspondence:
+// DLT triangulation (triangulation3D.m:51-63) from camera Pfin[0] = K1 [I|0], camera
+// `camB` and (mode TRI_RECONST) camera `aux`, then a mode-specific epilogue.
+// A single non-inlined copy serves the cheirality vote, the t3 scale and Reconst
+// (code size: see the instruction-cache note in wave_eig.h).
+//   TRI_VOTE    : aux = candidate pose [R|t] (row-major 3x4); returns sum_n sign(X1(3)) + sign(X2(3))
+//   TRI_SCALE   : aux = [K3*R3 | u3 = K3*t3]; num/den of R_t_from_TFT.m:72-73 -> w->pa[0..1]
+//   TRI_RECONST : aux = third camera; dehomogenised points -> `out` (3 x N column-major)
+constexpr int TRI_VOTE = 0, TRI_SCALE = 1, TRI_RECONST = 2;
+__device__ __attribute__((noinline)) int tri_pass(PoseLds* w, const double* pts, int N, int mode, int view, const double* camB,
+                                                   const double* aux, double* __restrict__ out) {
+    const int lane = lane_id();
+    double PA[12], PB[12], AX[12];
+    load_uniform12(w->Pfin[0], PA);
+    load_uniform12(camB, PB);
+    load_uniform12(aux, AX);
+    int score = 0;
+    double num = 0.0, den = 0.0;
+#pragma unroll 1
+    for (int i = lane; i < N; i += WAVE) {
+        const Pt6 p = load_pt(pts, i);
+        double S[4][4];
+        tri_zero(S);
+        tri_accum(S, PA, p.v[0], p.v[1]);
+        tri_accum(S, PB, (view == 1) ? p.v[2] : p.v[4], (view == 1) ? p.v[3] : p.v[5]);
+        if (mode == TRI_RECONST) tri_accum(S, AX, p.v[4], p.v[5]);
+        double X[4];
+        spd_min_eigvec<4>(S, X);
+        const double iw = 1.0 / X[3];
+        const double X0 = X[0] * iw, X1 = X[1] * iw, X2 = X[2] * iw;                 // X./X(4)
+        if (mode == TRI_VOTE) {
+            const double z2 = AX[8] * X0 + AX[9] * X1 + AX[10] * X2 + AX[11];         // [R t]*X1   (:99)
+            score += (int)sgn(X2) + (int)sgn(z2);                                      // :100
+        } else if (mode == TRI_SCALE) {
+            double X3[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) X3[r] = AX[4 * r] * X0 + AX[4 * r + 1] * X1 + AX[4 * r + 2] * X2;   // X3 = K3*R3*X  (:71)
+            const double u3[3] = {AX[3], AX[7], AX[11]};
+            const double p3[3] = {p.v[4], p.v[5], 1.0};
+            double c1[3], c2[3];
+            cross3(p3, X3, c1);
+            cross3(p3, u3, c2);
+            num += c1[0] * c2[0] + c1[1] * c2[1] + c1[2] * c2[2];
+            den += c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2];
+        } else {
+            out[3 * (long)i + 0] = X0;
+            out[3 * (long)i + 1] = X1;
+            out[3 * (long)i + 2] = X2;
+        }
+    }
+    if (mode == TRI_VOTE) return wave_sum_i(score);
+    if (mode == TRI_SCALE) {
+        num = wave_sum(num);
+        den = wave_sum(den);
+        wave_sync();
+        if (lane == 0) { w->pa[0] = num; w->pa[1] = den; }
+        wave_sync();
+    }
+    return 0;
 }
 
 // recover_R_t (R_t_from_TFT.m:82-106 == LinearFPoseEstimation.m:84-109):
@@ -240,6 +339,12 @@ __device__ inline int recover_poses(PoseLds* w, const double* Ein, const double*
         const int call = lane >> 1, cd = lane & 1;
         const Mat3 K = load_K(w->calm, call + 1);
         compose_camera(K, w->cand[call] + 9 * cd, w->cand[call] + 18, w->P[lane]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) w->candRt[lane][4 * r + c] = w->cand[call][9 * cd + 3 * r + c];
+            w->candRt[lane][4 * r + 3] = w->cand[call][18 + r];
+        }
     }
     if (lane == 4) {                                                         // P1 = K1 [I | 0]
         const Mat3 K1 = load_K(w->calm, 0);
@@ -247,28 +352,12 @@ __device__ inline int recover_poses(PoseLds* w, const double* Ein, const double*
         for (int r = 0; r < 3; ++r) { w->Pfin[0][4 * r] = K1.m[r][0]; w->Pfin[0][4 * r + 1] = K1.m[r][1]; w->Pfin[0][4 * r + 2] = K1.m[r][2]; w->Pfin[0][4 * r + 3] = 0.0; }
     }
     wave_sync();
+    phase_stamp(dbg, 10);
     int status = ST_OK;
+#pragma unroll 1
     for (int call = 0; call < 2; ++call) {
-        int sc[2] = {0, 0};
-        for (int i = lane; i < N; i += WAVE) {
-            const Pt6 p = load_pt(pts, i);
-            const double x2 = p.v[2 + 2 * call], y2 = p.v[3 + 2 * call];
-#pragma unroll
-            for (int cd = 0; cd < 2; ++cd) {
-                double S[4][4];
-                tri_zero(S);
-                tri_accum(S, w->Pfin[0], p.v[0], p.v[1]);
-                tri_accum(S, w->P[2 * call + cd], x2, y2);
-                double X[4];
-                spd_min_eigvec<4>(S, X);
-                const double* R = w->cand[call] + 9 * cd;
-                const double* t = w->cand[call] + 18;
-                const double X0 = X[0] / X[3], X1 = X[1] / X[3], X2 = X[2] / X[3];      // X1./X1(4)   (:98)
-                const double z2 = R[6] * X0 + R[7] * X1 + R[8] * X2 + t[2];              // [R t]*X1    (:99)
-                sc[cd] += (int)sgn(X2) + (int)sgn(z2);
-            }
-        }
-        const int sR = wave_sum_i(sc[0]), sRp = wave_sum_i(sc[1]);
+        const int sR = tri_pass(w, pts, N, TRI_VOTE, call + 1, w->P[2 * call], w->candRt[2 * call], nullptr);
+        const int sRp = tri_pass(w, pts, N, TRI_VOTE, call + 1, w->P[2 * call + 1], w->candRt[2 * call + 1], nullptr);
         // reference order: k=1 (R,t), k=2 (R,-t), k=3 (Rp,-t), k=4 (Rp,t)   (:92-104)
         const int score[4] = {sR, -sR, -sRp, sRp};
         int seen = 0, pick = -1;
@@ -290,44 +379,11 @@ __device__ inline int recover_poses(PoseLds* w, const double* Ein, const double*
 // t3 scale, R_t_from_TFT.m:68-74 == LinearFPoseEstimation.m:64-70.  Scales w->Rt[1](:,4) in place.
 __device__ inline void scale_t3(PoseLds* w, const double* pts, int N, double* dbg) {
     const int lane = lane_id();
-    if (lane == 0) {
-        const Mat3 K2 = load_K(w->calm, 1);
-        double R[9], t[3];
-        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R[3 * r + c] = w->Rt[0][4 * r + c]; t[r] = w->Rt[0][4 * r + 3]; }
-        compose_camera(K2, R, t, w->Pfin[1]);
-    }
+    if (lane < 2)                                                            // Pfin[1] = K2 [R2|t2];  Pfin[2] = [K3*R3 | u3 = K3*t3]   (:68,:71)
+        compose_camera_from_pose(load_K(w->calm, lane + 1), w->Rt[lane], w->Pfin[lane + 1]);
     wave_sync();
-    const Mat3 K3 = load_K(w->calm, 2);
-    double K3R3[9], u3[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) K3R3[3 * r + c] = K3.m[r][0] * w->Rt[1][c] + K3.m[r][1] * w->Rt[1][4 + c] + K3.m[r][2] * w->Rt[1][8 + c];
-        u3[r] = K3.m[r][0] * w->Rt[1][3] + K3.m[r][1] * w->Rt[1][7] + K3.m[r][2] * w->Rt[1][11];     // u3 = K3*t3  (:68)
-    }
-    double num = 0.0, den = 0.0;
-    for (int i = lane; i < N; i += WAVE) {
-        const Pt6 p = load_pt(pts, i);
-        double S[4][4];
-        tri_zero(S);
-        tri_accum(S, w->Pfin[0], p.v[0], p.v[1]);
-        tri_accum(S, w->Pfin[1], p.v[2], p.v[3]);
-        double X[4];
-        spd_min_eigvec<4>(S, X);
-        const double Xd[3] = {X[0] / X[3], X[1] / X[3], X[2] / X[3]};       // :70
-        double X3[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) X3[r] = K3R3[3 * r] * Xd[0] + K3R3[3 * r + 1] * Xd[1] + K3R3[3 * r + 2] * Xd[2];   // :71
-        const double p3[3] = {p.v[4], p.v[5], 1.0};
-        double c1[3], c2[3];
-        cross3(p3, X3, c1);
-        cross3(p3, u3, c2);
-        num += c1[0] * c2[0] + c1[1] * c2[1] + c1[2] * c2[2];
-        den += c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2];
-    }
-    num = wave_sum(num);
-    den = wave_sum(den);
-    const double lam = -num / den;                                           // :72-73
+    tri_pass(w, pts, N, TRI_SCALE, 1, w->Pfin[1], w->Pfin[2], nullptr);      // X from views 1,2 (:69-70)
+    const double lam = -w->pa[0] / w->pa[1];                                 // :72-73
     if (dbg && lane == 0) dbg[68] = lam;
     wave_sync();
     if (lane < 3) w->Rt[1][4 * lane + 3] *= lam;                             // :74
@@ -338,26 +394,9 @@ __device__ inline void scale_t3(PoseLds* w, const double* pts, int N, double* db
 // recovered poses, dehomogenised, written as 3 x N column-major.
 __device__ inline void final_reconst(PoseLds* w, const double* pts, int N, double* __restrict__ out) {
     const int lane = lane_id();
-    if (lane == 0) {
-        const Mat3 K3 = load_K(w->calm, 2);
-        double R[9], t[3];
-        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R[3 * r + c] = w->Rt[1][4 * r + c]; t[r] = w->Rt[1][4 * r + 3]; }
-        compose_camera(K3, R, t, w->Pfin[2]);
-    }
+    if (lane == 0) compose_camera_from_pose(load_K(w->calm, 2), w->Rt[1], w->Pfin[2]);
     wave_sync();
-    for (int i = lane; i < N; i += WAVE) {
-        const Pt6 p = load_pt(pts, i);
-        double S[4][4];
-        tri_zero(S);
-        tri_accum(S, w->Pfin[0], p.v[0], p.v[1]);
-        tri_accum(S, w->Pfin[1], p.v[2], p.v[3]);
-        tri_accum(S, w->Pfin[2], p.v[4], p.v[5]);
-        double X[4];
-        spd_min_eigvec<4>(S, X);
-        out[3 * (long)i + 0] = X[0] / X[3];
-        out[3 * (long)i + 1] = X[1] / X[3];
-        out[3 * (long)i + 2] = X[2] / X[3];
-    }
+    tri_pass(w, pts, N, TRI_RECONST, 1, w->Pfin[1], w->Pfin[2], out);
 }
 
 // write the chosen poses (row-major in LDS) as MATLAB column-major 3x4 arrays

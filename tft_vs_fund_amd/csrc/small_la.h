@@ -98,6 +98,7 @@ __device__ __forceinline__ int spd_min_eigvec(const double (&S)[n][n], double (&
     for (int i = 0; i < n; ++i) x[i] = x0;
     double rprev2 = 1.0;
     int it = 0;
+#pragma unroll 1
     for (; it < maxit;) {
         double y[n];
         // forward L y = x
@@ -162,6 +163,7 @@ __device__ __forceinline__ void jacobi3(double (&A)[3][3], double (&V)[3][3]) {
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+#pragma unroll 1
     for (int sweep = 0; sweep < 24; ++sweep) {
         const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
         const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];

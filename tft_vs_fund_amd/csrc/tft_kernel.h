@@ -14,15 +14,26 @@
 //     G = A'A = sum_n (h1 h1') (x) (C3'C3) (x) (C2'C2)
 // has only 6 x 4 x 4 = 96 distinct entries: products of the monomials
 //   p1 = {x1^2, x1 y1, x1, y1^2, y1, 1},  q3 = {1, x3, y3, x3^2+y3^2},  q2 likewise.
-// The wave accumulates those 96 sums (one correspondence per lane, halving
-// butterfly across lanes), expands them to the 27x27 G in LDS, and takes the
-// eigenvector of the smallest eigenvalue (== V(:,end) of svd(A), :64-67).
+// With M_h the 4x4 moment block of p1-monomial h, every quadratic form of G is a
+// 4x4 bilinear form:  (u (x) a3 (x) a2)' G (v (x) b3 (x) b2)
+//     = sum_{i,i'} u_i v_i'  c3' M_{h(i,i')} c2,
+//   c2 = (a2_0 b2_0 + a2_1 b2_1, -(a2_0 b2_2 + a2_2 b2_0), -(a2_1 b2_2 + a2_2 b2_1), a2_2 b2_2), c3 likewise.
+// The wave accumulates the 96 sums (one correspondence per lane, halving
+// butterfly across lanes); lane r then builds row r of G in registers and the
+// wave takes the eigenvector of the smallest eigenvalue (== V(:,end) of
+// svd(A), :64-67) with wave_min_eigvec_reg<27>.  G itself never exists in memory.
 //
 // Constrained re-solve (:82-91): range(E) = { T : Q2' T_i Q3 has a zero lower
 // right 2x2 block }, with Q2 = [e21 | complement], Q3 = [e31 | complement]
 // orthonormal.  An orthonormal basis Up of range(E) is therefore 15 columns of
-// I3 (x) Q3 (x) Q2; (A Up)'(A Up) = Up' G Up is a 15x15 matrix assembled from G,
-// no second pass over the data.  rank(E) = 15 always (e21, e31 are unit vectors).
+// I3 (x) Q3 (x) Q2; (A Up)'(A Up) = Up' G Up is a 15x15 matrix whose entries are
+// again 4x4 bilinear forms of the moments -- no second pass over the data.
+// rank(E) = 15 always (e21, e31 are unit vectors).
+//
+// Two instantiations: k_linear_tft_pose<false> (Cholesky inverse iteration; a
+// triplet whose iteration does not converge is marked ST_RETRY) and
+// k_linear_tft_pose<true> (Jacobi sweeps in LDS; run as a fix-up pass over the
+// ST_RETRY triplets, or for the whole batch with TFF_OPT_SOLVER = 1).
 #pragma once
 #include "pose_common.h"
 
@@ -40,20 +51,27 @@ struct LinearTftArgs {
     double* T;               // B x 27
     double* reconst;         // B x 3N or null
     int* iter;               // B or null
-    int* status;             // B or null
+    int* status;             // B (never null inside the library: the context supplies one)
     double* dbg;             // B x DBG_STRIDE or null
 };
 
-// sign and q-monomial index of entry (j,j') of C'C,  C = [1 0 -x; 0 1 -y]
-__device__ __forceinline__ void ctc_entry(int j, int jp, int& sign, int& idx) {
-    const int a = (j < jp) ? j : jp, b = (j < jp) ? jp : j;
-    if (b < 2) { sign = (a == b) ? 1 : 0; idx = 0; }
-    else if (a < 2) { sign = -1; idx = 1 + a; }
-    else { sign = 1; idx = 3; }
+// c-vector of a pair of 3-vectors (see header): bilinear weights of the q-monomials
+__device__ __forceinline__ void cvec(const double* a, const double* b, double (&c)[4]) {
+    c[0] = a[0] * b[0] + a[1] * b[1];
+    c[1] = -(a[0] * b[2] + a[2] * b[0]);
+    c[2] = -(a[1] * b[2] + a[2] * b[1]);
+    c[3] = a[2] * b[2];
 }
 __device__ __forceinline__ int hht_index(int i, int ip) {          // index into p1 of entry (i,i') of h1 h1'
     const int a = (i < ip) ? i : ip, b = (i < ip) ? ip : i;
     return (a == 0) ? b : ((a == 1) ? 2 + b : 5);
+}
+__device__ __forceinline__ double bilinear44(const double* M, const double (&c3)[4], const double (&c2)[4]) {
+    double acc = 0.0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        acc += c3[p] * (M[4 * p] * c2[0] + M[4 * p + 1] * c2[1] + M[4 * p + 2] * c2[2] + M[4 * p + 3] * c2[3]);
+    return acc;
 }
 
 // 96 moment sums -> w->mom.  Three passes of 32 accumulators per lane.
@@ -62,6 +80,7 @@ __device__ inline void accumulate_moments(PoseLds* w, const double* pts, int N) 
     const double s1 = w->nrm[0], ox1 = w->nrm[1], oy1 = w->nrm[2];
     const double s2 = w->nrm[3], ox2 = w->nrm[4], oy2 = w->nrm[5];
     const double s3 = w->nrm[6], ox3 = w->nrm[7], oy3 = w->nrm[8];
+#pragma unroll 1
     for (int pass = 0; pass < 3; ++pass) {
         double acc[32];
 #pragma unroll
@@ -74,10 +93,8 @@ __device__ inline void accumulate_moments(PoseLds* w, const double* pts, int N) 
             const double x3 = s3 * p.v[4] + ox3, y3 = s3 * p.v[5] + oy3;
             const double q2[4] = {1.0, x2, y2, x2 * x2 + y2 * y2};
             const double q3[4] = {1.0, x3, y3, x3 * x3 + y3 * y3};
-            double pa, pb;
-            if (pass == 0) { pa = x1 * x1; pb = x1 * y1; }
-            else if (pass == 1) { pa = x1; pb = y1 * y1; }
-            else { pa = y1; pb = 1.0; }
+            const double pa = (pass == 0) ? x1 * x1 : ((pass == 1) ? x1 : y1);
+            const double pb = (pass == 0) ? x1 * y1 : ((pass == 1) ? y1 * y1 : 1.0);
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -93,21 +110,32 @@ __device__ inline void accumulate_moments(PoseLds* w, const double* pts, int N) 
     wave_sync();
 }
 
-// expand the moments into the full 27x27 Gram matrix (ld 27)
-__device__ inline void build_gram27(PoseLds* w) {
-    const int lane = lane_id();
-    for (int e = lane; e < 729; e += WAVE) {
-        const int r = e / 27, c = e % 27;
-        const int i = r / 9, k = (r % 9) / 3, j = r % 3;
-        const int ip = c / 9, kp = (c % 9) / 3, jp = c % 3;
-        int sg2, i2, sg3, i3;
-        ctc_entry(j, jp, sg2, i2);
-        ctc_entry(k, kp, sg3, i3);
-        const int sg = sg2 * sg3;
-        const double m = w->mom[16 * hht_index(i, ip) + 4 * i3 + i2];
-        w->G[e] = (sg == 0) ? 0.0 : ((sg > 0) ? m : -m);
+// sign and q-monomial index of entry (j,j') of C'C,  C = [1 0 -x; 0 1 -y]:
+// C'C = [1 0 -x; 0 1 -y; -x -y x^2+y^2]  <->  q-indices [0 . 1; . 0 2; 1 2 3]
+__device__ __forceinline__ void ctc_entry(int j, int jp, double& sign, int& idx) {
+    const int a = (j < jp) ? j : jp, b = (j < jp) ? jp : j;
+    if (b < 2) { sign = (a == b) ? 1.0 : 0.0; idx = 0; }
+    else if (a < 2) { sign = -1.0; idx = 1 + a; }
+    else { sign = 1.0; idx = 3; }
+}
+// Row r = (j,k,i) of G: entry (j',k',i') = s2(j,j') s3(k,k') mom[h(i,i')][i3(k,k')][i2(j,j')].
+__device__ __forceinline__ void gram_row27(const double* mom, int r, double (&g)[27], double& diag) {
+    const int i = r / 9, k = (r % 9) / 3, j = r % 3;
+    double s2[3], s3[3];
+    int i2[3], i3[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { ctc_entry(j, q, s2[q], i2[q]); ctc_entry(k, q, s3[q], i3[q]); }
+#pragma unroll
+    for (int ip = 0; ip < 3; ++ip) {
+        const double* M = mom + 16 * hht_index(i, ip);
+#pragma unroll
+        for (int kp = 0; kp < 3; ++kp)
+#pragma unroll
+            for (int jp = 0; jp < 3; ++jp) g[jp + 3 * kp + 9 * ip] = s2[jp] * s3[kp] * M[4 * i3[kp] + i2[jp]];
     }
-    wave_sync();
+    diag = 0.0;
+#pragma unroll
+    for (int c = 0; c < 27; ++c) diag = (c == r) ? g[c] : diag;
 }
 
 // orthonormal frame [e | q | q'] of a unit vector e, row-major Q[3*r + c]
@@ -117,79 +145,93 @@ __device__ __forceinline__ void frame_of(const double* e, double* Q) {
     if (a0 <= a1 && a0 <= a2) ax[0] = 1.0; else if (a1 <= a2) ax[1] = 1.0; else ax[2] = 1.0;
     double q1[3], q2[3];
     cross3(e, ax, q1);
-    const double n1 = 1.0 / sqrt(q1[0] * q1[0] + q1[1] * q1[1] + q1[2] * q1[2]);
+    const double n1 = rsqrt(q1[0] * q1[0] + q1[1] * q1[1] + q1[2] * q1[2]);
     q1[0] *= n1; q1[1] *= n1; q1[2] *= n1;
     cross3(e, q1, q2);
-    const double n2 = 1.0 / sqrt(q2[0] * q2[0] + q2[1] * q2[1] + q2[2] * q2[2]);
+    const double n2 = rsqrt(q2[0] * q2[0] + q2[1] * q2[1] + q2[2] * q2[2]);
 #pragma unroll
     for (int r = 0; r < 3; ++r) { Q[3 * r] = e[r]; Q[3 * r + 1] = q1[r]; Q[3 * r + 2] = q2[r] * n2; }
 }
 
-// eigenvector of the smallest eigenvalue of the n x n matrix at Gm (ld n),
-// workspace Lw (n*n); Gm is destroyed when the Jacobi path runs.
-__device__ inline double solve_min_eigvec(double* Gm, double* Lw, int n, int flags, int* its) {
-    int it = 0;
-    double r2 = 0.0, x;
-    bool need_jacobi = (flags & FLAG_JACOBI) != 0;
-    if (!need_jacobi) {
-        x = wave_min_eigvec(Gm, Lw, n, n, 60, &it, &r2);
-        need_jacobi = !(r2 < 1e-20);          // inverse iteration stalled (tiny spectral gap) or NaN
-    }
-    if (need_jacobi) {
-        int sw = 0;
-        x = wave_jacobi_min_eigvec(Gm, Lw, n, n, &sw);
-        it = 1000 + sw;
-    }
-    *its = it;
-    return x;
+// column a = (i, m) of Up: the 3-vectors (Q2 column jj, Q3 column kk), (jj,kk) = m<3 ? (0,m) : (m-2,0)
+__device__ __forceinline__ void up_factors(const double* Q, int m, double (&a2)[3], double (&a3)[3]) {
+    const int jj = (m < 3) ? 0 : m - 2, kk = (m < 3) ? m : 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { a2[q] = Q[3 * q + jj]; a3[q] = Q[9 + 3 * q + kk]; }
 }
 
 // linearTFT.m:33-91 on the normalised correspondences.  Leaves the constrained
 // tensor in w->t, the epipoles in w->epi and (if want_P) linearTFT's `a`
 // (P2 = [reshape(a(1:9),3,3) e21], P3 = [reshape(a(10:18),3,3) e31]) in w->pa.
-__device__ inline void linear_tft_wave(PoseLds* w, const double* pts, int N, int flags, bool want_P, double* dbg) {
+// Returns false when an eigen-solve did not converge (JAC = false only).
+template <bool JAC>
+__device__ inline bool linear_tft_wave(PoseLds* w, JacobiLds* jw, const double* pts, int N, bool want_P, double* dbg) {
     const int lane = lane_id();
     accumulate_moments(w, pts, N);
-    build_gram27(w);
+    phase_stamp(dbg, 2);
     int it1 = 0, it2 = 0;
-    {
-        const double x = solve_min_eigvec(w->G, w->L, 27, flags, &it1);      // :64-67
+    bool ok = true;
+    {                                                                        // :64-67
+        double g[27], diag, x;
+        gram_row27(w->mom, (lane < 27) ? lane : 0, g, diag);
+        phase_stamp(dbg, 3);
+        if (JAC) {
+            if (lane < 27) for (int c = 0; c < 27; ++c) jw->A[lane * 27 + c] = g[c];
+            wave_sync();
+            x = wave_jacobi_min_eigvec(jw->A, jw->V, 27, 27, &it1);
+            it1 += 1000;
+        } else {
+            double r2;
+            x = wave_min_eigvec_reg<27>(g, diag, w->Lp, 50, &it1, &r2);
+            ok = ok && eig_converged(r2);
+        }
         if (lane < 27) w->t[lane] = x;
         wave_sync();
-        if (it1 >= 1000) build_gram27(w);                                    // Jacobi consumed G
     }
     if (dbg && lane < 27) dbg[lane] = w->t[lane];
+    phase_stamp(dbg, 4);
     epipoles_from_tensor(w->t, w->nullv, w->epi, false);                     // :71-79
+    phase_stamp(dbg, 5);
     if (dbg && lane < 6) dbg[27 + lane] = w->epi[lane];
     if (lane == 0) frame_of(w->epi, w->Q);                                   // Q2 from e21
     if (lane == 1) frame_of(w->epi + 3, w->Q + 9);                           // Q3 from e31
     wave_sync();
-    // Gp = Up' G Up (15x15) at L[0..225); column a = (i, m): (jj,kk) = m<3 ? (0,m) : (m-2,0)
-    double* Gp = w->L;
-    double* Lp = w->L + 225;
-    for (int e = lane; e < 225; e += WAVE) {
-        const int a = e / 15, b = e % 15;
-        const int ia = a / 5, ma = a % 5, ib = b / 5, mb = b % 5;
-        const int jja = (ma < 3) ? 0 : ma - 2, kka = (ma < 3) ? ma : 0;
-        const int jjb = (mb < 3) ? 0 : mb - 2, kkb = (mb < 3) ? mb : 0;
-        double acc = 0.0;
-        for (int k = 0; k < 3; ++k)
-            for (int j = 0; j < 3; ++j) {
-                const double wa = w->Q[3 * j + jja] * w->Q[9 + 3 * k + kka];
-                const double* grow = w->G + (j + 3 * k + 9 * ia) * 27 + 9 * ib;
-                double inner = 0.0;
-                for (int kp = 0; kp < 3; ++kp)
-                    for (int jp = 0; jp < 3; ++jp) inner += grow[jp + 3 * kp] * (w->Q[3 * jp + jjb] * w->Q[9 + 3 * kp + kkb]);
-                acc += wa * inner;
-            }
-        Gp[e] = acc;
+    // Gp = Up' G Up (15x15), lower triangle, packed into Lp; entry (a,b), a = 5 i + m
+    double* Gp = w->Lp;
+    for (int e = lane; e < 120; e += WAVE) {
+        int a = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        while (tri_index(a + 1, 0) <= e) ++a;
+        while (tri_index(a, 0) > e) --a;
+        const int b = e - tri_index(a, 0);
+        double a2[3], a3[3], b2[3], b3[3], c2[4], c3[4];
+        up_factors(w->Q, a % 5, a2, a3);
+        up_factors(w->Q, b % 5, b2, b3);
+        cvec(a2, b2, c2);
+        cvec(a3, b3, c3);
+        Gp[e] = bilinear44(w->mom + 16 * hht_index(a / 5, b / 5), c3, c2);
     }
     wave_sync();
-    {
-        const double x = solve_min_eigvec(Gp, Lp, 15, flags, &it2);          // :84
+    phase_stamp(dbg, 6);
+    {                                                                        // :84
+        double g[15], diag = 0.0, x;
+        const int r = (lane < 15) ? lane : 0;
+#pragma unroll
+        for (int c = 0; c < 15; ++c) { g[c] = (c <= r) ? Gp[tri_index(r, c)] : 0.0; diag = (c == r) ? g[c] : diag; }
+        wave_sync();
+        if (JAC) {
+            if (lane < 15) for (int c = 0; c < 15; ++c) { if (c <= lane) { jw->A[lane * 15 + c] = g[c]; jw->A[c * 15 + lane] = g[c]; } }
+            wave_sync();
+            x = wave_jacobi_min_eigvec(jw->A, jw->V, 15, 15, &it2);
+            it2 += 1000;
+        } else {
+            double r2;
+            x = wave_min_eigvec_reg<15>(g, diag, w->Lp, 50, &it2, &r2);
+            ok = ok && eig_converged(r2);
+        }
         if (lane < 15) w->tp[lane] = x;
         wave_sync();
     }
+    phase_stamp(dbg, 7);
     if (lane < 27) {                                                         // t = Up * tp   (:85)
         const int i = lane / 9, k = (lane % 9) / 3, j = lane % 3;
         double acc = 0.0;
@@ -221,21 +263,24 @@ __device__ inline void linear_tft_wave(PoseLds* w, const double* pts, int N, int
         for (int j = 0; j < 3; ++j) { w->pa[3 * i + j] = ai[j] + c * e21[j]; w->pa[9 + 3 * i + j] = bi[j] + c * e31[j]; }
     }
     wave_sync();
+    return ok;
 }
 
 // R_t_from_TFT.m:40-76 on the de-normalised tensor w->T1.
 __device__ inline int rt_from_tft_wave(PoseLds* w, const double* pts, int N, double* dbg) {
     const int lane = lane_id();
-    const Mat3 K1 = load_K(w->calm, 0), K2 = load_K(w->calm, 1), K3 = load_K(w->calm, 2);
-    transform_tft_inverse(w->T1, w->T2, K1, K2, K3);                        // :44
+    transform_tft_inverse(w->T1, w->T2, w->Lp, [w](int v) { return load_K(w->calm, v); });   // :44
     epipoles_from_tensor(w->T2, w->nullv, w->epi, true);                     // :47-55
     double* Ein = w->Minv;                                                   // 18 doubles of scratch
     if (lane < 2) {
         const double* e21 = w->epi; const double* e31 = w->epi + 3;
         Mat3 M;                                                              // [T1*e T2*e T3*e]
+#pragma unroll
         for (int i = 0; i < 3; ++i)
+#pragma unroll
             for (int r = 0; r < 3; ++r) {
                 double acc = 0.0;
+#pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     // lane 0: (T_i e31)(r) = sum_k T(r,k,i) e31(k); lane 1: (T_i' e21)(r) = sum_j T(j,r,i) e21(j)
                     acc += (lane == 0) ? w->T2[r + 3 * q + 9 * i] * e31[q] : w->T2[q + 3 * r + 9 * i] * e21[q];
@@ -244,6 +289,7 @@ __device__ inline int rt_from_tft_wave(PoseLds* w, const double* pts, int N, dou
             }
         const double* e = (lane == 0) ? e21 : e31;
         const double sg = (lane == 0) ? 1.0 : -1.0;                          // E31 = -crossM(epi31)*[...]  (:58)
+#pragma unroll
         for (int c = 0; c < 3; ++c) {
             Ein[9 * lane + 0 + c] = sg * (-e[2] * M.m[1][c] + e[1] * M.m[2][c]);
             Ein[9 * lane + 3 + c] = sg * (e[2] * M.m[0][c] - e[0] * M.m[2][c]);
@@ -251,27 +297,35 @@ __device__ inline int rt_from_tft_wave(PoseLds* w, const double* pts, int N, dou
         }
     }
     wave_sync();
+    phase_stamp(dbg, 9);
     const int st = recover_poses(w, Ein, pts, N, dbg);                       // :61,:64
+    phase_stamp(dbg, 11);
     scale_t3(w, pts, N, dbg);                                                // :68-74
+    phase_stamp(dbg, 12);
     return st;
 }
 
-__global__ void __launch_bounds__(64) k_linear_tft_pose(const LinearTftArgs a) {
+template <bool JAC>
+__global__ void __launch_bounds__(64, 2) k_linear_tft_pose(const LinearTftArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
     PoseLds* w = reinterpret_cast<PoseLds*>(smem);
+    constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
+    JacobiLds* jw = JAC ? reinterpret_cast<JacobiLds*>(smem + base) : nullptr;
+    double* lds_pts = smem + base + (JAC ? ((JACOBI_LDS_DOUBLES + 1) & ~1) : 0);
     const int lane = lane_id();
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
+        if ((a.flags & FLAG_ONLY_RETRY) && a.status[b] != ST_RETRY) continue;      // wave-uniform
         const int N = a.N;
         double* dbg = a.dbg ? a.dbg + b * DBG_STRIDE : nullptr;
         const double* src = a.corresp + b * 6 * (long)N;
         const double* pts = src;
+        wave_sync();
         if (a.flags & FLAG_STAGE_LDS) {
-            double* lp = smem + ((POSE_LDS_DOUBLES + 1) & ~1);
-            wave_sync();
-            stage_points(src, lp, N);
-            pts = lp;
+            stage_points(src, lds_pts, N);
+            pts = lds_pts;
         }
         if (lane < 27) w->calm[lane] = a.calm[b * a.calm_stride + lane];
+        phase_stamp(dbg, 0);
         int status = ST_OK;
         if (N < 7) {                                                         // experiments.m:99
             status = ST_TOO_FEW;
@@ -282,22 +336,28 @@ __global__ void __launch_bounds__(64) k_linear_tft_pose(const LinearTftArgs a) {
         } else {
             normalise3(pts, N, w->nrm);                                      // LinearTFTPoseEstimation.m:45-47
             if (dbg && lane < 9) dbg[71 + lane] = w->nrm[lane];
-            linear_tft_wave(w, pts, N, a.flags, false, dbg);                 // :50
-            transform_tft_inverse(w->t, w->T1, normal_matrix(w->nrm, 0), normal_matrix(w->nrm, 1), normal_matrix(w->nrm, 2));   // :53
-            status = rt_from_tft_wave(w, pts, N, dbg);                       // :56
-            write_poses(w, a.Rt2 + b * 12, a.Rt3 + b * 12);
-            if (lane < 27) a.T[b * 27 + lane] = w->T1[lane];
-            if (a.reconst) final_reconst(w, pts, N, a.reconst + b * 3 * (long)N);   // :59-60
-            // non-finite outputs -> status 2
-            double chk = (lane < 12) ? w->Rt[0][lane] : ((lane < 24) ? w->Rt[1][lane - 12] : ((lane < 51) ? w->T1[lane - 24] : 0.0));
-            const bool bad = !(fabs(chk) <= 1.79e308);
-            if (wave_any(bad) && status == ST_OK) status = ST_NONFINITE;
+            phase_stamp(dbg, 1);
+            const bool ok = linear_tft_wave<JAC>(w, jw, pts, N, false, dbg);  // :50
+            phase_stamp(dbg, 8);
+            if (!ok) {
+                status = ST_RETRY;                                           // redone by k_linear_tft_pose<true>
+            } else {
+                transform_tft_inverse(w->t, w->T1, w->Lp, [w](int v) { return normal_matrix(w->nrm, v); });   // :53
+                status = rt_from_tft_wave(w, pts, N, dbg);                   // :56
+                write_poses(w, a.Rt2 + b * 12, a.Rt3 + b * 12);
+                if (lane < 27) a.T[b * 27 + lane] = w->T1[lane];
+                if (a.reconst) final_reconst(w, pts, N, a.reconst + b * 3 * (long)N);   // :59-60
+                phase_stamp(dbg, 13);
+                // non-finite outputs -> status 2
+                double chk = (lane < 12) ? w->Rt[0][lane] : ((lane < 24) ? w->Rt[1][lane - 12] : ((lane < 51) ? w->T1[lane - 24] : 0.0));
+                const bool bad = !(fabs(chk) <= 1.79e308);
+                if (wave_any(bad) && status == ST_OK) status = ST_NONFINITE;
+            }
         }
         if (lane == 0) {
             if (a.iter) a.iter[b] = 0;                                       // :62
-            if (a.status) a.status[b] = status;
+            a.status[b] = status;
         }
-        wave_sync();
     }
 }
 

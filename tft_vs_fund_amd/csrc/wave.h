@@ -37,6 +37,7 @@ __device__ inline double wave_bcast(double v, int src) {
 }
 __device__ inline int wave_shfl_xor_i(int v, int mask) { return (int)emu::exchange((uint64_t)(uint32_t)v, lane_id() ^ mask); }
 __device__ inline int wave_bcast_i(int v, int src) { return (int)emu::exchange((uint64_t)(uint32_t)v, src); }
+__device__ inline double wave_uniform(double v) { return v; }
 #else
 #define TFF_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 // Lanes of one wavefront exchange data through LDS without a workgroup
@@ -57,15 +58,56 @@ __device__ __forceinline__ double wave_bcast(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int wave_bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+// v holds the same value in every lane: move it to scalar registers (v_readfirstlane) so
+// that it costs SGPRs, not VGPRs, while it stays live across a per-lane loop.
+__device__ __forceinline__ double wave_uniform(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return __hiloint2double(hi, lo);
+}
 #endif
 
-// Butterfly reductions: every lane ends with the same value, summed in a
-// fixed order, so results are bit-reproducible run to run.
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
+// Coarse phase stamps for the *_debug_dev entry points (shader clock, lane 0):
+// dbg[80 + slot].  A null dbg (every production entry point) skips them.
+__device__ __forceinline__ void phase_stamp(double* dbg, int slot) {
+#ifndef TFF_CPU_EMU
+    if (dbg) {
+        const long long t = clock64();
+        if (lane_id() == 0) dbg[80 + slot] = (double)t;
+    }
+#else
+    (void)dbg; (void)slot;
+#endif
+}
+
+// Reductions: every lane ends with the same value, summed in a fixed order, so
+// results are bit-reproducible run to run.
+#ifdef TFF_CPU_EMU
+__device__ inline double wave_sum(double v) {
     for (int m = 32; m >= 1; m >>= 1) v += wave_shfl_xor(v, m);
     return v;
 }
+#else
+// DPP row operations + two cross-row steps (v_readlane): ~20 VALU instructions
+// and no LDS crossbar round trips (the ds_bpermute butterfly costs ~40
+// instructions and six dependent LDS latencies).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);     // bound_ctrl: out-of-row sources read 0
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_mov<0x111>(v);            // row_shr:1
+    v += dpp_mov<0x112>(v);            // row_shr:2
+    v += dpp_mov<0x114>(v);            // row_shr:4
+    v += dpp_mov<0x118>(v);            // row_shr:8   -> lane 15 of every row of 16 holds the row sum
+    const double r0 = wave_bcast(v, 15), r1 = wave_bcast(v, 31), r2 = wave_bcast(v, 47), r3 = wave_bcast(v, 63);
+    return (r0 + r1) + (r2 + r3);
+}
+#endif
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { double o = wave_shfl_xor(v, m); v = (o > v) ? o : v; }

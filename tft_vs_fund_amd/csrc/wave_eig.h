@@ -1,72 +1,93 @@
-// Wavefront-cooperative symmetric eigen-solvers on matrices held in LDS
-// (n <= 32: one lane per row).  Used for the 27x27 and 15x15 Gram matrices of
-// linearTFT (linearTFT.m:64-67 and :84, where the reference runs a full
-// svd(A) of the 4N x 27 / 4N x 15 design matrix and keeps V(:,end)) and the
-// 9x9 Gram matrix of linearF (linearF.m:54-55).
+// Wavefront-cooperative symmetric eigen-solvers (n <= 32: one lane per row).
+// Used for the 27x27 and 15x15 Gram matrices of linearTFT (linearTFT.m:64-67
+// and :84, where the reference runs a full svd(A) of the 4N x 27 / 4N x 15
+// design matrix and keeps V(:,end)) and the 9x9 Gram matrix of linearF
+// (linearF.m:54-55).
 //
-//   wave_min_eigvec : Cholesky of G + delta*I, then inverse iteration until the
-//                     iterate stops moving.  Cost ~ n^3/6 + iters * 2 n^2 flops
-//                     per wave; typical iters = 4..6 (sigma_27/sigma_26 ~ 0.02).
-//   wave_jacobi_min_eigvec : cyclic Jacobi sweeps (all rotations, rows and
-//                     columns updated by the 64 lanes through LDS); the
-//                     gap-independent fallback when inverse iteration has not
-//                     converged, and selectable for every solve with
-//                     TFF_SOLVER_JACOBI for cross-checking.
+//   wave_min_eigvec_reg<n> : lane r owns row r of the matrix IN REGISTERS.
+//       Right-looking Cholesky of G + delta*I with v_readlane broadcasts of the
+//       pivot column: no LDS traffic and no memory latency in the dependency
+//       chain.  Fully unrolled (compile-time register indices): the kernels are
+//       VALU-issue-bound (a lone wave retires ~1 fp64 instruction per 8 cycles),
+//       so executed instruction count is what matters -- a rolled variant with a
+//       sliding register window was 6 KB instead of 25 KB of code but executed
+//       twice the instructions and ran 1.5x slower.  The factor is stored once
+//       to LDS in packed form; inverse iteration then reads the lane's own row
+//       (forward solve) and own column (backward solve) back into registers.
+//       Typical 4..6 iterations (sigma_27/sigma_26 ~ 0.02).
+//   wave_jacobi_min_eigvec : cyclic two-sided Jacobi on a full n x n matrix and
+//       its eigenvector matrix in LDS -- the gap-independent solver.  Lives in
+//       the LDS-heavy kernel variant only (fix-up pass for triplets whose
+//       inverse iteration did not converge, and TFF_OPT_SOLVER = 1).
 #pragma once
 #include "wave.h"
 
 namespace tff {
 
-// G, L: n x n row-major with leading dimension ld in LDS.  G is read only.
-// On return lane r (< n) holds component r of the unit eigenvector (0 on the
-// other lanes); *iters gets the iteration count, *resid2 the last squared step.
-__device__ inline double wave_min_eigvec(const double* G, double* L, const int n, const int ld,
-                                         const int maxit, int* iters, double* resid2) {
+__device__ __forceinline__ int tri_index(int r, int c) { return (r * (r + 1)) / 2 + c; }   // packed lower, c <= r
+
+// g[c] = G[lane][c] for c <= lane (entries c > lane are ignored), diag = G[lane][lane].
+// Lp: n(n+1)/2 doubles of LDS.  On return lane r (< n) holds component r of the
+// unit eigenvector of the smallest eigenvalue; *iters = iterations used,
+// *resid2 = last squared step (convergence when < ~1e-20).
+template <int n>
+__device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, double* Lp, const int maxit,
+                                             int* iters, double* resid2) {
     const int lane = lane_id();
-    const double tr = wave_sum(lane < n ? G[lane * ld + lane] : 0.0);
+    const double tr = wave_sum(lane < n ? diag : 0.0);
     const double delta = 1e-14 * tr;
     const double pfloor = 1e-3 * delta + 1e-300;
-    const int lr = lane & 7, lc = lane >> 3;
-    // L <- lower(G) + delta I
-    for (int r = lr; r < n; r += 8)
-        for (int c = lc; c <= r; c += 8) L[r * ld + c] = G[r * ld + c] + ((r == c) ? delta : 0.0);
-    wave_sync();
-    double myinv = 0.0;   // 1/L[lane][lane]
+#pragma unroll
+    for (int c = 0; c < n; ++c) g[c] += (c == lane) ? delta : 0.0;
+    double myinv = 0.0;                                     // 1 / L[lane][lane]
+#pragma unroll
     for (int k = 0; k < n; ++k) {
-        double d = L[k * ld + k];
+        double d = wave_bcast(g[k], k);                     // pivot (lane k's diagonal, fully updated)
         d = (d > pfloor) ? d : pfloor;
-        const double rs = 1.0 / sqrt(d);
-        wave_sync();                                        // everyone has read the pivot before lane k overwrites it
-        if (lane >= k && lane < n) {
-            const double v = (lane == k) ? d * rs : L[lane * ld + k] * rs;
-            L[lane * ld + k] = v;
-            if (lane == k) myinv = rs;
+        const double rs = rsqrt(d);
+        g[k] = (lane == k) ? d * rs : g[k] * rs;            // column k of L (rows >= k meaningful)
+        myinv = (lane == k) ? rs : myinv;
+#pragma unroll
+        for (int c = k + 1; c < n; ++c) {
+            const double lck = wave_bcast(g[k], c);         // L[c][k]
+            g[c] -= g[k] * lck;                             // L[r][c] -= L[r][k] L[c][k]   (meaningful for r >= c)
         }
-        wave_sync();
-        for (int r = k + 1 + lr; r < n; r += 8) {
-            const double lrk = L[r * ld + k];
-            for (int c = k + 1 + lc; c <= r; c += 8) L[r * ld + c] -= lrk * L[c * ld + k];
-        }
-        wave_sync();
     }
-    double x = (lane < n) ? 1.0 / sqrt((double)n) : 0.0;
+    wave_sync();
+#pragma unroll
+    for (int c = 0; c < n; ++c)
+        if (c <= lane && lane < n) Lp[tri_index(lane, c)] = g[c];
+    wave_sync();
+    double x = (lane < n) ? rsqrt((double)n) : 0.0;
     double rprev2 = 1.0, r2 = 1.0;
     int it = 0;
+#pragma unroll 1
     while (it < maxit) {
         double y = x;
-        for (int j = 0; j < n; ++j) {                       // forward  L y = x
-            const double yj = wave_bcast(y * myinv, j);
-            if (lane == j) y = yj;
-            else if (lane > j && lane < n) y -= L[lane * ld + j] * yj;
+        {
+            double row[n];                                  // L[lane][j], j < lane
+#pragma unroll
+            for (int j = 0; j < n; ++j) row[j] = (j < lane && lane < n) ? Lp[tri_index(lane, j)] : 0.0;
+#pragma unroll
+            for (int j = 0; j < n; ++j) {                   // forward  L y = x
+                const double yj = wave_bcast(y * myinv, j);
+                y = (lane == j) ? yj : y - row[j] * yj;     // row[j] = 0 for lanes <= j: finished entries stay
+            }
         }
-        for (int j = n - 1; j >= 0; --j) {                  // backward L' z = y
-            const double zj = wave_bcast(y * myinv, j);
-            if (lane == j) y = zj;
-            else if (lane < j) y -= L[j * ld + lane] * zj;
+        {
+            double col[n];                                  // L[j][lane], j > lane
+#pragma unroll
+            for (int j = 0; j < n; ++j) col[j] = (j > lane) ? Lp[tri_index(j, lane)] : 0.0;
+#pragma unroll
+            for (int j = n - 1; j >= 0; --j) {              // backward L' z = y
+                const double zj = wave_bcast(y * myinv, j);
+                y = (lane == j) ? zj : y - col[j] * zj;
+            }
         }
+        if (lane >= n) y = 0.0;
         const double nn = wave_sum(y * y);
         const double dot = wave_sum(y * x);
-        const double rn = 1.0 / sqrt(nn);
+        const double rn = rsqrt(nn);
         const double yn = y * ((dot < 0.0) ? -rn : rn);
         const double dd = yn - x;
         r2 = wave_sum(dd * dd);
@@ -80,6 +101,7 @@ __device__ inline double wave_min_eigvec(const double* G, double* L, const int n
     *resid2 = r2;
     return x;
 }
+__device__ __forceinline__ bool eig_converged(double resid2) { return resid2 < 1e-20; }
 
 // Cyclic Jacobi on A (n x n, ld, symmetric, full storage, DESTROYED) with
 // eigenvectors accumulated in V (n x n, ld); returns, per lane r < n,
@@ -98,7 +120,7 @@ __device__ inline double wave_jacobi_min_eigvec(double* A, double* V, const int 
         for (int p = 0; p < n - 1; ++p) {
             for (int q = p + 1; q < n; ++q) {
                 const double apq = A[p * ld + q], app = A[p * ld + p], aqq = A[q * ld + q];
-                // relative threshold (de Rijk): keeps small eigenvalues accurate
+                // relative threshold (de Rijk): keeps small eigenvalues accurate,
                 // plus an absolute floor so rounding noise under a zero eigenvalue is not chased
                 if (!(fabs(apq) > 1.1e-16 * sqrt(fabs(app * aqq)) && fabs(apq) > absfloor)) continue;   // wave-uniform
                 ++rotations;
@@ -126,8 +148,7 @@ __device__ inline double wave_jacobi_min_eigvec(double* A, double* V, const int 
         if (rotations == 0) break;
     }
     *sweeps_out = sweep;
-    // index of the smallest diagonal entry (wave-uniform scan, n <= 32)
-    int best = 0;
+    int best = 0;                                             // smallest diagonal entry (wave-uniform scan)
     double bv = A[0];
     for (int k = 1; k < n; ++k) { const double d = A[k * ld + k]; if (d < bv) { bv = d; best = k; } }
     double x = (lane < n) ? V[lane * ld + best] : 0.0;
