@@ -27,7 +27,7 @@ constexpr int DBG_STRIDE = 128;       // doubles per triplet in the optional deb
 // ---- per-wave LDS workspace ------------------------------------------------
 struct PoseLds {
     double mom[96];        // 6 x 4 x 4 moment sums of the normalised correspondences: mom[16*h + 4*i3 + i2]
-    double Lp[378];        // packed lower Cholesky factor (27x27), reused for the 15x15 / 9x9 sub-problems
+    double Lp[729];        // Cholesky factor workspace (27x27 square), reused for the 15x15 / 9x9 sub-problems and as scratch
     double nrm[9];         // per view: s, ox, oy  (Normal_v = [s 0 ox; 0 s oy; 0 0 1])
     double t[27];          // tensor, vec order j + 3k + 9i  <->  T(j,k,i)   (linearTFT.m:67)
     double T1[27];         // tensor after de-normalisation (output T)

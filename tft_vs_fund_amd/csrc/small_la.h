@@ -82,7 +82,7 @@ __device__ __forceinline__ int spd_min_eigvec(const double (&S)[n][n], double (&
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
         d = (d > pfloor) ? d : pfloor;
-        const double rs = 1.0 / sqrt(d);
+        const double rs = rsqrt(d);
         L[j][j] = d * rs;
         inv[j] = rs;
 #pragma unroll
@@ -93,7 +93,7 @@ __device__ __forceinline__ int spd_min_eigvec(const double (&S)[n][n], double (&
             L[i][j] = s * rs;
         }
     }
-    const double x0 = 1.0 / sqrt((double)n);
+    const double x0 = (n == 4) ? 0.5 : 0.57735026918962576;
 #pragma unroll
     for (int i = 0; i < n; ++i) x[i] = x0;
     double rprev2 = 1.0;
@@ -120,7 +120,7 @@ __device__ __forceinline__ int spd_min_eigvec(const double (&S)[n][n], double (&
         double nn = 0.0, dot = 0.0;
 #pragma unroll
         for (int i = 0; i < n; ++i) { nn += y[i] * y[i]; dot += y[i] * x[i]; }
-        const double rn = 1.0 / sqrt(nn);
+        const double rn = rsqrt(nn);
         const double sg = (dot < 0.0) ? -rn : rn;
         double r2 = 0.0;
 #pragma unroll
@@ -144,7 +144,7 @@ __device__ __forceinline__ void jacobi3_rotate(double (&A)[3][3], double (&V)[3]
     const double app = A[p][p], aqq = A[q][q];
     const double tau = (aqq - app) / (2.0 * apq);
     const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-    const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+    const double c = rsqrt(1.0 + t * t), s = t * c;
     A[p][p] = app - t * apq;
     A[q][q] = aqq + t * apq;
     A[p][q] = A[q][p] = 0.0;
@@ -207,13 +207,13 @@ __device__ __forceinline__ void svd3(const Mat3& E, Mat3& U, Mat3& V, double (&s
         u1[k] = E.m[k][0] * V.m[0][0] + E.m[k][1] * V.m[1][0] + E.m[k][2] * V.m[2][0];
         u2[k] = E.m[k][0] * V.m[0][1] + E.m[k][1] * V.m[1][1] + E.m[k][2] * V.m[2][1];
     }
-    double n1 = 1.0 / sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+    double n1 = rsqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) u1[k] *= n1;
     const double d12 = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) u2[k] -= d12 * u1[k];
-    double n2 = 1.0 / sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+    double n2 = rsqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) u2[k] *= n2;
     cross3(u1, u2, u3);

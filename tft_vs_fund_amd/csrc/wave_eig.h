@@ -27,7 +27,7 @@ namespace tff {
 __device__ __forceinline__ int tri_index(int r, int c) { return (r * (r + 1)) / 2 + c; }   // packed lower, c <= r
 
 // g[c] = G[lane][c] for c <= lane (entries c > lane are ignored), diag = G[lane][lane].
-// Lp: n(n+1)/2 doubles of LDS.  On return lane r (< n) holds component r of the
+// Lp: n*n doubles of LDS.  On return lane r (< n) holds component r of the
 // unit eigenvector of the smallest eigenvalue; *iters = iterations used,
 // *resid2 = last squared step (convergence when < ~1e-20).
 template <int n>
@@ -53,11 +53,16 @@ __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, 
             g[c] -= g[k] * lck;                             // L[r][c] -= L[r][k] L[c][k]   (meaningful for r >= c)
         }
     }
+    // Store L as a full n x n square (row-major, ld = n) with zeros above the diagonal and
+    // L_jj - 1 ON the diagonal: the solves below then need neither masked loads nor a
+    // per-step select, because on the pivot lane  y - (L_jj - 1) * (y / L_jj) = y / L_jj.
     wave_sync();
+    if (lane < n) {
 #pragma unroll
-    for (int c = 0; c < n; ++c)
-        if (c <= lane && lane < n) Lp[tri_index(lane, c)] = g[c];
+        for (int c = 0; c < n; ++c) Lp[lane * n + c] = (c < lane) ? g[c] : ((c == lane) ? g[c] - 1.0 : 0.0);
+    }
     wave_sync();
+    const int rl = (lane < n) ? lane : 0;
     double x = (lane < n) ? rsqrt((double)n) : 0.0;
     double rprev2 = 1.0, r2 = 1.0;
     int it = 0;
@@ -65,23 +70,23 @@ __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, 
     while (it < maxit) {
         double y = x;
         {
-            double row[n];                                  // L[lane][j], j < lane
+            double row[n];                                  // L[lane][j] (0 for j > lane)
 #pragma unroll
-            for (int j = 0; j < n; ++j) row[j] = (j < lane && lane < n) ? Lp[tri_index(lane, j)] : 0.0;
+            for (int j = 0; j < n; ++j) row[j] = Lp[rl * n + j];
 #pragma unroll
             for (int j = 0; j < n; ++j) {                   // forward  L y = x
                 const double yj = wave_bcast(y * myinv, j);
-                y = (lane == j) ? yj : y - row[j] * yj;     // row[j] = 0 for lanes <= j: finished entries stay
+                y -= row[j] * yj;
             }
         }
         {
-            double col[n];                                  // L[j][lane], j > lane
+            double col[n];                                  // L[j][lane] (0 for j < lane)
 #pragma unroll
-            for (int j = 0; j < n; ++j) col[j] = (j > lane) ? Lp[tri_index(j, lane)] : 0.0;
+            for (int j = 0; j < n; ++j) col[j] = Lp[j * n + rl];
 #pragma unroll
             for (int j = n - 1; j >= 0; --j) {              // backward L' z = y
                 const double zj = wave_bcast(y * myinv, j);
-                y = (lane == j) ? zj : y - col[j] * zj;
+                y -= col[j] * zj;
             }
         }
         if (lane >= n) y = 0.0;
