@@ -85,6 +85,16 @@ int tff_linear_tft_pose_batch_debug_dev(tff_ctx* ctx, const double* corresp, con
                                         int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
                                         int32_t* iter, int32_t* status, double* dbg);
 
+/* LinearFPoseEstimation (F_methods/LinearFPoseEstimation.m:42-109): Normalize2Ddata x3 ->
+ * linearF x2 (F_methods/linearF.m:32-62) -> recover_R_t x2 -> t3 scale -> (Reconst) ->
+ * T = TFT_from_P (TFT_methods/TFT_from_P.m:25-33).  Needs N >= 8 (status TFF_ST_TOO_FEW otherwise). */
+int tff_linear_f_pose_batch_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                                int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                int32_t* iter, int32_t* status);
+int tff_linear_f_pose_batch_host(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                                 int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                 int32_t* iter, int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

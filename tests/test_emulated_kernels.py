@@ -28,13 +28,13 @@ def _p(a):
     return ctypes.c_void_p(a.ctypes.data) if a is not None else None
 
 
-def run_linear_tft(lib, C, CalM, flags=0, reconst=True):
+def run_linear_tft(lib, C, CalM, flags=0, reconst=True, entry="emu_linear_tft_pose"):
     B, N, _ = C.shape
     calm = calm_colmajor(CalM)
     Rt2 = np.zeros((B, 12)); Rt3 = np.zeros((B, 12)); T = np.zeros((B, 27))
     Rec = np.zeros((B, N, 3)) if reconst else None
     it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32); dbg = np.zeros((B, 128))
-    lib.emu_linear_tft_pose(_p(C), _p(calm), ctypes.c_long(0), ctypes.c_long(B), ctypes.c_int(N), ctypes.c_int(flags),
+    getattr(lib, entry)(_p(C), _p(calm), ctypes.c_long(0), ctypes.c_long(B), ctypes.c_int(N), ctypes.c_int(flags),
                             _p(Rt2), _p(Rt3), _p(T), _p(Rec), _p(it), _p(st), _p(dbg))
     return dict(R_t_2=Rt2.reshape(B, 4, 3).transpose(0, 2, 1), R_t_3=Rt3.reshape(B, 4, 3).transpose(0, 2, 1),
                 T=T.reshape(B, 3, 3, 3).transpose(0, 3, 2, 1), Reconst=None if Rec is None else Rec.transpose(0, 2, 1),
@@ -60,4 +60,24 @@ def test_linear_tft_kernel_matches_oracle(emu, N, sigma, flags):
 def test_too_few_points_sets_status(emu):
     C, CalM, _, _ = generate_scene_batch(1, 6, noise=1.0, seed=1)
     out = run_linear_tft(emu, C, CalM)
+    assert out["status"][0] == 1 and np.all(np.isnan(out["T"][0]))
+
+
+@pytest.mark.parametrize("N,sigma,flags", [(8, 1.0, 0), (12, 1.0, 0), (70, 0.0, 0), (130, 1.0, 0), (12, 1.0, FLAG_JACOBI)])
+def test_linear_f_kernel_matches_oracle(emu, N, sigma, flags):
+    B = 2
+    C, CalM, Rt0, _ = generate_scene_batch(B, N, noise=sigma, seed=200 + N)
+    out = run_linear_tft(emu, C, CalM, flags, entry="emu_linear_f_pose")
+    assert np.all(out["status"] == 0) and np.all(out["iter"] == 0)
+    for b in range(B):
+        R2, R3, Rec, T, _ = O.LinearFPoseEstimation(C[b].T.copy(), CalM)
+        tol = 1e-9 if N >= 12 else 1e-6
+        assert rel_err_T(out["T"][b], T) < tol
+        assert rel_err(out["R_t_2"][b], R2) < tol and rel_err(out["R_t_3"][b], R3) < tol
+        assert rel_err(out["Reconst"][b], Rec) < tol
+
+
+def test_linear_f_needs_8_points(emu):
+    C, CalM, _, _ = generate_scene_batch(1, 7, noise=1.0, seed=1)
+    out = run_linear_tft(emu, C, CalM, entry="emu_linear_f_pose")
     assert out["status"][0] == 1 and np.all(np.isnan(out["T"][0]))

@@ -184,3 +184,92 @@ def test_full_size_properties(gpu_ctx):
         assert max(rel_err_T(jT[b], T[b]) for b in range(512)) < 1e-9
     finally:
         gpu_ctx.set_solver("invit")
+
+
+# ---------------------------------------------------------------------------
+# LinearFPoseEstimation (F_methods/LinearFPoseEstimation.m, linearF.m, TFT_from_P.m)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("solver", ["invit", "jacobi"])
+def test_linear_f_golden_synthetic(gpu_ctx, golden_dir, solver):
+    g = np.load(os.path.join(golden_dir, "synthetic_linear.npz"))
+    gpu_ctx.set_solver(solver)
+    try:
+        for ci, pre in golden_cases(g):
+            C, CalM = g[pre + "Corresp"], g[pre + "CalM"]
+            out = gpu_ctx.pose_batch("LinearFPoseEstimation", C, CalM, reconst=True)
+            if C.shape[1] < 8:
+                assert np.all(out["status"] == 1)                       # linearF.m:35-37
+                continue
+            assert np.all(out["status"] == 0) and np.all(out["iter"] == 0)
+            tol = TOL if C.shape[1] >= 12 else TOL_MINIMAL
+            for b in range(C.shape[0]):
+                assert rel_err_T(out["T"][b], g[pre + "f_T"][b]) < tol, (ci, b)
+                assert rel_err(out["R_t_2"][b], g[pre + "f_Rt2"][b]) < tol, (ci, b)
+                assert rel_err(out["R_t_3"][b], g[pre + "f_Rt3"][b]) < tol, (ci, b)
+                assert rel_err(out["Reconst"][b], g[pre + "f_Rec"][b]) < tol, (ci, b)
+    finally:
+        gpu_ctx.set_solver("invit")
+
+
+def test_linear_f_golden_epfl(gpu_ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "epfl.npz"))
+    for n in range(int(g["count"])):
+        pre = "t%d_" % n
+        Cs = g[pre + "sample"]
+        out = gpu_ctx.pose_batch("LinearFPoseEstimation", np.ascontiguousarray(Cs.T)[None], g[pre + "CalM"], reconst=True)
+        assert out["status"][0] == 0
+        assert rel_err_T(out["T"][0], g[pre + "f_T"]) < TOL
+        assert rel_err(out["R_t_2"][0], g[pre + "f_Rt2"]) < TOL
+        assert rel_err(out["R_t_3"][0], g[pre + "f_Rt3"]) < TOL
+        assert rel_err(out["Reconst"][0], g[pre + "f_Rec"]) < 1e-8
+
+
+@pytest.mark.parametrize("N,sigma,seed", [(8, 1.0, 1), (9, 2.0, 2), (64, 1.0, 4), (65, 1.0, 5), (200, 1.0, 6), (257, 0.0, 7), (1500, 1.0, 9)])
+def test_linear_f_vs_oracle_seeded(gpu_ctx, N, sigma, seed):
+    from tft_vs_fund_amd import api
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    O = _oracle()
+    B = 5
+    C, CalM, Rt0, _ = generate_scene_batch(B, N, noise=sigma, seed=seed)
+    out = gpu_ctx.pose_batch("LinearFPoseEstimation", C, CalM, reconst=True)
+    assert np.all(out["status"] == 0)
+    tol = TOL if N >= 12 else TOL_MINIMAL
+    for b in range(B):
+        R2, R3, Rec, T, _ = O.LinearFPoseEstimation(C[b].T.copy(), CalM)
+        assert rel_err_T(out["T"][b], T) < tol
+        assert rel_err(out["R_t_2"][b], R2) < tol and rel_err(out["R_t_3"][b], R3) < tol
+        assert rel_err(out["Reconst"][b], Rec) < tol
+    if N == 9:
+        R2, R3, Rec, T, it = api.LinearFPoseEstimation(C[0].T.copy(), CalM)      # reference-shaped call
+        o2, _, _, oT, _ = O.LinearFPoseEstimation(C[0].T.copy(), CalM)
+        assert rel_err(R2, o2) < tol and rel_err_T(T, oT) < tol and it == 0
+        with pytest.raises(ValueError):
+            api.LinearFPoseEstimation(C[0].T[:, :7].copy(), CalM)               # linearF.m:35-37
+
+
+def test_linear_f_full_size_properties(gpu_ctx):
+    """configs[2] second half: the same 10k x 200 batch through LinearFPoseEstimation."""
+    import torch
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    B, N = 10000, 200
+    C, CalM, Rt0, _ = generate_scene_batch(B, N, noise=1.0, seed=4321)
+    d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
+    out = gpu_ctx.pose_batch("LinearFPoseEstimation", d, calm, reconst=False)
+    torch.cuda.synchronize()
+    assert int((out["status"] != 0).sum()) == 0
+    T = out["T"].cpu().numpy(); R2 = out["R_t_2"].cpu().numpy(); R3 = out["R_t_3"].cpu().numpy()
+    assert np.allclose(np.sqrt((T.reshape(B, -1) ** 2).sum(1)), 1.0, atol=1e-12)          # TFT_from_P.m:33
+    for R in (R2[:, :, :3], R3[:, :, :3]):
+        assert np.abs(np.einsum("bij,bkj->bik", R, R) - np.eye(3)).max() < 1e-9
+        assert np.abs(np.linalg.det(R) - 1).max() < 1e-9
+    assert np.abs(np.linalg.norm(R2[:, :, 3], axis=1) - 1).max() < 1e-12
+    cosr = (np.einsum("ij,bij->b", Rt0[1][:, :3], R3[:, :, :3]) - 1) / 2
+    assert np.degrees(np.arccos(np.clip(cosr, -1, 1))).max() < 3.0
+    # T is exactly the trifocal tensor of the returned cameras: its trilinearities vanish on reprojected points
+    O = _oracle()
+    K = CalM[0:3]
+    for b in (0, 17, 9999):
+        Tref = O.TFT_from_P(K @ np.eye(3, 4), K @ R2[b], K @ R3[b])
+        assert rel_err_T(T[b], Tref) < 1e-9
+    h = gpu_ctx.pose_batch("LinearFPoseEstimation", C[:64], CalM, reconst=False)
+    assert np.array_equal(h["T"], T[:64])

@@ -86,6 +86,7 @@ def load_library(path=None):
 # reference method name -> C entry point stem
 POSE_METHODS = {
     "LinearTFTPoseEstimation": "tff_linear_tft_pose_batch",
+    "LinearFPoseEstimation": "tff_linear_f_pose_batch",
 }
 
 # every symbol include/tftfund.h declares (checked by the CPU test-suite)
@@ -93,6 +94,7 @@ EXPORTED_SYMBOLS = [
     "tff_version", "tff_last_error", "tff_ctx_create", "tff_ctx_destroy", "tff_ctx_set_stream",
     "tff_ctx_use_own_stream", "tff_ctx_get_stream", "tff_ctx_set_option", "tff_ctx_synchronize",
     "tff_linear_tft_pose_batch_dev", "tff_linear_tft_pose_batch_host", "tff_linear_tft_pose_batch_debug_dev",
+    "tff_linear_f_pose_batch_dev", "tff_linear_f_pose_batch_host",
 ]
 
 
@@ -247,3 +249,8 @@ def _single(method, Corresp, CalM, nargout=5):
 def LinearTFTPoseEstimation(Corresp, CalM):
     """Drop-in for TFT_methods/LinearTFTPoseEstimation.m (same inputs/outputs)."""
     return _single("LinearTFTPoseEstimation", Corresp, CalM)
+
+
+def LinearFPoseEstimation(Corresp, CalM):
+    """Drop-in for F_methods/LinearFPoseEstimation.m (same inputs/outputs; needs N >= 8)."""
+    return _single("LinearFPoseEstimation", Corresp, CalM)

@@ -79,8 +79,9 @@ int check_common(const tff_ctx* c, const void* corresp, const void* calm, int64_
 // Two launches on the context's stream: the inverse-iteration kernel for the whole
 // batch, then the Jacobi kernel over the (rare) triplets it marked ST_RETRY.
 // With TFF_OPT_SOLVER = 1 only the Jacobi kernel runs, for every triplet.
-int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
-                      double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+template <class KMain, class KJac>
+int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     if (B == 0) return 0;
     if (!Rt2 || !Rt3 || !T) return fail(TFF_E_INVALID, "null output pointer");
@@ -95,17 +96,66 @@ int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int
         tff::LinearTftArgs m = a;
         m.flags = staged_flags(c, N, a.flags, false);
         const size_t lds = tff::pose_lds_bytes(N, m.flags, false);
-        if (int r = ensure_lds(tff::k_linear_tft_pose<false>, lds)) return r;
-        hipLaunchKernelGGL(tff::k_linear_tft_pose<false>, dim3(tff::pose_grid(B)), dim3(64), lds, c->stream, m);
+        if (int r = ensure_lds(kmain, lds)) return r;
+        hipLaunchKernelGGL(kmain, dim3(tff::pose_grid(B)), dim3(64), lds, c->stream, m);
         TFF_HIP(hipGetLastError());
         a.flags |= tff::FLAG_ONLY_RETRY;
     }
     a.flags = staged_flags(c, N, a.flags, true);
     const size_t lds = tff::pose_lds_bytes(N, a.flags, true);
-    if (int r = ensure_lds(tff::k_linear_tft_pose<true>, lds)) return r;
+    if (int r = ensure_lds(kjac, lds)) return r;
     const unsigned grid = (c->solver == 0) ? (unsigned)(B < 1024 ? B : 1024) : tff::pose_grid(B);
-    hipLaunchKernelGGL(tff::k_linear_tft_pose<true>, dim3(grid), dim3(64), lds, c->stream, a);
+    hipLaunchKernelGGL(kjac, dim3(grid), dim3(64), lds, c->stream, a);
     TFF_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
+                      double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+    return launch_pose(c, tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
+                       reconst, iter, status, dbg);
+}
+int launch_linear_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
+                    double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+    return launch_pose(c, tff::k_linear_f_pose<false>, tff::k_linear_f_pose<true>, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
+                       reconst, iter, status, dbg);
+}
+
+typedef int (*pose_launcher)(tff_ctx*, const double*, const double*, int64_t, int64_t, int32_t, double*, double*, double*, double*,
+                             int32_t*, int32_t*, double*);
+
+// host-pointer variant of any pose method: H2D, launch, D2H, synchronise
+int pose_batch_host(pose_launcher launch, tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                    int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status) {
+    if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
+    if (B == 0) return 0;
+    if (!Rt2 || !Rt3 || !T) return fail(TFF_E_INVALID, "null output pointer");
+    TFF_HIP(hipSetDevice(c->device));
+    const size_t nin = (size_t)B * 6 * (size_t)N * sizeof(double);
+    const size_t ncal = (calm_stride ? (size_t)B : 1) * 27 * sizeof(double);
+    const size_t per_out = (12 + 12 + 27 + (reconst ? 3 * (size_t)N : 0)) * sizeof(double);
+    if (int r = c->in.reserve(nin ? nin : 8)) return r;
+    if (int r = c->calm.reserve(ncal)) return r;
+    if (int r = c->out.reserve((size_t)B * per_out)) return r;
+    if (int r = c->idx.reserve((size_t)B * 2 * sizeof(int32_t))) return r;
+    double* d_in = (double*)c->in.p;
+    double* d_cal = (double*)c->calm.p;
+    double* d_Rt2 = (double*)c->out.p;
+    double* d_Rt3 = d_Rt2 + (size_t)B * 12;
+    double* d_T = d_Rt3 + (size_t)B * 12;
+    double* d_rec = reconst ? d_T + (size_t)B * 27 : nullptr;
+    int32_t* d_it = (int32_t*)c->idx.p;
+    int32_t* d_st = d_it + B;
+    if (nin) TFF_HIP(hipMemcpyAsync(d_in, corresp, nin, hipMemcpyHostToDevice, c->stream));
+    TFF_HIP(hipMemcpyAsync(d_cal, calm, ncal, hipMemcpyHostToDevice, c->stream));
+    if (int r = launch(c, d_in, d_cal, calm_stride, B, N, d_Rt2, d_Rt3, d_T, d_rec, d_it, d_st, nullptr)) return r;
+    TFF_HIP(hipMemcpyAsync(Rt2, d_Rt2, (size_t)B * 12 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TFF_HIP(hipMemcpyAsync(Rt3, d_Rt3, (size_t)B * 12 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TFF_HIP(hipMemcpyAsync(T, d_T, (size_t)B * 27 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (reconst && N) TFF_HIP(hipMemcpyAsync(reconst, d_rec, (size_t)B * 3 * (size_t)N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (iter) TFF_HIP(hipMemcpyAsync(iter, d_it, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (status) TFF_HIP(hipMemcpyAsync(status, d_st, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    TFF_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -185,36 +235,18 @@ int tff_linear_tft_pose_batch_debug_dev(tff_ctx* c, const double* corresp, const
 int tff_linear_tft_pose_batch_host(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
                                    int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
                                    int32_t* status) {
-    if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
-    if (B == 0) return 0;
-    if (!Rt2 || !Rt3 || !T) return fail(TFF_E_INVALID, "null output pointer");
-    TFF_HIP(hipSetDevice(c->device));
-    const size_t nin = (size_t)B * 6 * (size_t)N * sizeof(double);
-    const size_t ncal = (calm_stride ? (size_t)B : 1) * 27 * sizeof(double);
-    const size_t per_out = (12 + 12 + 27 + (reconst ? 3 * (size_t)N : 0)) * sizeof(double);
-    if (int r = c->in.reserve(nin ? nin : 8)) return r;
-    if (int r = c->calm.reserve(ncal)) return r;
-    if (int r = c->out.reserve((size_t)B * per_out)) return r;
-    if (int r = c->idx.reserve((size_t)B * 2 * sizeof(int32_t))) return r;
-    double* d_in = (double*)c->in.p;
-    double* d_cal = (double*)c->calm.p;
-    double* d_Rt2 = (double*)c->out.p;
-    double* d_Rt3 = d_Rt2 + (size_t)B * 12;
-    double* d_T = d_Rt3 + (size_t)B * 12;
-    double* d_rec = reconst ? d_T + (size_t)B * 27 : nullptr;
-    int32_t* d_it = (int32_t*)c->idx.p;
-    int32_t* d_st = d_it + B;
-    if (nin) TFF_HIP(hipMemcpyAsync(d_in, corresp, nin, hipMemcpyHostToDevice, c->stream));
-    TFF_HIP(hipMemcpyAsync(d_cal, calm, ncal, hipMemcpyHostToDevice, c->stream));
-    if (int r = launch_linear_tft(c, d_in, d_cal, calm_stride, B, N, d_Rt2, d_Rt3, d_T, d_rec, d_it, d_st, nullptr)) return r;
-    TFF_HIP(hipMemcpyAsync(Rt2, d_Rt2, (size_t)B * 12 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    TFF_HIP(hipMemcpyAsync(Rt3, d_Rt3, (size_t)B * 12 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    TFF_HIP(hipMemcpyAsync(T, d_T, (size_t)B * 27 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (reconst && N) TFF_HIP(hipMemcpyAsync(reconst, d_rec, (size_t)B * 3 * (size_t)N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (iter) TFF_HIP(hipMemcpyAsync(iter, d_it, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (status) TFF_HIP(hipMemcpyAsync(status, d_st, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    TFF_HIP(hipStreamSynchronize(c->stream));
-    return 0;
+    return pose_batch_host(launch_linear_tft, c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status);
+}
+
+int tff_linear_f_pose_batch_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                                int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                                int32_t* status) {
+    return launch_linear_f(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, nullptr);
+}
+int tff_linear_f_pose_batch_host(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                                 int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                                 int32_t* status) {
+    return pose_batch_host(launch_linear_f, c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status);
 }
 
 }  // extern "C"

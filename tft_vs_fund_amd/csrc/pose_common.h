@@ -44,6 +44,8 @@ struct PoseLds {
     double Rt[2][12];      // chosen poses, row-major 3x4
     double Pfin[3][12];    // final cameras
     double pa[18];         // linearTFT's a (18) -> P2, P3 of the constrained solution
+    double nrm2[9];        // linearF's inner normalisation (of the already normalised points)
+    double Fm[18];         // F21, F31 (row-major)
 };
 // extra workspace of the Jacobi kernel variant: full matrix + eigenvector matrix
 struct JacobiLds {
@@ -84,11 +86,21 @@ __device__ inline void stage_points(const double* __restrict__ src, double* dst,
 }
 
 // Normalize2Ddata.m:33-39 for the three views at once.  nrm[3v..3v+2] = s, ox, oy.
-__device__ inline void normalise3(const double* pts, int N, double* nrm) {
+// `pre` (9 doubles or null) is an affine map applied to the raw points first
+// (x' = s x + ox): linearF normalises points that LinearFPoseEstimation has
+// already normalised (linearF.m:45-46 after LinearFPoseEstimation.m:46-48).
+__device__ __forceinline__ Pt6 premap(Pt6 p, const double* pre) {
+    if (pre) {
+#pragma unroll
+        for (int v = 0; v < 3; ++v) { p.v[2 * v] = pre[3 * v] * p.v[2 * v] + pre[3 * v + 1]; p.v[2 * v + 1] = pre[3 * v] * p.v[2 * v + 1] + pre[3 * v + 2]; }
+    }
+    return p;
+}
+__device__ inline void normalise3(const double* pts, int N, double* nrm, const double* pre = nullptr) {
     const int lane = lane_id();
     double s[6] = {0, 0, 0, 0, 0, 0};
     for (int i = lane; i < N; i += WAVE) {
-        const Pt6 p = load_pt(pts, i);
+        const Pt6 p = premap(load_pt(pts, i), pre);
 #pragma unroll
         for (int k = 0; k < 6; ++k) s[k] += p.v[k];
     }
@@ -97,7 +109,7 @@ __device__ inline void normalise3(const double* pts, int N, double* nrm) {
     for (int k = 0; k < 6; ++k) c[k] = wave_sum(s[k]) / (double)N;       // points0 = mean(points,2)
     double d[3] = {0, 0, 0};
     for (int i = lane; i < N; i += WAVE) {
-        const Pt6 p = load_pt(pts, i);
+        const Pt6 p = premap(load_pt(pts, i), pre);
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
             const double dx = p.v[2 * v] - c[2 * v], dy = p.v[2 * v + 1] - c[2 * v + 1];
