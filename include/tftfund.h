@@ -48,6 +48,7 @@ typedef struct tff_ctx tff_ctx;
 #define TFF_ST_TOO_FEW 1    /* N < 7 (TFT) or N < 8 (F): experiments.m:99, linearF.m:35-37 */
 #define TFF_ST_NONFINITE 2  /* NaN/Inf in the result: Gauss_Helmert.m:53-55,63-65 */
 #define TFF_ST_NO_POSE 3    /* no candidate with score >= 0: R_f unassigned in R_t_from_TFT.m:91-104 */
+#define TFF_ST_RANK 4       /* Gauss-Helmert: KKT system numerically rank deficient (pinv would truncate, Gauss_Helmert.m:67) */
 
 /* error codes (besides -hipError_t) */
 #define TFF_E_INVALID (-10001)
@@ -84,6 +85,19 @@ int tff_linear_tft_pose_batch_host(tff_ctx* ctx, const double* corresp, const do
 int tff_linear_tft_pose_batch_debug_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
                                         int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
                                         int32_t* iter, int32_t* status, double* dbg);
+
+/* ResslTFTPoseEstimation (TFT_methods/ResslTFTPoseEstimation.m:47-177): linearTFT, Ressl's 20-parameter /
+ * 2-constraint minimal parameterisation, Gauss-Helmert refinement (Optimization/Gauss_Helmert.m:38-83),
+ * then transform_TFT -> R_t_from_TFT -> (Reconst).  iter = Gauss-Helmert iterations.  N <= ~900. */
+int tff_ressl_tft_pose_batch_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                                 int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                 int32_t* iter, int32_t* status);
+int tff_ressl_tft_pose_batch_host(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                                  int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                  int32_t* iter, int32_t* status);
+int tff_ressl_tft_pose_batch_debug_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                                       int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                       int32_t* iter, int32_t* status, double* dbg);
 
 /* LinearFPoseEstimation (F_methods/LinearFPoseEstimation.m:42-109): Normalize2Ddata x3 ->
  * linearF x2 (F_methods/linearF.m:32-62) -> recover_R_t x2 -> t3 scale -> (Reconst) ->

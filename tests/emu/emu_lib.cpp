@@ -7,32 +7,39 @@
 
 // Same two-pass structure as the C ABI: inverse-iteration kernel, then the
 // Jacobi fix-up over ST_RETRY triplets (or Jacobi for everything with FLAG_JACOBI).
+typedef size_t (*lds_fn)(int, int, bool);
 template <class KMain, class KJac>
-static int emu_pose(KMain kmain, KJac kjac, const double* corresp, const double* calm, long calm_stride, long B, int N,
+static int emu_pose(KMain kmain, KJac kjac, lds_fn ldsfn, bool may_stage, const double* corresp, const double* calm, long calm_stride, long B, int N,
                     int flags, double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
     tff::LinearTftArgs a{corresp, calm, calm_stride, B, N, flags & ~tff::FLAG_JACOBI, Rt2, Rt3, T, reconst, iter, status, dbg};
     if (reconst) a.flags |= tff::FLAG_RECONST;
     const bool all_jacobi = (flags & tff::FLAG_JACOBI) != 0;
     if (!all_jacobi) {
-        a.flags = tff::pose_auto_flags(N, a.flags, false);
-        emu::launch(kmain, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, a.flags, false), a);
+        if (may_stage) a.flags = tff::pose_auto_flags(N, a.flags, false);
+        emu::launch(kmain, tff::pose_grid(B), 64, ldsfn(N, a.flags, false), a);
         bool any = false;
         for (long b = 0; b < B; ++b) any = any || status[b] == tff::ST_RETRY;
         if (!any) return 0;
         a.flags |= tff::FLAG_ONLY_RETRY;
     }
-    a.flags = tff::pose_auto_flags(N, a.flags & ~tff::FLAG_STAGE_LDS, true);
-    emu::launch(kjac, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, a.flags, true), a);
+    a.flags &= ~tff::FLAG_STAGE_LDS;
+    if (may_stage) a.flags = tff::pose_auto_flags(N, a.flags, true);
+    emu::launch(kjac, tff::pose_grid(B), 64, ldsfn(N, a.flags, true), a);
     return all_jacobi ? 0 : 1;
 }
 
 extern "C" int emu_linear_tft_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
                                    double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
-    return emu_pose(tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T,
+    return emu_pose(tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, true, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T,
                     reconst, iter, status, dbg);
 }
 extern "C" int emu_linear_f_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
                                  double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
-    return emu_pose(tff::k_linear_f_pose<false>, tff::k_linear_f_pose<true>, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T,
+    return emu_pose(tff::k_linear_f_pose<false>, tff::k_linear_f_pose<true>, tff::pose_lds_bytes, true, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T,
                     reconst, iter, status, dbg);
+}
+extern "C" int emu_ressl_tft_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                                  double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
+    return emu_pose(tff::k_ressl_tft_pose<false>, tff::k_ressl_tft_pose<true>, tff::ressl_lds_bytes, false, corresp, calm, calm_stride, B, N,
+                    flags, Rt2, Rt3, T, reconst, iter, status, dbg);
 }

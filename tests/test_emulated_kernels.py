@@ -81,3 +81,19 @@ def test_linear_f_needs_8_points(emu):
     C, CalM, _, _ = generate_scene_batch(1, 7, noise=1.0, seed=1)
     out = run_linear_tft(emu, C, CalM, entry="emu_linear_f_pose")
     assert out["status"][0] == 1 and np.all(np.isnan(out["T"][0]))
+
+
+def test_ressl_kernel_matches_block_checker(emu, golden_dir):
+    """Gauss-Helmert kernel on one N = 12 triplet: against the same-block-algebra restatement
+    (oracle/gh_block_oracle.py) and the dense oracle's golden output.  Tolerances: see
+    tests/test_gpu_parity.py (the algorithm is rounding-sensitive by construction)."""
+    import os
+    from oracle import gh_block_oracle as G
+    g = np.load(os.path.join(golden_dir, "synthetic_gh.npz"))
+    C, CalM = g["c1_Corresp"][1:2], g["c1_CalM"]
+    out = run_linear_tft(emu, C, CalM, entry="emu_ressl_tft_pose")
+    assert out["status"][0] == 0
+    R2, R3, Rec, T, it = G.ResslTFTPoseEstimation_blocks(C[0].T.copy(), CalM)
+    assert abs(int(out["iter"][0]) - it) <= 1 and abs(int(out["iter"][0]) - int(g["c1_ressl_iter"][1])) <= 2
+    assert rel_err_T(out["T"][0], T) < 2e-3 and rel_err(out["R_t_3"][0], R3) < 2e-3
+    assert rel_err_T(out["T"][0], g["c1_ressl_T"][1]) < 1e-2 and rel_err(out["R_t_3"][0], g["c1_ressl_Rt3"][1]) < 1e-2

@@ -33,7 +33,7 @@ TFF_OPT_SOLVER = 1
 TFF_OPT_STAGE_LDS = 2
 DEBUG_STRIDE = 128
 
-ST_OK, ST_TOO_FEW, ST_NONFINITE, ST_NO_POSE = 0, 1, 2, 3
+ST_OK, ST_TOO_FEW, ST_NONFINITE, ST_NO_POSE, ST_RANK = 0, 1, 2, 3, 4
 
 _c_dp = ctypes.c_void_p
 _POSE_SIG = [ctypes.c_void_p, _c_dp, _c_dp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
@@ -76,8 +76,11 @@ def load_library(path=None):
                 if fn is not None:
                     fn.argtypes = _POSE_SIG
                     fn.restype = ctypes.c_int
-        lib.tff_linear_tft_pose_batch_debug_dev.argtypes = _POSE_SIG + [_c_dp]
-        lib.tff_linear_tft_pose_batch_debug_dev.restype = ctypes.c_int
+        for name in POSE_METHODS.values():
+            fn = getattr(lib, name + "_debug_dev", None)
+            if fn is not None:
+                fn.argtypes = _POSE_SIG + [_c_dp]
+                fn.restype = ctypes.c_int
         if path is None:
             _lib = lib
         return lib
@@ -87,6 +90,7 @@ def load_library(path=None):
 POSE_METHODS = {
     "LinearTFTPoseEstimation": "tff_linear_tft_pose_batch",
     "LinearFPoseEstimation": "tff_linear_f_pose_batch",
+    "ResslTFTPoseEstimation": "tff_ressl_tft_pose_batch",
 }
 
 # every symbol include/tftfund.h declares (checked by the CPU test-suite)
@@ -95,6 +99,7 @@ EXPORTED_SYMBOLS = [
     "tff_ctx_use_own_stream", "tff_ctx_get_stream", "tff_ctx_set_option", "tff_ctx_synchronize",
     "tff_linear_tft_pose_batch_dev", "tff_linear_tft_pose_batch_host", "tff_linear_tft_pose_batch_debug_dev",
     "tff_linear_f_pose_batch_dev", "tff_linear_f_pose_batch_host",
+    "tff_ressl_tft_pose_batch_dev", "tff_ressl_tft_pose_batch_host", "tff_ressl_tft_pose_batch_debug_dev",
 ]
 
 
@@ -254,3 +259,8 @@ def LinearTFTPoseEstimation(Corresp, CalM):
 def LinearFPoseEstimation(Corresp, CalM):
     """Drop-in for F_methods/LinearFPoseEstimation.m (same inputs/outputs; needs N >= 8)."""
     return _single("LinearFPoseEstimation", Corresp, CalM)
+
+
+def ResslTFTPoseEstimation(Corresp, CalM):
+    """Drop-in for TFT_methods/ResslTFTPoseEstimation.m (iter = Gauss-Helmert iterations)."""
+    return _single("ResslTFTPoseEstimation", Corresp, CalM)

@@ -63,7 +63,7 @@ int staged_flags(const tff_ctx* c, int N, int flags, bool jacobi) {
 
 template <class K>
 int ensure_lds(K kernel, size_t bytes) {
-    if (bytes > 160 * 1024) return fail(TFF_E_INVALID, "N too large for LDS staging (set TFF_OPT_STAGE_LDS to 0)");
+    if (bytes > 160 * 1024) return fail(TFF_E_INVALID, "N too large for the 160 KiB LDS workspace of this method");
     if (bytes > 64 * 1024) TFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return 0;
 }
@@ -79,8 +79,10 @@ int check_common(const tff_ctx* c, const void* corresp, const void* calm, int64_
 // Two launches on the context's stream: the inverse-iteration kernel for the whole
 // batch, then the Jacobi kernel over the (rare) triplets it marked ST_RETRY.
 // With TFF_OPT_SOLVER = 1 only the Jacobi kernel runs, for every triplet.
+typedef size_t (*lds_fn)(int N, int flags, bool jacobi);
+
 template <class KMain, class KJac>
-int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, bool may_stage, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
                 int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     if (B == 0) return 0;
@@ -94,15 +96,15 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, const double* corresp, const
                          Rt2, Rt3, T, reconst, iter, status, dbg};
     if (c->solver == 0) {
         tff::LinearTftArgs m = a;
-        m.flags = staged_flags(c, N, a.flags, false);
-        const size_t lds = tff::pose_lds_bytes(N, m.flags, false);
+        m.flags = may_stage ? staged_flags(c, N, a.flags, false) : a.flags;
+        const size_t lds = ldsfn(N, m.flags, false);
         if (int r = ensure_lds(kmain, lds)) return r;
         hipLaunchKernelGGL(kmain, dim3(tff::pose_grid(B)), dim3(64), lds, c->stream, m);
         TFF_HIP(hipGetLastError());
         a.flags |= tff::FLAG_ONLY_RETRY;
     }
-    a.flags = staged_flags(c, N, a.flags, true);
-    const size_t lds = tff::pose_lds_bytes(N, a.flags, true);
+    if (may_stage) a.flags = staged_flags(c, N, a.flags, true);
+    const size_t lds = ldsfn(N, a.flags, true);
     if (int r = ensure_lds(kjac, lds)) return r;
     const unsigned grid = (c->solver == 0) ? (unsigned)(B < 1024 ? B : 1024) : tff::pose_grid(B);
     hipLaunchKernelGGL(kjac, dim3(grid), dim3(64), lds, c->stream, a);
@@ -112,13 +114,19 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, const double* corresp, const
 
 int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    return launch_pose(c, tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
+    return launch_pose(c, tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, true, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
                        reconst, iter, status, dbg);
 }
 int launch_linear_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    return launch_pose(c, tff::k_linear_f_pose<false>, tff::k_linear_f_pose<true>, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
+    return launch_pose(c, tff::k_linear_f_pose<false>, tff::k_linear_f_pose<true>, tff::pose_lds_bytes, true, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
                        reconst, iter, status, dbg);
+}
+
+int launch_ressl_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
+                      double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+    return launch_pose(c, tff::k_ressl_tft_pose<false>, tff::k_ressl_tft_pose<true>, tff::ressl_lds_bytes, false, corresp, calm, calm_stride,
+                       B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 
 typedef int (*pose_launcher)(tff_ctx*, const double*, const double*, int64_t, int64_t, int32_t, double*, double*, double*, double*,
@@ -236,6 +244,23 @@ int tff_linear_tft_pose_batch_host(tff_ctx* c, const double* corresp, const doub
                                    int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
                                    int32_t* status) {
     return pose_batch_host(launch_linear_tft, c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status);
+}
+
+int tff_ressl_tft_pose_batch_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                                  int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                                  int32_t* status) {
+    return launch_ressl_tft(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, nullptr);
+}
+int tff_ressl_tft_pose_batch_host(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                                   int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                                   int32_t* status) {
+    return pose_batch_host(launch_ressl_tft, c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status);
+}
+int tff_ressl_tft_pose_batch_debug_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride,
+                                       int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                       int32_t* iter, int32_t* status, double* dbg) {
+    if (!dbg) return fail(TFF_E_INVALID, "null debug buffer");
+    return launch_ressl_tft(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 
 int tff_linear_f_pose_batch_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,

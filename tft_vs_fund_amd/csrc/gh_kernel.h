@@ -1,0 +1,603 @@
+// Gauss-Helmert refinement of the trifocal tensor (Optimization/Gauss_Helmert.m:38-83)
+// and ResslTFTPoseEstimation (TFT_methods/ResslTFTPoseEstimation.m:47-177) as one
+// fused kernel, one wavefront per triplet.
+//
+// The reference builds dense 4N x 27 / 4N x 6N / 4N x 4N matrices and calls pinv on
+// an identity (6N x 6N) and on W (4N x 4N) every iteration.  Their structure is block
+// diagonal -- one 4 x 6 block B_i per correspondence -- so here
+//   W = B pinv(P) B'             -> 4x4 blocks W_i = B_i B_i'                    (:52, P = I)
+//   pinv(W + 1e-12 I) + 1e-12 I  -> per-lane Jacobi eigen-decomposition of each block with
+//                                   pinv's GLOBAL tolerance 4N * eps(max_i lambda_max)  (:57)
+//   A'WA, A'Ww                   -> A_i = Ap_i D (D = dT/dparams, wave-uniform), so
+//                                   A'WA = D' Ghat D with Ghat = sum_i Ap_i' W_i Ap_i
+//                                        = sum_i (h1 h1') (x) (K_i W_i K_i'),  K_i = S3 (x) S2 :
+//                                   6 x 45 + 27 sums accumulated one correspondence per lane in
+//                                   ten 30-accumulator sweeps (halving-butterfly reductions)  (:59-62)
+//   pinv(M + 1e-12 I) b          -> pivoted elimination of the (u+c) x (u+c) KKT system; equal to
+//                                   pinv whenever no singular value falls under its tolerance
+//                                   (the generic case; a numerically rank-deficient system is
+//                                   reported as status TFF_ST_RANK)                          (:67)
+//   v = -B' W (A dt - w)         -> per lane                                                (:69)
+// with the reference's stop tests, `factor = 1`, and the last step not applied when the
+// objective rises (:71-80).  Nothing of size 4N x anything is ever formed.
+//
+// Agreement with a dense LAPACK evaluation of the same formulas is ~1e-5 in the parameters,
+// not 1e-9: the exit test "objective rose" compares values that differ by ~1e-9 relative once
+// the iteration stagnates (see oracle/gh_block_oracle.py and DESIGN.md).
+#pragma once
+#include "tft_kernel.h"
+
+namespace tff {
+
+constexpr int ST_RANK = 4;            // KKT system numerically rank deficient (pinv truncation path not implemented)
+constexpr int GH_IT_MAX = 400;        // Gauss_Helmert.m:38
+constexpr double GH_TOL = 1e-6;       // Gauss_Helmert.m:39
+
+struct GhWork {                       // per-wave LDS carve-up for one Gauss-Helmert problem
+    double* p;      // u        parameters
+    double* dt;     // u + c    solution of the KKT system
+    double* Tc;     // 27       tensor of the current parameters
+    double* dT;     // 27       D * dt
+    double* D;      // 27 x u   dT/dp, row-major
+    double* G;      // 27 x 27  Ghat
+    double* H;      // 270 + 27 accumulated sums: H[6 e + hh] (e: lower triangle of the 9x9 Z), then ghat[27]
+    double* Y;      // 27 x u   Ghat * D
+    double* M;      // (u+c) x (u+c+1) augmented KKT matrix
+    double* xi;     // 6N       current estimates of the observations
+    double* pp;     // 14N      per correspondence: W+ (10, packed lower) and W+ w (4); then v (6)
+    int u, c;
+};
+__host__ __device__ inline int gh_lds_doubles(int u, int c, int N) {
+    const int n = u + c;
+    return 2 * ((u + 1) & ~1) + 2 * c + 28 + 28 + 27 * u + 729 + 298 + 27 * u + n * (n + 1) + 6 * N + 14 * N + 8;
+}
+__device__ inline GhWork gh_carve(double* base, int u, int c, int N) {
+    GhWork g;
+    const int n = u + c;
+    double* q = base;
+    g.p = q; q += (u + 1) & ~1;
+    g.dt = q; q += ((u + 1) & ~1) + 2 * c;
+    g.Tc = q; q += 28;
+    g.dT = q; q += 28;
+    g.D = q; q += 27 * u;
+    g.G = q; q += 729;
+    g.H = q; q += 298;
+    g.Y = q; q += 27 * u;
+    g.M = q; q += n * (n + 1);
+    g.xi = q; q += 6 * N;
+    g.pp = q; q += 14 * N;
+    g.u = u; g.c = c;
+    return g;
+}
+
+__device__ __forceinline__ double eps_of(double x) {                        // MATLAB eps(x) for normal x > 0
+    const long long e = (__double_as_longlong(x) >> 52) & 0x7ff;
+    return __longlong_as_double((e > 52 ? e - 52 : 1) << 52);
+}
+
+// ---- the per-correspondence trilinearity block (ResslTFTPoseEstimation.m:141-161) ----
+// quad(m) = vec(S2' m S3), S2 = [0 -1; -1 0; y2 x2], S3 likewise; entry a2 + 2 a3.
+__device__ __forceinline__ void tril_quad(const double (&m)[3][3], double x2, double y2, double x3, double y3, double (&o)[4]) {
+    double v0[3], v1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { v0[j] = y3 * m[j][2] - m[j][1]; v1[j] = x3 * m[j][2] - m[j][0]; }
+    o[0] = y2 * v0[2] - v0[1];
+    o[1] = x2 * v0[2] - v0[0];
+    o[2] = y2 * v1[2] - v1[1];
+    o[3] = x2 * v1[2] - v1[0];
+}
+__device__ __forceinline__ void tril_slices(const double (&T)[27], const double (&o)[6], double (&m)[3][3], double (&t1)[3][3], double (&t2)[3][3]) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            t1[j][k] = T[j + 3 * k];
+            t2[j][k] = T[j + 3 * k + 9];
+            m[j][k] = o[0] * t1[j][k] + o[1] * t2[j][k] + T[j + 3 * k + 18];
+        }
+}
+// f (4) and B (4 x 6) at the observation estimate o = [x1 y1 x2 y2 x3 y3]
+__device__ __forceinline__ void tril_block(const double (&T)[27], const double (&o)[6], double (&f)[4], double (&B)[4][6]) {
+    double m[3][3], t1[3][3], t2[3][3], c0[4], c1[4];
+    tril_slices(T, o, m, t1, t2);
+    tril_quad(m, o[2], o[3], o[4], o[5], f);
+    tril_quad(t1, o[2], o[3], o[4], o[5], c0);                               // :157
+    tril_quad(t2, o[2], o[3], o[4], o[5], c1);                               // :158
+    const double u3[2] = {o[5] * m[2][2] - m[2][1], o[4] * m[2][2] - m[2][0]};   // S3' J3' [x1;1]   (:159)
+    const double u2[2] = {o[3] * m[2][2] - m[1][2], o[2] * m[2][2] - m[0][2]};   // S2' K3 [x1;1]    (:160)
+#pragma unroll
+    for (int a3 = 0; a3 < 2; ++a3)
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {
+            const int r = a2 + 2 * a3;
+            B[r][0] = c0[r];
+            B[r][1] = c1[r];
+            B[r][2] = (a2 == 1) ? u3[a3] : 0.0;
+            B[r][3] = (a2 == 0) ? u3[a3] : 0.0;
+            B[r][4] = (a3 == 1) ? u2[a2] : 0.0;
+            B[r][5] = (a3 == 0) ? u2[a2] : 0.0;
+        }
+}
+__device__ __forceinline__ void load_uniform27(const double* p, double (&u)[27]) {
+#pragma unroll
+    for (int c = 0; c < 27; ++c) u[c] = wave_uniform(p[c]);
+}
+
+// cyclic Jacobi on a symmetric 4x4 (per lane); V accumulates eigenvectors when WITH_V
+template <bool WITH_V>
+__device__ __forceinline__ void jacobi4_rot(double (&A)[4][4], double (&V)[4][4], const int p, const int q) {
+    const double apq = A[p][q];
+    if (apq == 0.0) return;
+    const double app = A[p][p], aqq = A[q][q];
+    const double tau = (aqq - app) / (2.0 * apq);
+    const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+    const double c = rsqrt(1.0 + t * t), s = t * c;
+    A[p][p] = app - t * apq;
+    A[q][q] = aqq + t * apq;
+    A[p][q] = A[q][p] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (r == p || r == q) continue;
+        const double arp = A[r][p], arq = A[r][q];
+        A[r][p] = A[p][r] = c * arp - s * arq;
+        A[r][q] = A[q][r] = s * arp + c * arq;
+    }
+    if (WITH_V) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double vkp = V[k][p], vkq = V[k][q];
+            V[k][p] = c * vkp - s * vkq;
+            V[k][q] = s * vkp + c * vkq;
+        }
+    }
+}
+template <bool WITH_V>
+__device__ __forceinline__ void jacobi4(double (&A)[4][4], double (&V)[4][4]) {
+    if (WITH_V) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+#pragma unroll 1
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, dg = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dg += A[i][i] * A[i][i];
+#pragma unroll
+            for (int j = 0; j < i; ++j) off += A[i][j] * A[i][j];
+        }
+        if (!(off > 1e-36 * dg)) break;
+        jacobi4_rot<WITH_V>(A, V, 0, 1); jacobi4_rot<WITH_V>(A, V, 0, 2); jacobi4_rot<WITH_V>(A, V, 0, 3);
+        jacobi4_rot<WITH_V>(A, V, 1, 2); jacobi4_rot<WITH_V>(A, V, 1, 3); jacobi4_rot<WITH_V>(A, V, 2, 3);
+    }
+}
+__device__ __forceinline__ void block_W(const double (&B)[4][6], double (&W)[4][4]) {   // B B' + 1e-12 I
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double a = (i == j) ? 1e-12 : 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) a += B[i][k] * B[j][k];
+            W[i][j] = W[j][i] = a;
+        }
+}
+
+// K = S3 (x) S2 (9 x 4): row q = j + 3k, column a = a2 + 2 a3
+template <int j>
+__device__ __forceinline__ double S_el(int a, double x, double y) { return (j == 2) ? ((a == 0) ? y : x) : ((j == a) ? 0.0 : -1.0); }
+template <int q>
+__device__ __forceinline__ void K_row(double x2, double y2, double x3, double y3, double (&kr)[4]) {
+#pragma unroll
+    for (int a3 = 0; a3 < 2; ++a3)
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) kr[a2 + 2 * a3] = S_el<q % 3>(a2, x2, y2) * S_el<q / 3>(a3, x3, y3);
+}
+__host__ __device__ constexpr int tri_row_of(int e) { int r = 0; while ((r + 1) * (r + 2) / 2 <= e) ++r; return r; }
+__host__ __device__ constexpr int tri_col_of(int e) { return e - tri_row_of(e) * (tri_row_of(e) + 1) / 2; }
+
+struct GhPoint { double o[6]; double Wp[10]; double ww[4]; };
+__device__ __forceinline__ double wp_at(const double (&Wp)[10], int a, int b) { return (a >= b) ? Wp[a * (a + 1) / 2 + b] : Wp[b * (b + 1) / 2 + a]; }
+
+// five entries of Z = K W+ K' (x) six products h_a h_b -> 30 accumulators
+template <int E>
+__device__ __forceinline__ void gh_accum_entry(const GhPoint& pt, const double (&hh)[6], double* acc) {
+    constexpr int q = tri_row_of(E), qq = tri_col_of(E);
+    double kr[4], kc[4];
+    K_row<q>(pt.o[2], pt.o[3], pt.o[4], pt.o[5], kr);
+    K_row<qq>(pt.o[2], pt.o[3], pt.o[4], pt.o[5], kc);
+    double z = 0.0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        double y = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) y += kr[a] * wp_at(pt.Wp, a, b);
+        z += y * kc[b];
+    }
+#pragma unroll
+    for (int h = 0; h < 6; ++h) acc[h] += hh[h] * z;
+}
+template <int CH>
+__device__ __forceinline__ void gh_accum_chunk(const GhPoint& pt, const double (&hh)[6], double (&acc)[32]) {
+    if constexpr (CH < 9) {
+        gh_accum_entry<5 * CH + 0>(pt, hh, acc + 0);
+        gh_accum_entry<5 * CH + 1>(pt, hh, acc + 6);
+        gh_accum_entry<5 * CH + 2>(pt, hh, acc + 12);
+        gh_accum_entry<5 * CH + 3>(pt, hh, acc + 18);
+        gh_accum_entry<5 * CH + 4>(pt, hh, acc + 24);
+    }
+}
+// ghat[q + 9 i1] += h[i1] * (K[q] . ww)
+__device__ __forceinline__ void gh_accum_rhs(const GhPoint& pt, double (&acc)[32]) {
+    double kq[9];
+    {
+        double kr[4];
+#define TFF_KQ(Q) K_row<Q>(pt.o[2], pt.o[3], pt.o[4], pt.o[5], kr); kq[Q] = kr[0] * pt.ww[0] + kr[1] * pt.ww[1] + kr[2] * pt.ww[2] + kr[3] * pt.ww[3];
+        TFF_KQ(0) TFF_KQ(1) TFF_KQ(2) TFF_KQ(3) TFF_KQ(4) TFF_KQ(5) TFF_KQ(6) TFF_KQ(7) TFF_KQ(8)
+#undef TFF_KQ
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { acc[q] += pt.o[0] * kq[q]; acc[9 + q] += pt.o[1] * kq[q]; acc[18 + q] += kq[q]; }
+}
+
+template <int CH>
+__device__ inline void gh_sweep(const GhWork& g, int N) {
+    const int lane = lane_id();
+    double acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+#pragma unroll 1
+    for (int i = lane; i < N; i += WAVE) {
+        GhPoint pt;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pt.o[k] = g.xi[6 * i + k];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) pt.Wp[k] = g.pp[14 * i + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pt.ww[k] = g.pp[14 * i + 10 + k];
+        if constexpr (CH < 9) {
+            const double hh[6] = {pt.o[0] * pt.o[0], pt.o[0] * pt.o[1], pt.o[0], pt.o[1] * pt.o[1], pt.o[1], 1.0};
+            gh_accum_chunk<CH>(pt, hh, acc);
+        } else {
+            gh_accum_rhs(pt, acc);
+        }
+    }
+    const double tot = wave_reduce_scatter<32>(acc);
+    const int idx = reduce32_index(lane);
+    if ((lane & 1) == 0) {
+        if (CH < 9) { if (idx < 30) g.H[30 * CH + idx] = tot; }              // H[6 e + hh], e = 5 CH + idx/6
+        else if (idx < 27) g.H[270 + idx] = tot;
+    }
+}
+
+// Solve the n x n system held as an augmented n x (n+1) matrix in LDS by Gaussian elimination
+// with partial pivoting.  x -> sol[0..n).  Returns false when a pivot is negligible.
+__device__ inline bool wave_solve_pivoted(double* M, int n, double* sol) {
+    const int lane = lane_id();
+    const int ld = n + 1;
+    double amax = 0.0;
+    for (int e = lane; e < n * n; e += WAVE) { const double v = fabs(M[(e / n) * ld + e % n]); amax = (v > amax) ? v : amax; }
+    amax = wave_max(amax);
+    bool ok = amax > 0.0 && amax < 1e300;
+    const int lr = lane & 7, lc = lane >> 3;
+#pragma unroll 1
+    for (int k = 0; k < n; ++k) {
+        const double v = (lane >= k && lane < n) ? fabs(M[lane * ld + k]) : -1.0;
+        const double best = wave_max(v);
+        int pr = (v == best && lane >= k && lane < n) ? lane : 64;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const int o = wave_shfl_xor_i(pr, m); pr = (o < pr) ? o : pr; }
+        if (!(best > 1e-10 * amax)) ok = false;
+        if (pr >= 64) pr = k;
+        wave_sync();
+        if (pr != k && lane <= n) { const double a = M[k * ld + lane], b = M[pr * ld + lane]; M[k * ld + lane] = b; M[pr * ld + lane] = a; }
+        wave_sync();
+        const double ipiv = 1.0 / M[k * ld + k];
+        wave_sync();
+        for (int r = k + 1 + lr; r < n; r += 8) {
+            const double fct = M[r * ld + k] * ipiv;
+            for (int c = k + 1 + lc; c <= n; c += 8) M[r * ld + c] -= fct * M[k * ld + c];
+        }
+        wave_sync();
+    }
+#pragma unroll 1
+    for (int k = n - 1; k >= 0; --k) {                                       // back substitution on the last column
+        const double xk = M[k * ld + n] / M[k * ld + k];
+        wave_sync();
+        if (lane == 0) sol[k] = xk;
+        if (lane < k) M[lane * ld + n] -= M[lane * ld + k] * xk;
+        wave_sync();
+    }
+    return ok;
+}
+
+// ---- Ressl's minimal parameterisation (ResslTFTPoseEstimation.m:56-68,79,110-135,164-170) ----
+struct ResslModel {
+    int Ind;                                                                 // argmax |e21|, 0-based
+    static constexpr int U = 20, C = 2;
+    // initial parameters from linearTFT's output (w->t constrained tensor, w->epi)
+    __device__ inline void init(PoseLds* w, GhWork& g) {
+        const int lane = lane_id();
+        const double* e21 = w->epi; const double* e31 = w->epi + 3;
+        const double a0 = fabs(e21[0]), a1 = fabs(e21[1]), a2 = fabs(e21[2]);
+        Ind = (a0 >= a1 && a0 >= a2) ? 0 : ((a1 >= a2) ? 1 : 2);              // first maximum, as MATLAB max   (:57)
+        const double escale = 1.0 / e21[Ind];
+        const double n31 = rsqrt(e31[0] * e31[0] + e31[1] * e31[1] + e31[2] * e31[2]);
+        const int i2a = (Ind == 0) ? 1 : 0, i2b = (Ind == 2) ? 1 : 2;         // Ind2
+        // S(k,i) = T(Ind,k,i); aux = |S|_F; S /= aux; T /= aux   (:60-62)
+        double sv = (lane < 9) ? w->t[Ind + 3 * (lane % 3) + 9 * (lane / 3)] : 0.0;
+        const double aux = rsqrt(wave_sum(sv * sv));
+        sv *= aux;
+        if (lane < 9) g.p[lane] = sv;                                        // S(:) at k + 3i
+        if (lane == 0) { g.p[9] = e21[i2a] * escale; g.p[10] = e21[i2b] * escale; }
+        if (lane < 3) g.p[17 + lane] = e31[lane] * n31;
+        wave_sync();
+        if (lane < 6) {                                                      // mn(i, Ind2(m)) = e31' (T_i' - S(:,i) e21')(:, Ind2(m))   (:65-68)
+            const int i = lane % 3, m = lane / 3, j = (m == 0) ? i2a : i2b;
+            double acc = 0.0;
+            for (int k = 0; k < 3; ++k) acc += e31[k] * n31 * (w->t[j + 3 * k + 9 * i] * aux - g.p[k + 3 * i] * e21[j] * escale);
+            g.p[11 + i + 3 * m] = acc;
+        }
+        wave_sync();
+    }
+    // p -> Tc, D, and the constraint rows / right-hand side of the KKT matrix
+    __device__ inline void eval(GhWork& g) const {
+        const int lane = lane_id();
+        const int u = U, n = U + C, ld = n + 1;
+        const int i2a = (Ind == 0) ? 1 : 0, i2b = (Ind == 2) ? 1 : 2;
+        for (int e = lane; e < 27 * u; e += WAVE) g.D[e] = 0.0;
+        for (int e = lane; e < n * ld; e += WAVE) g.M[e] = 0.0;
+        wave_sync();
+        if (lane < 27) {
+            const int i = lane / 9, k = (lane % 9) / 3, j = lane % 3;
+            const double e21j = (j == Ind) ? 1.0 : g.p[(j == i2a) ? 9 : 10];
+            const double mnij = (j == Ind) ? 0.0 : g.p[11 + i + 3 * ((j == i2a) ? 0 : 1)];
+            const double S_ki = g.p[k + 3 * i], e31k = g.p[17 + k];
+            g.Tc[lane] = e21j * S_ki + mnij * e31k;                          // T(j,k,i)   (:118-120)
+            double* Dr = g.D + lane * u;
+            Dr[k + 3 * i] = e21j;                                            // d/dS(k,i)
+            if (j != Ind) { const int m = (j == i2a) ? 0 : 1; Dr[9 + m] = S_ki; Dr[11 + i + 3 * m] = e31k; }
+            Dr[17 + k] = mnij;                                               // d/de31(k)
+        }
+        // g = [|e31|^2 - 1; |S|^2 - 1], C rows 2 e31', 2 S(:)'   (:129-135)
+        double s31 = (lane < 3) ? g.p[17 + lane] : 0.0, sS = (lane < 9) ? g.p[lane] : 0.0;
+        const double g0 = wave_sum(s31 * s31) - 1.0, g1 = wave_sum(sS * sS) - 1.0;
+        if (lane < 3) { g.M[u * ld + 17 + lane] = 2.0 * s31; g.M[(17 + lane) * ld + u] = 2.0 * s31; }
+        if (lane < 9) { g.M[(u + 1) * ld + lane] = 2.0 * sS; g.M[lane * ld + u + 1] = 2.0 * sS; }
+        if (lane == 0) { g.M[u * ld + n] = -g0; g.M[(u + 1) * ld + n] = -g1; }
+        wave_sync();
+    }
+};
+
+// Gauss_Helmert.m:38-83 for a trilinearity model.  xi holds x0 on entry.  Returns iterations; status via *st.
+template <class Model>
+__device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, const double* pts, int N, int* st, double* dbg) {
+    const int lane = lane_id();
+    const int u = g.u, c = g.c, n = u + c, ld = n + 1;
+    // objFunc = v0' v0, v0 = x0 - x   (:45-46)
+    double objFunc = 0.0;
+    for (int i = lane; i < N; i += WAVE) {
+        const Pt6 x = premap(load_pt(pts, i), w->nrm);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { const double d = g.xi[6 * i + k] - x.v[k]; objFunc += d * d; }
+    }
+    objFunc = wave_sum(objFunc);
+    int it = 0;
+#pragma unroll 1
+    for (it = 1; it <= GH_IT_MAX; ++it) {
+        model.eval(g);                                                       // func(xi, ti, yi)   (:50)
+        double T[27];
+        load_uniform27(g.Tc, T);
+        // ---- W = B B', its largest eigenvalue -> pinv tolerance   (:52,:57) ----
+        double smax = 0.0;
+        bool finite = true;
+        for (int i = lane; i < N; i += WAVE) {
+            double o[6], f[4], B[4][6], W[4][4], V[4][4];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+            tril_block(T, o, f, B);
+            block_W(B, W);
+            double chk = 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) chk += W[a][0] + W[a][1] + W[a][2] + W[a][3];
+            finite = finite && (fabs(chk) <= 1.79e308);
+            jacobi4<false>(W, V);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+        }
+        smax = wave_max(smax);
+        if (wave_any(!finite) || !(smax <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
+        const double tolW = 4.0 * (double)N * eps_of(smax);
+        // ---- per block: W+ = pinv(W + 1e-12 I) + 1e-12 I,  w = -f - B (x - xi)   (:57-58) ----
+        for (int i = lane; i < N; i += WAVE) {
+            double o[6], f[4], B[4][6], W[4][4], V[4][4];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+            tril_block(T, o, f, B);
+            block_W(B, W);
+            jacobi4<true>(W, V);
+            double inv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) inv[a] = (W[a][a] > tolW) ? 1.0 / W[a][a] : 0.0;
+            double Wp[10];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b <= a; ++b)
+                    Wp[a * (a + 1) / 2 + b] = V[a][0] * inv[0] * V[b][0] + V[a][1] * inv[1] * V[b][1] + V[a][2] * inv[2] * V[b][2]
+                                              + V[a][3] * inv[3] * V[b][3] + ((a == b) ? 1e-12 : 0.0);
+            const Pt6 x = premap(load_pt(pts, i), w->nrm);
+            double wv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                double s = -f[a];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) s -= B[a][k] * (x.v[k] - o[k]);
+                wv[a] = s;
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) g.pp[14 * i + k] = Wp[k];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                g.pp[14 * i + 10 + a] = wp_at(Wp, a, 0) * wv[0] + wp_at(Wp, a, 1) * wv[1] + wp_at(Wp, a, 2) * wv[2] + wp_at(Wp, a, 3) * wv[3];
+        }
+        wave_sync();
+        // ---- Ghat = sum Ap' W+ Ap and ghat = sum Ap' W+ w   (:59-62) ----
+        gh_sweep<0>(g, N); gh_sweep<1>(g, N); gh_sweep<2>(g, N); gh_sweep<3>(g, N); gh_sweep<4>(g, N);
+        gh_sweep<5>(g, N); gh_sweep<6>(g, N); gh_sweep<7>(g, N); gh_sweep<8>(g, N); gh_sweep<9>(g, N);
+        wave_sync();
+        for (int e = lane; e < 729; e += WAVE) {                             // Ghat[(q,i1),(q',i1')] = H[6 tri(q,q') + hht(i1,i1')]
+            const int r = e / 27, cc = e % 27;
+            const int q = r % 9, i1 = r / 9, qq = cc % 9, i1p = cc / 9;
+            const int hi = (q > qq) ? q : qq, lo = (q > qq) ? qq : q;
+            g.G[e] = g.H[6 * (hi * (hi + 1) / 2 + lo) + hht_index(i1, i1p)];
+        }
+        wave_sync();
+        for (int e = lane; e < 27 * u; e += WAVE) {                          // Y = Ghat D
+            const int r = e / u, pcol = e % u;
+            double a = 0.0;
+            for (int k = 0; k < 27; ++k) a += g.G[r * 27 + k] * g.D[k * u + pcol];
+            g.Y[e] = a;
+        }
+        wave_sync();
+        for (int e = lane; e < u * u + u; e += WAVE) {                       // M = [D'Y + 1e-12 I ...], b = [D' ghat; -g]
+            const int pr = e / u, pc = e % u;
+            double a = 0.0;
+            if (e < u * u) {
+                for (int k = 0; k < 27; ++k) a += g.D[k * u + pr] * g.Y[k * u + pc];
+                g.M[pr * ld + pc] = a + ((pr == pc) ? 1e-12 : 0.0);
+            } else {
+                for (int k = 0; k < 27; ++k) a += g.D[k * u + pc] * g.H[270 + k];
+                g.M[pc * ld + n] = a;
+            }
+        }
+        if (lane < c) g.M[(u + lane) * ld + u + lane] = 1e-12;
+        wave_sync();
+        double chkM = 0.0;
+        for (int e = lane; e < n * ld; e += WAVE) chkM += g.M[e];
+        if (!(fabs(wave_sum(chkM)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
+        if (!wave_solve_pivoted(g.M, n, g.dt)) { *st = ST_RANK; break; }    // aux = pinv(M + 1e-12 I) * b   (:67)
+        wave_sync();
+        if (lane < 27) {                                                     // dT = D dt
+            double a = 0.0;
+            for (int k = 0; k < u; ++k) a += g.D[lane * u + k] * g.dt[k];
+            g.dT[lane] = a;
+        }
+        wave_sync();
+        double dTr[27];
+        load_uniform27(g.dT, dTr);
+        // ---- v = -B' W+ (A dt - w)   (:69) ----
+        double obj = 0.0, diff = 0.0;
+        for (int i = lane; i < N; i += WAVE) {
+            double o[6], f[4], B[4][6], Ad[4];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+            tril_block(T, o, f, B);
+            {
+                double m[3][3], t1[3][3], t2[3][3];
+                tril_slices(dTr, o, m, t1, t2);
+                tril_quad(m, o[2], o[3], o[4], o[5], Ad);                    // Ap_i (D dt)
+            }
+            double Wp[10], r[4];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) Wp[k] = g.pp[14 * i + k];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                r[a] = wp_at(Wp, a, 0) * Ad[0] + wp_at(Wp, a, 1) * Ad[1] + wp_at(Wp, a, 2) * Ad[2] + wp_at(Wp, a, 3) * Ad[3] - g.pp[14 * i + 10 + a];
+            const Pt6 x = premap(load_pt(pts, i), w->nrm);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const double v = -(B[0][k] * r[0] + B[1][k] * r[1] + B[2][k] * r[2] + B[3][k] * r[3]);
+                g.pp[14 * i + k] = v;
+                obj += v * v;
+                const double d = o[k] - x.v[k] - v;
+                diff += d * d;
+            }
+        }
+        obj = wave_sum(obj);
+        diff = wave_sum(diff);
+        const double dtk = (lane < u) ? g.dt[lane] : 0.0;
+        const double ndt2 = wave_sum(dtk * dtk);
+        if (dbg && lane == 0 && it <= 8) { dbg[96 + 3 * (it - 1)] = obj; dbg[97 + 3 * (it - 1)] = ndt2; dbg[98 + 3 * (it - 1)] = diff; }
+        if (sqrt(ndt2) < GH_TOL && sqrt(diff) < GH_TOL) break;               // :71-73 (dy is empty)
+        if (obj > objFunc) break;                                            // :75-76, factor = 1
+        objFunc = obj;                                                       // :78
+        for (int i = lane; i < N; i += WAVE) {                               // xi = x + v; ti = ti + dt   (:80)
+            const Pt6 x = premap(load_pt(pts, i), w->nrm);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) g.xi[6 * i + k] = x.v[k] + g.pp[14 * i + k];
+        }
+        if (lane < u) g.p[lane] += dtk;
+        wave_sync();
+    }
+    return (it > GH_IT_MAX) ? GH_IT_MAX : it;                                // :82
+}
+
+template <bool JAC>
+__global__ void __launch_bounds__(64, 1) k_ressl_tft_pose(const LinearTftArgs a) {
+    TFF_DYNAMIC_LDS(double, smem);
+    PoseLds* w = reinterpret_cast<PoseLds*>(smem);
+    constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
+    JacobiLds* jw = JAC ? reinterpret_cast<JacobiLds*>(smem + base) : nullptr;
+    double* ghbase = smem + base + (JAC ? ((JACOBI_LDS_DOUBLES + 1) & ~1) : 0);
+    const int lane = lane_id();
+    for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
+        if ((a.flags & FLAG_ONLY_RETRY) && a.status[b] != ST_RETRY) continue;
+        const int N = a.N;
+        double* dbg = a.dbg ? a.dbg + b * DBG_STRIDE : nullptr;
+        const double* pts = a.corresp + b * 6 * (long)N;                     // re-read through L2 (LDS is taken by the GH workspace)
+        wave_sync();
+        GhWork g = gh_carve(ghbase, ResslModel::U, ResslModel::C, N);
+        if (lane < 27) w->calm[lane] = a.calm[b * a.calm_stride + lane];
+        int status = ST_OK, iters = 0;
+        if (N < 7) {
+            status = ST_TOO_FEW;
+            const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+            if (lane < 12) { a.Rt2[b * 12 + lane] = qnan; a.Rt3[b * 12 + lane] = qnan; }
+            if (lane < 27) a.T[b * 27 + lane] = qnan;
+            if (a.reconst) for (int i = lane; i < 3 * N; i += WAVE) a.reconst[b * 3 * (long)N + i] = qnan;
+        } else {
+            normalise3(pts, N, w->nrm);                                      // ResslTFTPoseEstimation.m:48-50
+            const bool ok = linear_tft_wave<JAC>(w, jw, pts, N, true, dbg);  // :53
+            if (!ok) {
+                status = ST_RETRY;
+            } else {
+                ResslModel model;
+                model.init(w, g);                                            // :56-68,:79
+                // x_est: reprojection of the projective triangulation with P1 = [I|0], P2, P3   (:72-75)
+                if (lane < 12) {
+                    const int r = lane >> 2, c = lane & 3;
+                    w->Pfin[0][lane] = (r == c) ? 1.0 : 0.0;
+                    w->P[0][lane] = (c < 3) ? w->pa[3 * c + r] : w->epi[r];            // P2 = [reshape(a(1:9),3,3) e21]
+                    w->P[1][lane] = (c < 3) ? w->pa[9 + 3 * c + r] : w->epi[3 + r];    // P3 = [reshape(a(10:18),3,3) e31]
+                }
+                wave_sync();
+                tri_pass(w, pts, N, TRI_REPROJECT, 1, w->P[0], w->P[1], g.xi, w->nrm);
+                wave_sync();
+                int gst = ST_OK;
+                iters = gauss_helmert_wave(w, g, model, pts, N, &gst, dbg);  // :84
+                wave_sync();
+                model.eval(g);                                               // T from p_opt   (:87-94)
+                if (lane < 27) w->t[lane] = g.Tc[lane];
+                wave_sync();
+                transform_tft_inverse(w->t, w->T1, w->Lp, [w](int v) { return normal_matrix(w->nrm, v); });   // :96
+                status = rt_from_tft_wave(w, pts, N, dbg);                   // :99
+                if (gst != ST_OK) status = gst;
+                write_poses(w, a.Rt2 + b * 12, a.Rt3 + b * 12);
+                if (lane < 27) a.T[b * 27 + lane] = w->T1[lane];
+                if (a.reconst) final_reconst(w, pts, N, a.reconst + b * 3 * (long)N);   // :102-103
+                double chk = (lane < 12) ? w->Rt[0][lane] : ((lane < 24) ? w->Rt[1][lane - 12] : ((lane < 51) ? w->T1[lane - 24] : 0.0));
+                const bool bad = !(fabs(chk) <= 1.79e308);
+                if (wave_any(bad) && status == ST_OK) status = ST_NONFINITE;
+            }
+        }
+        if (lane == 0) {
+            if (a.iter) a.iter[b] = iters;
+            a.status[b] = status;
+        }
+    }
+}
+
+}  // namespace tff

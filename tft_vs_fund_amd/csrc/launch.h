@@ -2,6 +2,7 @@
 #pragma once
 #include "tft_kernel.h"
 #include "f_kernel.h"
+#include "gh_kernel.h"
 
 namespace tff {
 
@@ -17,6 +18,14 @@ inline size_t pose_lds_bytes(int N, int flags, bool jacobi) {
 inline int pose_auto_flags(int N, int flags, bool jacobi) {
     if (pose_lds_bytes(N, flags | FLAG_STAGE_LDS, jacobi) <= 64 * 1024) flags |= FLAG_STAGE_LDS;
     return flags;
+}
+// Gauss-Helmert kernels: correspondences are re-read through L2 (never staged); the LDS holds
+// the GH workspace instead (20 N + ~2.7k doubles for Ressl's 20 parameters / 2 constraints).
+inline size_t ressl_lds_bytes(int N, int /*flags*/, bool jacobi) {
+    size_t d = (size_t)((POSE_LDS_DOUBLES + 1) & ~1);
+    if (jacobi) d += (size_t)((JACOBI_LDS_DOUBLES + 1) & ~1);
+    d += (size_t)gh_lds_doubles(ResslModel::U, ResslModel::C, N);
+    return d * sizeof(double);
 }
 inline unsigned pose_grid(long B) { return (unsigned)((B < (1L << 30)) ? (B > 0 ? B : 1) : (1L << 30)); }
 

@@ -260,9 +260,13 @@ __device__ __forceinline__ void compose_camera_from_pose(const Mat3& K, const do
 //   TRI_VOTE    : aux = candidate pose [R|t] (row-major 3x4); returns sum_n sign(X1(3)) + sign(X2(3))
 //   TRI_SCALE   : aux = [K3*R3 | u3 = K3*t3]; num/den of R_t_from_TFT.m:72-73 -> w->pa[0..1]
 //   TRI_RECONST : aux = third camera; dehomogenised points -> `out` (3 x N column-major)
-constexpr int TRI_VOTE = 0, TRI_SCALE = 1, TRI_RECONST = 2;
+//   TRI_REPROJECT : aux = third camera; the three reprojections of the homogeneous point ->
+//                 `out` (6 x N), the initial observations of the Gauss-Helmert methods
+//                 (ResslTFTPoseEstimation.m:72-75)
+// `pre` (9 doubles or null): affine map applied to the raw correspondences first (normalised points).
+constexpr int TRI_VOTE = 0, TRI_SCALE = 1, TRI_RECONST = 2, TRI_REPROJECT = 3;
 __device__ __attribute__((noinline)) int tri_pass(PoseLds* w, const double* pts, int N, int mode, int view, const double* camB,
-                                                   const double* aux, double* __restrict__ out) {
+                                                   const double* aux, double* out, const double* pre = nullptr) {
     const int lane = lane_id();
     double PA[12], PB[12], AX[12];
     load_uniform12(w->Pfin[0], PA);
@@ -272,14 +276,26 @@ __device__ __attribute__((noinline)) int tri_pass(PoseLds* w, const double* pts,
     double num = 0.0, den = 0.0;
 #pragma unroll 1
     for (int i = lane; i < N; i += WAVE) {
-        const Pt6 p = load_pt(pts, i);
+        const Pt6 p = premap(load_pt(pts, i), pre);
         double S[4][4];
         tri_zero(S);
         tri_accum(S, PA, p.v[0], p.v[1]);
         tri_accum(S, PB, (view == 1) ? p.v[2] : p.v[4], (view == 1) ? p.v[3] : p.v[5]);
-        if (mode == TRI_RECONST) tri_accum(S, AX, p.v[4], p.v[5]);
+        if (mode >= TRI_RECONST) tri_accum(S, AX, p.v[4], p.v[5]);
         double X[4];
         spd_min_eigvec<4>(S, X);
+        if (mode == TRI_REPROJECT) {                                               // p_est = P*X; p(1:2)./p(3)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const double (&P)[12] = (v == 0) ? PA : ((v == 1) ? PB : AX);
+                const double a = P[0] * X[0] + P[1] * X[1] + P[2] * X[2] + P[3] * X[3];
+                const double b = P[4] * X[0] + P[5] * X[1] + P[6] * X[2] + P[7] * X[3];
+                const double c = P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11] * X[3];
+                out[6 * (long)i + 2 * v] = a / c;
+                out[6 * (long)i + 2 * v + 1] = b / c;
+            }
+            continue;
+        }
         const double iw = 1.0 / X[3];
         const double X0 = X[0] * iw, X1 = X[1] * iw, X2 = X[2] * iw;                 // X./X(4)
         if (mode == TRI_VOTE) {

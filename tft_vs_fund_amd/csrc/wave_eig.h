@@ -29,7 +29,7 @@ __device__ __forceinline__ int tri_index(int r, int c) { return (r * (r + 1)) / 
 // g[c] = G[lane][c] for c <= lane (entries c > lane are ignored), diag = G[lane][lane].
 // Lp: n*n doubles of LDS.  On return lane r (< n) holds component r of the
 // unit eigenvector of the smallest eigenvalue; *iters = iterations used,
-// *resid2 = last squared step (convergence when < ~1e-20).
+// *resid2 = 0 when the iteration converged, else the last squared step.
 template <int n>
 __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, double* Lp, const int maxit,
                                              int* iters, double* resid2) {
@@ -98,15 +98,17 @@ __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, 
         r2 = wave_sum(dd * dd);
         x = yn;
         ++it;
-        if (!(r2 > 1e-26)) break;
-        if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) break;
+        // |step|^2 = r2; the error of the new iterate is ~ rho |step| / (1 - rho) with rho ~ |step| / |previous step|
+        if (r2 <= 1e-26) { r2 = 0.0; break; }                                    // converged: stopped moving
+        if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) { r2 = 0.0; break; }   // converged: predicted error < 1e-13
+        if (!(r2 == r2)) break;                                                  // NaN: not converged
         rprev2 = r2;
     }
     *iters = it;
-    *resid2 = r2;
+    *resid2 = r2;                                                               // 0 when converged, last |step|^2 otherwise
     return x;
 }
-__device__ __forceinline__ bool eig_converged(double resid2) { return resid2 < 1e-20; }
+__device__ __forceinline__ bool eig_converged(double resid2) { return resid2 == 0.0; }
 
 // Cyclic Jacobi on A (n x n, ld, symmetric, full storage, DESTROYED) with
 // eigenvectors accumulated in V (n x n, ld); returns, per lane r < n,
