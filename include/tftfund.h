@@ -109,6 +109,46 @@ int tff_linear_f_pose_batch_host(tff_ctx* ctx, const double* corresp, const doub
                                  int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
                                  int32_t* iter, int32_t* status);
 
+/* ---- building blocks (device pointers; all arrays MATLAB column-major) ------------------------- */
+
+/* triangulation3D (auxiliar_functions/triangulation3D.m:32-64): M = 2 or 3 cameras (3x4 each, cam_stride 12*M per
+ * item or 0 = shared), pts B x (2M x N); X B x (4 x N) unit-norm homogeneous points, sign free, not dehomogenised. */
+int tff_triangulate_batch_dev(tff_ctx* ctx, const double* cams, int64_t cam_stride, const double* pts, int64_t B,
+                              int32_t M, int32_t N, double* X);
+
+/* ReprError (auxiliar_functions/ReprError.m:39-65) for three views: RMS over the 3N reprojected points; pts3d
+ * (B x 3 x N) or NULL to triangulate first (ReprError.m:43-44).  corresp_stride 6*N or 0 (one shared scene). */
+int tff_repr_error_batch_dev(tff_ctx* ctx, const double* cams, int64_t cam_stride, const double* corresp,
+                             int64_t corresp_stride, const double* pts3d, int64_t B, int32_t N, double* err);
+
+/* Inlier count of pose hypotheses against ONE shared scene (6 x Ns): cameras K1[I|0], K2 Rt2[b], K3 Rt3[b];
+ * a correspondence is an inlier when all six reprojection residuals after triangulation are <= threshold in
+ * absolute value (experiments_real.m:94-98).  counts B int32; err (B, RMS) optional. */
+int tff_inlier_count_batch_dev(tff_ctx* ctx, const double* scene, int32_t Ns, const double* calm, const double* Rt2,
+                               const double* Rt3, int64_t B, double threshold, int32_t* counts, double* err);
+
+/* transform_TFT (TFT_methods/transform_TFT.m:32-49), inverse = 0 or 1; M1..M3 3x3, m_stride 9 or 0 (shared). */
+int tff_transform_tft_batch_dev(tff_ctx* ctx, const double* T, const double* M1, const double* M2, const double* M3,
+                                int64_t m_stride, int64_t B, int32_t inverse, double* Tout);
+
+/* R_t_from_TFT (TFT_methods/R_t_from_TFT.m:40-106): pixel-coordinate tensor + CalM + Corresp -> poses. */
+int tff_rt_from_tft_batch_dev(tff_ctx* ctx, const double* T, const double* calm, int64_t calm_stride,
+                              const double* corresp, int64_t B, int32_t N, double* Rt2, double* Rt3, int32_t* status);
+
+/* linearTFT (TFT_methods/linearTFT.m:33-91) on points used as given (rows x1;y1;x2;y2;x3;y3 of corresp):
+ * T (27, unit norm), P2, P3 (3x4 each, P1 = [I|0]; both NULL to skip). */
+int tff_linear_tft_batch_dev(tff_ctx* ctx, const double* corresp, int64_t B, int32_t N, double* T, double* P2,
+                             double* P3, int32_t* status);
+
+/* Minimal-sample hypotheses (BASELINE.json config 4): hypothesis b = the n correspondences
+ * sample_idx[b*n .. b*n+n) of one shared scene (6 x Ns); n >= 7 (TFT) / 8 (F); shared CalM (27). */
+int tff_linear_tft_pose_sampled_dev(tff_ctx* ctx, const double* scene, int32_t Ns, const double* calm,
+                                    const int32_t* sample_idx, int64_t B, int32_t n, double* Rt2, double* Rt3,
+                                    double* T, int32_t* status);
+int tff_linear_f_pose_sampled_dev(tff_ctx* ctx, const double* scene, int32_t Ns, const double* calm,
+                                  const int32_t* sample_idx, int64_t B, int32_t n, double* Rt2, double* Rt3,
+                                  double* T, int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,21 @@ def load_library(path=None):
             if fn is not None:
                 fn.argtypes = _POSE_SIG + [_c_dp]
                 fn.restype = ctypes.c_int
+        V, I64, I32, F64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_double
+        protos = {
+            "tff_triangulate_batch_dev": [V, V, I64, V, I64, I32, I32, V],
+            "tff_repr_error_batch_dev": [V, V, I64, V, I64, V, I64, I32, V],
+            "tff_inlier_count_batch_dev": [V, V, I32, V, V, V, I64, F64, V, V],
+            "tff_transform_tft_batch_dev": [V, V, V, V, V, I64, I64, I32, V],
+            "tff_rt_from_tft_batch_dev": [V, V, V, I64, V, I64, I32, V, V, V],
+            "tff_linear_tft_batch_dev": [V, V, I64, I32, V, V, V, V],
+            "tff_linear_tft_pose_sampled_dev": [V, V, I32, V, V, I64, I32, V, V, V, V],
+            "tff_linear_f_pose_sampled_dev": [V, V, I32, V, V, I64, I32, V, V, V, V],
+        }
+        for name, sig in protos.items():
+            fn = getattr(lib, name)
+            fn.argtypes = sig
+            fn.restype = ctypes.c_int
         if path is None:
             _lib = lib
         return lib
@@ -100,6 +115,8 @@ EXPORTED_SYMBOLS = [
     "tff_linear_tft_pose_batch_dev", "tff_linear_tft_pose_batch_host", "tff_linear_tft_pose_batch_debug_dev",
     "tff_linear_f_pose_batch_dev", "tff_linear_f_pose_batch_host",
     "tff_ressl_tft_pose_batch_dev", "tff_ressl_tft_pose_batch_host", "tff_ressl_tft_pose_batch_debug_dev",
+    "tff_triangulate_batch_dev", "tff_repr_error_batch_dev", "tff_inlier_count_batch_dev", "tff_transform_tft_batch_dev",
+    "tff_rt_from_tft_batch_dev", "tff_linear_tft_batch_dev", "tff_linear_tft_pose_sampled_dev", "tff_linear_f_pose_sampled_dev",
 ]
 
 
@@ -221,6 +238,116 @@ class Context:
                    Reconst=rec.transpose(1, 2) if reconst else None, iter=it, status=st,
                    _raw=(Rt2, Rt3, T, rec))
         return out
+
+
+    # ---- building blocks (torch CUDA tensors or numpy arrays in; torch CUDA tensors out) ------------
+    def _t(self, a, dtype=None):
+        dtype = dtype or torch.float64
+        if isinstance(a, np.ndarray):
+            a = torch.from_numpy(np.ascontiguousarray(a))
+        return a.to(device=torch.device("cuda", self.device), dtype=dtype).contiguous()
+
+    def _begin(self):
+        self.set_stream(torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream)
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+    @staticmethod
+    def _cams_cm(cams):
+        """(..., 3, 4) row-major numpy/torch cameras -> column-major flat layout of the ABI."""
+        return cams.transpose(-1, -2).contiguous()
+
+    def triangulate(self, cams, pts):
+        """triangulation3D: cams (B, M, 3, 4) or (M, 3, 4) shared; pts (B, N, 2M).  -> (B, 4, N) unit homogeneous."""
+        self._begin()
+        pts = self._t(pts); B, N, M2 = pts.shape; M = M2 // 2
+        cams = self._cams_cm(self._t(cams))
+        stride = 12 * M if cams.dim() == 4 else 0
+        X = torch.empty((B, N, 4), dtype=torch.float64, device=pts.device)
+        _check(self.lib, self.lib.tff_triangulate_batch_dev(self.handle, self._p(cams), stride, self._p(pts), B, M, N, self._p(X)),
+               "tff_triangulate_batch_dev")
+        return X.transpose(1, 2)
+
+    def repr_error(self, cams, corresp, pts3d=None):
+        """ReprError: cams (B, 3, 3, 4) or (3, 3, 4); corresp (B, N, 6) or (N, 6) shared; pts3d (B, 3, N) or None."""
+        self._begin()
+        cams = self._cams_cm(self._t(cams))
+        cstride = 36 if cams.dim() == 4 else 0
+        corresp = self._t(corresp)
+        N = corresp.shape[-2]
+        B = cams.shape[0] if cstride else (corresp.shape[0] if corresp.dim() == 3 else 1)
+        pstride = 6 * N if corresp.dim() == 3 else 0
+        p3 = self._t(pts3d).transpose(1, 2).contiguous() if pts3d is not None else None
+        err = torch.empty(B, dtype=torch.float64, device=corresp.device)
+        _check(self.lib, self.lib.tff_repr_error_batch_dev(self.handle, self._p(cams), cstride, self._p(corresp), pstride,
+                                                           self._p(p3), B, N, self._p(err)), "tff_repr_error_batch_dev")
+        return err
+
+    def inlier_count(self, scene, calm, R_t_2, R_t_3, threshold=1.0, with_error=False):
+        """Inlier counts (experiments_real.m:94-98 rule) of B pose hypotheses against one scene (Ns, 6)."""
+        self._begin()
+        scene = self._t(scene); Ns = scene.shape[0]
+        calm = self._t(calm).t().contiguous().reshape(27)
+        r2 = self._cams_cm(self._t(R_t_2)); r3 = self._cams_cm(self._t(R_t_3)); B = r2.shape[0]
+        cnt = torch.empty(B, dtype=torch.int32, device=scene.device)
+        err = torch.empty(B, dtype=torch.float64, device=scene.device) if with_error else None
+        _check(self.lib, self.lib.tff_inlier_count_batch_dev(self.handle, self._p(scene), Ns, self._p(calm), self._p(r2), self._p(r3), B,
+                                                             float(threshold), self._p(cnt), self._p(err)), "tff_inlier_count_batch_dev")
+        return (cnt, err) if with_error else cnt
+
+    def transform_tft(self, T, M1, M2, M3, inverse=0):
+        """transform_TFT: T (B,3,3,3) indexed [b,j,k,i]; M1..M3 (3,3) shared or (B,3,3)."""
+        self._begin()
+        T = self._t(T); B = T.shape[0]
+        Tv = T.permute(0, 3, 2, 1).contiguous()                               # -> flat index j + 3k + 9i
+        Ms = [self._t(M).transpose(-1, -2).contiguous() for M in (M1, M2, M3)]
+        stride = 9 if Ms[0].dim() == 3 else 0
+        out = torch.empty((B, 27), dtype=torch.float64, device=T.device)
+        _check(self.lib, self.lib.tff_transform_tft_batch_dev(self.handle, self._p(Tv), self._p(Ms[0]), self._p(Ms[1]), self._p(Ms[2]),
+                                                              stride, B, int(inverse), self._p(out)), "tff_transform_tft_batch_dev")
+        return out.reshape(B, 3, 3, 3).permute(0, 3, 2, 1)
+
+    def rt_from_tft(self, T, calm, corresp):
+        """R_t_from_TFT: T (B,3,3,3) [b,j,k,i] in pixel coordinates, calm (9,3), corresp (B,N,6)."""
+        self._begin()
+        T = self._t(T); B = T.shape[0]
+        Tv = T.permute(0, 3, 2, 1).contiguous()
+        corresp = self._t(corresp); N = corresp.shape[1]
+        calm = self._t(calm).t().contiguous().reshape(27)
+        Rt2 = torch.empty((B, 12), dtype=torch.float64, device=T.device); Rt3 = torch.empty_like(Rt2)
+        st = torch.zeros(B, dtype=torch.int32, device=T.device)
+        _check(self.lib, self.lib.tff_rt_from_tft_batch_dev(self.handle, self._p(Tv), self._p(calm), 0, self._p(corresp), B, N,
+                                                            self._p(Rt2), self._p(Rt3), self._p(st)), "tff_rt_from_tft_batch_dev")
+        return Rt2.reshape(B, 4, 3).transpose(1, 2), Rt3.reshape(B, 4, 3).transpose(1, 2), st
+
+    def linear_tft(self, corresp):
+        """linearTFT on the given (already normalised, if desired) points: corresp (B,N,6) -> T (B,3,3,3), P2, P3 (B,3,4)."""
+        self._begin()
+        corresp = self._t(corresp); B, N, _ = corresp.shape
+        T = torch.empty((B, 27), dtype=torch.float64, device=corresp.device)
+        P2 = torch.empty((B, 12), dtype=torch.float64, device=corresp.device); P3 = torch.empty_like(P2)
+        st = torch.zeros(B, dtype=torch.int32, device=corresp.device)
+        _check(self.lib, self.lib.tff_linear_tft_batch_dev(self.handle, self._p(corresp), B, N, self._p(T), self._p(P2), self._p(P3),
+                                                           self._p(st)), "tff_linear_tft_batch_dev")
+        return T.reshape(B, 3, 3, 3).permute(0, 3, 2, 1), P2.reshape(B, 4, 3).transpose(1, 2), P3.reshape(B, 4, 3).transpose(1, 2), st
+
+    def pose_sampled(self, method, scene, calm, sample_idx):
+        """Minimal-sample hypotheses (config 4): scene (Ns, 6), sample_idx (B, n) int32 -> R_t_2, R_t_3 (B,3,4), T, status."""
+        self._begin()
+        scene = self._t(scene); Ns = scene.shape[0]
+        idx = self._t(sample_idx, torch.int32); B, n = idx.shape
+        calm = self._t(calm).t().contiguous().reshape(27)
+        Rt2 = torch.empty((B, 12), dtype=torch.float64, device=scene.device); Rt3 = torch.empty_like(Rt2)
+        T = torch.empty((B, 27), dtype=torch.float64, device=scene.device)
+        st = torch.zeros(B, dtype=torch.int32, device=scene.device)
+        fn = {"LinearTFTPoseEstimation": self.lib.tff_linear_tft_pose_sampled_dev,
+              "LinearFPoseEstimation": self.lib.tff_linear_f_pose_sampled_dev}[method]
+        _check(self.lib, fn(self.handle, self._p(scene), Ns, self._p(calm), self._p(idx), B, n, self._p(Rt2), self._p(Rt3), self._p(T),
+                            self._p(st)), "pose_sampled")
+        return dict(R_t_2=Rt2.reshape(B, 4, 3).transpose(1, 2), R_t_3=Rt3.reshape(B, 4, 3).transpose(1, 2),
+                    T=T.reshape(B, 3, 3, 3).permute(0, 3, 2, 1), status=st, _raw=(Rt2, Rt3, T))
 
 
 _default_ctx = {}

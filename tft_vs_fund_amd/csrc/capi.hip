@@ -50,6 +50,7 @@ struct tff_ctx {
     int solver = 0;
     int stage = -1;
     DevBuf in, calm, out, idx, scratch_status;
+    const int32_t* sample_idx = nullptr;   // set around a *_sampled_dev call
 };
 
 namespace {
@@ -93,7 +94,12 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, bool may_stage
         status = (int32_t*)c->scratch_status.p;
     }
     tff::LinearTftArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr),
-                         Rt2, Rt3, T, reconst, iter, status, dbg};
+                         Rt2, Rt3, T, reconst, iter, status, dbg, c->sample_idx};
+    if (c->sample_idx) {                   // gathered samples always live in LDS
+        if (!may_stage) return fail(TFF_E_INVALID, "sampled hypotheses are not supported by this method");
+        a.flags |= tff::FLAG_STAGE_LDS;
+        may_stage = false;
+    }
     if (c->solver == 0) {
         tff::LinearTftArgs m = a;
         m.flags = may_stage ? staged_flags(c, N, a.flags, false) : a.flags;
@@ -272,6 +278,119 @@ int tff_linear_f_pose_batch_host(tff_ctx* c, const double* corresp, const double
                                  int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
                                  int32_t* status) {
     return pose_batch_host(launch_linear_f, c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Building blocks (device pointers only)
+// ---------------------------------------------------------------------------------------------
+int tff_triangulate_batch_dev(tff_ctx* c, const double* cams, int64_t cam_stride, const double* pts, int64_t B, int32_t M,
+                              int32_t N, double* X) {
+    if (!c) return fail(TFF_E_INVALID, "null context");
+    if (B < 0 || N < 0 || (M != 2 && M != 3)) return fail(TFF_E_INVALID, "triangulate: M must be 2 or 3");    // triangulation3D.m:33,46
+    if (cam_stride != 0 && cam_stride != 12 * M) return fail(TFF_E_INVALID, "cam_stride must be 0 or 12*M");
+    if (B == 0 || N == 0) return 0;
+    if (!cams || !pts || !X) return fail(TFF_E_INVALID, "null pointer");
+    TFF_HIP(hipSetDevice(c->device));
+    tff::TriangulateArgs a{cams, (long)cam_stride, pts, (long)B, M, N, X};
+    hipLaunchKernelGGL(tff::k_triangulate, dim3(tff::pose_grid(B)), dim3(64), 0, c->stream, a);
+    TFF_HIP(hipGetLastError());
+    return 0;
+}
+
+int tff_repr_error_batch_dev(tff_ctx* c, const double* cams, int64_t cam_stride, const double* corresp, int64_t corresp_stride,
+                             const double* pts3d, int64_t B, int32_t N, double* err) {
+    if (!c) return fail(TFF_E_INVALID, "null context");
+    if (B < 0 || N < 0) return fail(TFF_E_INVALID, "negative size");
+    if (cam_stride != 0 && cam_stride != 36) return fail(TFF_E_INVALID, "cam_stride must be 0 or 36");
+    if (corresp_stride != 0 && corresp_stride != 6 * (int64_t)N) return fail(TFF_E_INVALID, "corresp_stride must be 0 or 6*N");
+    if (B == 0) return 0;
+    if (!cams || !corresp || !err) return fail(TFF_E_INVALID, "null pointer");
+    TFF_HIP(hipSetDevice(c->device));
+    tff::ReprErrorArgs a{cams, (long)cam_stride, nullptr, nullptr, nullptr, corresp, (long)corresp_stride, pts3d, (long)B, N, 0.0, err, nullptr};
+    hipLaunchKernelGGL(tff::k_repr_error, dim3(tff::pose_grid(B)), dim3(64), 0, c->stream, a);
+    TFF_HIP(hipGetLastError());
+    return 0;
+}
+
+int tff_inlier_count_batch_dev(tff_ctx* c, const double* scene, int32_t Ns, const double* calm, const double* Rt2, const double* Rt3,
+                               int64_t B, double threshold, int32_t* counts, double* err) {
+    if (!c) return fail(TFF_E_INVALID, "null context");
+    if (B < 0 || Ns < 0) return fail(TFF_E_INVALID, "negative size");
+    if (B == 0) return 0;
+    if (!scene || !calm || !Rt2 || !Rt3 || !counts) return fail(TFF_E_INVALID, "null pointer");
+    TFF_HIP(hipSetDevice(c->device));
+    tff::ReprErrorArgs a{nullptr, 0, calm, Rt2, Rt3, scene, 0, nullptr, (long)B, Ns, threshold, err, counts};
+    hipLaunchKernelGGL(tff::k_repr_error, dim3(tff::pose_grid(B)), dim3(64), 0, c->stream, a);
+    TFF_HIP(hipGetLastError());
+    return 0;
+}
+
+int tff_transform_tft_batch_dev(tff_ctx* c, const double* T, const double* M1, const double* M2, const double* M3, int64_t m_stride,
+                                int64_t B, int32_t inverse, double* Tout) {
+    if (!c) return fail(TFF_E_INVALID, "null context");
+    if (B < 0 || (m_stride != 0 && m_stride != 9) || (inverse != 0 && inverse != 1)) return fail(TFF_E_INVALID, "bad argument");
+    if (B == 0) return 0;
+    if (!T || !M1 || !M2 || !M3 || !Tout) return fail(TFF_E_INVALID, "null pointer");
+    TFF_HIP(hipSetDevice(c->device));
+    tff::TransformArgs a{T, M1, M2, M3, (long)m_stride, (long)B, inverse, Tout};
+    hipLaunchKernelGGL(tff::k_transform_tft, dim3(tff::pose_grid(B)), dim3(64), 0, c->stream, a);
+    TFF_HIP(hipGetLastError());
+    return 0;
+}
+
+int tff_rt_from_tft_batch_dev(tff_ctx* c, const double* T, const double* calm, int64_t calm_stride, const double* corresp, int64_t B,
+                              int32_t N, double* Rt2, double* Rt3, int32_t* status) {
+    if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
+    if (B == 0) return 0;
+    if (!T || !Rt2 || !Rt3) return fail(TFF_E_INVALID, "null pointer");
+    TFF_HIP(hipSetDevice(c->device));
+    tff::RtFromTftArgs a{T, calm, (long)calm_stride, corresp, (long)B, N, Rt2, Rt3, status};
+    const size_t lds = tff::pose_lds_bytes(N, 0, false);
+    hipLaunchKernelGGL(tff::k_rt_from_tft, dim3(tff::pose_grid(B)), dim3(64), lds, c->stream, a);
+    TFF_HIP(hipGetLastError());
+    return 0;
+}
+
+int tff_linear_tft_batch_dev(tff_ctx* c, const double* corresp, int64_t B, int32_t N, double* T, double* P2, double* P3,
+                             int32_t* status) {
+    if (!c) return fail(TFF_E_INVALID, "null context");
+    if (B < 0 || N < 0) return fail(TFF_E_INVALID, "negative size");
+    if (B == 0) return 0;
+    if (!corresp || !T || ((P2 == nullptr) != (P3 == nullptr))) return fail(TFF_E_INVALID, "null pointer (P2 and P3 come together)");
+    TFF_HIP(hipSetDevice(c->device));
+    if (!status) {
+        if (int r = c->scratch_status.reserve((size_t)B * sizeof(int32_t))) return r;
+        status = (int32_t*)c->scratch_status.p;
+    }
+    tff::LinearTftOnlyArgs a{corresp, (long)B, N, 0, T, P2, P3, status};
+    if (c->solver == 0) {
+        hipLaunchKernelGGL(tff::k_linear_tft<false>, dim3(tff::pose_grid(B)), dim3(64), tff::pose_lds_bytes(N, 0, false), c->stream, a);
+        TFF_HIP(hipGetLastError());
+        a.flags |= tff::FLAG_ONLY_RETRY;
+    }
+    const unsigned grid = (c->solver == 0) ? (unsigned)(B < 1024 ? B : 1024) : tff::pose_grid(B);
+    hipLaunchKernelGGL(tff::k_linear_tft<true>, dim3(grid), dim3(64), tff::pose_lds_bytes(N, 0, true), c->stream, a);
+    TFF_HIP(hipGetLastError());
+    return 0;
+}
+
+// Minimal-sample hypotheses (config 4): hypothesis b uses correspondences sample_idx[b*n .. b*n+n) of ONE shared scene.
+int tff_linear_tft_pose_sampled_dev(tff_ctx* c, const double* scene, int32_t Ns, const double* calm, const int32_t* sample_idx, int64_t B,
+                                    int32_t n, double* Rt2, double* Rt3, double* T, int32_t* status) {
+    if (!sample_idx || Ns <= 0) return fail(TFF_E_INVALID, "null sample indices / empty scene");
+    c->sample_idx = sample_idx;
+    const int r = launch_linear_tft(c, scene, calm, 0, B, n, Rt2, Rt3, T, nullptr, nullptr, status, nullptr);
+    c->sample_idx = nullptr;
+    return r;
+}
+int tff_linear_f_pose_sampled_dev(tff_ctx* c, const double* scene, int32_t Ns, const double* calm, const int32_t* sample_idx, int64_t B,
+                                  int32_t n, double* Rt2, double* Rt3, double* T, int32_t* status) {
+    if (!sample_idx || Ns <= 0) return fail(TFF_E_INVALID, "null sample indices / empty scene");
+    c->sample_idx = sample_idx;
+    const int r = launch_linear_f(c, scene, calm, 0, B, n, Rt2, Rt3, T, nullptr, nullptr, status, nullptr);
+    c->sample_idx = nullptr;
+    return r;
 }
 
 }  // extern "C"

@@ -99,7 +99,10 @@ __global__ void __launch_bounds__(64, 2) k_linear_f_pose(const LinearTftArgs a) 
         const double* src = a.corresp + b * 6 * (long)N;
         const double* pts = src;
         wave_sync();
-        if (a.flags & FLAG_STAGE_LDS) {
+        if (a.sample_idx) {
+            gather_points(a.corresp, a.sample_idx + b * (long)N, lds_pts, N);
+            pts = lds_pts;
+        } else if (a.flags & FLAG_STAGE_LDS) {
             stage_points(src, lds_pts, N);
             pts = lds_pts;
         }

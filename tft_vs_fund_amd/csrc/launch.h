@@ -3,6 +3,7 @@
 #include "tft_kernel.h"
 #include "f_kernel.h"
 #include "gh_kernel.h"
+#include "blocks_kernel.h"
 
 namespace tff {
 

@@ -85,6 +85,17 @@ __device__ inline void stage_points(const double* __restrict__ src, double* dst,
     wave_sync();
 }
 
+// Minimal-sample hypotheses (config 4): gather N correspondences of one shared scene by index.
+__device__ inline void gather_points(const double* __restrict__ scene, const int* __restrict__ idx, double* dst, int N) {
+    const int lane = lane_id();
+    for (int e = lane; e < 3 * N; e += WAVE) {
+        const int i = e / 3, part = e % 3;
+        const double2* s2 = reinterpret_cast<const double2*>(scene + 6 * (long)idx[i]);
+        reinterpret_cast<double2*>(dst)[e] = s2[part];
+    }
+    wave_sync();
+}
+
 // Normalize2Ddata.m:33-39 for the three views at once.  nrm[3v..3v+2] = s, ox, oy.
 // `pre` (9 doubles or null) is an affine map applied to the raw points first
 // (x' = s x + ox): linearF normalises points that LinearFPoseEstimation has

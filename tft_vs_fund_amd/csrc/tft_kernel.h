@@ -53,6 +53,7 @@ struct LinearTftArgs {
     int* iter;               // B or null
     int* status;             // B (never null inside the library: the context supplies one)
     double* dbg;             // B x DBG_STRIDE or null
+    const int* sample_idx;   // null, or B x N int32 indices into ONE shared scene at `corresp` (config 4: minimal samples)
 };
 
 // c-vector of a pair of 3-vectors (see header): bilinear weights of the q-monomials
@@ -320,7 +321,10 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose(const LinearTftArgs a
         const double* src = a.corresp + b * 6 * (long)N;
         const double* pts = src;
         wave_sync();
-        if (a.flags & FLAG_STAGE_LDS) {
+        if (a.sample_idx) {
+            gather_points(a.corresp, a.sample_idx + b * (long)N, lds_pts, N);
+            pts = lds_pts;
+        } else if (a.flags & FLAG_STAGE_LDS) {
             stage_points(src, lds_pts, N);
             pts = lds_pts;
         }
