@@ -99,6 +99,15 @@ int tff_ressl_tft_pose_batch_debug_dev(tff_ctx* ctx, const double* corresp, cons
                                        int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
                                        int32_t* iter, int32_t* status, double* dbg);
 
+/* FaugPapaTFTPoseEstimation (TFT_methods/FaugPapaTFTPoseEstimation.m:48-159): all 27 tensor entries as
+ * parameters, 12 algebraic constraints (3 determinants + 9 extended-rank), Gauss-Helmert refinement. */
+int tff_faugpapa_tft_pose_batch_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                                    int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                    int32_t* iter, int32_t* status);
+int tff_faugpapa_tft_pose_batch_host(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                                     int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                     int32_t* iter, int32_t* status);
+
 /* LinearFPoseEstimation (F_methods/LinearFPoseEstimation.m:42-109): Normalize2Ddata x3 ->
  * linearF x2 (F_methods/linearF.m:32-62) -> recover_R_t x2 -> t3 scale -> (Reconst) ->
  * T = TFT_from_P (TFT_methods/TFT_from_P.m:25-33).  Needs N >= 8 (status TFF_ST_TOO_FEW otherwise). */

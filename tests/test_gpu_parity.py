@@ -293,31 +293,36 @@ def _ressl_tol(N, same_iterations=True):
     return 1e-2 if N < 50 else 2e-3
 
 
-def test_ressl_golden_synthetic(gpu_ctx, golden_dir):
+GH_METHODS = [("ResslTFTPoseEstimation", "ressl"), ("FaugPapaTFTPoseEstimation", "faugpapa")]
+
+
+@pytest.mark.parametrize("method,key", GH_METHODS)
+def test_gh_golden_synthetic(gpu_ctx, golden_dir, method, key):
     g = np.load(os.path.join(golden_dir, "synthetic_gh.npz"))
     worst = {}
     for ci, pre in golden_cases(g):
         C, CalM = g[pre + "Corresp"], g[pre + "CalM"]
         N = C.shape[1]
-        out = gpu_ctx.pose_batch("ResslTFTPoseEstimation", C, CalM, reconst=True)
+        out = gpu_ctx.pose_batch(method, C, CalM, reconst=True)
         assert np.all(out["status"] == 0)
         for b in range(C.shape[0]):
-            dit = int(out["iter"][b]) - int(g[pre + "ressl_iter"][b])
+            dit = int(out["iter"][b]) - int(g[pre + key + "_iter"][b])
             assert abs(dit) <= 2
-            e = max(rel_err_T(out["T"][b], g[pre + "ressl_T"][b]), rel_err(out["R_t_2"][b], g[pre + "ressl_Rt2"][b]),
-                    rel_err(out["R_t_3"][b], g[pre + "ressl_Rt3"][b]))
+            e = max(rel_err_T(out["T"][b], g[pre + key + "_T"][b]), rel_err(out["R_t_2"][b], g[pre + key + "_Rt2"][b]),
+                    rel_err(out["R_t_3"][b], g[pre + key + "_Rt3"][b]))
             worst[(N, dit)] = max(worst.get((N, dit), 0), e)
             assert e < _ressl_tol(N, dit == 0), (ci, b, dit, e)
-            assert rel_err(out["Reconst"][b], g[pre + "ressl_Rec"][b]) < 10 * _ressl_tol(N, dit == 0)
-    print("Ressl worst relative deviation from the dense oracle by (N, iteration difference):", worst)
+            assert rel_err(out["Reconst"][b], g[pre + key + "_Rec"][b]) < 10 * _ressl_tol(N, dit == 0)
+    print(method, "worst relative deviation from the dense oracle by (N, iteration difference):", worst)
 
 
-def test_ressl_noise_free_is_exact(gpu_ctx):
+@pytest.mark.parametrize("method,key", GH_METHODS)
+def test_gh_noise_free_is_exact(gpu_ctx, method, key):
     """sigma = 0: the linear solution already satisfies every constraint; Gauss-Helmert stops at once and the
     ground truth is recovered to rounding (the known answer the oracle itself is pinned with)."""
     from tft_vs_fund_amd.scenes import generate_scene_batch
     C, CalM, Rt0, _ = generate_scene_batch(8, 40, noise=0.0, seed=3)
-    out = gpu_ctx.pose_batch("ResslTFTPoseEstimation", C, CalM, reconst=False)
+    out = gpu_ctx.pose_batch(method, C, CalM, reconst=False)
     assert np.all(out["status"] == 0) and np.all(out["iter"] <= 2)
     s = np.linalg.norm(Rt0[0][:, 3])
     for b in range(8):
@@ -326,7 +331,8 @@ def test_ressl_noise_free_is_exact(gpu_ctx):
         assert np.abs(out["R_t_3"][b][:, 3] - Rt0[1][:, 3] / s).max() < 1e-7
 
 
-def test_ressl_vs_oracle_metrics_and_iterations(gpu_ctx):
+@pytest.mark.parametrize("method,key", GH_METHODS)
+def test_gh_vs_oracle_metrics_and_iterations(gpu_ctx, method, key):
     """Downstream metrics (AngError, ReprError: what experiments.m:112-120 records) and the iteration histogram
     against the dense oracle on seeded scenes."""
     from tft_vs_fund_amd import api
@@ -334,11 +340,11 @@ def test_ressl_vs_oracle_metrics_and_iterations(gpu_ctx):
     O = _oracle()
     B, N = 12, 60
     C, CalM, Rt0, _ = generate_scene_batch(B, N, noise=1.0, seed=77)
-    out = gpu_ctx.pose_batch("ResslTFTPoseEstimation", C, CalM, reconst=True)
+    out = gpu_ctx.pose_batch(method, C, CalM, reconst=True)
     assert np.all(out["status"] == 0)
     dit = []
     for b in range(B):
-        R2, R3, Rec, T, it = O.ResslTFTPoseEstimation(C[b].T.copy(), CalM)
+        R2, R3, Rec, T, it = getattr(O, method)(C[b].T.copy(), CalM)
         dit.append(int(out["iter"][b]) - it)
         for k, (Rg, Ro) in enumerate(((out["R_t_2"][b], R2), (out["R_t_3"][b], R3))):
             rg, tg = O.AngError(Rt0[k], Rg); ro, to = O.AngError(Rt0[k], Ro)
@@ -348,20 +354,21 @@ def test_ressl_vs_oracle_metrics_and_iterations(gpu_ctx):
         eo = O.ReprError(P(R2, R3), C[b].T.copy(), Rec)
         assert abs(eg - eo) < 1e-3 * eo
     assert max(abs(d) for d in dit) <= 2 and sum(1 for d in dit if d == 0) >= B // 2
-    R2, R3, Rec, T, it = api.ResslTFTPoseEstimation(C[0].T.copy(), CalM)        # reference-shaped call
+    R2, R3, Rec, T, it = getattr(api, method)(C[0].T.copy(), CalM)              # reference-shaped call
     assert it == int(out["iter"][0]) and R2.shape == (3, 4) and T.shape == (3, 3, 3)
 
 
-def test_ressl_improves_on_linear_and_full_size(gpu_ctx):
-    """configs[2]: the 10k x 200 batch through ResslTFTPoseEstimation; the refinement must not be worse than
+@pytest.mark.parametrize("method,B", [("ResslTFTPoseEstimation", 2000), ("FaugPapaTFTPoseEstimation", 300)])
+def test_gh_improves_on_linear_and_full_size(gpu_ctx, method, B):
+    """configs[2]: N = 200 batches through the Gauss-Helmert methods; the refinement must not be worse than
     its linear initialisation in mean pose error."""
     import torch
     from tft_vs_fund_amd.scenes import generate_scene_batch
-    B, N = 2000, 200
+    N = 200
     C, CalM, Rt0, _ = generate_scene_batch(B, N, noise=1.0, seed=99)
     d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
     lin = gpu_ctx.pose_batch("LinearTFTPoseEstimation", d, calm, reconst=False)
-    res = gpu_ctx.pose_batch("ResslTFTPoseEstimation", d, calm, reconst=False)
+    res = gpu_ctx.pose_batch(method, d, calm, reconst=False)
     torch.cuda.synchronize()
     assert int((res["status"] != 0).sum()) == 0
     it = res["iter"].cpu().numpy()

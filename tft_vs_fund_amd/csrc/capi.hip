@@ -131,8 +131,13 @@ int launch_linear_f(tff_ctx* c, const double* corresp, const double* calm, int64
 
 int launch_ressl_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    return launch_pose(c, tff::k_ressl_tft_pose<false>, tff::k_ressl_tft_pose<true>, tff::ressl_lds_bytes, false, corresp, calm, calm_stride,
-                       B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    return launch_pose(c, tff::k_gh_tft_pose<tff::ResslModel, false>, tff::k_gh_tft_pose<tff::ResslModel, true>,
+                       tff::gh_lds_bytes<tff::ResslModel>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+}
+int launch_faugpapa_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
+                        double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+    return launch_pose(c, tff::k_gh_tft_pose<tff::FaugPapaModel, false>, tff::k_gh_tft_pose<tff::FaugPapaModel, true>,
+                       tff::gh_lds_bytes<tff::FaugPapaModel>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 
 typedef int (*pose_launcher)(tff_ctx*, const double*, const double*, int64_t, int64_t, int32_t, double*, double*, double*, double*,
@@ -267,6 +272,17 @@ int tff_ressl_tft_pose_batch_debug_dev(tff_ctx* c, const double* corresp, const 
                                        int32_t* iter, int32_t* status, double* dbg) {
     if (!dbg) return fail(TFF_E_INVALID, "null debug buffer");
     return launch_ressl_tft(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+}
+
+int tff_faugpapa_tft_pose_batch_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                                     int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                                     int32_t* status) {
+    return launch_faugpapa_tft(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, nullptr);
+}
+int tff_faugpapa_tft_pose_batch_host(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                                      int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                                      int32_t* status) {
+    return pose_batch_host(launch_faugpapa_tft, c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status);
 }
 
 int tff_linear_f_pose_batch_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,

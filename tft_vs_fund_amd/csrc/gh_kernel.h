@@ -43,13 +43,14 @@ struct GhWork {                       // per-wave LDS carve-up for one Gauss-Hel
     double* H;      // 270 + 27 accumulated sums: H[6 e + hh] (e: lower triangle of the 9x9 Z), then ghat[27]
     double* Y;      // 27 x u   Ghat * D
     double* M;      // (u+c) x (u+c+1) augmented KKT matrix
+    double* V;      // (u+c)^2 eigenvectors of the KKT matrix (pinv path)
     double* xi;     // 6N       current estimates of the observations
     double* pp;     // 14N      per correspondence: W+ (10, packed lower) and W+ w (4); then v (6)
     int u, c;
 };
 __host__ __device__ inline int gh_lds_doubles(int u, int c, int N) {
     const int n = u + c;
-    return 2 * ((u + 1) & ~1) + 2 * c + 28 + 28 + 27 * u + 729 + 298 + 27 * u + n * (n + 1) + 6 * N + 14 * N + 8;
+    return 2 * ((u + 1) & ~1) + 2 * c + 28 + 28 + 27 * u + 729 + 298 + 27 * u + n * (n + 1) + n * n + 6 * N + 14 * N + 8;
 }
 __device__ inline GhWork gh_carve(double* base, int u, int c, int N) {
     GhWork g;
@@ -64,6 +65,7 @@ __device__ inline GhWork gh_carve(double* base, int u, int c, int N) {
     g.H = q; q += 298;
     g.Y = q; q += 27 * u;
     g.M = q; q += n * (n + 1);
+    g.V = q; q += n * n;
     g.xi = q; q += 6 * N;
     g.pp = q; q += 14 * N;
     g.u = u; g.c = c;
@@ -313,10 +315,125 @@ __device__ inline bool wave_solve_pivoted(double* M, int n, double* sol) {
     return ok;
 }
 
+// cameras of the initial projective reconstruction: P1 = [I|0] -> Pfin[0], P2 -> P[0], P3 -> P[1] (row-major)
+__device__ inline void gh_linear_cameras(PoseLds* w) {
+    const int lane = lane_id();
+    if (lane < 12) {
+        const int r = lane >> 2, c = lane & 3;
+        w->Pfin[0][lane] = (r == c) ? 1.0 : 0.0;
+        w->P[0][lane] = (c < 3) ? w->pa[3 * c + r] : w->epi[r];              // P2 = [reshape(a(1:9),3,3) e21]    (linearTFT.m:89)
+        w->P[1][lane] = (c < 3) ? w->pa[9 + 3 * c + r] : w->epi[3 + r];      // P3 = [reshape(a(10:18),3,3) e31]  (linearTFT.m:90)
+    }
+    wave_sync();
+}
+
+__device__ __forceinline__ double det3(const double (&A)[3][3]) {
+    return A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0])
+         + A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+}
+// signed cofactor, FaugPapaTFTPoseEstimation.m:156-159 (`minor`), i and j static
+template <int i, int j>
+__device__ __forceinline__ double cof3(const double (&A)[3][3]) {
+    constexpr int r0 = (i == 0) ? 1 : 0, r1 = (i == 2) ? 1 : 2, c0 = (j == 0) ? 1 : 0, c1 = (j == 2) ? 1 : 2;
+    const double d = A[r0][c0] * A[r1][c1] - A[r0][c1] * A[r1][c0];
+    return ((i + j) % 2 == 0) ? d : -d;
+}
+
+// ---- Faugeras-Papadopoulo: all 27 entries, 12 algebraic constraints (FaugPapaTFTPoseEstimation.m:48-153) ----
+struct FaugPapaModel {
+    static constexpr int U = 27, C = 12;
+    static constexpr bool IDENTITY_D = true;
+    static constexpr bool REDUNDANT_CONSTRAINTS = true;     // trifocal tensors have codimension 9 < 12: singular KKT, pinv truncates
+    __device__ inline void init(PoseLds* w, GhWork& g) {                    // param0 = T(:)   (:65)
+        const int lane = lane_id();
+        if (lane < 27) g.p[lane] = w->t[lane];
+        wave_sync();
+        gh_linear_cameras(w);
+    }
+    __device__ inline void eval(GhWork& g) const {
+        const int lane = lane_id();
+        constexpr int u = U, n = U + C, ld = n + 1;
+        for (int e = lane; e < n * ld; e += WAVE) g.M[e] = 0.0;
+        if (lane < 27) g.Tc[lane] = g.p[lane];
+        wave_sync();
+        const double* T = g.Tc;
+        if (lane < 3) {                                                      // det(T_i) = 0   (:117-124)
+            const int i = lane;
+            double A[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) A[j][k] = T[j + 3 * k + 9 * i];
+            const int row = u + i;
+            g.M[row * ld + n] = -det3(A);
+#define TFF_C1(J, K) { const double v = cof3<J, K>(A); const int col = J + 3 * K + 9 * i; g.M[row * ld + col] = v; g.M[col * ld + row] = v; }
+            TFF_C1(0, 0) TFF_C1(0, 1) TFF_C1(0, 2) TFF_C1(1, 0) TFF_C1(1, 1) TFF_C1(1, 2) TFF_C1(2, 0) TFF_C1(2, 1) TFF_C1(2, 2)
+#undef TFF_C1
+        } else if (lane < 12) {                                              // extended rank constraints   (:126-150)
+            const int c9 = lane - 3;
+            // (k2,k3,l2,l3) in the nesting order of the reference's loops
+            const int k2 = (c9 >= 6) ? 1 : 0;
+            const int k3 = (c9 == 4 || c9 == 5 || c9 == 8) ? 1 : 0;
+            const int l2 = (c9 == 0 || c9 == 1 || c9 == 4) ? 1 : 2;
+            const int l3 = (c9 == 0 || c9 == 2 || c9 == 6) ? 1 : 2;
+            const int pk2k3 = k2 + 3 * k3, pk2l3 = k2 + 3 * l3, pl2l3 = l2 + 3 * l3, pl2k3 = l2 + 3 * k3;
+            double A1[3][3], A2[3][3], A3[3][3], A4[3][3];                   // rows: tensor positions, columns: slices
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double a = T[pk2k3 + 9 * i], b = T[pk2l3 + 9 * i], c = T[pl2l3 + 9 * i], d = T[pl2k3 + 9 * i];
+                A1[0][i] = a; A1[1][i] = b; A1[2][i] = c;
+                A2[0][i] = a; A2[1][i] = d; A2[2][i] = c;
+                A3[0][i] = d; A3[1][i] = b; A3[2][i] = c;
+                A4[0][i] = a; A4[1][i] = d; A4[2][i] = b;
+            }
+            const double d1 = det3(A1), d2 = det3(A2), d3 = det3(A3), d4 = det3(A4);
+            const int row = u + lane;
+            g.M[row * ld + n] = -(d1 * d2 - d3 * d4);
+#define TFF_C9(I1) { \
+            const double v0 = cof3<I1, 0>(A1) * d2 + d1 * cof3<I1, 0>(A2) - d3 * cof3<I1, 0>(A4); \
+            const double v1 = cof3<I1, 1>(A1) * d2 - cof3<I1, 1>(A3) * d4 - d3 * cof3<I1, 2>(A4); \
+            const double v2 = cof3<I1, 2>(A1) * d2 + d1 * cof3<I1, 2>(A2) - cof3<I1, 2>(A3) * d4; \
+            const double v3 = d1 * cof3<I1, 1>(A2) - cof3<I1, 0>(A3) * d4 - d3 * cof3<I1, 1>(A4); \
+            const int c0 = pk2k3 + 9 * I1, c1 = pk2l3 + 9 * I1, c2 = pl2l3 + 9 * I1, c3 = pl2k3 + 9 * I1; \
+            g.M[row * ld + c0] = v0; g.M[c0 * ld + row] = v0; g.M[row * ld + c1] = v1; g.M[c1 * ld + row] = v1; \
+            g.M[row * ld + c2] = v2; g.M[c2 * ld + row] = v2; g.M[row * ld + c3] = v3; g.M[c3 * ld + row] = v3; }
+            TFF_C9(0) TFF_C9(1) TFF_C9(2)
+#undef TFF_C9
+        }
+        wave_sync();
+    }
+};
+
+// x = pinv(M) b for the symmetric n x n matrix held (with b as column n) in the augmented n x (n+1) array:
+// eigen-decomposition M = V L V', singular values |lambda_k|, MATLAB's pinv tolerance n * eps(max |lambda|),
+// x = sum_{|lambda_k| > tol} v_k (v_k' b) / lambda_k.  Needed when the constraints are redundant (KKT singular).
+__device__ inline void wave_pinv_solve_sym(double* M, double* V, int n, double* sol, double* coef) {
+    const int lane = lane_id();
+    const int ld = n + 1;
+    wave_jacobi_sym(M, ld, V, n, n);
+    const double lam = (lane < n) ? M[lane * ld + lane] : 0.0;
+    const double amax = wave_max(fabs(lam));
+    const double tol = (double)n * eps_of(amax);
+    if (lane < n) {
+        double d = 0.0;
+        for (int r = 0; r < n; ++r) d += V[r * n + lane] * M[r * ld + n];
+        coef[lane] = (fabs(lam) > tol) ? d / lam : 0.0;
+    }
+    wave_sync();
+    if (lane < n) {
+        double x = 0.0;
+        for (int k = 0; k < n; ++k) x += V[lane * n + k] * coef[k];
+        sol[lane] = x;
+    }
+    wave_sync();
+}
+
 // ---- Ressl's minimal parameterisation (ResslTFTPoseEstimation.m:56-68,79,110-135,164-170) ----
 struct ResslModel {
     int Ind;                                                                 // argmax |e21|, 0-based
     static constexpr int U = 20, C = 2;
+    static constexpr bool IDENTITY_D = false;
+    static constexpr bool REDUNDANT_CONSTRAINTS = false;
     // initial parameters from linearTFT's output (w->t constrained tensor, w->epi)
     __device__ inline void init(PoseLds* w, GhWork& g) {
         const int lane = lane_id();
@@ -341,6 +458,7 @@ struct ResslModel {
             g.p[11 + i + 3 * m] = acc;
         }
         wave_sync();
+        gh_linear_cameras(w);
     }
     // p -> Tc, D, and the constraint rows / right-hand side of the KKT matrix
     __device__ inline void eval(GhWork& g) const {
@@ -455,22 +573,29 @@ __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, co
             g.G[e] = g.H[6 * (hi * (hi + 1) / 2 + lo) + hht_index(i1, i1p)];
         }
         wave_sync();
-        for (int e = lane; e < 27 * u; e += WAVE) {                          // Y = Ghat D
-            const int r = e / u, pcol = e % u;
-            double a = 0.0;
-            for (int k = 0; k < 27; ++k) a += g.G[r * 27 + k] * g.D[k * u + pcol];
-            g.Y[e] = a;
-        }
-        wave_sync();
-        for (int e = lane; e < u * u + u; e += WAVE) {                       // M = [D'Y + 1e-12 I ...], b = [D' ghat; -g]
-            const int pr = e / u, pc = e % u;
-            double a = 0.0;
-            if (e < u * u) {
-                for (int k = 0; k < 27; ++k) a += g.D[k * u + pr] * g.Y[k * u + pc];
-                g.M[pr * ld + pc] = a + ((pr == pc) ? 1e-12 : 0.0);
-            } else {
-                for (int k = 0; k < 27; ++k) a += g.D[k * u + pc] * g.H[270 + k];
-                g.M[pc * ld + n] = a;
+        if (Model::IDENTITY_D) {                                             // A = Ap: A'WA = Ghat, A'Ww = ghat
+            for (int e = lane; e < 729 + 27; e += WAVE) {
+                if (e < 729) g.M[(e / 27) * ld + e % 27] = g.G[e] + ((e / 27 == e % 27) ? 1e-12 : 0.0);
+                else g.M[(e - 729) * ld + n] = g.H[270 + e - 729];
+            }
+        } else {
+            for (int e = lane; e < 27 * u; e += WAVE) {                      // Y = Ghat D
+                const int r = e / u, pcol = e % u;
+                double a = 0.0;
+                for (int k = 0; k < 27; ++k) a += g.G[r * 27 + k] * g.D[k * u + pcol];
+                g.Y[e] = a;
+            }
+            wave_sync();
+            for (int e = lane; e < u * u + u; e += WAVE) {                   // M = [D'Y + 1e-12 I ...], b = [D' ghat; -g]
+                const int pr = e / u, pc = e % u;
+                double a = 0.0;
+                if (e < u * u) {
+                    for (int k = 0; k < 27; ++k) a += g.D[k * u + pr] * g.Y[k * u + pc];
+                    g.M[pr * ld + pc] = a + ((pr == pc) ? 1e-12 : 0.0);
+                } else {
+                    for (int k = 0; k < 27; ++k) a += g.D[k * u + pc] * g.H[270 + k];
+                    g.M[pc * ld + n] = a;
+                }
             }
         }
         if (lane < c) g.M[(u + lane) * ld + u + lane] = 1e-12;
@@ -478,11 +603,14 @@ __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, co
         double chkM = 0.0;
         for (int e = lane; e < n * ld; e += WAVE) chkM += g.M[e];
         if (!(fabs(wave_sum(chkM)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
-        if (!wave_solve_pivoted(g.M, n, g.dt)) { *st = ST_RANK; break; }    // aux = pinv(M + 1e-12 I) * b   (:67)
+        // aux = pinv(M + 1e-12 I) * b   (:67)
+        if (Model::REDUNDANT_CONSTRAINTS) wave_pinv_solve_sym(g.M, g.V, n, g.dt, g.Y);
+        else if (!wave_solve_pivoted(g.M, n, g.dt)) { *st = ST_RANK; break; }
         wave_sync();
         if (lane < 27) {                                                     // dT = D dt
             double a = 0.0;
-            for (int k = 0; k < u; ++k) a += g.D[lane * u + k] * g.dt[k];
+            if (Model::IDENTITY_D) a = g.dt[lane];
+            else for (int k = 0; k < u; ++k) a += g.D[lane * u + k] * g.dt[k];
             g.dT[lane] = a;
         }
         wave_sync();
@@ -535,8 +663,8 @@ __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, co
     return (it > GH_IT_MAX) ? GH_IT_MAX : it;                                // :82
 }
 
-template <bool JAC>
-__global__ void __launch_bounds__(64, 1) k_ressl_tft_pose(const LinearTftArgs a) {
+template <class Model, bool JAC>
+__global__ void __launch_bounds__(64, 1) k_gh_tft_pose(const LinearTftArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
     PoseLds* w = reinterpret_cast<PoseLds*>(smem);
     constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
@@ -549,7 +677,7 @@ __global__ void __launch_bounds__(64, 1) k_ressl_tft_pose(const LinearTftArgs a)
         double* dbg = a.dbg ? a.dbg + b * DBG_STRIDE : nullptr;
         const double* pts = a.corresp + b * 6 * (long)N;                     // re-read through L2 (LDS is taken by the GH workspace)
         wave_sync();
-        GhWork g = gh_carve(ghbase, ResslModel::U, ResslModel::C, N);
+        GhWork g = gh_carve(ghbase, Model::U, Model::C, N);
         if (lane < 27) w->calm[lane] = a.calm[b * a.calm_stride + lane];
         int status = ST_OK, iters = 0;
         if (N < 7) {
@@ -564,16 +692,9 @@ __global__ void __launch_bounds__(64, 1) k_ressl_tft_pose(const LinearTftArgs a)
             if (!ok) {
                 status = ST_RETRY;
             } else {
-                ResslModel model;
-                model.init(w, g);                                            // :56-68,:79
-                // x_est: reprojection of the projective triangulation with P1 = [I|0], P2, P3   (:72-75)
-                if (lane < 12) {
-                    const int r = lane >> 2, c = lane & 3;
-                    w->Pfin[0][lane] = (r == c) ? 1.0 : 0.0;
-                    w->P[0][lane] = (c < 3) ? w->pa[3 * c + r] : w->epi[r];            // P2 = [reshape(a(1:9),3,3) e21]
-                    w->P[1][lane] = (c < 3) ? w->pa[9 + 3 * c + r] : w->epi[3 + r];    // P3 = [reshape(a(10:18),3,3) e31]
-                }
-                wave_sync();
+                Model model;
+                model.init(w, g);                                            // initial parameters; cameras P1, P2, P3 of the linear solution
+                // x_est: reprojection of the projective triangulation with P1, P2, P3   (ResslTFT...m:72-75)
                 tri_pass(w, pts, N, TRI_REPROJECT, 1, w->P[0], w->P[1], g.xi, w->nrm);
                 wave_sync();
                 int gst = ST_OK;

@@ -22,10 +22,11 @@ inline int pose_auto_flags(int N, int flags, bool jacobi) {
 }
 // Gauss-Helmert kernels: correspondences are re-read through L2 (never staged); the LDS holds
 // the GH workspace instead (20 N + ~2.7k doubles for Ressl's 20 parameters / 2 constraints).
-inline size_t ressl_lds_bytes(int N, int /*flags*/, bool jacobi) {
+template <class Model>
+inline size_t gh_lds_bytes(int N, int /*flags*/, bool jacobi) {
     size_t d = (size_t)((POSE_LDS_DOUBLES + 1) & ~1);
     if (jacobi) d += (size_t)((JACOBI_LDS_DOUBLES + 1) & ~1);
-    d += (size_t)gh_lds_doubles(ResslModel::U, ResslModel::C, N);
+    d += (size_t)gh_lds_doubles(Model::U, Model::C, N);
     return d * sizeof(double);
 }
 inline unsigned pose_grid(long B) { return (unsigned)((B < (1L << 30)) ? (B > 0 ? B : 1) : (1L << 30)); }

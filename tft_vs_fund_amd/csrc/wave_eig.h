@@ -110,57 +110,64 @@ __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, 
 }
 __device__ __forceinline__ bool eig_converged(double resid2) { return resid2 == 0.0; }
 
-// Cyclic Jacobi on A (n x n, ld, symmetric, full storage, DESTROYED) with
-// eigenvectors accumulated in V (n x n, ld); returns, per lane r < n,
-// component r of the eigenvector of the smallest eigenvalue.  Rotation (p,q):
-// the lanes update the column pair of A and V, then the row pair of A.
-__device__ inline double wave_jacobi_min_eigvec(double* A, double* V, const int n, const int ld, int* sweeps_out) {
+// Cyclic Jacobi on the symmetric n x n matrix A (leading dimension lda, full storage, DESTROYED:
+// its diagonal ends up holding the eigenvalues) with the eigenvectors accumulated in the columns of
+// V (leading dimension ldv).  n <= 64 (one lane per row).  Rotation (p,q): the lanes update the
+// column pair of A and V, then the row pair of A.  Works for indefinite matrices (KKT systems).
+__device__ inline int wave_jacobi_sym(double* A, const int lda, double* V, const int ldv, const int n) {
     const int lane = lane_id();
-    const int lr = lane & 7, lc = lane >> 3;
-    for (int r = lr; r < n; r += 8)
-        for (int c = lc; c < n; c += 8) V[r * ld + c] = (r == c) ? 1.0 : 0.0;
-    const double absfloor = 1e-22 * wave_sum(lane < n ? fabs(A[lane * ld + lane]) : 0.0);
+    for (int e = lane; e < n * n; e += WAVE) V[(e / n) * ldv + e % n] = (e / n == e % n) ? 1.0 : 0.0;
+    const double absfloor = 1e-22 * wave_sum(lane < n ? fabs(A[lane * lda + lane]) : 0.0) + 1e-300;
     wave_sync();
     int sweep = 0;
+#pragma unroll 1
     for (; sweep < 40; ++sweep) {
         int rotations = 0;
+#pragma unroll 1
         for (int p = 0; p < n - 1; ++p) {
+#pragma unroll 1
             for (int q = p + 1; q < n; ++q) {
-                const double apq = A[p * ld + q], app = A[p * ld + p], aqq = A[q * ld + q];
+                const double apq = A[p * lda + q], app = A[p * lda + p], aqq = A[q * lda + q];
                 // relative threshold (de Rijk): keeps small eigenvalues accurate,
                 // plus an absolute floor so rounding noise under a zero eigenvalue is not chased
                 if (!(fabs(apq) > 1.1e-16 * sqrt(fabs(app * aqq)) && fabs(apq) > absfloor)) continue;   // wave-uniform
                 ++rotations;
                 const double tau = (aqq - app) / (2.0 * apq);
                 const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                const double c = rsqrt(1.0 + t * t), s = t * c;
                 wave_sync();
                 if (lane < n) {                               // columns p,q of A and V
-                    const double arp = A[lane * ld + p], arq = A[lane * ld + q];
-                    A[lane * ld + p] = c * arp - s * arq;
-                    A[lane * ld + q] = s * arp + c * arq;
-                    const double vrp = V[lane * ld + p], vrq = V[lane * ld + q];
-                    V[lane * ld + p] = c * vrp - s * vrq;
-                    V[lane * ld + q] = s * vrp + c * vrq;
+                    const double arp = A[lane * lda + p], arq = A[lane * lda + q];
+                    A[lane * lda + p] = c * arp - s * arq;
+                    A[lane * lda + q] = s * arp + c * arq;
+                    const double vrp = V[lane * ldv + p], vrq = V[lane * ldv + q];
+                    V[lane * ldv + p] = c * vrp - s * vrq;
+                    V[lane * ldv + q] = s * vrp + c * vrq;
                 }
                 wave_sync();
                 if (lane < n) {                               // rows p,q of A
-                    const double apr = A[p * ld + lane], aqr = A[q * ld + lane];
-                    A[p * ld + lane] = c * apr - s * aqr;
-                    A[q * ld + lane] = s * apr + c * aqr;
+                    const double apr = A[p * lda + lane], aqr = A[q * lda + lane];
+                    A[p * lda + lane] = c * apr - s * aqr;
+                    A[q * lda + lane] = s * apr + c * aqr;
                 }
                 wave_sync();
             }
         }
         if (rotations == 0) break;
     }
-    *sweeps_out = sweep;
+    return sweep;
+}
+
+// eigenvector of the smallest eigenvalue (see wave_jacobi_sym); per lane r < n component r
+__device__ inline double wave_jacobi_min_eigvec(double* A, double* V, const int n, const int ld, int* sweeps_out) {
+    const int lane = lane_id();
+    *sweeps_out = wave_jacobi_sym(A, ld, V, ld, n);
     int best = 0;                                             // smallest diagonal entry (wave-uniform scan)
     double bv = A[0];
     for (int k = 1; k < n; ++k) { const double d = A[k * ld + k]; if (d < bv) { bv = d; best = k; } }
     double x = (lane < n) ? V[lane * ld + best] : 0.0;
     const double nn = wave_sum(x * x);
-    return x * (1.0 / sqrt(nn));
+    return x * rsqrt(nn);
 }
 
 }  // namespace tff
