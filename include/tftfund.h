@@ -99,6 +99,16 @@ int tff_ressl_tft_pose_batch_debug_dev(tff_ctx* ctx, const double* corresp, cons
                                        int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
                                        int32_t* iter, int32_t* status, double* dbg);
 
+/* NordbergTFTPoseEstimation (TFT_methods/NordbergTFTPoseEstimation.m:47-222): three orthogonal matrices in
+ * axis-angle form + a 10-entry sparse tensor (19 parameters, 1 constraint), Gauss-Helmert refinement.
+ * The projective fix-up for rank-deficient P2/P3 (:56-62) is reported as TFF_ST_RANK, not applied. */
+int tff_nordberg_tft_pose_batch_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                                    int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                    int32_t* iter, int32_t* status);
+int tff_nordberg_tft_pose_batch_host(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                                     int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                     int32_t* iter, int32_t* status);
+
 /* FaugPapaTFTPoseEstimation (TFT_methods/FaugPapaTFTPoseEstimation.m:48-159): all 27 tensor entries as
  * parameters, 12 algebraic constraints (3 determinants + 9 extended-rank), Gauss-Helmert refinement. */
 int tff_faugpapa_tft_pose_batch_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,

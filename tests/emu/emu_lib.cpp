@@ -48,3 +48,8 @@ extern "C" int emu_faugpapa_tft_pose(const double* corresp, const double* calm, 
     return emu_pose(tff::k_gh_tft_pose<tff::FaugPapaModel, false>, tff::k_gh_tft_pose<tff::FaugPapaModel, true>,
                     tff::gh_lds_bytes<tff::FaugPapaModel>, false, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
+extern "C" int emu_nordberg_tft_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                                     double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
+    return emu_pose(tff::k_gh_tft_pose<tff::NordbergModel, false>, tff::k_gh_tft_pose<tff::NordbergModel, true>,
+                    tff::gh_lds_bytes<tff::NordbergModel>, false, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status, dbg);
+}

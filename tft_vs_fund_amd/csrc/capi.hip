@@ -134,6 +134,11 @@ int launch_ressl_tft(tff_ctx* c, const double* corresp, const double* calm, int6
     return launch_pose(c, tff::k_gh_tft_pose<tff::ResslModel, false>, tff::k_gh_tft_pose<tff::ResslModel, true>,
                        tff::gh_lds_bytes<tff::ResslModel>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
+int launch_nordberg_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
+                        double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+    return launch_pose(c, tff::k_gh_tft_pose<tff::NordbergModel, false>, tff::k_gh_tft_pose<tff::NordbergModel, true>,
+                       tff::gh_lds_bytes<tff::NordbergModel>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+}
 int launch_faugpapa_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                         double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     return launch_pose(c, tff::k_gh_tft_pose<tff::FaugPapaModel, false>, tff::k_gh_tft_pose<tff::FaugPapaModel, true>,
@@ -274,6 +279,16 @@ int tff_ressl_tft_pose_batch_debug_dev(tff_ctx* c, const double* corresp, const 
     return launch_ressl_tft(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 
+int tff_nordberg_tft_pose_batch_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                                     int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                                     int32_t* status) {
+    return launch_nordberg_tft(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, nullptr);
+}
+int tff_nordberg_tft_pose_batch_host(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                                      int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                                      int32_t* status) {
+    return pose_batch_host(launch_nordberg_tft, c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status);
+}
 int tff_faugpapa_tft_pose_batch_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
                                      int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
                                      int32_t* status) {

@@ -428,6 +428,169 @@ __device__ inline void wave_pinv_solve_sym(double* M, double* V, int n, double* 
     wave_sync();
 }
 
+// ---- Nordberg: three orthogonal matrices (axis-angle) + 10-entry sparse tensor, 19 parameters, 1 constraint
+//      (NordbergTFTPoseEstimation.m:47-222) ----
+struct NordbergModel {
+    static constexpr int U = 19, C = 1;
+    static constexpr bool IDENTITY_D = false;
+    static constexpr bool REDUNDANT_CONSTRAINTS = false;
+    int bad;                                                                 // rank-deficient P2/P3 fix-up (:56-62) not implemented
+
+    __device__ static __forceinline__ void sparse_pos(int k, int& c, int& d, int& j) {
+        // param_ind = [1,7,10,12,16,19:22,25] (1-based, column-major 3x3x3)   (:82)
+        const int idx = (k == 0) ? 0 : (k == 1) ? 6 : (k == 2) ? 9 : (k == 3) ? 11 : (k == 4) ? 15 : (k == 5) ? 18 : (k == 6) ? 19
+                      : (k == 7) ? 20 : (k == 8) ? 21 : 24;
+        c = idx % 3; d = (idx / 3) % 3; j = idx / 9;
+    }
+    // M (M'M)^(-1/2), then sign(det) * M   (:68-70)
+    __device__ static inline Mat3 orthogonalise(const Mat3& M) {
+        double S[3][3], Q[3][3];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) S[i][j] = M.m[0][i] * M.m[0][j] + M.m[1][i] * M.m[1][j] + M.m[2][i] * M.m[2][j];
+        jacobi3(S, Q);
+        Mat3 P;                                                              // (M'M)^(-1/2) = Q diag(lambda^-1/2) Q'
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+            P.m[i][j] = Q[i][0] * rsqrt(S[0][0]) * Q[j][0] + Q[i][1] * rsqrt(S[1][1]) * Q[j][1] + Q[i][2] * rsqrt(S[2][2]) * Q[j][2];
+        Mat3 R = mat3_mul(M, P);
+        const double sg = sgn(mat3_det(R));
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R.m[i][j] *= sg;
+        return R;
+    }
+    __device__ static inline void crossm(const double* v, Mat3& X) {
+        X.m[0][0] = 0; X.m[0][1] = -v[2]; X.m[0][2] = v[1];
+        X.m[1][0] = v[2]; X.m[1][1] = 0; X.m[1][2] = -v[0];
+        X.m[2][0] = -v[1]; X.m[2][1] = v[0]; X.m[2][2] = 0;
+    }
+    __device__ static inline void matvec(const Mat3& A, const double* x, double* y) {
+        for (int i = 0; i < 3; ++i) y[i] = A.m[i][0] * x[0] + A.m[i][1] * x[1] + A.m[i][2] * x[2];
+    }
+    // axis-angle of a rotation: vec = null vector of (R - I), angle by atan2   (:73-78)
+    __device__ static inline void axis_angle(const Mat3& R, double* out3) {
+        Mat3 D = R;
+        D.m[0][0] -= 1.0; D.m[1][1] -= 1.0; D.m[2][2] -= 1.0;
+        double v[3];
+        null3(D, v);
+        const double sn = (v[0] * (R.m[2][1] - R.m[1][2]) + v[1] * (R.m[0][2] - R.m[2][0]) + v[2] * (R.m[1][0] - R.m[0][1])) * 0.5;
+        const double cs = (R.m[0][0] + R.m[1][1] + R.m[2][2] - 1.0) * 0.5;
+        const double o = atan2(sn, cs);
+        out3[0] = v[0] * o; out3[1] = v[1] * o; out3[2] = v[2] * o;
+    }
+
+    __device__ inline void init(PoseLds* w, GhWork& g) {
+        const int lane = lane_id();
+        gh_linear_cameras(w);
+        double* rot = g.V;                                                   // scratch: U, V, W row-major (27)
+        bad = 0;
+        if (lane == 0) {
+            Mat3 A, B;
+            double a[3], b[3];
+            for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) { A.m[r][c] = w->P[0][4 * r + c]; B.m[r][c] = w->P[1][4 * r + c]; } a[r] = w->P[0][4 * r + 3]; b[r] = w->P[1][4 * r + 3]; }
+            // rank(P3(:,1:3)) < 3 or rank(P2(:,1:3)) < 3 (:57-61): generic tensors never hit it; reported, not silently mishandled
+            const double dA = mat3_det(A), dB = mat3_det(B);
+            double nA = 0, nB = 0;
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { nA += A.m[r][c] * A.m[r][c]; nB += B.m[r][c] * B.m[r][c]; }
+            const int deficient = (!(fabs(dA) > 1e-13 * nA * sqrt(nA))) || (!(fabs(dB) > 1e-13 * nB * sqrt(nB)));
+            double r3[3], s3[3];
+            matvec(mat3_inv(A), a, r3);                                      // r = A\a   (:65)
+            matvec(mat3_inv(B), b, s3);                                      // s = B\b   (:66)
+            Mat3 Xr, Xa, Xb, M0;
+            double t1[3], t2[3], t3[3];
+            crossm(r3, Xr); crossm(a, Xa); crossm(b, Xb);
+            // U = [r, crossM(r)^2 s, crossM(r) s]   (:68)
+            matvec(Xr, s3, t1); matvec(Xr, t1, t2);
+            for (int i = 0; i < 3; ++i) { M0.m[i][0] = r3[i]; M0.m[i][1] = t2[i]; M0.m[i][2] = t1[i]; }
+            const Mat3 Um = orthogonalise(M0);
+            // V = [a, crossM(a) A s, crossM(a)^2 A s]   (:69)
+            matvec(A, s3, t3); matvec(Xa, t3, t1); matvec(Xa, t1, t2);
+            for (int i = 0; i < 3; ++i) { M0.m[i][0] = a[i]; M0.m[i][1] = t1[i]; M0.m[i][2] = t2[i]; }
+            const Mat3 Vm = orthogonalise(M0);
+            // W = [b, crossM(b) B r, crossM(b)^2 B r]   (:70)
+            matvec(B, r3, t3); matvec(Xb, t3, t1); matvec(Xb, t1, t2);
+            for (int i = 0; i < 3; ++i) { M0.m[i][0] = b[i]; M0.m[i][1] = t1[i]; M0.m[i][2] = t2[i]; }
+            const Mat3 Wm = orthogonalise(M0);
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { rot[3 * i + j] = Um.m[i][j]; rot[9 + 3 * i + j] = Vm.m[i][j]; rot[18 + 3 * i + j] = Wm.m[i][j]; }
+            axis_angle(Um, g.p + 0);                                         // :73-78, :94
+            axis_angle(Vm, g.p + 3);
+            axis_angle(Wm, g.p + 6);
+            rot[27] = (double)deficient;
+        }
+        wave_sync();
+        bad = (int)rot[27];
+        // Ts = transf_t(T,U,V,W): Ts(a,b,i) = sum V(c,a) U(j,i) T(c,d,j) W(d,b); keep the 10 sparse entries, normalised   (:81-83)
+        double ts = 0.0;
+        if (lane < 10) {
+            int a, b, i;
+            sparse_pos(lane, a, b, i);
+            for (int j = 0; j < 3; ++j)
+                for (int c = 0; c < 3; ++c)
+                    for (int d = 0; d < 3; ++d) ts += rot[9 + 3 * c + a] * rot[3 * j + i] * w->t[c + 3 * d + 9 * j] * rot[18 + 3 * d + b];
+        }
+        const double nn = rsqrt(wave_sum(ts * ts));
+        wave_sync();
+        if (lane < 10) g.p[9 + lane] = ts * nn;
+        wave_sync();
+    }
+
+    __device__ inline void eval(GhWork& g) const {
+        const int lane = lane_id();
+        constexpr int u = U, n = U + C, ld = n + 1;
+        double* rot = g.V;                                                   // R_k (3 x 9) then dR_k/dx_m (3 x 3 x 9), row-major 3x3 each
+        for (int e = lane; e < n * ld; e += WAVE) g.M[e] = 0.0;
+        if (lane < 3) {                                                      // Rodrigues and its derivative   (:131-136, :181-198)
+            const double* x = g.p + 3 * lane;
+            const double o = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+            const double v[3] = {x[0] / o, x[1] / o, x[2] / o};
+            const double so = sin(o), co = cos(o);
+            Mat3 X, X2;
+            crossm(v, X);
+            X2 = mat3_mul(X, X);
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) rot[9 * lane + 3 * r + c] = ((r == c) ? 1.0 : 0.0) + so * X.m[r][c] + (1.0 - co) * X2.m[r][c];
+            for (int i = 0; i < 3; ++i) {
+                double ei[3] = {0, 0, 0};
+                ei[i] = 1.0;
+                Mat3 Xe;
+                crossm(ei, Xe);
+                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+                    const double vv = v[r] * v[c];
+                    rot[27 + 27 * lane + 9 * i + 3 * r + c] =
+                        -v[i] * so * ((r == c) ? 1.0 : 0.0) + v[i] * co * X.m[r][c] + so * (1.0 / o) * (Xe.m[r][c] - v[i] * X.m[r][c])
+                        + v[i] * so * vv + (1.0 - co) * (1.0 / o) * (v[r] * ei[c] + ei[r] * v[c] - 2.0 * v[i] * vv);
+                }
+            }
+        }
+        wave_sync();
+        const double* Ur = rot; const double* Vr = rot + 9; const double* Wr = rot + 18;
+        // T = transf_t(Ts, U', V', W'): T(a,b,i) = sum_k V(a,c_k) W(b,d_k) U(i,j_k) Ts_k   (:145)
+        for (int e = lane; e < 27 * (u + 1); e += WAVE) {
+            const int r = e % 27, col = e / 27;                              // col 0..18: J columns; col 19: T itself
+            const int i = r / 9, b = (r % 9) / 3, a = r % 3;
+            double acc = 0.0;
+            if (col >= 9 && col < 19) {                                      // d/dparamT_k   (:176-179)
+                int c, d, j;
+                sparse_pos(col - 9, c, d, j);
+                acc = Vr[3 * a + c] * Wr[3 * b + d] * Ur[3 * i + j];
+            } else {
+                const int which = (col < 9) ? col / 3 : -1, m = col % 3;     // derivative w.r.t. rotation `which`, component m   (:199-203)
+                const double* dR = rot + 27 + 27 * ((which < 0) ? 0 : which) + 9 * m;
+                for (int k = 0; k < 10; ++k) {
+                    int c, d, j;
+                    sparse_pos(k, c, d, j);
+                    const double fu = (which == 0) ? dR[3 * i + j] : Ur[3 * i + j];
+                    const double fv = (which == 1) ? dR[3 * a + c] : Vr[3 * a + c];
+                    const double fw = (which == 2) ? dR[3 * b + d] : Wr[3 * b + d];
+                    acc += fv * fw * fu * g.p[9 + k];
+                }
+            }
+            if (col < 19) g.D[r * u + col] = acc; else g.Tc[r] = acc;
+        }
+        // g = |paramT|^2 - 1, C(1,10:19) = 2 paramT'   (:208-210)
+        const double pk = (lane < 10) ? g.p[9 + lane] : 0.0;
+        const double g0 = wave_sum(pk * pk) - 1.0;
+        if (lane < 10) { g.M[u * ld + 9 + lane] = 2.0 * pk; g.M[(9 + lane) * ld + u] = 2.0 * pk; }
+        if (lane == 0) g.M[u * ld + n] = -g0;
+        wave_sync();
+    }
+};
+
 // ---- Ressl's minimal parameterisation (ResslTFTPoseEstimation.m:56-68,79,110-135,164-170) ----
 struct ResslModel {
     int Ind;                                                                 // argmax |e21|, 0-based
@@ -663,6 +826,9 @@ __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, co
     return (it > GH_IT_MAX) ? GH_IT_MAX : it;                                // :82
 }
 
+template <class Model> __device__ __forceinline__ int gh_model_bad(const Model&) { return 0; }
+template <> __device__ __forceinline__ int gh_model_bad<NordbergModel>(const NordbergModel& m) { return m.bad; }
+
 template <class Model, bool JAC>
 __global__ void __launch_bounds__(64, 1) k_gh_tft_pose(const LinearTftArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
@@ -694,6 +860,7 @@ __global__ void __launch_bounds__(64, 1) k_gh_tft_pose(const LinearTftArgs a) {
             } else {
                 Model model;
                 model.init(w, g);                                            // initial parameters; cameras P1, P2, P3 of the linear solution
+                const int model_bad = gh_model_bad(model);
                 // x_est: reprojection of the projective triangulation with P1, P2, P3   (ResslTFT...m:72-75)
                 tri_pass(w, pts, N, TRI_REPROJECT, 1, w->P[0], w->P[1], g.xi, w->nrm);
                 wave_sync();
@@ -706,6 +873,7 @@ __global__ void __launch_bounds__(64, 1) k_gh_tft_pose(const LinearTftArgs a) {
                 transform_tft_inverse(w->t, w->T1, w->Lp, [w](int v) { return normal_matrix(w->nrm, v); });   // :96
                 status = rt_from_tft_wave(w, pts, N, dbg);                   // :99
                 if (gst != ST_OK) status = gst;
+                if (model_bad) status = ST_RANK;
                 write_poses(w, a.Rt2 + b * 12, a.Rt3 + b * 12);
                 if (lane < 27) a.T[b * 27 + lane] = w->T1[lane];
                 if (a.reconst) final_reconst(w, pts, N, a.reconst + b * 3 * (long)N);   // :102-103
