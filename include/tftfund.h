@@ -58,6 +58,8 @@ typedef struct tff_ctx tff_ctx;
 #define TFF_OPT_SOLVER 1    /* 0: Cholesky inverse iteration with Jacobi fallback (default); 1: Jacobi sweeps only */
 #define TFF_OPT_STAGE_LDS 2 /* -1 auto (default), 0 re-read correspondences through L2, 1 stage them in LDS */
 
+#define TFF_OPT_KERNEL 3    /* LinearTFT: 0 one wavefront per triplet (default); 1 paired kernel, two triplets per workgroup (slower; A/B only) */
+
 #define TFF_DEBUG_STRIDE 128 /* doubles per triplet written by the *_debug_dev entry points */
 
 int tff_version(void);

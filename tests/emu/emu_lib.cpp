@@ -53,3 +53,20 @@ extern "C" int emu_nordberg_tft_pose(const double* corresp, const double* calm, 
     return emu_pose(tff::k_gh_tft_pose<tff::NordbergModel, false>, tff::k_gh_tft_pose<tff::NordbergModel, true>,
                     tff::gh_lds_bytes<tff::NordbergModel>, false, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
+
+// the paired kernel (TFF_OPT_KERNEL = 1): two triplets per 128-thread workgroup + Jacobi fix-up
+extern "C" int emu_linear_tft_pose_pair(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                                        double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
+    tff::LinearTftArgs a{corresp, calm, calm_stride, B, N, flags & ~tff::FLAG_JACOBI, Rt2, Rt3, T, reconst, iter, status, dbg, nullptr};
+    if (reconst) a.flags |= tff::FLAG_RECONST;
+    tff::LinearTftArgs m = a;
+    m.flags = tff::pair_auto_flags(N, m.flags);
+    emu::launch(tff::k_linear_tft_pose_pair, tff::pose_grid((B + 1) / 2), 128, tff::pair_lds_bytes(N, m.flags, false), m);
+    bool any = false;
+    for (long b = 0; b < B; ++b) any = any || status[b] == tff::ST_RETRY;
+    if (!any) return 0;
+    a.flags |= tff::FLAG_ONLY_RETRY;
+    a.flags = tff::pose_auto_flags(N, a.flags, true);
+    emu::launch(tff::k_linear_tft_pose<true>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, a.flags, true), a);
+    return 1;
+}

@@ -379,3 +379,23 @@ def test_gh_improves_on_linear_and_full_size(gpu_ctx, method, B):
         c = (np.einsum("ij,bij->b", Rt0[1][:, :3], R) - 1) / 2
         return np.degrees(np.arccos(np.clip(c, -1, 1)))
     assert rot_err(res["R_t_3"]).mean() <= rot_err(lin["R_t_3"]).mean() * 1.02
+
+
+def test_paired_kernel_variant_agrees(gpu_ctx):
+    """TFF_OPT_KERNEL = 1 (two triplets per workgroup, half-wavefront middle section) against the default kernel."""
+    import torch
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    C, CalM, _, _ = generate_scene_batch(513, 60, noise=1.0, seed=808)          # odd batch: the last workgroup has one triplet
+    d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
+    ref = gpu_ctx.pose_batch("LinearTFTPoseEstimation", d, calm, reconst=True)
+    gpu_ctx.set_kernel_variant(1)
+    try:
+        out = gpu_ctx.pose_batch("LinearTFTPoseEstimation", d, calm, reconst=True)
+    finally:
+        gpu_ctx.set_kernel_variant(0)
+    torch.cuda.synchronize()
+    assert int((out["status"] != 0).sum()) == 0
+    T0 = ref["T"].cpu().numpy(); T1 = out["T"].cpu().numpy()
+    assert max(rel_err_T(T1[b], T0[b]) for b in range(513)) < 1e-9
+    assert rel_err(out["R_t_3"].cpu().numpy(), ref["R_t_3"].cpu().numpy()) < 1e-9
+    assert rel_err(out["Reconst"].cpu().numpy(), ref["Reconst"].cpu().numpy()) < 1e-8

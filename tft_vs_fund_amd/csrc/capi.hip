@@ -51,6 +51,7 @@ struct tff_ctx {
     int stage = -1;
     DevBuf in, calm, out, idx, scratch_status;
     const int32_t* sample_idx = nullptr;   // set around a *_sampled_dev call
+    int kernel_variant = 0;                // TFF_OPT_KERNEL
 };
 
 namespace {
@@ -118,10 +119,42 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, bool may_stage
     return 0;
 }
 
+// LinearTFTPoseEstimation: one wavefront per triplet + Jacobi fix-up.  TFF_OPT_KERNEL = 1 selects the paired
+// kernel (two triplets per workgroup, half-wavefront middle section) instead -- measured slower on MI355X
+// (0.57-0.63 ms vs 0.47 ms per 10k x 200 batch: its per-half broadcasts ride the LDS crossbar inside the
+// sequential triangular solves), kept for A/B measurements.
 int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    return launch_pose(c, tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, true, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
-                       reconst, iter, status, dbg);
+    if (c->solver != 0 || c->kernel_variant == 0)
+        return launch_pose(c, tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, true, corresp, calm, calm_stride,
+                           B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
+    if (B == 0) return 0;
+    if (!Rt2 || !Rt3 || !T) return fail(TFF_E_INVALID, "null output pointer");
+    TFF_HIP(hipSetDevice(c->device));
+    if (!status) {
+        if (int r = c->scratch_status.reserve((size_t)B * sizeof(int32_t))) return r;
+        status = (int32_t*)c->scratch_status.p;
+    }
+    tff::LinearTftArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr),
+                         Rt2, Rt3, T, reconst, iter, status, dbg, c->sample_idx};
+    {
+        tff::LinearTftArgs m = a;
+        if (c->sample_idx || c->stage > 0) m.flags |= tff::FLAG_STAGE_LDS;
+        else if (c->stage < 0) m.flags = tff::pair_auto_flags(N, m.flags);
+        const size_t lds = tff::pair_lds_bytes(N, m.flags, false);
+        if (int r = ensure_lds(tff::k_linear_tft_pose_pair, lds)) return r;
+        hipLaunchKernelGGL(tff::k_linear_tft_pose_pair, dim3(tff::pose_grid((B + 1) / 2)), dim3(128), lds, c->stream, m);
+        TFF_HIP(hipGetLastError());
+    }
+    a.flags |= tff::FLAG_ONLY_RETRY;
+    if (c->sample_idx) a.flags |= tff::FLAG_STAGE_LDS;
+    else a.flags = staged_flags(c, N, a.flags, true);
+    const size_t lds = tff::pose_lds_bytes(N, a.flags, true);
+    if (int r = ensure_lds(tff::k_linear_tft_pose<true>, lds)) return r;
+    hipLaunchKernelGGL(tff::k_linear_tft_pose<true>, dim3((unsigned)(B < 1024 ? B : 1024)), dim3(64), lds, c->stream, a);
+    TFF_HIP(hipGetLastError());
+    return 0;
 }
 int launch_linear_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
@@ -232,6 +265,7 @@ int tff_ctx_set_option(tff_ctx* c, int option, long value) {
     switch (option) {
         case TFF_OPT_SOLVER: if (value != 0 && value != 1) return fail(TFF_E_INVALID, "solver must be 0 or 1"); c->solver = (int)value; return 0;
         case TFF_OPT_STAGE_LDS: if (value < -1 || value > 1) return fail(TFF_E_INVALID, "stage_lds must be -1, 0 or 1"); c->stage = (int)value; return 0;
+        case TFF_OPT_KERNEL: if (value != 0 && value != 1) return fail(TFF_E_INVALID, "kernel must be 0 or 1"); c->kernel_variant = (int)value; return 0;
         default: return fail(TFF_E_INVALID, "unknown option");
     }
 }

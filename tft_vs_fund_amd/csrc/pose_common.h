@@ -153,8 +153,9 @@ __device__ __forceinline__ Mat3 normal_matrix(const double* nrm, int v) {
 // ones, lanes 0/1 then the null vector of each stacked 3x3.  epi[0..2] = e21,
 // epi[3..5] = e31.  fix_sign: multiply by sign of the own third component
 // (R_t_from_TFT.m:50,55).
+template <int G>
 __device__ __attribute__((noinline)) void epipoles_from_tensor(const double* t, double* nullv, double* epi, bool fix_sign) {
-    const int lane = lane_id();
+    const int lane = Group<G>::lane();
     if (lane < 6) {
         const int i = (lane < 3) ? lane : lane - 3;
         Mat3 M;
@@ -189,9 +190,9 @@ __device__ __attribute__((noinline)) void epipoles_from_tensor(const double* t, 
 // followed by the Frobenius normalisation.  to/tn are 27-vectors in LDS; `mats`
 // is 27 doubles of LDS scratch (M1, inv(M2), inv(M3) row-major) so that the
 // lane-dependent indices address memory, not registers.
-template <class MatFn>
+template <int G = 64, class MatFn>
 __device__ inline void transform_tft_inverse(const double* to, double* tn, double* mats, MatFn matrix_of) {
-    const int lane = lane_id();
+    const int lane = Group<G>::lane();
     if (lane < 3) {
         Mat3 M = matrix_of(lane);
         if (lane > 0) M = mat3_inv(M);
@@ -213,7 +214,7 @@ __device__ inline void transform_tft_inverse(const double* to, double* tn, doubl
                 val += mats[9 + 3 * j + c] * mix * mats[18 + 3 * k + d];
             }
     }
-    const double nn = wave_sum(val * val);
+    const double nn = Group<G>::sum(val * val);
     wave_sync();
     if (lane < 27) tn[lane] = val * rsqrt(nn);
     wave_sync();
@@ -347,8 +348,9 @@ __device__ __attribute__((noinline)) int tri_pass(PoseLds* w, const double* pts,
 // mirrored camera is the original with its 4th column negated), so only two of
 // the four triangulation passes are evaluated; the selection loop below replays
 // the reference's order and its `>=` rule on all four scores.
-__device__ inline int recover_poses(PoseLds* w, const double* Ein, const double* pts, int N, double* dbg) {
-    const int lane = lane_id();
+template <int G>
+__device__ inline void recover_prepare(PoseLds* w, const double* Ein) {
+    const int lane = Group<G>::lane();
     if (lane < 2) {
         Mat3 E, U, V;
 #pragma unroll
@@ -391,6 +393,10 @@ __device__ inline int recover_poses(PoseLds* w, const double* Ein, const double*
         for (int r = 0; r < 3; ++r) { w->Pfin[0][4 * r] = K1.m[r][0]; w->Pfin[0][4 * r + 1] = K1.m[r][1]; w->Pfin[0][4 * r + 2] = K1.m[r][2]; w->Pfin[0][4 * r + 3] = 0.0; }
     }
     wave_sync();
+}
+
+__device__ inline int recover_vote(PoseLds* w, const double* pts, int N, double* dbg) {
+    const int lane = lane_id();
     phase_stamp(dbg, 10);
     int status = ST_OK;
 #pragma unroll 1
@@ -413,6 +419,11 @@ __device__ inline int recover_poses(PoseLds* w, const double* Ein, const double*
         wave_sync();
     }
     return status;
+}
+
+__device__ inline int recover_poses(PoseLds* w, const double* Ein, const double* pts, int N, double* dbg) {
+    recover_prepare<64>(w, Ein);
+    return recover_vote(w, pts, N, dbg);
 }
 
 // t3 scale, R_t_from_TFT.m:68-74 == LinearFPoseEstimation.m:64-70.  Scales w->Rt[1](:,4) in place.

@@ -161,21 +161,23 @@ __device__ __forceinline__ void up_factors(const double* Q, int m, double (&a2)[
     for (int q = 0; q < 3; ++q) { a2[q] = Q[3 * q + jj]; a3[q] = Q[9 + 3 * q + kk]; }
 }
 
-// linearTFT.m:33-91 on the normalised correspondences.  Leaves the constrained
-// tensor in w->t, the epipoles in w->epi and (if want_P) linearTFT's `a`
+// linearTFT.m:64-91 from the 96 moment sums in w->mom: everything of linearTFT after the data pass,
+// for the lane group G (the whole wavefront, or one half of it working on its own triplet).
+// Leaves the constrained tensor in w->t, the epipoles in w->epi and (if want_P) linearTFT's `a`
 // (P2 = [reshape(a(1:9),3,3) e21], P3 = [reshape(a(10:18),3,3) e31]) in w->pa.
 // Returns false when an eigen-solve did not converge (JAC = false only).
-template <bool JAC>
-__device__ inline bool linear_tft_wave(PoseLds* w, JacobiLds* jw, const double* pts, int N, bool want_P, double* dbg) {
-    const int lane = lane_id();
-    accumulate_moments(w, pts, N);
-    phase_stamp(dbg, 2);
+template <bool JAC, int G>
+__device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, bool want_P, double* dbg) {
+    static_assert(!JAC || G == 64, "the Jacobi solver works on whole wavefronts");
+    using Grp = Group<G>;
+    const int lane = Grp::lane();
+    const int wl = Grp::index() * G;                                         // first lane of this group (stamp writer)
     int it1 = 0, it2 = 0;
     bool ok = true;
     {                                                                        // :64-67
         double g[27], diag, x;
         gram_row27(w->mom, (lane < 27) ? lane : 0, g, diag);
-        phase_stamp(dbg, 3);
+        phase_stamp(dbg, 3, wl);
         if (JAC) {
             if (lane < 27) for (int c = 0; c < 27; ++c) jw->A[lane * 27 + c] = g[c];
             wave_sync();
@@ -183,23 +185,23 @@ __device__ inline bool linear_tft_wave(PoseLds* w, JacobiLds* jw, const double* 
             it1 += 1000;
         } else {
             double r2;
-            x = wave_min_eigvec_reg<27>(g, diag, w->Lp, 50, &it1, &r2);
+            x = wave_min_eigvec_reg<27, G>(g, diag, w->Lp, 50, &it1, &r2);
             ok = ok && eig_converged(r2);
         }
         if (lane < 27) w->t[lane] = x;
         wave_sync();
     }
     if (dbg && lane < 27) dbg[lane] = w->t[lane];
-    phase_stamp(dbg, 4);
-    epipoles_from_tensor(w->t, w->nullv, w->epi, false);                     // :71-79
-    phase_stamp(dbg, 5);
+    phase_stamp(dbg, 4, wl);
+    epipoles_from_tensor<G>(w->t, w->nullv, w->epi, false);                  // :71-79
+    phase_stamp(dbg, 5, wl);
     if (dbg && lane < 6) dbg[27 + lane] = w->epi[lane];
     if (lane == 0) frame_of(w->epi, w->Q);                                   // Q2 from e21
     if (lane == 1) frame_of(w->epi + 3, w->Q + 9);                           // Q3 from e31
     wave_sync();
     // Gp = Up' G Up (15x15), lower triangle, packed into Lp; entry (a,b), a = 5 i + m
     double* Gp = w->Lp;
-    for (int e = lane; e < 120; e += WAVE) {
+    for (int e = lane; e < 120; e += G) {
         int a = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while (tri_index(a + 1, 0) <= e) ++a;
         while (tri_index(a, 0) > e) --a;
@@ -212,7 +214,7 @@ __device__ inline bool linear_tft_wave(PoseLds* w, JacobiLds* jw, const double* 
         Gp[e] = bilinear44(w->mom + 16 * hht_index(a / 5, b / 5), c3, c2);
     }
     wave_sync();
-    phase_stamp(dbg, 6);
+    phase_stamp(dbg, 6, wl);
     {                                                                        // :84
         double g[15], diag = 0.0, x;
         const int r = (lane < 15) ? lane : 0;
@@ -226,13 +228,13 @@ __device__ inline bool linear_tft_wave(PoseLds* w, JacobiLds* jw, const double* 
             it2 += 1000;
         } else {
             double r2;
-            x = wave_min_eigvec_reg<15>(g, diag, w->Lp, 50, &it2, &r2);
+            x = wave_min_eigvec_reg<15, G>(g, diag, w->Lp, 50, &it2, &r2);
             ok = ok && eig_converged(r2);
         }
         if (lane < 15) w->tp[lane] = x;
         wave_sync();
     }
-    phase_stamp(dbg, 7);
+    phase_stamp(dbg, 7, wl);
     if (lane < 27) {                                                         // t = Up * tp   (:85)
         const int i = lane / 9, k = (lane % 9) / 3, j = lane % 3;
         double acc = 0.0;
@@ -267,11 +269,21 @@ __device__ inline bool linear_tft_wave(PoseLds* w, JacobiLds* jw, const double* 
     return ok;
 }
 
-// R_t_from_TFT.m:40-76 on the de-normalised tensor w->T1.
-__device__ inline int rt_from_tft_wave(PoseLds* w, const double* pts, int N, double* dbg) {
-    const int lane = lane_id();
-    transform_tft_inverse(w->T1, w->T2, w->Lp, [w](int v) { return load_K(w->calm, v); });   // :44
-    epipoles_from_tensor(w->T2, w->nullv, w->epi, true);                     // :47-55
+// linearTFT.m:33-91 on the normalised correspondences (data pass + the rest), whole wavefront.
+template <bool JAC>
+__device__ inline bool linear_tft_wave(PoseLds* w, JacobiLds* jw, const double* pts, int N, bool want_P, double* dbg) {
+    accumulate_moments(w, pts, N);
+    phase_stamp(dbg, 2);
+    return linear_tft_middle<JAC, 64>(w, jw, want_P, dbg);
+}
+
+// R_t_from_TFT.m:44-58 and the decomposition of E21, E31 (:85-88): the lane-sparse part of
+// R_t_from_TFT on the de-normalised tensor w->T1, up to the candidate cameras.
+template <int G>
+__device__ inline void rt_prepare(PoseLds* w, double* dbg) {
+    const int lane = Group<G>::lane();
+    transform_tft_inverse<G>(w->T1, w->T2, w->Lp, [w](int v) { return load_K(w->calm, v); });   // :44
+    epipoles_from_tensor<G>(w->T2, w->nullv, w->epi, true);                  // :47-55
     double* Ein = w->Minv;                                                   // 18 doubles of scratch
     if (lane < 2) {
         const double* e21 = w->epi; const double* e31 = w->epi + 3;
@@ -298,8 +310,14 @@ __device__ inline int rt_from_tft_wave(PoseLds* w, const double* pts, int N, dou
         }
     }
     wave_sync();
-    phase_stamp(dbg, 9);
-    const int st = recover_poses(w, Ein, pts, N, dbg);                       // :61,:64
+    phase_stamp(dbg, 9, Group<G>::index() * G);
+    recover_prepare<G>(w, Ein);                                              // svd(E), candidate poses and cameras
+}
+
+// R_t_from_TFT.m:40-76 on the de-normalised tensor w->T1 (whole wavefront).
+__device__ inline int rt_from_tft_wave(PoseLds* w, const double* pts, int N, double* dbg) {
+    rt_prepare<64>(w, dbg);
+    const int st = recover_vote(w, pts, N, dbg);                             // :61,:64
     phase_stamp(dbg, 11);
     scale_t3(w, pts, N, dbg);                                                // :68-74
     phase_stamp(dbg, 12);
@@ -362,6 +380,97 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose(const LinearTftArgs a
             if (a.iter) a.iter[b] = 0;                                       // :62
             a.status[b] = status;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The paired kernel (TFF_OPT_KERNEL = 1; NOT the default): two triplets per 128-thread workgroup.
+//   wave w: stage + Normalize2Ddata + moment sums of triplet 2b + w        (one correspondence per lane)
+//   barrier
+//   wave 0: the lane-sparse middle section of BOTH triplets, one per half-wavefront
+//           (27x27 / 15x15 eigen-solves, epipoles, transform_TFT x2, E21/E31, 3x3 SVDs, candidate cameras);
+//           wave 1 sleeps at the barrier and costs no issue slots
+//   barrier
+//   wave w: cheirality vote, t3 scale, outputs, optional Reconst of triplet 2b + w
+// Those middle stages keep at most 27 of 64 lanes busy, so sharing one instruction stream between
+// two triplets halves their VALU instruction count per triplet.  Measured on MI355X it is nevertheless
+// 1.2-1.3x SLOWER than k_linear_tft_pose<false> (0.57-0.63 ms vs 0.47 ms per 10k x 200 batch at every
+// occupancy tried): a per-half broadcast cannot use v_readlane (the source differs between the halves)
+// and goes through ds_bpermute, whose ~100-cycle latency sits on the sequential dependency chain of the
+// triangular solves while the partner wave idles at the barrier.  Kept, with its tests, as the
+// Group<32> reference implementation and for A/B measurements.
+// Triplets whose inverse iteration does not converge are marked ST_RETRY for k_linear_tft_pose<true>.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128, 2) k_linear_tft_pose_pair(const LinearTftArgs a) {
+    TFF_DYNAMIC_LDS(double, smem);
+    const int N = a.N;
+    constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
+    const int per_wave = base + (((a.flags & FLAG_STAGE_LDS) || a.sample_idx) ? ((6 * N + 1) & ~1) : 0);
+    const int lane = lane_id(), wave = wave_in_block();
+    PoseLds* w = reinterpret_cast<PoseLds*>(smem + wave * per_wave);
+    double* lds_pts = smem + wave * per_wave + base;
+    __shared__ int ok_flag[2];
+    for (long pb = 2L * blockIdx.x; pb < a.B; pb += 2L * gridDim.x) {
+        const long b = (pb + wave < a.B) ? pb + wave : a.B - 1;               // an odd batch: the last triplet is done twice
+        double* dbg = a.dbg ? a.dbg + b * DBG_STRIDE : nullptr;
+        const double* src = a.corresp + b * 6 * (long)N;
+        const double* pts = src;
+        if (a.sample_idx) {
+            gather_points(a.corresp, a.sample_idx + b * (long)N, lds_pts, N);
+            pts = lds_pts;
+        } else if (a.flags & FLAG_STAGE_LDS) {
+            stage_points(src, lds_pts, N);
+            pts = lds_pts;
+        }
+        if (lane < 27) w->calm[lane] = a.calm[b * a.calm_stride + lane];
+        phase_stamp(dbg, 0);
+        if (N >= 7) {
+            normalise3(pts, N, w->nrm);                                      // LinearTFTPoseEstimation.m:45-47
+            if (dbg && lane < 9) dbg[71 + lane] = w->nrm[lane];
+            phase_stamp(dbg, 1);
+            accumulate_moments(w, pts, N);                                   // data pass of linearTFT   (:50)
+            phase_stamp(dbg, 2);
+        }
+        __syncthreads();
+        if (wave == 0 && N >= 7) {
+            const int half = lane >> 5;
+            PoseLds* wh = reinterpret_cast<PoseLds*>(smem + half * per_wave);
+            const long bh = (pb + half < a.B) ? pb + half : a.B - 1;
+            double* dbgh = a.dbg ? a.dbg + bh * DBG_STRIDE : nullptr;
+            const bool ok = linear_tft_middle<false, 32>(wh, nullptr, false, dbgh);
+            phase_stamp(dbgh, 8, half * 32);
+            transform_tft_inverse<32>(wh->t, wh->T1, wh->Lp, [wh](int v) { return normal_matrix(wh->nrm, v); });   // :53
+            rt_prepare<32>(wh, dbgh);                                        // R_t_from_TFT up to the candidate cameras   (:56)
+            if ((lane & 31) == 0) ok_flag[half] = ok ? 1 : 0;
+        }
+        __syncthreads();
+        int status = ST_OK;
+        if (N < 7) {                                                         // experiments.m:99
+            status = ST_TOO_FEW;
+            const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+            if (lane < 12) { a.Rt2[b * 12 + lane] = qnan; a.Rt3[b * 12 + lane] = qnan; }
+            if (lane < 27) a.T[b * 27 + lane] = qnan;
+            if (a.reconst) for (int i = lane; i < 3 * N; i += WAVE) a.reconst[b * 3 * (long)N + i] = qnan;
+        } else if (!ok_flag[wave]) {
+            status = ST_RETRY;                                               // redone by k_linear_tft_pose<true>
+        } else {
+            status = recover_vote(w, pts, N, dbg);                           // R_t_from_TFT.m:61,:64
+            phase_stamp(dbg, 11);
+            scale_t3(w, pts, N, dbg);                                        // :68-74
+            phase_stamp(dbg, 12);
+            write_poses(w, a.Rt2 + b * 12, a.Rt3 + b * 12);
+            if (lane < 27) a.T[b * 27 + lane] = w->T1[lane];
+            if (a.reconst) final_reconst(w, pts, N, a.reconst + b * 3 * (long)N);   // :59-60
+            phase_stamp(dbg, 13);
+            double chk = (lane < 12) ? w->Rt[0][lane] : ((lane < 24) ? w->Rt[1][lane - 12] : ((lane < 51) ? w->T1[lane - 24] : 0.0));
+            const bool bad = !(fabs(chk) <= 1.79e308);
+            if (wave_any(bad) && status == ST_OK) status = ST_NONFINITE;
+        }
+        if (lane == 0) {
+            if (a.iter) a.iter[b] = 0;                                       // :62
+            a.status[b] = status;
+        }
+        __syncthreads();
     }
 }
 

@@ -70,14 +70,14 @@ __device__ __forceinline__ double wave_uniform(double v) {
 
 // Coarse phase stamps for the *_debug_dev entry points (shader clock, lane 0):
 // dbg[80 + slot].  A null dbg (every production entry point) skips them.
-__device__ __forceinline__ void phase_stamp(double* dbg, int slot) {
+__device__ __forceinline__ void phase_stamp(double* dbg, int slot, int writer_lane = 0) {
 #ifndef TFF_CPU_EMU
     if (dbg) {
         const long long t = clock64();
-        if (lane_id() == 0) dbg[80 + slot] = (double)t;
+        if (lane_id() == writer_lane) dbg[80 + slot] = (double)t;
     }
 #else
-    (void)dbg; (void)slot;
+    (void)dbg; (void)slot; (void)writer_lane;
 #endif
 }
 
@@ -119,6 +119,46 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return v;
 }
 __device__ __forceinline__ bool wave_any(bool p) { return wave_sum_i(p ? 1 : 0) != 0; }
+
+// ---- lane groups ------------------------------------------------------------------------------
+// The lane-sparse stages (27x27 / 15x15 eigen-solves, epipoles, 3x3 SVDs: 27, 15, 6 or 2 busy
+// lanes) are written against a lane GROUP: Group<64> is the whole wavefront, Group<32> one half of
+// it, so that one wavefront can run those stages for two triplets at once, one per half.
+template <int G> struct Group;
+template <> struct Group<64> {
+    static constexpr int size = 64;
+    __device__ static __forceinline__ int lane() { return lane_id(); }           // lane index inside the group
+    __device__ static __forceinline__ int index() { return 0; }                  // which group of the wavefront
+    __device__ static __forceinline__ double bcast(double v, int src) { return wave_bcast(v, src); }
+    __device__ static __forceinline__ double sum(double v) { return wave_sum(v); }
+};
+template <> struct Group<32> {
+    static constexpr int size = 32;
+    __device__ static __forceinline__ int lane() { return lane_id() & 31; }
+    __device__ static __forceinline__ int index() { return lane_id() >> 5; }
+#ifdef TFF_CPU_EMU
+    __device__ static inline double bcast(double v, int src) {
+        uint64_t u; std::memcpy(&u, &v, 8);
+        u = emu::exchange(u, (lane_id() & 32) | src);
+        std::memcpy(&v, &u, 8); return v;
+    }
+    __device__ static inline double sum(double v) {
+        for (int m = 16; m >= 1; m >>= 1) v += wave_shfl_xor(v, m);
+        return v;
+    }
+#else
+    // per-half broadcast: the source differs between the halves, so it goes through the LDS crossbar
+    __device__ static __forceinline__ double bcast(double v, int src) { return __shfl(v, (lane_id() & 32) | src, 64); }
+    __device__ static __forceinline__ double sum(double v) {
+        v += dpp_mov<0x111>(v);        // row_shr:1
+        v += dpp_mov<0x112>(v);        // row_shr:2
+        v += dpp_mov<0x114>(v);        // row_shr:4
+        v += dpp_mov<0x118>(v);        // row_shr:8 -> lane 15 of every 16-lane row holds its row sum
+        const int h = lane_id() & 32;
+        return __shfl(v, h | 15, 64) + __shfl(v, h | 31, 64);
+    }
+#endif
+};
 
 // Reduce K (= 32) per-lane values over the 64 lanes with a halving
 // ("transposing") butterfly: K-1+1 shuffles instead of 6K.  On return lane l

@@ -30,11 +30,12 @@ __device__ __forceinline__ int tri_index(int r, int c) { return (r * (r + 1)) / 
 // Lp: n*n doubles of LDS.  On return lane r (< n) holds component r of the
 // unit eigenvector of the smallest eigenvalue; *iters = iterations used,
 // *resid2 = 0 when the iteration converged, else the last squared step.
-template <int n>
+template <int n, int G = 64>
 __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, double* Lp, const int maxit,
                                              int* iters, double* resid2) {
-    const int lane = lane_id();
-    const double tr = wave_sum(lane < n ? diag : 0.0);
+    using Grp = Group<G>;                                   // one lane group per matrix (the whole wave, or one half of it)
+    const int lane = Grp::lane();
+    const double tr = Grp::sum(lane < n ? diag : 0.0);
     const double delta = 1e-14 * tr;
     const double pfloor = 1e-3 * delta + 1e-300;
 #pragma unroll
@@ -42,14 +43,14 @@ __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, 
     double myinv = 0.0;                                     // 1 / L[lane][lane]
 #pragma unroll
     for (int k = 0; k < n; ++k) {
-        double d = wave_bcast(g[k], k);                     // pivot (lane k's diagonal, fully updated)
+        double d = Grp::bcast(g[k], k);                     // pivot (lane k's diagonal, fully updated)
         d = (d > pfloor) ? d : pfloor;
         const double rs = rsqrt(d);
         g[k] = (lane == k) ? d * rs : g[k] * rs;            // column k of L (rows >= k meaningful)
         myinv = (lane == k) ? rs : myinv;
 #pragma unroll
         for (int c = k + 1; c < n; ++c) {
-            const double lck = wave_bcast(g[k], c);         // L[c][k]
+            const double lck = Grp::bcast(g[k], c);         // L[c][k]
             g[c] -= g[k] * lck;                             // L[r][c] -= L[r][k] L[c][k]   (meaningful for r >= c)
         }
     }
@@ -64,10 +65,11 @@ __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, 
     wave_sync();
     const int rl = (lane < n) ? lane : 0;
     double x = (lane < n) ? rsqrt((double)n) : 0.0;
-    double rprev2 = 1.0, r2 = 1.0;
+    double rprev2 = 1.0, res = 1.0;
     int it = 0;
+    bool done = false;                                      // per group; the loop itself is wave-uniform
 #pragma unroll 1
-    while (it < maxit) {
+    while (true) {
         double y = x;
         {
             double row[n];                                  // L[lane][j] (0 for j > lane)
@@ -75,7 +77,7 @@ __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, 
             for (int j = 0; j < n; ++j) row[j] = Lp[rl * n + j];
 #pragma unroll
             for (int j = 0; j < n; ++j) {                   // forward  L y = x
-                const double yj = wave_bcast(y * myinv, j);
+                const double yj = Grp::bcast(y * myinv, j);
                 y -= row[j] * yj;
             }
         }
@@ -85,27 +87,30 @@ __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, 
             for (int j = 0; j < n; ++j) col[j] = Lp[j * n + rl];
 #pragma unroll
             for (int j = n - 1; j >= 0; --j) {              // backward L' z = y
-                const double zj = wave_bcast(y * myinv, j);
+                const double zj = Grp::bcast(y * myinv, j);
                 y -= col[j] * zj;
             }
         }
         if (lane >= n) y = 0.0;
-        const double nn = wave_sum(y * y);
-        const double dot = wave_sum(y * x);
+        const double nn = Grp::sum(y * y);
+        const double dot = Grp::sum(y * x);
         const double rn = rsqrt(nn);
         const double yn = y * ((dot < 0.0) ? -rn : rn);
         const double dd = yn - x;
-        r2 = wave_sum(dd * dd);
-        x = yn;
-        ++it;
-        // |step|^2 = r2; the error of the new iterate is ~ rho |step| / (1 - rho) with rho ~ |step| / |previous step|
-        if (r2 <= 1e-26) { r2 = 0.0; break; }                                    // converged: stopped moving
-        if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) { r2 = 0.0; break; }   // converged: predicted error < 1e-13
-        if (!(r2 == r2)) break;                                                  // NaN: not converged
-        rprev2 = r2;
+        const double r2 = Grp::sum(dd * dd);
+        if (!done) {
+            x = yn;
+            ++it;
+            // |step|^2 = r2; the error of the new iterate is ~ rho |step| / (1 - rho) with rho ~ |step| / |previous step|
+            if (r2 <= 1e-26) { res = 0.0; done = true; }                                     // converged: stopped moving
+            else if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) { res = 0.0; done = true; }   // predicted error < 1e-13
+            else if (!(r2 == r2) || it >= maxit) { res = (r2 == r2) ? r2 : 1.0; done = true; }             // NaN / iteration cap: not converged
+            rprev2 = r2;
+        }
+        if (!wave_any(!done)) break;
     }
     *iters = it;
-    *resid2 = r2;                                                               // 0 when converged, last |step|^2 otherwise
+    *resid2 = res;                                                              // 0 when converged, last |step|^2 otherwise
     return x;
 }
 __device__ __forceinline__ bool eig_converged(double resid2) { return resid2 == 0.0; }

@@ -14,7 +14,9 @@ Rt2 = torch.empty(B * 12, dtype=torch.float64, device="cuda"); Rt3 = torch.empty
 T = torch.empty(B * 27, dtype=torch.float64, device="cuda"); rec = torch.empty(B * 3 * N, dtype=torch.float64, device="cuda")
 it = torch.zeros(B, dtype=torch.int32, device="cuda"); st = torch.zeros(B, dtype=torch.int32, device="cuda")
 p = lambda t: ctypes.c_void_p(t.data_ptr())
-for name, stem in api.POSE_METHODS.items():
+variants = [(n, st, 0) for n, st in api.POSE_METHODS.items()] + [("LinearTFT (paired kernel, A/B)", "tff_linear_tft_pose_batch", 1)]
+for name, stem, variant in variants:
+    ctx.set_kernel_variant(variant)
     fn = getattr(lib, stem + "_dev")
     for with_rec in (False, True):
         args = (ctx.handle, p(d), p(calm), 0, B, N, p(Rt2), p(Rt3), p(T), p(rec) if with_rec else None, p(it), p(st))
