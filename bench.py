@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=10000)
     ap.add_argument("--ncorr", type=int, default=200)
-    ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="triplets timed on the CPU (default: 16 per host core, at least 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -167,7 +167,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(C, CalM, min(args.cpu_sample, B))
+            sample = args.cpu_sample or max(1024, 16 * (os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(C, CalM, min(sample, B))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

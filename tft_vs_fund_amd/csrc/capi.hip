@@ -113,7 +113,7 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, bool may_stage
     if (may_stage) a.flags = staged_flags(c, N, a.flags, true);
     const size_t lds = ldsfn(N, a.flags, true);
     if (int r = ensure_lds(kjac, lds)) return r;
-    const unsigned grid = (c->solver == 0) ? (unsigned)(B < 1024 ? B : 1024) : tff::pose_grid(B);
+    const unsigned grid = (c->solver == 0) ? (unsigned)(B < 8192 ? B : 8192) : tff::pose_grid(B);
     hipLaunchKernelGGL(kjac, dim3(grid), dim3(64), lds, c->stream, a);
     TFF_HIP(hipGetLastError());
     return 0;
@@ -152,7 +152,7 @@ int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int
     else a.flags = staged_flags(c, N, a.flags, true);
     const size_t lds = tff::pose_lds_bytes(N, a.flags, true);
     if (int r = ensure_lds(tff::k_linear_tft_pose<true>, lds)) return r;
-    hipLaunchKernelGGL(tff::k_linear_tft_pose<true>, dim3((unsigned)(B < 1024 ? B : 1024)), dim3(64), lds, c->stream, a);
+    hipLaunchKernelGGL(tff::k_linear_tft_pose<true>, dim3((unsigned)(B < 8192 ? B : 8192)), dim3(64), lds, c->stream, a);
     TFF_HIP(hipGetLastError());
     return 0;
 }
@@ -434,7 +434,7 @@ int tff_linear_tft_batch_dev(tff_ctx* c, const double* corresp, int64_t B, int32
         TFF_HIP(hipGetLastError());
         a.flags |= tff::FLAG_ONLY_RETRY;
     }
-    const unsigned grid = (c->solver == 0) ? (unsigned)(B < 1024 ? B : 1024) : tff::pose_grid(B);
+    const unsigned grid = (c->solver == 0) ? (unsigned)(B < 8192 ? B : 8192) : tff::pose_grid(B);
     hipLaunchKernelGGL(tff::k_linear_tft<true>, dim3(grid), dim3(64), tff::pose_lds_bytes(N, 0, true), c->stream, a);
     TFF_HIP(hipGetLastError());
     return 0;

@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(64, 2) k_linear_f_pose(const LinearTftArgs a) 
                     x = wave_jacobi_min_eigvec(jw->A, jw->V, 9, 9, &its);
                 } else {
                     double r2;
-                    x = wave_min_eigvec_reg<9>(g, diag, w->Lp, 50, &its, &r2);
+                    x = wave_min_eigvec_reg<9>(g, diag, w->Lp, EIG_MAXIT, &its, &r2);
                     ok = ok && eig_converged(r2);
                 }
                 if (dbg && lane == 0) dbg[69 + pair] = (double)its;

@@ -56,6 +56,11 @@ struct LinearTftArgs {
     const int* sample_idx;   // null, or B x N int32 indices into ONE shared scene at `corresp` (config 4: minimal samples)
 };
 
+// Inverse-iteration cap before a triplet is handed to the Jacobi fix-up pass: 300 iterations (~0.13 M
+// instructions) are still ~10x cheaper than the LDS Jacobi, and cover spectral-gap ratios up to ~0.9
+// (minimal 7-point samples, samples with outliers); typical well-posed triplets use 4.
+constexpr int EIG_MAXIT = 300;
+
 // c-vector of a pair of 3-vectors (see header): bilinear weights of the q-monomials
 __device__ __forceinline__ void cvec(const double* a, const double* b, double (&c)[4]) {
     c[0] = a[0] * b[0] + a[1] * b[1];
@@ -185,7 +190,7 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, bool want_P,
             it1 += 1000;
         } else {
             double r2;
-            x = wave_min_eigvec_reg<27, G>(g, diag, w->Lp, 50, &it1, &r2);
+            x = wave_min_eigvec_reg<27, G>(g, diag, w->Lp, EIG_MAXIT, &it1, &r2);
             ok = ok && eig_converged(r2);
         }
         if (lane < 27) w->t[lane] = x;
@@ -228,7 +233,7 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, bool want_P,
             it2 += 1000;
         } else {
             double r2;
-            x = wave_min_eigvec_reg<15, G>(g, diag, w->Lp, 50, &it2, &r2);
+            x = wave_min_eigvec_reg<15, G>(g, diag, w->Lp, EIG_MAXIT, &it2, &r2);
             ok = ok && eig_converged(r2);
         }
         if (lane < 15) w->tp[lane] = x;

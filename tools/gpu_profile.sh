@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for profiles/: kernel trace + stats, then PMC passes (separately) for HBM traffic.
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof_r1
+OUT=$R/gpurun_out/prof_r1b
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 3"
@@ -11,5 +11,5 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OU
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/pmc_sq.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -- $CMD > $OUT/pmc_sq2.log 2>&1
 cd $R
-find gpurun_out/prof_r1 -name "*.csv" | head -30
-python3 tools/summarize_profile.py gpurun_out/prof_r1 | tee gpurun_out/prof_r1/summary.txt
+find gpurun_out/prof_r1b -name "*.csv" | head -30
+python3 tools/summarize_profile.py gpurun_out/prof_r1b | tee gpurun_out/prof_r1b/summary.txt
