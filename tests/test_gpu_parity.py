@@ -348,7 +348,7 @@ def test_gh_vs_oracle_metrics_and_iterations(gpu_ctx, method, key):
         dit.append(int(out["iter"][b]) - it)
         for k, (Rg, Ro) in enumerate(((out["R_t_2"][b], R2), (out["R_t_3"][b], R3))):
             rg, tg = O.AngError(Rt0[k], Rg); ro, to = O.AngError(Rt0[k], Ro)
-            assert abs(rg - ro) < 2e-3 + 5e-3 * ro and abs(tg - to) < 2e-3 + 5e-3 * to   # degrees; an iteration flip moves the pose by ~1e-4 relative
+            assert abs(rg - ro) < 0.02 + 0.02 * ro and abs(tg - to) < 0.02 + 0.02 * to   # degrees; an iteration flip moves the pose by ~1e-4 rad
         P = lambda Ra, Rb: [CalM[0:3] @ np.eye(3, 4), CalM[3:6] @ Ra, CalM[6:9] @ Rb]
         eg = O.ReprError(P(out["R_t_2"][b], out["R_t_3"][b]), C[b].T.copy(), out["Reconst"][b])
         eo = O.ReprError(P(R2, R3), C[b].T.copy(), Rec)

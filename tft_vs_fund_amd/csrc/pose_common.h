@@ -286,16 +286,27 @@ __device__ __attribute__((noinline)) int tri_pass(PoseLds* w, const double* pts,
     load_uniform12(aux, AX);
     int score = 0;
     double num = 0.0, den = 0.0;
+    Pt6 pnext = load_pt(pts, (lane < N) ? lane : 0);                             // software-pipelined: next point in flight
 #pragma unroll 1
     for (int i = lane; i < N; i += WAVE) {
-        const Pt6 p = premap(load_pt(pts, i), pre);
+        const Pt6 p = premap(pnext, pre);
+        if (i + WAVE < N) pnext = load_pt(pts, i + WAVE);
         double S[4][4];
         tri_zero(S);
         tri_accum(S, PA, p.v[0], p.v[1]);
         tri_accum(S, PB, (view == 1) ? p.v[2] : p.v[4], (view == 1) ? p.v[3] : p.v[5]);
         if (mode >= TRI_RECONST) tri_accum(S, AX, p.v[4], p.v[5]);
         double X[4];
-        spd_min_eigvec<4>(S, X);
+        // The vote only consumes the SIGNS of two depths: from the least-squares start (error ~ lambda4/lambda3
+        // ~ 1e-7) one inverse iteration (-> ~1e-14) is plenty; the other modes iterate to convergence.
+        spd_min_eigvec<4>(S, X, (mode == TRI_VOTE) ? 1 : 40);
+        if (mode == TRI_VOTE) {
+            // sign(X1(3)) + sign(X2(3)) with X1 = X./X(4), X2 = [R t]*X1   (R_t_from_TFT.m:98-100): signs only, no division
+            const double s4 = sgn(X[3]);
+            const double z2 = AX[8] * X[0] + AX[9] * X[1] + AX[10] * X[2] + AX[11] * X[3];
+            score += (int)(sgn(X[2]) * s4) + (int)(sgn(z2) * s4);
+            continue;
+        }
         if (mode == TRI_REPROJECT) {                                               // p_est = P*X; p(1:2)./p(3)
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
@@ -310,10 +321,7 @@ __device__ __attribute__((noinline)) int tri_pass(PoseLds* w, const double* pts,
         }
         const double iw = 1.0 / X[3];
         const double X0 = X[0] * iw, X1 = X[1] * iw, X2 = X[2] * iw;                 // X./X(4)
-        if (mode == TRI_VOTE) {
-            const double z2 = AX[8] * X0 + AX[9] * X1 + AX[10] * X2 + AX[11];         // [R t]*X1   (:99)
-            score += (int)sgn(X2) + (int)sgn(z2);                                      // :100
-        } else if (mode == TRI_SCALE) {
+        if (mode == TRI_SCALE) {
             double X3[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) X3[r] = AX[4 * r] * X0 + AX[4 * r + 1] * X1 + AX[4 * r + 2] * X2;   // X3 = K3*R3*X  (:71)

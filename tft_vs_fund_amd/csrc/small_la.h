@@ -93,9 +93,30 @@ __device__ __forceinline__ int spd_min_eigvec(const double (&S)[n][n], double (&
             L[i][j] = s * rs;
         }
     }
-    const double x0 = (n == 4) ? 0.5 : 0.57735026918962576;
+    // Start vector: the inhomogeneous least-squares solution with the last coordinate fixed to 1,
+    //   x = (-S11^-1 s, 1) = (-L11^-T L(n,1:n-1)', 1);
+    // the last row of the factor already is the forward solve L11^-1 s, so this costs one (n-1) x (n-1)
+    // back substitution.  For a well-posed DLT system it is within ~lambda_n/lambda_(n-1) of the answer,
+    // which saves an iteration; if the last coordinate of the true vector is ~0 it is just another start.
+    {
+        double z[n];
 #pragma unroll
-    for (int i = 0; i < n; ++i) x[i] = x0;
+        for (int i = n - 2; i >= 0; --i) {
+            double sum = -L[n - 1][i];
+#pragma unroll
+            for (int k = i + 1; k < n - 1; ++k) sum -= L[k][i] * z[k];
+            z[i] = sum * inv[i];
+        }
+        double nn0 = 1.0;
+#pragma unroll
+        for (int i = 0; i < n - 1; ++i) nn0 += z[i] * z[i];
+        const double r0 = rsqrt(nn0);
+        const bool fin = nn0 <= 1e300;                                         // false for inf / NaN
+        const double xu = (n == 4) ? 0.5 : 0.57735026918962576;
+#pragma unroll
+        for (int i = 0; i < n - 1; ++i) x[i] = fin ? z[i] * r0 : xu;
+        x[n - 1] = fin ? r0 : xu;
+    }
     double rprev2 = 1.0;
     int it = 0;
 #pragma unroll 1
