@@ -120,6 +120,17 @@ int tff_faugpapa_tft_pose_batch_host(tff_ctx* ctx, const double* corresp, const 
                                      int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
                                      int32_t* iter, int32_t* status);
 
+/* OptimFPoseEstimation (F_methods/OptimFPoseEstimation.m:44-73): two fundamental matrices, each refined by
+ * optimF (F_methods/optimF.m:34-109: linearF start, 9 parameters, constraints det F = 0 and |F| = 1, one
+ * epipolar equation per correspondence, Gauss-Helmert) -> recover_R_t x2 -> t3 scale -> (Reconst) ->
+ * T = TFT_from_P.  iter = it1 + it2.  Needs N >= 8. */
+int tff_optim_f_pose_batch_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                               int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                               int32_t* iter, int32_t* status);
+int tff_optim_f_pose_batch_host(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                                int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                int32_t* iter, int32_t* status);
+
 /* LinearFPoseEstimation (F_methods/LinearFPoseEstimation.m:42-109): Normalize2Ddata x3 ->
  * linearF x2 (F_methods/linearF.m:32-62) -> recover_R_t x2 -> t3 scale -> (Reconst) ->
  * T = TFT_from_P (TFT_methods/TFT_from_P.m:25-33).  Needs N >= 8 (status TFF_ST_TOO_FEW otherwise). */

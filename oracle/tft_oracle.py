@@ -782,3 +782,78 @@ def FaugPapaTFTPoseEstimation(Corresp, CalM, return_debug=False):
     if return_debug:
         return R_t_2, R_t_3, Reconst, T, it, dict(reason=reason, param0=param0, param=param)
     return R_t_2, R_t_3, Reconst, T, it
+
+
+# --------------------------------------------------------------------------
+# F_methods/optimF.m, F_methods/OptimFPoseEstimation.m   
+# --------------------------------------------------------------------------
+def _constraintsGH_F(x, p):
+    """optimF.m:83-109"""
+    N = x.shape[0] // 4
+    xr = x.reshape(4, N, order='F')
+    F = p.reshape(3, 3, order='F')
+    Fl = p                                    # F(k), 1-based linear index k -> Fl[k-1]
+    g = np.array([np.linalg.det(F), np.sum(Fl ** 2) - 1])
+    C = np.array([[Fl[4] * Fl[8] - Fl[5] * Fl[7], Fl[5] * Fl[6] - Fl[3] * Fl[8], Fl[3] * Fl[7] - Fl[4] * Fl[6],
+                   Fl[2] * Fl[7] - Fl[1] * Fl[8], Fl[0] * Fl[8] - Fl[2] * Fl[6], Fl[1] * Fl[6] - Fl[0] * Fl[7],
+                   Fl[1] * Fl[5] - Fl[2] * Fl[4], Fl[2] * Fl[3] - Fl[0] * Fl[5], Fl[0] * Fl[4] - Fl[1] * Fl[3]],
+                  2 * Fl])
+    f = np.zeros(N); A = np.zeros((N, 9)); B = np.zeros((N, 4 * N))
+    for i in range(N):
+        x1 = np.array([xr[0, i], xr[1, i], 1.0]); x2 = np.array([xr[2, i], xr[3, i], 1.0])
+        f[i] = x2 @ F @ x1
+        A[i, :] = [x1[0] * x2[0], x1[0] * x2[1], x1[0], x1[1] * x2[0], x1[1] * x2[1], x1[1], x2[0], x2[1], 1]
+        B[i, 4 * i:4 * i + 4] = [Fl[2] + Fl[0] * x2[0] + Fl[1] * x2[1], Fl[5] + Fl[3] * x2[0] + Fl[4] * x2[1],
+                                 Fl[6] + Fl[0] * x1[0] + Fl[3] * x1[1], Fl[7] + Fl[1] * x1[0] + Fl[4] * x1[1]]
+    return f, g, A, B, C, np.zeros((2, 0))
+
+
+def optimF(p1, p2, return_debug=False):
+    """F_methods/optimF.m:34-77"""
+    N = p1.shape[1]
+    if N != p2.shape[1] or N < 8:
+        raise ValueError('At least 8 correspondences are necessary to compute the fundamental matrix linearly')
+    if p1.shape[0] == 3:
+        p1 = p1[0:2, :] / p1[2:3, :]
+        p2 = p2[0:2, :] / p2[2:3, :]
+    x1, Normal1 = Normalize2Ddata(p1)
+    x2, Normal2 = Normalize2Ddata(p2)
+    F = linearF(x1, x2)
+    F = F / np.sqrt(np.sum(F.reshape(9, order='F') ** 2))                  # :50
+    U, _, _ = _svd(F)
+    epi21 = U[:, 2]                                                        # :53
+    P1 = np.eye(3, 4)
+    P2 = np.hstack([crossM(epi21) @ F, epi21.reshape(3, 1)])               # :55
+    points3D = triangulation3D([P1, P2], np.vstack([x1, x2]))
+    p1_est = P1 @ points3D; p1_est = p1_est[0:2, :] / p1_est[2:3, :]
+    p2_est = P2 @ points3D; p2_est = p2_est[0:2, :] / p2_est[2:3, :]
+    p = F.reshape(9, order='F')
+    x = np.vstack([x1[0:2, :], x2[0:2, :]]).reshape(4 * N, order='F')
+    x_est = np.vstack([p1_est, p2_est]).reshape(4 * N, order='F')
+    _, p_opt, _, it, reason = Gauss_Helmert(lambda a, b, c: _constraintsGH_F(a, b), x_est, p, np.zeros(0), x, None, True)
+    F = p_opt.reshape(3, 3, order='F')
+    F = Normal2.T @ F @ Normal1                                            # :72
+    U, D, V = _svd(F)
+    D = D.copy(); D[2] = 0
+    F = U @ np.diag(D) @ V.T                                               # :75-76
+    if return_debug:
+        return F, it, dict(reason=reason, p0=p, p_opt=p_opt)
+    return F, it
+
+
+def OptimFPoseEstimation(Corresp, CalM):
+    """F_methods/OptimFPoseEstimation.m:44-73"""
+    K1, K2, K3 = CalM[0:3, :], CalM[3:6, :], CalM[6:9, :]
+    F21, it1 = optimF(Corresp[0:2, :], Corresp[2:4, :])
+    F31, it2 = optimF(Corresp[0:2, :], Corresp[4:6, :])
+    it = it1 + it2
+    P1cam = np.hstack([K1, np.zeros((3, 1))])
+    R2, t2 = _recover_R_t_core(K2.T @ F21 @ K1, P1cam, K2, Corresp[0:2, :], Corresp[2:4, :])
+    R3, t3 = _recover_R_t_core(K3.T @ F31 @ K1, P1cam, K3, Corresp[0:2, :], Corresp[4:6, :])
+    lam = _t3_scale(K1, K2, K3, R2, t2, R3, t3, Corresp)
+    t3 = lam * t3
+    R_t_2 = np.hstack([R2, t2.reshape(3, 1)])
+    R_t_3 = np.hstack([R3, t3.reshape(3, 1)])
+    Reconst = _final_reconst(CalM, R_t_2, R_t_3, Corresp)
+    T = TFT_from_P(K1 @ np.eye(3, 4), K2 @ R_t_2, K3 @ R_t_3)
+    return R_t_2, R_t_3, Reconst, T, it

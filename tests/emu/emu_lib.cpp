@@ -35,7 +35,12 @@ extern "C" int emu_linear_tft_pose(const double* corresp, const double* calm, lo
 }
 extern "C" int emu_linear_f_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
                                  double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
-    return emu_pose(tff::k_linear_f_pose<false>, tff::k_linear_f_pose<true>, tff::pose_lds_bytes, true, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T,
+    return emu_pose(tff::k_f_pose<false, 0>, tff::k_f_pose<true, 0>, tff::pose_lds_bytes, true, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T,
+                    reconst, iter, status, dbg);
+}
+extern "C" int emu_optim_f_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                                double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
+    return emu_pose(tff::k_f_pose<false, 1>, tff::k_f_pose<true, 1>, tff::optimf_lds_bytes, false, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T,
                     reconst, iter, status, dbg);
 }
 extern "C" int emu_ressl_tft_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,

@@ -15,8 +15,9 @@ the literal numpy/LAPACK restatement of the .m files -- run on
 
 Run from the repo root (needs /root/reference for the EPFL part only):
     python tests/golden/make_golden.py
-Outputs: synthetic_linear.npz, synthetic_gh.npz, epfl.npz  (inputs + expected
-outputs; no reference source text).
+Outputs: synthetic_linear.npz, synthetic_gh.npz, epfl.npz, optimf.npz  (inputs +
+expected outputs; no reference source text).  optimf.npz (OptimFPoseEstimation)
+covers synthetic scenes and the 100-correspondence EPFL samples of epfl.npz.
 """
 import os
 import sys
@@ -106,6 +107,37 @@ def make_synthetic_gh():
     np.savez_compressed(os.path.join(HERE, "synthetic_gh.npz"), **data)
 
 
+OPTIMF_CASES = [(8, 1.0, 41, 3), (12, 1.0, 42, 3), (12, 3.0, 43, 2), (50, 0.0, 44, 2), (100, 1.0, 45, 3), (200, 1.0, 46, 3),
+                (200, 3.0, 47, 2), (700, 1.0, 48, 2)]
+
+
+def make_optimf():
+    """OptimFPoseEstimation (F_methods/OptimFPoseEstimation.m) on synthetic scenes and on the EPFL samples of epfl.npz."""
+    data = {}
+    for ci, (N, sigma, seed, B) in enumerate(OPTIMF_CASES):
+        C, CalM, Rt0, _ = generate_scene_batch(B, N, noise=sigma, seed=seed)
+        pre = "c%d_" % ci
+        data[pre + "Corresp"] = C
+        data[pre + "CalM"] = CalM
+        data[pre + "meta"] = np.array([N, sigma, seed, B], dtype=np.float64)
+        acc = {k: [] for k in ("Rt2", "Rt3", "T", "Rec", "iter")}
+        for b in range(B):
+            R2, R3, Rec, T, it = O.OptimFPoseEstimation(C[b].T.copy(), CalM)
+            acc["Rt2"].append(R2); acc["Rt3"].append(R3); acc["T"].append(T); acc["Rec"].append(Rec); acc["iter"].append(it)
+        for k in ("Rt2", "Rt3", "T", "Rec"):
+            data[pre + "optimf_" + k] = np.stack(acc[k])
+        data[pre + "optimf_iter"] = np.array(acc["iter"], dtype=np.int32)
+        print("optimf case", ci, N, sigma, acc["iter"], flush=True)
+    g = np.load(os.path.join(HERE, "epfl.npz"))
+    for n in range(int(g["count"])):
+        pre = "t%d_" % n
+        R2, R3, Rec, T, it = O.OptimFPoseEstimation(g[pre + "sample"].copy(), g[pre + "CalM"])
+        data[pre + "optimf_Rt2"] = R2; data[pre + "optimf_Rt3"] = R3; data[pre + "optimf_T"] = T; data[pre + "optimf_Rec"] = Rec
+        data[pre + "optimf_iter"] = np.array(it)
+        print("optimf epfl", n, it, flush=True)
+    np.savez_compressed(os.path.join(HERE, "optimf.npz"), **data)
+
+
 def _read_camera(path):
     """Data/readCalibrationOrientation_EPFL.m: K (3 rows), skip, R' (3 rows), C, size."""
     with open(path) as f:
@@ -169,10 +201,12 @@ def make_epfl():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["linear", "gh", "epfl"]
+    what = sys.argv[1:] or ["linear", "gh", "epfl", "optimf"]
     if "linear" in what:
         make_synthetic_linear()
     if "gh" in what:
         make_synthetic_gh()
     if "epfl" in what:
         make_epfl()
+    if "optimf" in what:
+        make_optimf()

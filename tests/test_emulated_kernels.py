@@ -96,6 +96,29 @@ def test_linear_f_needs_8_points(emu):
     assert out["status"][0] == 1 and np.all(np.isnan(out["T"][0]))
 
 
+def test_optim_f_kernel_matches_golden(emu, golden_dir):
+    """OptimFPoseEstimation kernel (linearF start + per-pair Gauss-Helmert with scalar weight blocks): the
+    epipolar model is well conditioned, so iteration counts and results match the dense oracle to rounding."""
+    import os
+    g = np.load(os.path.join(golden_dir, "optimf.npz"))
+    for pre, flags in (("c0_", 0), ("c1_", 0), ("c3_", 0), ("c1_", FLAG_JACOBI)):
+        C, CalM = g[pre + "Corresp"][:2], g[pre + "CalM"]
+        out = run_linear_tft(emu, C, CalM, flags, entry="emu_optim_f_pose")
+        assert np.all(out["status"] == 0)
+        for b in range(2):
+            assert int(out["iter"][b]) == int(g[pre + "optimf_iter"][b])
+            assert rel_err_T(out["T"][b], g[pre + "optimf_T"][b]) < 1e-8
+            assert rel_err(out["R_t_2"][b], g[pre + "optimf_Rt2"][b]) < 1e-8 and rel_err(out["R_t_3"][b], g[pre + "optimf_Rt3"][b]) < 1e-8
+            assert rel_err(out["Reconst"][b], g[pre + "optimf_Rec"][b]) < 1e-8
+    e = np.load(os.path.join(golden_dir, "epfl.npz"))
+    out = run_linear_tft(emu, np.ascontiguousarray(e["t3_sample"].T)[None], e["t3_CalM"], entry="emu_optim_f_pose")
+    assert out["status"][0] == 0 and int(out["iter"][0]) == int(g["t3_optimf_iter"])
+    assert rel_err_T(out["T"][0], g["t3_optimf_T"]) < 1e-8 and rel_err(out["R_t_3"][0], g["t3_optimf_Rt3"]) < 1e-8
+    C, CalM, _, _ = generate_scene_batch(1, 7, noise=1.0, seed=1)
+    out = run_linear_tft(emu, C, CalM, entry="emu_optim_f_pose")
+    assert out["status"][0] == 1 and np.all(np.isnan(out["T"][0]))          # optimF.m:36-38
+
+
 def test_ressl_kernel_matches_block_checker(emu, golden_dir):
     """Gauss-Helmert kernel on one N = 12 triplet: against the same-block-algebra restatement
     (oracle/gh_block_oracle.py) and the dense oracle's golden output.  Tolerances: see

@@ -22,7 +22,7 @@ from tft_vs_fund_amd.scenes import generate_scene_batch
 from helpers import rel_err_T, rel_err, golden_cases
 
 METHODS = ["LinearTFTPoseEstimation", "LinearFPoseEstimation", "ResslTFTPoseEstimation",
-           "NordbergTFTPoseEstimation", "FaugPapaTFTPoseEstimation"]
+           "NordbergTFTPoseEstimation", "FaugPapaTFTPoseEstimation", "OptimFPoseEstimation"]
 
 
 @pytest.mark.parametrize("method", METHODS)
@@ -101,6 +101,37 @@ def test_golden_linear_reproduces(golden_dir):
             R2, R3, Rec, T, it = O.LinearFPoseEstimation(C[b].T.copy(), CalM)
             assert rel_err_T(T, g[pre + "f_T"][b]) < 1e-10
             assert rel_err(R2, g[pre + "f_Rt2"][b]) < 1e-10 and rel_err(R3, g[pre + "f_Rt3"][b]) < 1e-10
+
+
+def test_golden_optimf_reproduces_and_refines(golden_dir):
+    """optimf.npz reproduces from the oracle; on noisy scenes optimF's Gauss-Helmert step lowers the
+    reprojection error of its linearF start (what the refinement is for, OptimFPoseEstimation.m:48-49)."""
+    g = np.load(os.path.join(golden_dir, "optimf.npz"))
+    for ci, pre in golden_cases(g):
+        C, CalM = g[pre + "Corresp"], g[pre + "CalM"]
+        if C.shape[1] > 200:
+            continue
+        Cb = C[0].T.copy()
+        R2, R3, Rec, T, it = O.OptimFPoseEstimation(Cb, CalM)
+        assert it == int(g[pre + "optimf_iter"][0])
+        assert rel_err_T(T, g[pre + "optimf_T"][0]) < 1e-9 and rel_err(R3, g[pre + "optimf_Rt3"][0]) < 1e-9
+        if g[pre + "meta"][1] > 0 and C.shape[1] >= 50:
+            L2, L3, LRec, _, _ = O.LinearFPoseEstimation(Cb, CalM)
+            P = lambda Ra, Rb: [CalM[0:3] @ np.eye(3, 4), CalM[3:6] @ Ra, CalM[6:9] @ Rb]
+            assert O.ReprError(P(R2, R3), Cb) < O.ReprError(P(L2, L3), Cb)
+
+
+def test_optimF_two_view_properties():
+    """optimF.m:34-109: the refined F is rank 2, satisfies the epipolar constraint exactly on noise-free
+    points after one Gauss-Helmert iteration, and needs 8 correspondences (:36-38)."""
+    C, CalM, Rt0, _ = generate_scene_batch(1, 30, noise=0.0, seed=9)
+    Cb = C[0].T.copy()
+    F, it = O.optimF(Cb[0:2], Cb[2:4])
+    assert it == 1 and np.linalg.svd(F, compute_uv=False)[2] < 1e-12 * np.linalg.norm(F)
+    x1 = np.vstack([Cb[0:2], np.ones(30)]); x2 = np.vstack([Cb[2:4], np.ones(30)])
+    assert np.max(np.abs(np.einsum("in,ij,jn->n", x2, F, x1))) < 1e-9 * np.linalg.norm(F) * 1e6
+    with pytest.raises(ValueError):
+        O.optimF(Cb[0:2, :7], Cb[2:4, :7])
 
 
 def test_golden_epfl_linear_quality(golden_dir):

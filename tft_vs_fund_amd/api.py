@@ -109,6 +109,7 @@ POSE_METHODS = {
     "ResslTFTPoseEstimation": "tff_ressl_tft_pose_batch",
     "FaugPapaTFTPoseEstimation": "tff_faugpapa_tft_pose_batch",
     "NordbergTFTPoseEstimation": "tff_nordberg_tft_pose_batch",
+    "OptimFPoseEstimation": "tff_optim_f_pose_batch",
 }
 
 # every symbol include/tftfund.h declares (checked by the CPU test-suite)
@@ -120,6 +121,7 @@ EXPORTED_SYMBOLS = [
     "tff_ressl_tft_pose_batch_dev", "tff_ressl_tft_pose_batch_host", "tff_ressl_tft_pose_batch_debug_dev",
     "tff_faugpapa_tft_pose_batch_dev", "tff_faugpapa_tft_pose_batch_host",
     "tff_nordberg_tft_pose_batch_dev", "tff_nordberg_tft_pose_batch_host",
+    "tff_optim_f_pose_batch_dev", "tff_optim_f_pose_batch_host",
     "tff_triangulate_batch_dev", "tff_repr_error_batch_dev", "tff_inlier_count_batch_dev", "tff_transform_tft_batch_dev",
     "tff_rt_from_tft_batch_dev", "tff_linear_tft_batch_dev", "tff_linear_tft_pose_sampled_dev", "tff_linear_f_pose_sampled_dev",
 ]
@@ -410,3 +412,8 @@ def FaugPapaTFTPoseEstimation(Corresp, CalM):
 def NordbergTFTPoseEstimation(Corresp, CalM):
     """Drop-in for TFT_methods/NordbergTFTPoseEstimation.m (iter = Gauss-Helmert iterations)."""
     return _single("NordbergTFTPoseEstimation", Corresp, CalM)
+
+
+def OptimFPoseEstimation(Corresp, CalM):
+    """Drop-in for F_methods/OptimFPoseEstimation.m (iter = it1 + it2 Gauss-Helmert iterations of the two optimF calls)."""
+    return _single("OptimFPoseEstimation", Corresp, CalM)

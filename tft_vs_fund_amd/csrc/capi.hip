@@ -158,7 +158,12 @@ int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int
 }
 int launch_linear_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    return launch_pose(c, tff::k_linear_f_pose<false>, tff::k_linear_f_pose<true>, tff::pose_lds_bytes, true, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
+    return launch_pose(c, tff::k_f_pose<false, 0>, tff::k_f_pose<true, 0>, tff::pose_lds_bytes, true, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
+                       reconst, iter, status, dbg);
+}
+int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
+                   double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+    return launch_pose(c, tff::k_f_pose<false, 1>, tff::k_f_pose<true, 1>, tff::optimf_lds_bytes, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
                        reconst, iter, status, dbg);
 }
 
@@ -332,6 +337,16 @@ int tff_faugpapa_tft_pose_batch_host(tff_ctx* c, const double* corresp, const do
                                       int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
                                       int32_t* status) {
     return pose_batch_host(launch_faugpapa_tft, c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status);
+}
+int tff_optim_f_pose_batch_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                                int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                                int32_t* status) {
+    return launch_optim_f(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, nullptr);
+}
+int tff_optim_f_pose_batch_host(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                                 int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                                 int32_t* status) {
+    return pose_batch_host(launch_optim_f, c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status);
 }
 
 int tff_linear_f_pose_batch_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,

@@ -17,6 +17,7 @@
 #pragma once
 #include "pose_common.h"
 #include "tft_kernel.h"
+#include "gh_kernel.h"
 
 namespace tff {
 
@@ -84,13 +85,192 @@ __device__ inline void tft_from_cameras(PoseLds* w, double* tout) {     // camer
     if (lane < 27) tout[lane] = val * rsqrt(nn);                           // :33
 }
 
-template <bool JAC>
-__global__ void __launch_bounds__(64, 2) k_linear_f_pose(const LinearTftArgs a) {
+// ---- optimF: Gauss-Helmert refinement of one fundamental matrix (F_methods/optimF.m:34-109) ----
+// One epipolar equation per correspondence, so the blocks of Gauss_Helmert.m are scalars:
+//   W_i = B_i B_i' (1x1), pinv(W + 1e-12 I) + 1e-12 I diagonal with pinv's global tolerance N eps(max W),
+//   A'WA = sum_i W_i a_i a_i' (45 sums) and A'Ww (9 sums): two 32-accumulator sweeps, 11 x 11 KKT system.
+struct OptimFLds {
+    double p[10];          // F(:) column-major (9)
+    double dt[12];         // KKT solution (9 + 2)
+    double H[56];          // 45 + 9 accumulated sums
+    double M[11 * 12];     // augmented KKT matrix
+};
+constexpr int OPTIMF_FIXED_DOUBLES = (int)(sizeof(OptimFLds) / sizeof(double));
+__host__ __device__ inline int optimf_lds_doubles(int N) { return OPTIMF_FIXED_DOUBLES + 8 * N + 2; }   // + xi (4N) + v (4N)
+
+// per correspondence: f = x2' F x1, a (1x9), B (1x4)   (optimF.m:101-107); o = [x1 y1 x2 y2], Fl = F(:) column-major
+__device__ __forceinline__ void epi_block(const double (&Fl)[9], const double (&o)[4], double& f, double (&a)[9], double (&B)[4]) {
+    const double x1 = o[0], y1 = o[1], x2 = o[2], y2 = o[3];
+    a[0] = x1 * x2; a[1] = x1 * y2; a[2] = x1; a[3] = y1 * x2; a[4] = y1 * y2; a[5] = y1; a[6] = x2; a[7] = y2; a[8] = 1.0;
+    f = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) f += Fl[k] * a[k];
+    B[0] = Fl[2] + Fl[0] * x2 + Fl[1] * y2;
+    B[1] = Fl[5] + Fl[3] * x2 + Fl[4] * y2;
+    B[2] = Fl[6] + Fl[0] * x1 + Fl[3] * y1;
+    B[3] = Fl[7] + Fl[1] * x1 + Fl[4] * y1;
+}
+
+// x (normalised observations of views 1 and v2) for correspondence i
+__device__ __forceinline__ void obs4(const double* pts, int i, const double* nrm, int v2, double (&x)[4]) {
+    const Pt6 p = premap(load_pt(pts, i), nrm);
+    x[0] = p.v[0]; x[1] = p.v[1]; x[2] = p.v[2 * v2]; x[3] = p.v[2 * v2 + 1];
+}
+
+// Gauss_Helmert.m:38-83 specialised to optimF's callback.  g.p holds F(:), xi the initial estimates.  Returns iterations.
+__device__ inline int gauss_helmert_f_wave(PoseLds* w, OptimFLds* g, double* xi, double* vbuf, const double* pts, int N, int v2, int* st) {
+    const int lane = lane_id();
+    constexpr int u = 9, n = 11, ld = 12;
+    double objFunc = 0.0;
+    for (int i = lane; i < N; i += WAVE) {
+        double x[4];
+        obs4(pts, i, w->nrm, v2, x);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const double d = xi[4 * i + k] - x[k]; objFunc += d * d; }
+    }
+    objFunc = wave_sum(objFunc);
+    int it = 0;
+#pragma unroll 1
+    for (it = 1; it <= 400; ++it) {
+        double Fl[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Fl[k] = wave_uniform(g->p[k]);
+        // W = B B' (+1e-12), its maximum -> pinv tolerance   (Gauss_Helmert.m:52,57)
+        double smax = 0.0;
+        for (int i = lane; i < N; i += WAVE) {
+            double o[4] = {xi[4 * i], xi[4 * i + 1], xi[4 * i + 2], xi[4 * i + 3]}, f, a[9], B[4];
+            epi_block(Fl, o, f, a, B);
+            const double wv = B[0] * B[0] + B[1] * B[1] + B[2] * B[2] + B[3] * B[3] + 1e-12;
+            smax = (wv > smax) ? wv : smax;
+            if (!(wv <= 1.79e308)) smax = wv;                                // NaN/Inf propagates
+        }
+        smax = wave_max(smax);
+        if (!(smax <= 1.79e308)) { *st = ST_NONFINITE; break; }              // :53-55
+        const double tolW = (double)N * eps_of(smax);
+        // sums: H[0..44] = lower triangle of sum W a a', H[45..53] = sum W w a
+#pragma unroll 1
+        for (int sweep = 0; sweep < 2; ++sweep) {
+            double acc[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+            for (int i = lane; i < N; i += WAVE) {
+                double o[4] = {xi[4 * i], xi[4 * i + 1], xi[4 * i + 2], xi[4 * i + 3]}, f, a[9], B[4], x[4];
+                epi_block(Fl, o, f, a, B);
+                const double wv = B[0] * B[0] + B[1] * B[1] + B[2] * B[2] + B[3] * B[3] + 1e-12;
+                const double Wp = ((wv > tolW) ? 1.0 / wv : 0.0) + 1e-12;    // :57
+                obs4(pts, i, w->nrm, v2, x);
+                const double wr = -f - (B[0] * (x[0] - o[0]) + B[1] * (x[1] - o[1]) + B[2] * (x[2] - o[2]) + B[3] * (x[3] - o[3]));   // :58
+                double wa[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) wa[k] = Wp * a[k];
+                if (sweep == 0) {
+                    int e = 0;
+#pragma unroll
+                    for (int r = 0; r < 9; ++r)
+#pragma unroll
+                        for (int c = 0; c <= r; ++c) { if (e < 32) acc[e] += wa[r] * a[c]; ++e; }
+                } else {
+                    int e = 0;
+#pragma unroll
+                    for (int r = 0; r < 9; ++r)
+#pragma unroll
+                        for (int c = 0; c <= r; ++c) { if (e >= 32) acc[e - 32] += wa[r] * a[c]; ++e; }
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) acc[13 + k] += wa[k] * wr;
+                }
+            }
+            const double tot = wave_reduce_scatter<32>(acc);
+            const int idx = reduce32_index(lane);
+            if ((lane & 1) == 0 && (sweep == 0 || idx < 22)) g->H[32 * sweep + idx] = tot;
+        }
+        wave_sync();
+        // KKT matrix: [N + 1e-12 I, C'; C, 1e-12 I], b = [A'Ww; -g]   (:59-62), constraints optimF.m:90-95
+        for (int e = lane; e < n * ld; e += WAVE) g->M[e] = 0.0;
+        wave_sync();
+        for (int e = lane; e < 81 + 9; e += WAVE) {
+            if (e < 81) {
+                const int r = e / 9, c = e % 9, hi = (r > c) ? r : c, lo = (r > c) ? c : r;
+                g->M[r * ld + c] = g->H[hi * (hi + 1) / 2 + lo] + ((r == c) ? 1e-12 : 0.0);
+            } else {
+                g->M[(e - 81) * ld + n] = g->H[45 + e - 81];
+            }
+        }
+        if (lane == 0) {
+            const double* F = g->p;                                          // F(k+1) = F[k]
+            const double C0[9] = {F[4] * F[8] - F[5] * F[7], F[5] * F[6] - F[3] * F[8], F[3] * F[7] - F[4] * F[6],
+                                  F[2] * F[7] - F[1] * F[8], F[0] * F[8] - F[2] * F[6], F[1] * F[6] - F[0] * F[7],
+                                  F[1] * F[5] - F[2] * F[4], F[2] * F[3] - F[0] * F[5], F[0] * F[4] - F[1] * F[3]};
+            double det = F[0] * C0[0] + F[3] * C0[3] + F[6] * C0[6];          // det(F) by the first row (F(1,1),F(1,2),F(1,3) = F[0],F[3],F[6])
+            double nn = 0.0;
+            for (int k = 0; k < 9; ++k) {
+                g->M[9 * ld + k] = C0[k]; g->M[k * ld + 9] = C0[k];
+                g->M[10 * ld + k] = 2.0 * F[k]; g->M[k * ld + 10] = 2.0 * F[k];
+                nn += F[k] * F[k];
+            }
+            g->M[9 * ld + 9] = 1e-12; g->M[10 * ld + 10] = 1e-12;
+            g->M[9 * ld + n] = -det; g->M[10 * ld + n] = -(nn - 1.0);
+        }
+        wave_sync();
+        double chk = 0.0;
+        for (int e = lane; e < n * ld; e += WAVE) chk += g->M[e];
+        if (!(fabs(wave_sum(chk)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
+        if (!wave_solve_pivoted(g->M, n, g->dt)) { *st = ST_RANK; break; }   // :67
+        wave_sync();
+        double dt[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dt[k] = wave_uniform(g->dt[k]);
+        // v = -B' W (A dt - w)   (:69)
+        double obj = 0.0, diff = 0.0, ndt2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) ndt2 += dt[k] * dt[k];
+        for (int i = lane; i < N; i += WAVE) {
+            double o[4] = {xi[4 * i], xi[4 * i + 1], xi[4 * i + 2], xi[4 * i + 3]}, f, a[9], B[4], x[4];
+            epi_block(Fl, o, f, a, B);
+            const double wv = B[0] * B[0] + B[1] * B[1] + B[2] * B[2] + B[3] * B[3] + 1e-12;
+            const double Wp = ((wv > tolW) ? 1.0 / wv : 0.0) + 1e-12;
+            obs4(pts, i, w->nrm, v2, x);
+            const double wr = -f - (B[0] * (x[0] - o[0]) + B[1] * (x[1] - o[1]) + B[2] * (x[2] - o[2]) + B[3] * (x[3] - o[3]));
+            double adt = 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) adt += a[k] * dt[k];
+            const double r = Wp * (adt - wr);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double v = -B[k] * r;
+                vbuf[4 * i + k] = v;
+                obj += v * v;
+                const double d = o[k] - x[k] - v;
+                diff += d * d;
+            }
+        }
+        obj = wave_sum(obj);
+        diff = wave_sum(diff);
+        if (sqrt(ndt2) < 1e-6 && sqrt(diff) < 1e-6) break;                   // :71-73
+        if (obj > objFunc) break;                                            // :75-76
+        objFunc = obj;
+        for (int i = lane; i < N; i += WAVE) {                               // xi = x + v; ti += dt   (:80)
+            double x[4];
+            obs4(pts, i, w->nrm, v2, x);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xi[4 * i + k] = x[k] + vbuf[4 * i + k];
+        }
+        if (lane < 9) g->p[lane] += g->dt[lane];
+        wave_sync();
+    }
+    return (it > 400) ? 400 : it;
+}
+
+// METHOD 0: LinearFPoseEstimation; METHOD 1: OptimFPoseEstimation (F_methods/OptimFPoseEstimation.m:44-73)
+template <bool JAC, int METHOD>
+__global__ void __launch_bounds__(64, 2) k_f_pose(const LinearTftArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
     PoseLds* w = reinterpret_cast<PoseLds*>(smem);
     constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
     JacobiLds* jw = JAC ? reinterpret_cast<JacobiLds*>(smem + base) : nullptr;
-    double* lds_pts = smem + base + (JAC ? ((JACOBI_LDS_DOUBLES + 1) & ~1) : 0);
+    double* extra = smem + base + (JAC ? ((JACOBI_LDS_DOUBLES + 1) & ~1) : 0);
+    OptimFLds* og = (METHOD == 1) ? reinterpret_cast<OptimFLds*>(extra) : nullptr;
+    double* oxi = extra + ((OPTIMF_FIXED_DOUBLES + 1) & ~1);                 // METHOD 1: xi (4N), then v (4N)
+    double* lds_pts = (METHOD == 1) ? oxi + 8 * a.N + 2 : extra;             // staged correspondences (METHOD 0, or sampled)
     const int lane = lane_id();
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
         if ((a.flags & FLAG_ONLY_RETRY) && a.status[b] != ST_RETRY) continue;      // wave-uniform
@@ -107,20 +287,20 @@ __global__ void __launch_bounds__(64, 2) k_linear_f_pose(const LinearTftArgs a) 
             pts = lds_pts;
         }
         if (lane < 27) w->calm[lane] = a.calm[b * a.calm_stride + lane];
-        int status = ST_OK;
-        if (N < 8) {                                                         // linearF.m:35-37
+        int status = ST_OK, iters = 0;
+        if (N < 8) {                                                         // linearF.m:35-37, optimF.m:36-38
             status = ST_TOO_FEW;
             const double qnan = __longlong_as_double(0x7ff8000000000000LL);
             if (lane < 12) { a.Rt2[b * 12 + lane] = qnan; a.Rt3[b * 12 + lane] = qnan; }
             if (lane < 27) a.T[b * 27 + lane] = qnan;
             if (a.reconst) for (int i = lane; i < 3 * N; i += WAVE) a.reconst[b * 3 * (long)N + i] = qnan;
         } else {
-            normalise3(pts, N, w->nrm);                                      // LinearFPoseEstimation.m:46-48
+            normalise3(pts, N, w->nrm);                                      // LinearFPoseEstimation.m:46-48 / optimF.m:46-47
             normalise3(pts, N, w->nrm2, w->nrm);                             // linearF.m:45-46 (on the normalised points)
             accumulate_moments_f(w, pts, N);
             bool ok = true;
 #pragma unroll 1
-            for (int pair = 0; pair < 2; ++pair) {                           // linearF(x1,x2), linearF(x1,x3)   (:51-52)
+            for (int pair = 0; pair < 2; ++pair) {                           // linearF(x1,x2), linearF(x1,x3)
                 double g[9], diag = 0.0, x;
                 const int r = (lane < 9) ? lane : 0, i = r / 3, j = r % 3;
 #pragma unroll
@@ -146,39 +326,94 @@ __global__ void __launch_bounds__(64, 2) k_linear_f_pose(const LinearTftArgs a) 
             if (!ok) {
                 status = ST_RETRY;
             } else {
-                double* Ein = w->Minv;
-                if (lane < 2) {
-                    const int v2 = lane + 1;                                 // second view of this pair
+                if (lane < 2) {                                              // linearF.m:58-62: inner de-normalisation, rank 2
+                    const int v2 = lane + 1;
                     Mat3 F;
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
                         for (int c = 0; c < 3; ++c) F.m[r][c] = w->Fm[9 * lane + 3 * r + c];
-                    F = mat3_mul(mat3_mul(mat3_T(normal_matrix(w->nrm2, v2)), F), normal_matrix(w->nrm2, 0));   // linearF.m:58
-                    double v3[3];                                            // rank 2: F - (F v3) v3'   (linearF.m:61-62)
+                    F = mat3_mul(mat3_mul(mat3_T(normal_matrix(w->nrm2, v2)), F), normal_matrix(w->nrm2, 0));
+                    double v3[3], fv[3];
                     null3(F, v3);
-                    double fv[3];
 #pragma unroll
                     for (int r = 0; r < 3; ++r) fv[r] = F.m[r][0] * v3[0] + F.m[r][1] * v3[1] + F.m[r][2] * v3[2];
+                    double nn = 0.0;
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) F.m[r][c] -= fv[r] * v3[c];
-                    F = mat3_mul(mat3_mul(mat3_T(normal_matrix(w->nrm, v2)), F), normal_matrix(w->nrm, 0));     // LinearFPoseEstimation.m:55-56
-                    const Mat3 E = mat3_mul(mat3_mul(mat3_T(load_K(w->calm, v2)), F), load_K(w->calm, 0));      // :86
+                        for (int c = 0; c < 3; ++c) { F.m[r][c] -= fv[r] * v3[c]; nn += F.m[r][c] * F.m[r][c]; }
+                    const double sc = (METHOD == 1) ? rsqrt(nn) : 1.0;       // optimF.m:50: F = F / |F|_F
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) w->Fm[9 * lane + 3 * r + c] = F.m[r][c] * sc;
+                }
+                wave_sync();
+                int gst = ST_OK;
+                if (METHOD == 1) {
+#pragma unroll 1
+                    for (int pair = 0; pair < 2; ++pair) {                   // [F21,it1] = optimF(...), [F31,it2] = optimF(...)   (:48-49)
+                        if (lane == 0) {
+                            Mat3 F, Ft;
+                            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) F.m[r][c] = w->Fm[9 * pair + 3 * r + c];
+                            Ft = mat3_T(F);
+                            double e[3];
+                            null3(Ft, e);                                    // epi21 = U(:,3): left null vector   (optimF.m:53)
+                            // P1 = [I|0] -> Pfin[0];  P2 = [crossM(epi21)*F, epi21] -> P[0]   (:54-55)
+                            for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) w->Pfin[0][4 * r + c] = (r == c) ? 1.0 : 0.0;
+                            for (int c = 0; c < 3; ++c) {
+                                w->P[0][c] = -e[2] * F.m[1][c] + e[1] * F.m[2][c];
+                                w->P[0][4 + c] = e[2] * F.m[0][c] - e[0] * F.m[2][c];
+                                w->P[0][8 + c] = -e[1] * F.m[0][c] + e[0] * F.m[1][c];
+                            }
+                            w->P[0][3] = e[0]; w->P[0][7] = e[1]; w->P[0][11] = e[2];
+                        }
+                        if (lane < 9) og->p[lane] = w->Fm[9 * pair + 3 * (lane % 3) + lane / 3];   // p = F(:) column-major   (:61)
+                        wave_sync();
+                        tri_pass(w, pts, N, TRI_REPROJECT2, pair + 1, w->P[0], w->P[0], oxi, w->nrm);   // x_est   (:56-60)
+                        wave_sync();
+                        iters += gauss_helmert_f_wave(w, og, oxi, oxi + 4 * N + 2, pts, N, pair + 1, &gst);   // :66
+                        wave_sync();
+                        if (lane < 9) w->Fm[9 * pair + 3 * (lane % 3) + lane / 3] = og->p[lane];   // F = reshape(p_opt,3,3)   (:69)
+                        wave_sync();
+                    }
+                }
+                double* Ein = w->Minv;
+                if (lane < 2) {
+                    const int v2 = lane + 1;
+                    Mat3 F;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) F.m[r][c] = w->Fm[9 * lane + 3 * r + c];
+                    // LinearFPoseEstimation.m:55-56 / optimF.m:72: back to pixel coordinates
+                    F = mat3_mul(mat3_mul(mat3_T(normal_matrix(w->nrm, v2)), F), normal_matrix(w->nrm, 0));
+                    if (METHOD == 1) {                                       // optimF.m:75-76: rank 2 again
+                        double v3[3], fv[3];
+                        null3(F, v3);
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) fv[r] = F.m[r][0] * v3[0] + F.m[r][1] * v3[1] + F.m[r][2] * v3[2];
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) F.m[r][c] -= fv[r] * v3[c];
+                    }
+                    const Mat3 E = mat3_mul(mat3_mul(mat3_T(load_K(w->calm, v2)), F), load_K(w->calm, 0));      // recover_R_t: E = K2' F K1
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
                         for (int c = 0; c < 3; ++c) Ein[9 * lane + 3 * r + c] = E.m[r][c];
                 }
                 wave_sync();
-                status = recover_poses(w, Ein, pts, N, dbg);                 // :59-60
-                scale_t3(w, pts, N, dbg);                                    // :64-70
+                status = recover_poses(w, Ein, pts, N, dbg);
+                if (gst != ST_OK) status = gst;
+                scale_t3(w, pts, N, dbg);
                 write_poses(w, a.Rt2 + b * 12, a.Rt3 + b * 12);
                 if (lane == 0) compose_camera_from_pose(load_K(w->calm, 2), w->Rt[1], w->Pfin[2]);   // K3 [R3 | lam t3]
                 wave_sync();
-                if (a.reconst) tri_pass(w, pts, N, TRI_RECONST, 1, w->Pfin[1], w->Pfin[2], a.reconst + b * 3 * (long)N);   // :75-76
-                tft_from_cameras(w, w->T1);                                  // :78
+                if (a.reconst) tri_pass(w, pts, N, TRI_RECONST, 1, w->Pfin[1], w->Pfin[2], a.reconst + b * 3 * (long)N);
+                tft_from_cameras(w, w->T1);
                 wave_sync();
                 if (lane < 27) a.T[b * 27 + lane] = w->T1[lane];
                 double chk = (lane < 12) ? w->Rt[0][lane] : ((lane < 24) ? w->Rt[1][lane - 12] : ((lane < 51) ? w->T1[lane - 24] : 0.0));
@@ -187,7 +422,7 @@ __global__ void __launch_bounds__(64, 2) k_linear_f_pose(const LinearTftArgs a) 
             }
         }
         if (lane == 0) {
-            if (a.iter) a.iter[b] = 0;                                       // :77
+            if (a.iter) a.iter[b] = iters;
             a.status[b] = status;
         }
     }

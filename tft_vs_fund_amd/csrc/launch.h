@@ -29,6 +29,14 @@ inline size_t gh_lds_bytes(int N, int /*flags*/, bool jacobi) {
     d += (size_t)gh_lds_doubles(Model::U, Model::C, N);
     return d * sizeof(double);
 }
+// OptimFPoseEstimation: xi and v (4N each) + the 11 x 11 KKT workspace
+inline size_t optimf_lds_bytes(int N, int flags, bool jacobi) {
+    size_t d = (size_t)((POSE_LDS_DOUBLES + 1) & ~1);
+    if (jacobi) d += (size_t)((JACOBI_LDS_DOUBLES + 1) & ~1);
+    d += (size_t)((OPTIMF_FIXED_DOUBLES + 1) & ~1) + 8 * (size_t)N + 2;
+    if (flags & FLAG_STAGE_LDS) d += 6 * (size_t)N;
+    return d * sizeof(double);
+}
 // paired kernel: two triplets (two waves) per workgroup
 inline size_t pair_lds_bytes(int N, int flags, bool /*jacobi*/) {
     size_t d = (size_t)((POSE_LDS_DOUBLES + 1) & ~1);

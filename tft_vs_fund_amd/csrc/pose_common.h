@@ -275,8 +275,10 @@ __device__ __forceinline__ void compose_camera_from_pose(const Mat3& K, const do
 //   TRI_REPROJECT : aux = third camera; the three reprojections of the homogeneous point ->
 //                 `out` (6 x N), the initial observations of the Gauss-Helmert methods
 //                 (ResslTFTPoseEstimation.m:72-75)
+//   TRI_REPROJECT2 : two views only (Pfin[0], camB; `view` picks the second view's coordinates); the two
+//                 reprojections -> `out` (4 x N), the initial observations of optimF (optimF.m:56-60)
 // `pre` (9 doubles or null): affine map applied to the raw correspondences first (normalised points).
-constexpr int TRI_VOTE = 0, TRI_SCALE = 1, TRI_RECONST = 2, TRI_REPROJECT = 3;
+constexpr int TRI_VOTE = 0, TRI_SCALE = 1, TRI_RECONST = 2, TRI_REPROJECT = 3, TRI_REPROJECT2 = 4;
 __device__ __attribute__((noinline)) int tri_pass(PoseLds* w, const double* pts, int N, int mode, int view, const double* camB,
                                                    const double* aux, double* out, const double* pre = nullptr) {
     const int lane = lane_id();
@@ -295,7 +297,7 @@ __device__ __attribute__((noinline)) int tri_pass(PoseLds* w, const double* pts,
         tri_zero(S);
         tri_accum(S, PA, p.v[0], p.v[1]);
         tri_accum(S, PB, (view == 1) ? p.v[2] : p.v[4], (view == 1) ? p.v[3] : p.v[5]);
-        if (mode >= TRI_RECONST) tri_accum(S, AX, p.v[4], p.v[5]);
+        if (mode == TRI_RECONST || mode == TRI_REPROJECT) tri_accum(S, AX, p.v[4], p.v[5]);
         double X[4];
         // The vote only consumes the SIGNS of two depths: from the least-squares start (error ~ lambda4/lambda3
         // ~ 1e-7) one inverse iteration (-> ~1e-14) is plenty; the other modes iterate to convergence.
@@ -305,6 +307,18 @@ __device__ __attribute__((noinline)) int tri_pass(PoseLds* w, const double* pts,
             const double s4 = sgn(X[3]);
             const double z2 = AX[8] * X[0] + AX[9] * X[1] + AX[10] * X[2] + AX[11] * X[3];
             score += (int)(sgn(X[2]) * s4) + (int)(sgn(z2) * s4);
+            continue;
+        }
+        if (mode == TRI_REPROJECT2) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const double (&P)[12] = (v == 0) ? PA : PB;
+                const double a = P[0] * X[0] + P[1] * X[1] + P[2] * X[2] + P[3] * X[3];
+                const double b = P[4] * X[0] + P[5] * X[1] + P[6] * X[2] + P[7] * X[3];
+                const double c = P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11] * X[3];
+                out[4 * (long)i + 2 * v] = a / c;
+                out[4 * (long)i + 2 * v + 1] = b / c;
+            }
             continue;
         }
         if (mode == TRI_REPROJECT) {                                               // p_est = P*X; p(1:2)./p(3)
