@@ -172,6 +172,12 @@ int tff_rt_from_tft_batch_dev(tff_ctx* ctx, const double* T, const double* calm,
 int tff_linear_tft_batch_dev(tff_ctx* ctx, const double* corresp, int64_t B, int32_t N, double* T, double* P2,
                              double* P3, int32_t* status);
 
+/* linearF (F_methods/linearF.m:32-62; refine = 0) or optimF (F_methods/optimF.m:34-78; refine = 1) for the view
+ * pairs (1,2) and (1,3) of each item: F21, F31 (B x 9, 3x3 column-major, x2' F21 x1 = 0).  linearF normalises its
+ * inputs itself; iter (optimF: it1 + it2) may be NULL.  Needs N >= 8. */
+int tff_linear_f_batch_dev(tff_ctx* ctx, const double* corresp, int64_t B, int32_t N, int32_t refine, double* F21,
+                           double* F31, int32_t* iter, int32_t* status);
+
 /* Minimal-sample hypotheses (BASELINE.json config 4): hypothesis b = the n correspondences
  * sample_idx[b*n .. b*n+n) of one shared scene (6 x Ns); n >= 7 (TFT) / 8 (F); shared CalM (27). */
 int tff_linear_tft_pose_sampled_dev(tff_ctx* ctx, const double* scene, int32_t Ns, const double* calm,

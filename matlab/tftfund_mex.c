@@ -3,7 +3,8 @@
  *
  *   [R_t_2, R_t_3, Reconst, T, iter] = tftfund_mex(method, Corresp, CalM)
  *
- * method : 'linear_tft' | 'linear_f'     (one entry per tff_<method>_pose_batch_host symbol)
+ * method : 'linear_tft' | 'linear_f' | 'ressl_tft' | 'nordberg_tft' | 'faugpapa_tft' | 'optim_f'
+ *          (one entry per tff_<method>_pose_batch_host symbol)
  * Corresp: 6 x N double, or 6 x N x B for a batch of B triplets
  * CalM   : 9 x 3 double (shared) or 9 x 3 x B
  * Outputs follow the reference's calling convention (experiments.m:108):
@@ -48,6 +49,10 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (mxGetString(prhs[0], method, sizeof method)) mexErrMsgIdAndTxt("tftfund:method", "method must be a string");
     if (!strcmp(method, "linear_tft")) fn = tff_linear_tft_pose_batch_host;
     else if (!strcmp(method, "linear_f")) fn = tff_linear_f_pose_batch_host;
+    else if (!strcmp(method, "ressl_tft")) fn = tff_ressl_tft_pose_batch_host;
+    else if (!strcmp(method, "nordberg_tft")) fn = tff_nordberg_tft_pose_batch_host;
+    else if (!strcmp(method, "faugpapa_tft")) fn = tff_faugpapa_tft_pose_batch_host;
+    else if (!strcmp(method, "optim_f")) fn = tff_optim_f_pose_batch_host;
     else mexErrMsgIdAndTxt("tftfund:method", "unknown method '%s'", method);
     if (!mxIsDouble(prhs[1]) || mxIsComplex(prhs[1]) || !mxIsDouble(prhs[2]) || mxIsComplex(prhs[2]))
         mexErrMsgIdAndTxt("tftfund:type", "Corresp and CalM must be real double");

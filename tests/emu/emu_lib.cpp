@@ -43,6 +43,20 @@ extern "C" int emu_optim_f_pose(const double* corresp, const double* calm, long 
     return emu_pose(tff::k_f_pose<false, 1>, tff::k_f_pose<true, 1>, tff::optimf_lds_bytes, false, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T,
                     reconst, iter, status, dbg);
 }
+// building block: linearF / optimF per view pair (tff_linear_f_batch_dev)
+extern "C" int emu_linear_f(const double* corresp, long B, int N, int refine, double* F21, double* F31, int* iter, int* status) {
+    tff::LinearFOnlyArgs a{corresp, B, N, 0, F21, F31, iter, status};
+    if (refine) {
+        emu::launch(tff::k_linear_f<false, 1>, tff::pose_grid(B), 64, tff::optimf_lds_bytes(N, 0, false), a);
+        a.flags |= tff::FLAG_ONLY_RETRY;
+        emu::launch(tff::k_linear_f<true, 1>, tff::pose_grid(B), 64, tff::optimf_lds_bytes(N, 0, true), a);
+    } else {
+        emu::launch(tff::k_linear_f<false, 0>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
+        a.flags |= tff::FLAG_ONLY_RETRY;
+        emu::launch(tff::k_linear_f<true, 0>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, 0, true), a);
+    }
+    return 0;
+}
 extern "C" int emu_ressl_tft_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
                                   double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
     return emu_pose(tff::k_gh_tft_pose<tff::ResslModel, false>, tff::k_gh_tft_pose<tff::ResslModel, true>, tff::gh_lds_bytes<tff::ResslModel>, false, corresp, calm, calm_stride, B, N,

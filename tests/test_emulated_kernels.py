@@ -119,6 +119,24 @@ def test_optim_f_kernel_matches_golden(emu, golden_dir):
     assert out["status"][0] == 1 and np.all(np.isnan(out["T"][0]))          # optimF.m:36-38
 
 
+@pytest.mark.parametrize("refine", [0, 1])
+def test_linear_f_block_kernel(emu, refine):
+    """k_linear_f: linearF / optimF for the pairs (1,2), (1,3) (the tff_linear_f_batch_dev building block)."""
+    B, N = 2, 20
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=77)
+    F21 = np.zeros((B, 9)); F31 = np.zeros((B, 9)); it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32)
+    emu.emu_linear_f(_p(C), ctypes.c_long(B), ctypes.c_int(N), ctypes.c_int(refine), _p(F21), _p(F31), _p(it), _p(st))
+    assert np.all(st == 0)
+    for b in range(B):
+        Cb = C[b].T.copy()
+        if refine:
+            (f21, i1), (f31, i2) = O.optimF(Cb[0:2], Cb[2:4]), O.optimF(Cb[0:2], Cb[4:6])
+            assert it[b] == i1 + i2
+        else:
+            f21, f31 = O.linearF(Cb[0:2], Cb[2:4]), O.linearF(Cb[0:2], Cb[4:6])
+        assert rel_err_T(F21[b].reshape(3, 3).T, f21) < 1e-8 and rel_err_T(F31[b].reshape(3, 3).T, f31) < 1e-8
+
+
 def test_ressl_kernel_matches_block_checker(emu, golden_dir):
     """Gauss-Helmert kernel on one N = 12 triplet: against the same-block-algebra restatement
     (oracle/gh_block_oracle.py) and the dense oracle's golden output.  Tolerances: see

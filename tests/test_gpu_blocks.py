@@ -96,6 +96,28 @@ def test_linear_tft_and_rt_from_tft_blocks(gpu_ctx):
         assert rel_err(R2[b].cpu().numpy(), r2) < TOL and rel_err(R3[b].cpu().numpy(), r3) < TOL
 
 
+def test_linear_f_and_optim_f_blocks(gpu_ctx):
+    """tff_linear_f_batch_dev: linearF (linearF.m:32-62) and optimF (optimF.m:34-78) per view pair; F is sign-free."""
+    O = _O()
+    C, CalM, Rt0, _ = _scene(5, 60, 1.0, 18)
+    for refine in (False, True):
+        F21, F31, it, st = gpu_ctx.linear_f(C, refine=refine)
+        assert int(st.sum()) == 0
+        F21 = F21.cpu().numpy(); F31 = F31.cpu().numpy(); it = it.cpu().numpy()
+        for b in range(5):
+            Cb = C[b].T.copy()
+            if refine:
+                (f21, i1), (f31, i2) = O.optimF(Cb[0:2], Cb[2:4]), O.optimF(Cb[0:2], Cb[4:6])
+                assert int(it[b]) == i1 + i2
+            else:
+                f21, f31 = O.linearF(Cb[0:2], Cb[2:4]), O.linearF(Cb[0:2], Cb[4:6])
+                assert int(it[b]) == 0
+            assert rel_err_T(F21[b], f21) < 1e-8 and rel_err_T(F31[b], f31) < 1e-8
+            assert np.linalg.svd(F21[b], compute_uv=False)[2] < 1e-12 * np.linalg.norm(F21[b])     # rank 2
+    F21, F31, it, st = gpu_ctx.linear_f(C[:, :7], refine=False)
+    assert np.all(st.cpu().numpy() == 1)                                                            # linearF.m:35-37
+
+
 def test_config4_minimal_hypotheses_and_inlier_counts(gpu_ctx):
     """RANSAC-style: hypotheses from 7 (TFT) / 8 (F) correspondences of one scene with 25 % gross outliers;
     int32 inlier counts by the 1-px rule of experiments_real.m:94-98.  Checked hypothesis by hypothesis

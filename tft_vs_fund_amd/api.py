@@ -90,6 +90,7 @@ def load_library(path=None):
             "tff_transform_tft_batch_dev": [V, V, V, V, V, I64, I64, I32, V],
             "tff_rt_from_tft_batch_dev": [V, V, V, I64, V, I64, I32, V, V, V],
             "tff_linear_tft_batch_dev": [V, V, I64, I32, V, V, V, V],
+            "tff_linear_f_batch_dev": [V, V, I64, I32, I32, V, V, V, V],
             "tff_linear_tft_pose_sampled_dev": [V, V, I32, V, V, I64, I32, V, V, V, V],
             "tff_linear_f_pose_sampled_dev": [V, V, I32, V, V, I64, I32, V, V, V, V],
         }
@@ -123,7 +124,7 @@ EXPORTED_SYMBOLS = [
     "tff_nordberg_tft_pose_batch_dev", "tff_nordberg_tft_pose_batch_host",
     "tff_optim_f_pose_batch_dev", "tff_optim_f_pose_batch_host",
     "tff_triangulate_batch_dev", "tff_repr_error_batch_dev", "tff_inlier_count_batch_dev", "tff_transform_tft_batch_dev",
-    "tff_rt_from_tft_batch_dev", "tff_linear_tft_batch_dev", "tff_linear_tft_pose_sampled_dev", "tff_linear_f_pose_sampled_dev",
+    "tff_rt_from_tft_batch_dev", "tff_linear_tft_batch_dev", "tff_linear_f_batch_dev", "tff_linear_tft_pose_sampled_dev", "tff_linear_f_pose_sampled_dev",
 ]
 
 
@@ -343,6 +344,16 @@ class Context:
         _check(self.lib, self.lib.tff_linear_tft_batch_dev(self.handle, self._p(corresp), B, N, self._p(T), self._p(P2), self._p(P3),
                                                            self._p(st)), "tff_linear_tft_batch_dev")
         return T.reshape(B, 3, 3, 3).permute(0, 3, 2, 1), P2.reshape(B, 4, 3).transpose(1, 2), P3.reshape(B, 4, 3).transpose(1, 2), st
+
+    def linear_f(self, corresp, refine=False):
+        """linearF (refine=False) / optimF (refine=True) for view pairs (1,2), (1,3): corresp (B,N,6) -> F21, F31 (B,3,3), iter, status."""
+        self._begin()
+        corresp = self._t(corresp); B, N, _ = corresp.shape
+        F21 = torch.empty((B, 9), dtype=torch.float64, device=corresp.device); F31 = torch.empty_like(F21)
+        it = torch.zeros(B, dtype=torch.int32, device=corresp.device); st = torch.zeros_like(it)
+        _check(self.lib, self.lib.tff_linear_f_batch_dev(self.handle, self._p(corresp), B, N, int(bool(refine)), self._p(F21), self._p(F31),
+                                                         self._p(it), self._p(st)), "tff_linear_f_batch_dev")
+        return F21.reshape(B, 3, 3).transpose(1, 2), F31.reshape(B, 3, 3).transpose(1, 2), it, st
 
     def pose_sampled(self, method, scene, calm, sample_idx):
         """Minimal-sample hypotheses (config 4): scene (Ns, 6), sample_idx (B, n) int32 -> R_t_2, R_t_3 (B,3,4), T, status."""

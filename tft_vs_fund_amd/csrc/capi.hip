@@ -455,6 +455,43 @@ int tff_linear_tft_batch_dev(tff_ctx* c, const double* corresp, int64_t B, int32
     return 0;
 }
 
+// linearF (refine = 0) / optimF (refine = 1) for the view pairs (1,2) and (1,3)
+int tff_linear_f_batch_dev(tff_ctx* c, const double* corresp, int64_t B, int32_t N, int32_t refine, double* F21, double* F31,
+                           int32_t* iter, int32_t* status) {
+    if (!c) return fail(TFF_E_INVALID, "null context");
+    if (B < 0 || N < 0) return fail(TFF_E_INVALID, "negative size");
+    if (B == 0) return 0;
+    if (!corresp || !F21 || !F31) return fail(TFF_E_INVALID, "null pointer");
+    TFF_HIP(hipSetDevice(c->device));
+    if (!status) {
+        if (int r = c->scratch_status.reserve((size_t)B * sizeof(int32_t))) return r;
+        status = (int32_t*)c->scratch_status.p;
+    }
+    tff::LinearFOnlyArgs a{corresp, (long)B, N, 0, F21, F31, iter, status};
+    const unsigned fix_grid = (c->solver == 0) ? (unsigned)(B < 8192 ? B : 8192) : tff::pose_grid(B);
+    if (refine) {
+        if (c->solver == 0) {
+            const size_t lds = tff::optimf_lds_bytes(N, 0, false);
+            if (int r = ensure_lds(tff::k_linear_f<false, 1>, lds)) return r;
+            hipLaunchKernelGGL((tff::k_linear_f<false, 1>), dim3(tff::pose_grid(B)), dim3(64), lds, c->stream, a);
+            TFF_HIP(hipGetLastError());
+            a.flags |= tff::FLAG_ONLY_RETRY;
+        }
+        const size_t lds = tff::optimf_lds_bytes(N, 0, true);
+        if (int r = ensure_lds(tff::k_linear_f<true, 1>, lds)) return r;
+        hipLaunchKernelGGL((tff::k_linear_f<true, 1>), dim3(fix_grid), dim3(64), lds, c->stream, a);
+    } else {
+        if (c->solver == 0) {
+            hipLaunchKernelGGL((tff::k_linear_f<false, 0>), dim3(tff::pose_grid(B)), dim3(64), tff::pose_lds_bytes(N, 0, false), c->stream, a);
+            TFF_HIP(hipGetLastError());
+            a.flags |= tff::FLAG_ONLY_RETRY;
+        }
+        hipLaunchKernelGGL((tff::k_linear_f<true, 0>), dim3(fix_grid), dim3(64), tff::pose_lds_bytes(N, 0, true), c->stream, a);
+    }
+    TFF_HIP(hipGetLastError());
+    return 0;
+}
+
 // Minimal-sample hypotheses (config 4): hypothesis b uses correspondences sample_idx[b*n .. b*n+n) of ONE shared scene.
 int tff_linear_tft_pose_sampled_dev(tff_ctx* c, const double* scene, int32_t Ns, const double* calm, const int32_t* sample_idx, int64_t B,
                                     int32_t n, double* Rt2, double* Rt3, double* T, int32_t* status) {

@@ -260,6 +260,100 @@ __device__ inline int gauss_helmert_f_wave(PoseLds* w, OptimFLds* g, double* xi,
     return (it > 400) ? 400 : it;
 }
 
+// linearF(x1,x2) and linearF(x1,x3) (F_methods/linearF.m:45-62) on the points premapped by w->nrm, with linearF's own
+// normalisation in w->nrm2: 8-point DLT through the 72 moment sums, inner de-normalisation, rank-2 projection.
+// Result: w->Fm[9 pair + 3 r + c] (row-major), optionally scaled to unit Frobenius norm.  false: eigen-solver wants the Jacobi pass.
+template <bool JAC>
+__device__ inline bool linear_f_wave(PoseLds* w, JacobiLds* jw, const double* pts, int N, double* dbg, bool unit_norm) {
+    const int lane = lane_id();
+    accumulate_moments_f(w, pts, N);
+    bool ok = true;
+#pragma unroll 1
+    for (int pair = 0; pair < 2; ++pair) {                                   // linearF(x1,x2), linearF(x1,x3)
+        double g[9], diag = 0.0, x;
+        const int r = (lane < 9) ? lane : 0, i = r / 3, j = r % 3;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            g[c] = w->mom[36 * pair + 6 * hht_index(i, c / 3) + hht_index(j, c % 3)];
+            diag = (c == r) ? g[c] : diag;
+        }
+        int its = 0;
+        if (JAC) {
+            if (lane < 9) for (int c = 0; c < 9; ++c) jw->A[lane * 9 + c] = g[c];
+            wave_sync();
+            x = wave_jacobi_min_eigvec(jw->A, jw->V, 9, 9, &its);
+        } else {
+            double r2;
+            x = wave_min_eigvec_reg<9>(g, diag, w->Lp, EIG_MAXIT, &its, &r2);
+            ok = ok && eig_converged(r2);
+        }
+        if (dbg && lane == 0) dbg[69 + pair] = (double)its;
+        // F = reshape(V(:,9),3,3): F(rr,cc) = v[rr + 3 cc]   (linearF.m:55); stored row-major
+        if (lane < 9) w->Fm[9 * pair + 3 * (lane % 3) + lane / 3] = x;
+        wave_sync();
+    }
+    if (!ok) return false;
+    if (lane < 2) {                                                          // linearF.m:58-62: inner de-normalisation, rank 2
+        const int v2 = lane + 1;
+        Mat3 F;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) F.m[r][c] = w->Fm[9 * lane + 3 * r + c];
+        F = mat3_mul(mat3_mul(mat3_T(normal_matrix(w->nrm2, v2)), F), normal_matrix(w->nrm2, 0));
+        double v3[3], fv[3];
+        null3(F, v3);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) fv[r] = F.m[r][0] * v3[0] + F.m[r][1] * v3[1] + F.m[r][2] * v3[2];
+        double nn = 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { F.m[r][c] -= fv[r] * v3[c]; nn += F.m[r][c] * F.m[r][c]; }
+        const double sc = unit_norm ? rsqrt(nn) : 1.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) w->Fm[9 * lane + 3 * r + c] = F.m[r][c] * sc;
+    }
+    wave_sync();
+    return true;
+}
+
+// optimF.m:52-69 for both pairs: initial x_est by two-view triangulation with P1 = [I|0], P2 = [crossM(epi21) F, epi21],
+// then Gauss-Helmert on F(:).  w->Fm holds the unit-norm linear F (x-frame) on entry, the refined one on exit.  Returns it1 + it2.
+__device__ inline int optim_f_refine(PoseLds* w, OptimFLds* og, double* oxi, const double* pts, int N, int* gst) {
+    const int lane = lane_id();
+    int iters = 0;
+#pragma unroll 1
+    for (int pair = 0; pair < 2; ++pair) {
+        if (lane == 0) {
+            Mat3 F, Ft;
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) F.m[r][c] = w->Fm[9 * pair + 3 * r + c];
+            Ft = mat3_T(F);
+            double e[3];
+            null3(Ft, e);                                                    // epi21 = U(:,3): left null vector   (optimF.m:53)
+            // P1 = [I|0] -> Pfin[0];  P2 = [crossM(epi21)*F, epi21] -> P[0]   (:54-55)
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) w->Pfin[0][4 * r + c] = (r == c) ? 1.0 : 0.0;
+            for (int c = 0; c < 3; ++c) {
+                w->P[0][c] = -e[2] * F.m[1][c] + e[1] * F.m[2][c];
+                w->P[0][4 + c] = e[2] * F.m[0][c] - e[0] * F.m[2][c];
+                w->P[0][8 + c] = -e[1] * F.m[0][c] + e[0] * F.m[1][c];
+            }
+            w->P[0][3] = e[0]; w->P[0][7] = e[1]; w->P[0][11] = e[2];
+        }
+        if (lane < 9) og->p[lane] = w->Fm[9 * pair + 3 * (lane % 3) + lane / 3];   // p = F(:) column-major   (:61)
+        wave_sync();
+        tri_pass(w, pts, N, TRI_REPROJECT2, pair + 1, w->P[0], w->P[0], oxi, w->nrm);   // x_est   (:56-60)
+        wave_sync();
+        iters += gauss_helmert_f_wave(w, og, oxi, oxi + 4 * N + 2, pts, N, pair + 1, gst);   // :66
+        wave_sync();
+        if (lane < 9) w->Fm[9 * pair + 3 * (lane % 3) + lane / 3] = og->p[lane];   // F = reshape(p_opt,3,3)   (:69)
+        wave_sync();
+    }
+    return iters;
+}
+
 // METHOD 0: LinearFPoseEstimation; METHOD 1: OptimFPoseEstimation (F_methods/OptimFPoseEstimation.m:44-73)
 template <bool JAC, int METHOD>
 __global__ void __launch_bounds__(64, 2) k_f_pose(const LinearTftArgs a) {
@@ -297,88 +391,13 @@ __global__ void __launch_bounds__(64, 2) k_f_pose(const LinearTftArgs a) {
         } else {
             normalise3(pts, N, w->nrm);                                      // LinearFPoseEstimation.m:46-48 / optimF.m:46-47
             normalise3(pts, N, w->nrm2, w->nrm);                             // linearF.m:45-46 (on the normalised points)
-            accumulate_moments_f(w, pts, N);
-            bool ok = true;
-#pragma unroll 1
-            for (int pair = 0; pair < 2; ++pair) {                           // linearF(x1,x2), linearF(x1,x3)
-                double g[9], diag = 0.0, x;
-                const int r = (lane < 9) ? lane : 0, i = r / 3, j = r % 3;
-#pragma unroll
-                for (int c = 0; c < 9; ++c) {
-                    g[c] = w->mom[36 * pair + 6 * hht_index(i, c / 3) + hht_index(j, c % 3)];
-                    diag = (c == r) ? g[c] : diag;
-                }
-                int its = 0;
-                if (JAC) {
-                    if (lane < 9) for (int c = 0; c < 9; ++c) jw->A[lane * 9 + c] = g[c];
-                    wave_sync();
-                    x = wave_jacobi_min_eigvec(jw->A, jw->V, 9, 9, &its);
-                } else {
-                    double r2;
-                    x = wave_min_eigvec_reg<9>(g, diag, w->Lp, EIG_MAXIT, &its, &r2);
-                    ok = ok && eig_converged(r2);
-                }
-                if (dbg && lane == 0) dbg[69 + pair] = (double)its;
-                // F = reshape(V(:,9),3,3): F(rr,cc) = v[rr + 3 cc]   (linearF.m:55); stored row-major
-                if (lane < 9) w->Fm[9 * pair + 3 * (lane % 3) + lane / 3] = x;
-                wave_sync();
-            }
+            const bool ok = linear_f_wave<JAC>(w, jw, pts, N, dbg, METHOD == 1);   // optimF.m:50: F = F / |F|_F
             if (!ok) {
                 status = ST_RETRY;
             } else {
-                if (lane < 2) {                                              // linearF.m:58-62: inner de-normalisation, rank 2
-                    const int v2 = lane + 1;
-                    Mat3 F;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) F.m[r][c] = w->Fm[9 * lane + 3 * r + c];
-                    F = mat3_mul(mat3_mul(mat3_T(normal_matrix(w->nrm2, v2)), F), normal_matrix(w->nrm2, 0));
-                    double v3[3], fv[3];
-                    null3(F, v3);
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) fv[r] = F.m[r][0] * v3[0] + F.m[r][1] * v3[1] + F.m[r][2] * v3[2];
-                    double nn = 0.0;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) { F.m[r][c] -= fv[r] * v3[c]; nn += F.m[r][c] * F.m[r][c]; }
-                    const double sc = (METHOD == 1) ? rsqrt(nn) : 1.0;       // optimF.m:50: F = F / |F|_F
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) w->Fm[9 * lane + 3 * r + c] = F.m[r][c] * sc;
-                }
                 wave_sync();
                 int gst = ST_OK;
-                if (METHOD == 1) {
-#pragma unroll 1
-                    for (int pair = 0; pair < 2; ++pair) {                   // [F21,it1] = optimF(...), [F31,it2] = optimF(...)   (:48-49)
-                        if (lane == 0) {
-                            Mat3 F, Ft;
-                            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) F.m[r][c] = w->Fm[9 * pair + 3 * r + c];
-                            Ft = mat3_T(F);
-                            double e[3];
-                            null3(Ft, e);                                    // epi21 = U(:,3): left null vector   (optimF.m:53)
-                            // P1 = [I|0] -> Pfin[0];  P2 = [crossM(epi21)*F, epi21] -> P[0]   (:54-55)
-                            for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) w->Pfin[0][4 * r + c] = (r == c) ? 1.0 : 0.0;
-                            for (int c = 0; c < 3; ++c) {
-                                w->P[0][c] = -e[2] * F.m[1][c] + e[1] * F.m[2][c];
-                                w->P[0][4 + c] = e[2] * F.m[0][c] - e[0] * F.m[2][c];
-                                w->P[0][8 + c] = -e[1] * F.m[0][c] + e[0] * F.m[1][c];
-                            }
-                            w->P[0][3] = e[0]; w->P[0][7] = e[1]; w->P[0][11] = e[2];
-                        }
-                        if (lane < 9) og->p[lane] = w->Fm[9 * pair + 3 * (lane % 3) + lane / 3];   // p = F(:) column-major   (:61)
-                        wave_sync();
-                        tri_pass(w, pts, N, TRI_REPROJECT2, pair + 1, w->P[0], w->P[0], oxi, w->nrm);   // x_est   (:56-60)
-                        wave_sync();
-                        iters += gauss_helmert_f_wave(w, og, oxi, oxi + 4 * N + 2, pts, N, pair + 1, &gst);   // :66
-                        wave_sync();
-                        if (lane < 9) w->Fm[9 * pair + 3 * (lane % 3) + lane / 3] = og->p[lane];   // F = reshape(p_opt,3,3)   (:69)
-                        wave_sync();
-                    }
-                }
+                if (METHOD == 1) iters = optim_f_refine(w, og, oxi, pts, N, &gst);   // [F21,it1] = optimF(...), [F31,it2] = optimF(...)   (:48-49)
                 double* Ein = w->Minv;
                 if (lane < 2) {
                     const int v2 = lane + 1;
@@ -424,6 +443,79 @@ __global__ void __launch_bounds__(64, 2) k_f_pose(const LinearTftArgs a) {
         if (lane == 0) {
             if (a.iter) a.iter[b] = iters;
             a.status[b] = status;
+        }
+    }
+}
+
+// ---- building blocks: linearF / optimF for the view pairs (1,2) and (1,3) of each item ----------------------
+struct LinearFOnlyArgs {
+    const double* corresp;   // B x (6 x N) pixel (or any) coordinates, rows x1;y1;x2;y2;x3;y3
+    long B; int N; int flags;
+    double* F21; double* F31;   // B x 9 each, 3x3 column-major: x2' F21 x1 = 0, x3' F31 x1 = 0
+    int* iter;               // REFINE: it1 + it2 (or null)
+    int* status;
+};
+// REFINE 0: linearF(p1,p2) (F_methods/linearF.m:32-62); REFINE 1: optimF(p1,p2) (F_methods/optimF.m:34-78)
+template <bool JAC, int REFINE>
+__global__ void __launch_bounds__(64, 2) k_linear_f(const LinearFOnlyArgs a) {
+    TFF_DYNAMIC_LDS(double, smem);
+    PoseLds* w = reinterpret_cast<PoseLds*>(smem);
+    constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
+    JacobiLds* jw = JAC ? reinterpret_cast<JacobiLds*>(smem + base) : nullptr;
+    double* extra = smem + base + (JAC ? ((JACOBI_LDS_DOUBLES + 1) & ~1) : 0);
+    OptimFLds* og = REFINE ? reinterpret_cast<OptimFLds*>(extra) : nullptr;
+    double* oxi = extra + ((OPTIMF_FIXED_DOUBLES + 1) & ~1);
+    const int lane = lane_id();
+    for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
+        if ((a.flags & FLAG_ONLY_RETRY) && a.status[b] != ST_RETRY) continue;
+        wave_sync();
+        const int N = a.N;
+        const double* pts = a.corresp + b * 6 * (long)N;
+        int st = ST_OK, iters = 0;
+        if (N < 8) {                                                         // linearF.m:35-37, optimF.m:36-38
+            st = ST_TOO_FEW;
+            const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+            if (lane < 9) { a.F21[b * 9 + lane] = qnan; a.F31[b * 9 + lane] = qnan; }
+        } else {
+            if (REFINE) {
+                normalise3(pts, N, w->nrm);                                  // optimF.m:46-47
+            } else {
+                if (lane < 9) w->nrm[lane] = (lane % 3 == 0) ? 1.0 : 0.0;    // points used as given
+                wave_sync();
+            }
+            normalise3(pts, N, w->nrm2, w->nrm);                             // linearF.m:45-46
+            if (!linear_f_wave<JAC>(w, jw, pts, N, nullptr, REFINE != 0)) {
+                st = ST_RETRY;
+            } else {
+                if (REFINE) iters = optim_f_refine(w, og, oxi, pts, N, &st);
+                if (lane < 2) {
+                    Mat3 F;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) F.m[r][c] = w->Fm[9 * lane + 3 * r + c];
+                    if (REFINE) {                                            // optimF.m:72-76: de-normalise, rank 2
+                        F = mat3_mul(mat3_mul(mat3_T(normal_matrix(w->nrm, lane + 1)), F), normal_matrix(w->nrm, 0));
+                        double v3[3], fv[3];
+                        null3(F, v3);
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) fv[r] = F.m[r][0] * v3[0] + F.m[r][1] * v3[1] + F.m[r][2] * v3[2];
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) F.m[r][c] -= fv[r] * v3[c];
+                    }
+                    double* out = (lane == 0 ? a.F21 : a.F31) + b * 9;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) out[3 * c + r] = F.m[r][c];
+                }
+            }
+        }
+        if (lane == 0) {
+            if (a.iter) a.iter[b] = iters;
+            a.status[b] = st;
         }
     }
 }

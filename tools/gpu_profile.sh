@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for profiles/: kernel trace + stats, then PMC passes (separately) for HBM traffic.
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof_r1b
+OUT=$R/gpurun_out/prof_r1b; rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 3"
