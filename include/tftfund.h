@@ -48,6 +48,7 @@ typedef struct tff_ctx tff_ctx;
 #define TFF_ST_TOO_FEW 1    /* N < 7 (TFT) or N < 8 (F): experiments.m:99, linearF.m:35-37 */
 #define TFF_ST_NONFINITE 2  /* NaN/Inf in the result: Gauss_Helmert.m:53-55,63-65 */
 #define TFF_ST_NO_POSE 3    /* no candidate with score >= 0: R_f unassigned in R_t_from_TFT.m:91-104 */
+#define TFF_ST_NO_PARAM 5   /* PiColPoseEstimation.m:84-89: error('The minimal param could not be found') */
 #define TFF_ST_RANK 4       /* Gauss-Helmert: KKT system numerically rank deficient (pinv would truncate, Gauss_Helmert.m:67) */
 
 /* error codes (besides -hipError_t) */
@@ -119,6 +120,32 @@ int tff_faugpapa_tft_pose_batch_dev(tff_ctx* ctx, const double* corresp, const d
 int tff_faugpapa_tft_pose_batch_host(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
                                      int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
                                      int32_t* iter, int32_t* status);
+
+/* PiPoseEstimation (TFT_methods/PiPoseEstimation.m:50-182): Ponce-Hebert Pi matrices from the linear solution
+ * (27 parameters, 9 constraints), 3 epipolar equations + 1 trilinearity per correspondence, Gauss-Helmert.
+ * PiColPoseEstimation (TFT_methods/PiColPoseEstimation.m:50-218): the variant for collinear camera centres
+ * (11 constraints, 3 + 2 equations per correspondence); TFF_ST_NO_PARAM where the reference raises
+ * 'The minimal param could not be found'. */
+int tff_pi_pose_batch_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                          int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                          int32_t* iter, int32_t* status);
+int tff_pi_pose_batch_host(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                           int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                           int32_t* iter, int32_t* status);
+int tff_picol_pose_batch_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                             int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                             int32_t* iter, int32_t* status);
+int tff_picol_pose_batch_host(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                              int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                              int32_t* iter, int32_t* status);
+
+/* Pi / PiCol (collinear != 0) with the start of the Gauss-Helmert iteration exposed: init_p (B x 27, the vector `pi`
+ * of PiPoseEstimation.m:86 / PiColPoseEstimation.m:113) and init_x (B x 6N, `x_est`).  The Pi matrices depend on sign
+ * and basis choices the reference leaves to svd (null(P), null(M.')); PiCol's result depends on them
+ * (PiColPoseEstimation.m:93-94 is not covariant), so parity for it is checked from this common start. */
+int tff_pi_pose_batch_debug_dev(tff_ctx* ctx, int32_t collinear, const double* corresp, const double* calm,
+                                int64_t calm_stride, int64_t B, int32_t N, double* Rt2, double* Rt3, double* T,
+                                double* reconst, int32_t* iter, int32_t* status, double* init_p, double* init_x);
 
 /* OptimFPoseEstimation (F_methods/OptimFPoseEstimation.m:44-73): two fundamental matrices, each refined by
  * optimF (F_methods/optimF.m:34-109: linearF start, 9 parameters, constraints det F = 0 and |F| = 1, one

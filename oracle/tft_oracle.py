@@ -857,3 +857,228 @@ def OptimFPoseEstimation(Corresp, CalM):
     Reconst = _final_reconst(CalM, R_t_2, R_t_3, Corresp)
     T = TFT_from_P(K1 @ np.eye(3, 4), K2 @ R_t_2, K3 @ R_t_3)
     return R_t_2, R_t_3, Reconst, T, it
+
+
+# ---- Ponce-Hebert Pi-matrix methods -------------------
+def _pi_constraintsGH(x, pi):
+    """TFT_methods/PiPoseEstimation.m:109-182 (3 epipolar equations + 1 trilinearity per point, 9 constraints)."""
+    N = x.shape[0] // 6
+    pi21, pi31, pi41 = pi[0:3], pi[3:6], pi[6:9]
+    pi12, pi32, pi42 = pi[9:12], pi[12:15], pi[15:18]
+    pi13, pi23, pi43 = pi[18:21], pi[21:24], pi[24:27]
+    F12 = np.outer(pi41, pi32) - np.outer(pi31, pi42)                       # :118-120
+    F13 = np.outer(pi41, pi23) - np.outer(pi21, pi43)
+    F23 = np.outer(pi42, pi13) - np.outer(pi12, pi43)
+    g = np.array([pi41 @ pi41 - 1, pi42 @ pi42 - 1, pi43 @ pi43 - 1,
+                  pi21 @ pi21 - 1, pi32 @ pi32 - 1, pi13 @ pi13 - 1,
+                  pi21 @ pi41, pi32 @ pi42, pi13 @ pi43])                   # :123-125
+    C = np.zeros((9, 27))                                                   # :128-137
+    C[0, 6:9] = 2 * pi41
+    C[1, 15:18] = 2 * pi42
+    C[2, 24:27] = 2 * pi43
+    C[3, 0:3] = 2 * pi21
+    C[4, 12:15] = 2 * pi32
+    C[5, 18:21] = 2 * pi13
+    C[6, 0:3] = pi41; C[6, 6:9] = pi21
+    C[7, 12:15] = pi42; C[7, 15:18] = pi32
+    C[8, 18:21] = pi43; C[8, 24:27] = pi13
+    f = np.zeros(4 * N)
+    A = np.zeros((4 * N, 27))
+    B = np.zeros((4 * N, 6 * N))
+    for i in range(N):
+        ind = 6 * i
+        p1 = np.array([x[ind], x[ind + 1], 1.0])
+        p2 = np.array([x[ind + 2], x[ind + 3], 1.0])
+        p3 = np.array([x[ind + 4], x[ind + 5], 1.0])
+        r = 4 * i
+        a21, a31, a41 = pi21 @ p1, pi31 @ p1, pi41 @ p1
+        a12, a32, a42 = pi12 @ p2, pi32 @ p2, pi42 @ p2
+        a13, a23, a43 = pi13 @ p3, pi23 @ p3, pi43 @ p3
+        f[r:r + 4] = [p1 @ F12 @ p2, p1 @ F13 @ p3, p2 @ F23 @ p3, a21 * a32 * a13 - a31 * a12 * a23]   # :152-153
+        A[r, 3:9] = np.concatenate([-a42 * p1, a32 * p1])                   # :156-164
+        A[r, 12:18] = np.concatenate([a41 * p2, -a31 * p2])
+        A[r + 1, 0:3] = -a43 * p1; A[r + 1, 6:9] = a23 * p1
+        A[r + 1, 21:27] = np.concatenate([a41 * p3, -a21 * p3])
+        A[r + 2, 9:12] = -a43 * p2; A[r + 2, 15:18] = a13 * p2
+        A[r + 2, 18:21] = a42 * p3; A[r + 2, 24:27] = -a12 * p3
+        A[r + 3, 0:6] = np.concatenate([p1 * a32 * a13, -p1 * a12 * a23])
+        A[r + 3, 9:15] = np.concatenate([-a31 * a23 * p2, a21 * a13 * p2])
+        A[r + 3, 18:24] = np.concatenate([a21 * a32 * p3, -a31 * a12 * p3])
+        B[r, ind:ind + 2] = (F12 @ p2)[0:2]; B[r, ind + 2:ind + 4] = (p1 @ F12)[0:2]            # :166-171
+        B[r + 1, ind:ind + 2] = (F13 @ p3)[0:2]; B[r + 1, ind + 4:ind + 6] = (p1 @ F13)[0:2]
+        B[r + 2, ind + 2:ind + 4] = (F23 @ p3)[0:2]; B[r + 2, ind + 4:ind + 6] = (p2 @ F23)[0:2]
+        B[r + 3, ind:ind + 2] = (pi21 * a32 * a13 - pi31 * a12 * a23)[0:2]
+        B[r + 3, ind + 2:ind + 4] = (pi32 * a21 * a13 - pi12 * a31 * a23)[0:2]
+        B[r + 3, ind + 4:ind + 6] = (pi13 * a21 * a32 - pi23 * a31 * a12)[0:2]
+    return f, g, A, B, C, np.zeros((9, 0))
+
+
+def _pi_finish(P1, P2, P3, Normal1, Normal2, Normal3, CalM, Corresp):
+    T = TFT_from_P(P1, P2, P3)
+    T = transform_TFT(T, Normal1, Normal2, Normal3, 1)
+    R_t_2, R_t_3 = R_t_from_TFT(T, CalM, Corresp)
+    return R_t_2, R_t_3, _final_reconst(CalM, R_t_2, R_t_3, Corresp), T
+
+
+def PiPoseEstimation(Corresp, CalM, return_debug=False, null=null, cam_signs=(1.0, 1.0), init_only=False):
+    """TFT_methods/PiPoseEstimation.m:50-105.  `null` / `cam_signs` / `init_only`: see PiColPoseEstimation
+    (here the sign choices only relabel an equivalent problem)."""
+    inv = np.linalg.inv
+    x1, Normal1 = Normalize2Ddata(Corresp[0:2, :])
+    x2, Normal2 = Normalize2Ddata(Corresp[2:4, :])
+    x3, Normal3 = Normalize2Ddata(Corresp[4:6, :])
+    _, P1, P2, P3 = linearTFT(x1, x2, x3)
+    P2, P3 = cam_signs[0] * P2, cam_signs[1] * P3
+    M = np.hstack([null(P1), null(P2), null(P3)])                           # :61-63
+    M = np.hstack([M, null(M.T)])
+    P1, P2, P3 = P1 @ M, P2 @ M, P3 @ M
+    Pi1 = inv(P1[:, 1:4]); Pi2 = inv(P2[:, [0, 2, 3]]); Pi3 = inv(P3[:, [0, 1, 3]])             # :66-69
+    Pi1 = np.vstack([np.zeros(3), Pi1])
+    Pi2 = np.vstack([Pi2[0], np.zeros(3), Pi2[1:3]])
+    Pi3 = np.vstack([Pi3[0:2], np.zeros(3), Pi3[2]])
+    Pi1 = Pi1 / np.linalg.norm(Pi1[3]); Pi2 = Pi2 / np.linalg.norm(Pi2[3]); Pi3 = Pi3 / np.linalg.norm(Pi3[3])   # :72
+    Q = np.eye(4)                                                           # :73-76
+    Q[0, 0] = 1.0 / np.linalg.norm(Pi3[0] - (Pi3[0] @ Pi3[3]) * Pi3[3]); Q[0, 3] = -Q[0, 0] * (Pi3[0] @ Pi3[3])
+    Q[1, 1] = 1.0 / np.linalg.norm(Pi1[1] - (Pi1[1] @ Pi1[3]) * Pi1[3]); Q[1, 3] = -Q[1, 1] * (Pi1[1] @ Pi1[3])
+    Q[2, 2] = 1.0 / np.linalg.norm(Pi2[2] - (Pi2[2] @ Pi2[3]) * Pi2[3]); Q[2, 3] = -Q[2, 2] * (Pi2[2] @ Pi2[3])
+    Pi1, Pi2, Pi3 = Q @ Pi1, Q @ Pi2, Q @ Pi3
+    Qi = inv(Q)
+    P1, P2, P3 = P1 @ Qi, P2 @ Qi, P3 @ Qi                                  # :79
+    x, x_est = _gh_initial_obs(P1, P2, P3, x1, x2, x3)                      # :80-83, :87-88
+    pi = np.concatenate([Pi1[1:4].reshape(9), Pi2[[0, 2, 3]].reshape(9), Pi3[[0, 1, 3]].reshape(9)])   # :86 (rows, via .')
+    if init_only:
+        return pi, x_est
+    func = lambda a, b, c: _pi_constraintsGH(a, b)
+    _, pi_opt, _, it, reason = Gauss_Helmert(func, x_est, pi, np.zeros(0), x, None, True)
+    Pi1 = pi_opt[0:9].reshape(3, 3); Pi2 = pi_opt[9:18].reshape(3, 3); Pi3 = pi_opt[18:27].reshape(3, 3)   # :94-96
+    P1 = np.zeros((3, 4)); P2 = np.zeros((3, 4)); P3 = np.zeros((3, 4))
+    P1[:, 1:4] = inv(Pi1)
+    P2[:, [0, 2, 3]] = inv(Pi2)
+    P3[:, [0, 1, 3]] = inv(Pi3)
+    R_t_2, R_t_3, Reconst, T = _pi_finish(P1, P2, P3, Normal1, Normal2, Normal3, CalM, Corresp)
+    if return_debug:
+        return R_t_2, R_t_3, Reconst, T, it, dict(reason=reason, p0=pi, p_opt=pi_opt, x_est=x_est)
+    return R_t_2, R_t_3, Reconst, T, it
+
+
+def _picol_constraintsGH(x, pi):
+    """TFT_methods/PiColPoseEstimation.m:134-218 (3 epipolar equations + 2 trilinearities per point, 11 constraints).
+    Restated literally, including the sign of A(ind2+4,1:3) (:176), which is not the derivative of f(ind2+4)."""
+    N = x.shape[0] // 6
+    pi21, pi31, pi41 = pi[0:3], pi[3:6], pi[6:9]
+    pi12, pi32, pi42 = pi[9:12], pi[12:15], pi[15:18]
+    w3, pi33, pi43 = pi[18:21], pi[21:24], pi[24:27]
+    F12 = np.outer(pi41, pi32) - np.outer(pi31, pi42)                       # :144-146
+    F13 = np.outer(pi41, pi33) - np.outer(pi31, pi43)
+    F23 = np.outer(pi42, pi33) - np.outer(pi32, pi43)
+    g = np.array([pi21 @ pi21 - 1, pi12 @ pi12 - 1, w3 @ w3 - 1, pi33 @ pi33 - 1, pi43 @ pi43 - 1,
+                  pi21 @ pi31, pi21 @ pi41, pi31 @ pi41, pi12 @ pi32, pi12 @ pi42, pi32 @ pi42])   # :149-152
+    C = np.zeros((11, 27))                                                  # :155-160
+    C[0, 0:3] = 2 * pi21; C[1, 9:12] = 2 * pi12
+    C[2, 18:21] = 2 * w3; C[3, 21:24] = 2 * pi33; C[4, 24:27] = 2 * pi43
+    C[5, 0:6] = np.concatenate([pi31, pi21]); C[8, 9:15] = np.concatenate([pi32, pi12])
+    C[6, 0:3] = pi41; C[6, 6:9] = pi21; C[9, 9:12] = pi42; C[9, 15:18] = pi12
+    C[7, 3:9] = np.concatenate([pi41, pi31]); C[10, 12:18] = np.concatenate([pi42, pi32])
+    f = np.zeros(5 * N)
+    A = np.zeros((5 * N, 27))
+    B = np.zeros((5 * N, 6 * N))
+    for i in range(N):
+        ind = 6 * i
+        p1 = np.array([x[ind], x[ind + 1], 1.0])
+        p2 = np.array([x[ind + 2], x[ind + 3], 1.0])
+        p3 = np.array([x[ind + 4], x[ind + 5], 1.0])
+        r = 5 * i
+        a21, a31, a41 = pi21 @ p1, pi31 @ p1, pi41 @ p1
+        a12, a32, a42 = pi12 @ p2, pi32 @ p2, pi42 @ p2
+        aw3, a33, a43 = w3 @ p3, pi33 @ p3, pi43 @ p3
+        f[r:r + 5] = [p1 @ F12 @ p2, p1 @ F13 @ p3, p2 @ F23 @ p3,
+                      a31 * a32 * aw3 + (a31 * a12 - a21 * a32) * a33,
+                      a41 * a42 * aw3 + (a41 * a12 - a21 * a42) * a43]      # :175-177
+        A[r, 3:9] = np.concatenate([-a42 * p1, a32 * p1]); A[r, 12:18] = np.concatenate([a41 * p2, -a31 * p2])       # :180-181
+        A[r + 1, 3:9] = np.concatenate([-a43 * p1, a33 * p1]); A[r + 1, 21:27] = np.concatenate([a41 * p3, -a31 * p3])   # :182-183
+        A[r + 2, 12:18] = np.concatenate([-a43 * p2, a33 * p2]); A[r + 2, 21:27] = np.concatenate([a42 * p3, -a32 * p3])  # :184-185
+        A[r + 3, 0:6] = np.concatenate([p1 * a32 * a33, p1 * (a32 * aw3 + a12 * a33)])                                 # :186-189
+        A[r + 3, 9:15] = np.concatenate([p2 * a31 * a33, p2 * (a31 * aw3 - a21 * a33)])
+        A[r + 3, 18:24] = np.concatenate([p3 * a31 * a32, p3 * (a31 * a12 - a21 * a32)])
+        A[r + 4, 0:3] = -p1 * a42 * a43; A[r + 4, 6:9] = p1 * (a42 * aw3 + a12 * a43)                                   # :190-193
+        A[r + 4, 9:12] = p2 * a41 * a43; A[r + 4, 15:18] = p2 * (a41 * aw3 - a21 * a43)
+        A[r + 4, 18:21] = p3 * a41 * a42; A[r + 4, 24:27] = p3 * (a41 * a12 - a21 * a42)
+        B[r, ind:ind + 2] = (F12 @ p2)[0:2]; B[r, ind + 2:ind + 4] = (p1 @ F12)[0:2]                                    # :195-197
+        B[r + 1, ind:ind + 2] = (F13 @ p3)[0:2]; B[r + 1, ind + 4:ind + 6] = (p1 @ F13)[0:2]
+        B[r + 2, ind + 2:ind + 4] = (F23 @ p3)[0:2]; B[r + 2, ind + 4:ind + 6] = (p2 @ F23)[0:2]
+        B[r + 3, ind:ind + 2] = (pi31 * (a32 * aw3 + a12 * a33) - pi21 * a32 * a33)[0:2]                              # :198-201
+        B[r + 3, ind + 2:ind + 4] = (a31 * pi32 * aw3 + (a31 * pi12 - a21 * pi32) * a33)[0:2]
+        B[r + 3, ind + 4:ind + 6] = (a31 * a32 * w3 + (a31 * a12 - a21 * a32) * pi33)[0:2]
+        B[r + 4, ind:ind + 2] = (pi41 * a42 * aw3 + (pi41 * a12 - pi21 * a42) * a43)[0:2]                             # :202-205
+        B[r + 4, ind + 2:ind + 4] = (a41 * pi42 * aw3 + (a41 * pi12 - a21 * pi42) * a43)[0:2]
+        B[r + 4, ind + 4:ind + 6] = (a41 * a42 * w3 + (a41 * a12 - a21 * a42) * pi43)[0:2]
+    return f, g, A, B, C, np.zeros((11, 0))
+
+
+def PiColPoseEstimation(Corresp, CalM, return_debug=False, null=null, cam_signs=(1.0, 1.0), init_only=False):
+    """TFT_methods/PiColPoseEstimation.m:50-129 (Ponce-Hebert parameterisation for collinear camera centres).
+
+    The result depends on sign/basis choices the reference leaves to MATLAB's svd: the signs of the
+    projective cameras P2, P3 of linearTFT (epipoles are sign-free), the sign of every null(P) and
+    the basis of the two-dimensional null(M.') -- :93-94 divide by u1.'*B*v2 where covariance needs
+    u2.'*B*v2, so these gauges do not cancel.  `null` and `cam_signs` expose them to the tests (the
+    defaults are LAPACK's, as literal as a restatement can be); `init_only` returns (pi, x_est)."""
+    inv = np.linalg.inv
+    nrm = np.linalg.norm
+    x1, Normal1 = Normalize2Ddata(Corresp[0:2, :])
+    x2, Normal2 = Normalize2Ddata(Corresp[2:4, :])
+    x3, Normal3 = Normalize2Ddata(Corresp[4:6, :])
+    _, P1, P2, P3 = linearTFT(x1, x2, x3)
+    P2, P3 = cam_signs[0] * P2, cam_signs[1] * P3
+    M = np.hstack([null(P1), null(P2)])                                     # :61-63
+    coeff = np.linalg.lstsq(M, null(P3), rcond=None)[0].ravel()             # M\null(P3): 4x2 least squares
+    M = np.hstack([coeff[0] * M[:, 0:1], coeff[1] * M[:, 1:2], null(M.T)])
+    P1, P2, P3 = P1 @ M, P2 @ M, P3 @ M
+    Pi1 = inv(P1[:, 1:4]); Pi2 = inv(P2[:, [0, 2, 3]]); Pi3 = inv(P3[:, 1:4])                    # :66-69
+    Pi1 = np.vstack([np.zeros(3), Pi1])
+    Pi2 = np.vstack([Pi2[0], np.zeros(3), Pi2[1:3]])
+    Pi3 = np.vstack([np.zeros(3), Pi3])
+    Pi1 = Pi1 / nrm(Pi1[3]); Pi2 = Pi2 / nrm(Pi2[3]); Pi3 = Pi3 / nrm(Pi3[3])                    # :72
+    Q1 = np.eye(4)
+    u1, v1 = Pi1[2].copy(), Pi1[3].copy()
+    u2, v2 = Pi2[2].copy(), Pi2[3].copy()
+    tol = 1e-10                                                             # :79-89
+    A = (v1 @ v1) * (u2 @ v2) - (u1 @ v1) * (v2 @ v2)
+    B = (v1 @ v1) * (u2 @ u2) - (u1 @ u1) * (v2 @ v2)
+    C = (u1 @ v1) * (u2 @ u2) - (u1 @ u1) * (u2 @ v2)
+    if abs(A) > tol and (B * B - 4 * A * C) >= 0 and abs(C) > tol:
+        Q1[2, 3] = (-B + np.sqrt(B * B - 4 * A * C)) / (2 * A)
+        Q1[3, 2] = (-B + np.sqrt(B * B - 4 * A * C)) / (2 * C)
+    else:
+        raise ValueError('The minimal param could not be found')
+    A = np.outer(u1, v1) - np.outer(v1, u1); B = np.outer(u2, v2) - np.outer(v2, u2)             # :90-94
+    Q1[1, 3] = (Pi1[1] @ A @ u1) / (u1 @ A @ v1)
+    Q1[1, 2] = (Pi1[1] @ A.T @ v1) / (u1 @ A @ v1)
+    Q1[0, 3] = (Pi2[0] @ B @ u2) / (u1 @ B @ v2)
+    Q1[0, 2] = (Pi2[0] @ B.T @ v2) / (u1 @ B @ v2)
+    Pi1, Pi2, Pi3 = Q1 @ Pi1, Q1 @ Pi2, Q1 @ Pi3                           # :96-104
+    Pi1 = Pi1 / nrm(Pi1[1])
+    Pi2 = Pi2 / nrm(Pi2[0])
+    Pi3 = Pi3 / nrm(Pi3[1] - Pi3[0])
+    Q2 = np.eye(4)
+    Q2[2, 2] = 1.0 / nrm(Pi3[2])
+    Q2[3, 3] = 1.0 / nrm(Pi3[3])
+    Pi1, Pi2, Pi3 = Q2 @ Pi1, Q2 @ Pi2, Q2 @ Pi3
+    Pi3[0:2] = Pi3[0:2] - Pi3[[0, 0]]
+    Qi = inv(Q2 @ Q1)                                                       # :106
+    P1, P2, P3 = P1 @ Qi, P2 @ Qi, P3 @ Qi
+    x, x_est = _gh_initial_obs(P1, P2, P3, x1, x2, x3)                      # :107-110, :114-115
+    pi = np.concatenate([Pi1[1:4].reshape(9), Pi2[[0, 2, 3]].reshape(9), Pi3[1:4].reshape(9)])   # :113
+    if init_only:
+        return pi, x_est
+    func = lambda a, b, c: _picol_constraintsGH(a, b)
+    _, pi_opt, _, it, reason = Gauss_Helmert(func, x_est, pi, np.zeros(0), x, None, True)
+    Pi1 = pi_opt[0:9].reshape(3, 3); Pi2 = pi_opt[9:18].reshape(3, 3); Pi3 = pi_opt[18:27].reshape(3, 3)   # :121-123
+    P1 = np.zeros((3, 4)); P2 = np.zeros((3, 4)); P3 = np.zeros((3, 4))
+    P1[:, 1:4] = inv(Pi1)
+    P2[:, [0, 2, 3]] = inv(Pi2)
+    P3[:, 1:4] = inv(Pi3); P3[:, 0] = -P3[:, 1]                             # :127
+    R_t_2, R_t_3, Reconst, T = _pi_finish(P1, P2, P3, Normal1, Normal2, Normal3, CalM, Corresp)
+    if return_debug:
+        return R_t_2, R_t_3, Reconst, T, it, dict(reason=reason, p0=pi, p_opt=pi_opt, x_est=x_est)
+    return R_t_2, R_t_3, Reconst, T, it

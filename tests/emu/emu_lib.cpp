@@ -10,8 +10,9 @@
 typedef size_t (*lds_fn)(int, int, bool);
 template <class KMain, class KJac>
 static int emu_pose(KMain kmain, KJac kjac, lds_fn ldsfn, bool may_stage, const double* corresp, const double* calm, long calm_stride, long B, int N,
-                    int flags, double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
-    tff::LinearTftArgs a{corresp, calm, calm_stride, B, N, flags & ~tff::FLAG_JACOBI, Rt2, Rt3, T, reconst, iter, status, dbg};
+                    int flags, double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg,
+                    double* init_p = nullptr, double* init_x = nullptr) {
+    tff::LinearTftArgs a{corresp, calm, calm_stride, B, N, flags & ~tff::FLAG_JACOBI, Rt2, Rt3, T, reconst, iter, status, dbg, nullptr, init_p, init_x};
     if (reconst) a.flags |= tff::FLAG_RECONST;
     const bool all_jacobi = (flags & tff::FLAG_JACOBI) != 0;
     if (!all_jacobi) {
@@ -42,6 +43,25 @@ extern "C" int emu_optim_f_pose(const double* corresp, const double* calm, long 
                                 double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
     return emu_pose(tff::k_f_pose<false, 1>, tff::k_f_pose<true, 1>, tff::optimf_lds_bytes, false, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T,
                     reconst, iter, status, dbg);
+}
+extern "C" int emu_pi_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                           double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
+    return emu_pose(tff::k_pi_tft_pose<tff::PiModel, false>, tff::k_pi_tft_pose<tff::PiModel, true>, tff::pi_lds_bytes<tff::PiModel>, false,
+                    corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status, dbg);
+}
+extern "C" int emu_picol_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                              double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
+    return emu_pose(tff::k_pi_tft_pose<tff::PiColModel, false>, tff::k_pi_tft_pose<tff::PiColModel, true>, tff::pi_lds_bytes<tff::PiColModel>, false,
+                    corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status, dbg);
+}
+// Pi / PiCol with the start of the Gauss-Helmert iteration exposed (tff_pi_pose_batch_debug_dev)
+extern "C" int emu_pi_pose_debug(int collinear, const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                                 double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* init_p, double* init_x) {
+    if (collinear)
+        return emu_pose(tff::k_pi_tft_pose<tff::PiColModel, false>, tff::k_pi_tft_pose<tff::PiColModel, true>, tff::pi_lds_bytes<tff::PiColModel>, false,
+                        corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status, nullptr, init_p, init_x);
+    return emu_pose(tff::k_pi_tft_pose<tff::PiModel, false>, tff::k_pi_tft_pose<tff::PiModel, true>, tff::pi_lds_bytes<tff::PiModel>, false,
+                    corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status, nullptr, init_p, init_x);
 }
 // building block: linearF / optimF per view pair (tff_linear_f_batch_dev)
 extern "C" int emu_linear_f(const double* corresp, long B, int N, int refine, double* F21, double* F31, int* iter, int* status) {

@@ -15,9 +15,11 @@ the literal numpy/LAPACK restatement of the .m files -- run on
 
 Run from the repo root (needs /root/reference for the EPFL part only):
     python tests/golden/make_golden.py
-Outputs: synthetic_linear.npz, synthetic_gh.npz, epfl.npz, optimf.npz  (inputs +
+Outputs: synthetic_linear.npz, synthetic_gh.npz, epfl.npz, optimf.npz, pi.npz  (inputs +
 expected outputs; no reference source text).  optimf.npz (OptimFPoseEstimation)
-covers synthetic scenes and the 100-correspondence EPFL samples of epfl.npz.
+covers synthetic scenes and the 100-correspondence EPFL samples of epfl.npz; pi.npz holds
+PiPoseEstimation on the same kinds of input and PiColPoseEstimation on scenes with collinear
+camera centres (angle = 180 in generateSyntheticScene.m's terms), LAPACK sign conventions.
 """
 import os
 import sys
@@ -138,6 +140,42 @@ def make_optimf():
     np.savez_compressed(os.path.join(HERE, "optimf.npz"), **data)
 
 
+PI_CASES = [(12, 1.0, 51, 3, None), (12, 0.25, 52, 2, None), (50, 1.0, 53, 3, None), (100, 3.0, 54, 2, None), (200, 1.0, 55, 3, None),
+            (40, 0.0, 56, 2, None)]
+PICOL_CASES = [(40, 0.0, 61, 3, 180), (12, 1.0, 62, 3, 180), (50, 1.0, 63, 3, 180), (200, 1.0, 64, 2, 180)]
+
+
+def make_pi():
+    """PiPoseEstimation / PiColPoseEstimation (TFT_methods/Pi*.m) goldens."""
+    data = {}
+    for key, fn, cases in (("pi", O.PiPoseEstimation, PI_CASES), ("picol", O.PiColPoseEstimation, PICOL_CASES)):
+        for ci, (N, sigma, seed, B, angle) in enumerate(cases):
+            C, CalM, Rt0, _ = generate_scene_batch(B, N, noise=sigma, seed=seed, angle=angle)
+            pre = "%s%d_" % (key[0] if key == "pi" else "q", ci)
+            data[pre + "Corresp"] = C
+            data[pre + "CalM"] = CalM
+            data[pre + "Rt0"] = np.stack(Rt0)
+            data[pre + "meta"] = np.array([N, sigma, seed, B, -1 if angle is None else angle], dtype=np.float64)
+            acc = {k: [] for k in ("Rt2", "Rt3", "T", "Rec", "iter", "reason")}
+            for b in range(B):
+                R2, R3, Rec, T, it, d = fn(C[b].T.copy(), CalM, True)
+                acc["Rt2"].append(R2); acc["Rt3"].append(R3); acc["T"].append(T); acc["Rec"].append(Rec)
+                acc["iter"].append(it); acc["reason"].append(d["reason"])
+            for k in ("Rt2", "Rt3", "T", "Rec"):
+                data[pre + key + "_" + k] = np.stack(acc[k])
+            data[pre + key + "_iter"] = np.array(acc["iter"], dtype=np.int32)
+            data[pre + key + "_reason"] = np.array(acc["reason"])
+            print(key, "case", ci, N, sigma, acc["iter"], acc["reason"], flush=True)
+    g = np.load(os.path.join(HERE, "epfl.npz"))
+    for n in range(int(g["count"])):
+        pre = "t%d_" % n
+        R2, R3, Rec, T, it = O.PiPoseEstimation(g[pre + "sample"].copy(), g[pre + "CalM"])
+        data[pre + "pi_Rt2"] = R2; data[pre + "pi_Rt3"] = R3; data[pre + "pi_T"] = T; data[pre + "pi_Rec"] = Rec
+        data[pre + "pi_iter"] = np.array(it)
+        print("pi epfl", n, it, flush=True)
+    np.savez_compressed(os.path.join(HERE, "pi.npz"), **data)
+
+
 def _read_camera(path):
     """Data/readCalibrationOrientation_EPFL.m: K (3 rows), skip, R' (3 rows), C, size."""
     with open(path) as f:
@@ -201,7 +239,7 @@ def make_epfl():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["linear", "gh", "epfl", "optimf"]
+    what = sys.argv[1:] or ["linear", "gh", "epfl", "optimf", "pi"]
     if "linear" in what:
         make_synthetic_linear()
     if "gh" in what:
@@ -210,3 +248,5 @@ if __name__ == "__main__":
         make_epfl()
     if "optimf" in what:
         make_optimf()
+    if "pi" in what:
+        make_pi()

@@ -20,3 +20,52 @@ def golden_cases(npz, prefix="c"):
     while "%s%d_meta" % (prefix, i) in npz:
         yield i, "%s%d_" % (prefix, i)
         i += 1
+
+
+# ---- Pi methods: the sign/basis conventions of the HIP kernel, as hooks for the oracle --------------------
+def _cross4(r0, r1, r2):
+    Mx = np.stack([r0, r1, r2])
+    n = np.array([(-1) ** j * np.linalg.det(np.delete(Mx, j, axis=1)) for j in range(4)])
+    return n / np.linalg.norm(n)
+
+
+def kernel_null_convention(A):
+    """null(A) with the conventions of csrc/pi_kernel.h: generalised cross product for a 3x4 (or 3 row vectors);
+    for the 2x4 of PiColPoseEstimation.m:63 the projection of the coordinate axis farthest from the plane and its
+    orthogonal complement.  MATLAB leaves these signs / this basis to svd."""
+    from oracle import tft_oracle as O
+    if A.shape == (3, 4):
+        return _cross4(A[0], A[1], A[2]).reshape(4, 1)
+    if A.shape == (2, 4):
+        n1, n2 = A[0], A[1]
+        q2 = n2 - (n1 @ n2) * n1
+        q2 = q2 / np.linalg.norm(q2)
+        best, v3 = -1.0, None
+        for ax in range(4):
+            e = np.eye(4)[ax] - n1[ax] * n1 - q2[ax] * q2
+            if e @ e > best:
+                best, v3 = e @ e, e / np.linalg.norm(e)
+        return np.stack([v3, _cross4(n1, q2, v3)], axis=1)
+    return O.null(A)
+
+
+def oracle_in_kernel_convention(method, Cb, CalM, init_p, init_x, tol=1e-8):
+    """Runs the oracle's Pi / PiCol method under the svd sign convention that reproduces the kernel's start
+    (init_p, init_x): the kernel's null-space construction and one of the four sign choices of the projective
+    cameras P2, P3 of linearTFT.  Returns (outputs, max deviation of the start) -- the start must match to `tol`
+    up to the sign of each pi vector (an overall sign of P_k flips all pi vectors of view k)."""
+    from oracle import tft_oracle as O
+    fn = getattr(O, method)
+    best = (np.inf, None)
+    for s2 in (1.0, -1.0):
+        for s3 in (1.0, -1.0):
+            p0, xe = fn(Cb, CalM, null=kernel_null_convention, cam_signs=(s2, s3), init_only=True)
+            d = 0.0
+            for blk in range(9):
+                a, o = init_p[3 * blk:3 * blk + 3], p0[3 * blk:3 * blk + 3]
+                d = max(d, min(np.abs(a - o).max(), np.abs(a + o).max()))
+            d = max(d, np.abs(init_x - xe).max())
+            if d < best[0]:
+                best = (d, (s2, s3))
+    assert best[0] < tol, "no sign convention reproduces the kernel's start (best deviation %.2e)" % best[0]
+    return fn(Cb, CalM, True, null=kernel_null_convention, cam_signs=best[1]), best[0]

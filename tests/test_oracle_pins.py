@@ -22,7 +22,7 @@ from tft_vs_fund_amd.scenes import generate_scene_batch
 from helpers import rel_err_T, rel_err, golden_cases
 
 METHODS = ["LinearTFTPoseEstimation", "LinearFPoseEstimation", "ResslTFTPoseEstimation",
-           "NordbergTFTPoseEstimation", "FaugPapaTFTPoseEstimation", "OptimFPoseEstimation"]
+           "NordbergTFTPoseEstimation", "FaugPapaTFTPoseEstimation", "OptimFPoseEstimation", "PiPoseEstimation"]
 
 
 @pytest.mark.parametrize("method", METHODS)
@@ -132,6 +132,57 @@ def test_optimF_two_view_properties():
     assert np.max(np.abs(np.einsum("in,ij,jn->n", x2, F, x1))) < 1e-9 * np.linalg.norm(F) * 1e6
     with pytest.raises(ValueError):
         O.optimF(Cb[0:2, :7], Cb[2:4, :7])
+
+
+def test_picol_noise_free_collinear_scene_recovers_ground_truth():
+    """PiColPoseEstimation is the variant for collinear camera centres (generateSyntheticScene.m:45-50, angle = 180)."""
+    C, CalM, Rt0, X = generate_scene_batch(2, 40, noise=0.0, seed=4, angle=180)
+    s = np.linalg.norm(Rt0[0][:, 3])
+    for b in range(2):
+        R2, R3, Rec, T, it = O.PiColPoseEstimation(C[b].T.copy(), CalM)
+        assert np.max(np.abs(R2[:, :3] - Rt0[0][:, :3])) < 1e-8 and np.max(np.abs(R3[:, :3] - Rt0[1][:, :3])) < 1e-8
+        assert np.max(np.abs(R3[:, 3] - Rt0[1][:, 3] / s)) < 1e-7
+
+
+@pytest.mark.parametrize("name,angle", [("Pi", None), ("PiCol", 180)])
+def test_pi_callbacks_are_consistent(name, angle):
+    """The GH callbacks of the Pi methods: f vanishes at the exact reprojections of a noise-free scene, B and C are
+    the true Jacobians (finite differences), and so is A -- except PiColPoseEstimation.m:186, whose sign for
+    dA(ind2+4)/dpi21 the restatement keeps as the reference has it."""
+    func = O._pi_constraintsGH if name == "Pi" else O._picol_constraintsGH
+    fn = O.PiPoseEstimation if name == "Pi" else O.PiColPoseEstimation
+    E = 4 if name == "Pi" else 5
+    C, CalM, _, _ = generate_scene_batch(1, 15, noise=0.0, seed=3, angle=angle)
+    p0, xe = fn(C[0].T.copy(), CalM, init_only=True)
+    f = func(xe, p0)[0]
+    assert np.abs(f).max() < 1e-12
+    rng = np.random.default_rng(0)
+    x = xe + 0.01 * rng.standard_normal(xe.shape); p = p0 + 0.01 * rng.standard_normal(27)
+    f, g, A, B, Cm, D = func(x, p)
+    h = 1e-6
+    An = np.zeros_like(A); Cn = np.zeros_like(Cm); Bn = np.zeros_like(B)
+    for k in range(27):
+        dp = np.zeros(27); dp[k] = h
+        fp, gp = func(x, p + dp)[:2]; fm, gm = func(x, p - dp)[:2]
+        An[:, k] = (fp - fm) / (2 * h); Cn[:, k] = (gp - gm) / (2 * h)
+    for k in range(x.size):
+        dx = np.zeros(x.size); dx[k] = h
+        Bn[:, k] = (func(x + dx, p)[0] - func(x - dx, p)[0]) / (2 * h)
+    assert np.abs(B - Bn).max() < 1e-7 and np.abs(Cm - Cn).max() < 1e-7
+    bad = {(int(r % E), int(c)) for r, c in np.argwhere(np.abs(A - An) > 1e-6)}
+    assert bad == (set() if name == "Pi" else {(3, 0), (3, 1), (3, 2)})
+
+
+def test_golden_pi_reproduces(golden_dir):
+    g = np.load(os.path.join(golden_dir, "pi.npz"))
+    for key, fn, prefix in (("pi", O.PiPoseEstimation, "p"), ("picol", O.PiColPoseEstimation, "q")):
+        for ci, pre in golden_cases(g, prefix):
+            C, CalM = g[pre + "Corresp"], g[pre + "CalM"]
+            if C.shape[1] > 100:
+                continue
+            R2, R3, Rec, T, it = fn(C[0].T.copy(), CalM)
+            assert it == int(g[pre + key + "_iter"][0])
+            assert rel_err_T(T, g[pre + key + "_T"][0]) < 1e-9 and rel_err(R3, g[pre + key + "_Rt3"][0]) < 1e-9
 
 
 def test_golden_epfl_linear_quality(golden_dir):

@@ -34,7 +34,7 @@ TFF_OPT_STAGE_LDS = 2
 TFF_OPT_KERNEL = 3
 DEBUG_STRIDE = 128
 
-ST_OK, ST_TOO_FEW, ST_NONFINITE, ST_NO_POSE, ST_RANK = 0, 1, 2, 3, 4
+ST_OK, ST_TOO_FEW, ST_NONFINITE, ST_NO_POSE, ST_RANK, ST_NO_PARAM = 0, 1, 2, 3, 4, 5
 
 _c_dp = ctypes.c_void_p
 _POSE_SIG = [ctypes.c_void_p, _c_dp, _c_dp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
@@ -91,6 +91,7 @@ def load_library(path=None):
             "tff_rt_from_tft_batch_dev": [V, V, V, I64, V, I64, I32, V, V, V],
             "tff_linear_tft_batch_dev": [V, V, I64, I32, V, V, V, V],
             "tff_linear_f_batch_dev": [V, V, I64, I32, I32, V, V, V, V],
+            "tff_pi_pose_batch_debug_dev": [V, I32, V, V, I64, I64, I32, V, V, V, V, V, V, V, V],
             "tff_linear_tft_pose_sampled_dev": [V, V, I32, V, V, I64, I32, V, V, V, V],
             "tff_linear_f_pose_sampled_dev": [V, V, I32, V, V, I64, I32, V, V, V, V],
         }
@@ -111,6 +112,8 @@ POSE_METHODS = {
     "FaugPapaTFTPoseEstimation": "tff_faugpapa_tft_pose_batch",
     "NordbergTFTPoseEstimation": "tff_nordberg_tft_pose_batch",
     "OptimFPoseEstimation": "tff_optim_f_pose_batch",
+    "PiPoseEstimation": "tff_pi_pose_batch",
+    "PiColPoseEstimation": "tff_picol_pose_batch",
 }
 
 # every symbol include/tftfund.h declares (checked by the CPU test-suite)
@@ -123,6 +126,8 @@ EXPORTED_SYMBOLS = [
     "tff_faugpapa_tft_pose_batch_dev", "tff_faugpapa_tft_pose_batch_host",
     "tff_nordberg_tft_pose_batch_dev", "tff_nordberg_tft_pose_batch_host",
     "tff_optim_f_pose_batch_dev", "tff_optim_f_pose_batch_host",
+    "tff_pi_pose_batch_dev", "tff_pi_pose_batch_host", "tff_picol_pose_batch_dev", "tff_picol_pose_batch_host",
+    "tff_pi_pose_batch_debug_dev",
     "tff_triangulate_batch_dev", "tff_repr_error_batch_dev", "tff_inlier_count_batch_dev", "tff_transform_tft_batch_dev",
     "tff_rt_from_tft_batch_dev", "tff_linear_tft_batch_dev", "tff_linear_f_batch_dev", "tff_linear_tft_pose_sampled_dev", "tff_linear_f_pose_sampled_dev",
 ]
@@ -235,7 +240,16 @@ class Context:
         self.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         out = dict()
-        if debug:
+        if debug and stem in ("tff_pi_pose_batch", "tff_picol_pose_batch"):
+            # the start of the Gauss-Helmert iteration: `pi` (27) and `x_est` (6N) per triplet
+            ip = torch.zeros((B, 27), dtype=torch.float64, device=dev)
+            ix = torch.zeros((B, 6 * N), dtype=torch.float64, device=dev)
+            _check(self.lib, self.lib.tff_pi_pose_batch_debug_dev(self.handle, int(stem == "tff_picol_pose_batch"), p(corresp), p(calm_cm), stride,
+                                                                  B, N, p(Rt2), p(Rt3), p(T), p(rec), p(it), p(st), p(ip), p(ix)),
+                   "tff_pi_pose_batch_debug_dev")
+            out["init_p"] = ip
+            out["init_x"] = ix
+        elif debug:
             dbg = torch.zeros((B, DEBUG_STRIDE), dtype=torch.float64, device=dev)
             fn = getattr(self.lib, stem + "_debug_dev")
             _check(self.lib, fn(self.handle, p(corresp), p(calm_cm), stride, B, N, p(Rt2), p(Rt3), p(T), p(rec), p(it), p(st),
@@ -396,6 +410,8 @@ def _single(method, Corresp, CalM, nargout=5):
         raise ValueError("not enough correspondences for %s (N=%d)" % (method, N))
     if st == ST_NO_POSE:
         raise RuntimeError("%s: no pose candidate with non-negative cheirality score" % method)
+    if st == ST_NO_PARAM:
+        raise ValueError("The minimal param could not be found")
     rec = out["Reconst"][0] if out["Reconst"] is not None else None
     return out["R_t_2"][0], out["R_t_3"][0], rec, out["T"][0], int(out["iter"][0])
 
@@ -428,3 +444,13 @@ def NordbergTFTPoseEstimation(Corresp, CalM):
 def OptimFPoseEstimation(Corresp, CalM):
     """Drop-in for F_methods/OptimFPoseEstimation.m (iter = it1 + it2 Gauss-Helmert iterations of the two optimF calls)."""
     return _single("OptimFPoseEstimation", Corresp, CalM)
+
+
+def PiPoseEstimation(Corresp, CalM):
+    """Drop-in for TFT_methods/PiPoseEstimation.m (iter = Gauss-Helmert iterations)."""
+    return _single("PiPoseEstimation", Corresp, CalM)
+
+
+def PiColPoseEstimation(Corresp, CalM):
+    """Drop-in for TFT_methods/PiColPoseEstimation.m (collinear camera centres; iter = Gauss-Helmert iterations)."""
+    return _single("PiColPoseEstimation", Corresp, CalM)

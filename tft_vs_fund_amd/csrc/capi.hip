@@ -51,6 +51,7 @@ struct tff_ctx {
     int stage = -1;
     DevBuf in, calm, out, idx, scratch_status;
     const int32_t* sample_idx = nullptr;   // set around a *_sampled_dev call
+    double* init_p = nullptr; double* init_x = nullptr;   // set around tff_pi_pose_batch_debug_dev
     int kernel_variant = 0;                // TFF_OPT_KERNEL
 };
 
@@ -95,7 +96,7 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, bool may_stage
         status = (int32_t*)c->scratch_status.p;
     }
     tff::LinearTftArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr),
-                         Rt2, Rt3, T, reconst, iter, status, dbg, c->sample_idx};
+                         Rt2, Rt3, T, reconst, iter, status, dbg, c->sample_idx, c->init_p, c->init_x};
     if (c->sample_idx) {                   // gathered samples always live in LDS
         if (!may_stage) return fail(TFF_E_INVALID, "sampled hypotheses are not supported by this method");
         a.flags |= tff::FLAG_STAGE_LDS;
@@ -137,7 +138,7 @@ int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int
         status = (int32_t*)c->scratch_status.p;
     }
     tff::LinearTftArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr),
-                         Rt2, Rt3, T, reconst, iter, status, dbg, c->sample_idx};
+                         Rt2, Rt3, T, reconst, iter, status, dbg, c->sample_idx, c->init_p, c->init_x};
     {
         tff::LinearTftArgs m = a;
         if (c->sample_idx || c->stage > 0) m.flags |= tff::FLAG_STAGE_LDS;
@@ -181,6 +182,17 @@ int launch_faugpapa_tft(tff_ctx* c, const double* corresp, const double* calm, i
                         double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     return launch_pose(c, tff::k_gh_tft_pose<tff::FaugPapaModel, false>, tff::k_gh_tft_pose<tff::FaugPapaModel, true>,
                        tff::gh_lds_bytes<tff::FaugPapaModel>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+}
+
+int launch_pi(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
+              double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+    return launch_pose(c, tff::k_pi_tft_pose<tff::PiModel, false>, tff::k_pi_tft_pose<tff::PiModel, true>,
+                       tff::pi_lds_bytes<tff::PiModel>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+}
+int launch_picol(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
+                 double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+    return launch_pose(c, tff::k_pi_tft_pose<tff::PiColModel, false>, tff::k_pi_tft_pose<tff::PiColModel, true>,
+                       tff::pi_lds_bytes<tff::PiColModel>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 
 typedef int (*pose_launcher)(tff_ctx*, const double*, const double*, int64_t, int64_t, int32_t, double*, double*, double*, double*,
@@ -337,6 +349,32 @@ int tff_faugpapa_tft_pose_batch_host(tff_ctx* c, const double* corresp, const do
                                       int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
                                       int32_t* status) {
     return pose_batch_host(launch_faugpapa_tft, c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status);
+}
+int tff_pi_pose_batch_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                           int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status) {
+    return launch_pi(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, nullptr);
+}
+int tff_pi_pose_batch_host(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                            int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status) {
+    return pose_batch_host(launch_pi, c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status);
+}
+int tff_picol_pose_batch_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                              int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status) {
+    return launch_picol(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, nullptr);
+}
+int tff_picol_pose_batch_host(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                               int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status) {
+    return pose_batch_host(launch_picol, c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status);
+}
+int tff_pi_pose_batch_debug_dev(tff_ctx* c, int32_t collinear, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                                 int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status,
+                                 double* init_p, double* init_x) {
+    if (!c) return fail(TFF_E_INVALID, "null context");
+    if ((init_p == nullptr) != (init_x == nullptr)) return fail(TFF_E_INVALID, "init_p and init_x come together");
+    c->init_p = init_p; c->init_x = init_x;
+    const int r = (collinear ? launch_picol : launch_pi)(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, nullptr);
+    c->init_p = nullptr; c->init_x = nullptr;
+    return r;
 }
 int tff_optim_f_pose_batch_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
                                 int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,

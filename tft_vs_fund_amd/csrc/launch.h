@@ -4,6 +4,7 @@
 #include "f_kernel.h"
 #include "gh_kernel.h"
 #include "blocks_kernel.h"
+#include "pi_kernel.h"
 
 namespace tff {
 
@@ -27,6 +28,14 @@ inline size_t gh_lds_bytes(int N, int /*flags*/, bool jacobi) {
     size_t d = (size_t)((POSE_LDS_DOUBLES + 1) & ~1);
     if (jacobi) d += (size_t)((JACOBI_LDS_DOUBLES + 1) & ~1);
     d += (size_t)gh_lds_doubles(Model::U, Model::C, N);
+    return d * sizeof(double);
+}
+// Pi-matrix Gauss-Helmert kernels: xi (6N), per-correspondence W+ / W+w (14N or 20N), 36x37 / 38x39 KKT system
+template <class Model>
+inline size_t pi_lds_bytes(int N, int /*flags*/, bool jacobi) {
+    size_t d = (size_t)((POSE_LDS_DOUBLES + 1) & ~1);
+    if (jacobi) d += (size_t)((JACOBI_LDS_DOUBLES + 1) & ~1);
+    d += (size_t)pi_lds_doubles(Model::E, Model::C, N, Model::PINV_KKT);
     return d * sizeof(double);
 }
 // OptimFPoseEstimation: xi and v (4N each) + the 11 x 11 KKT workspace

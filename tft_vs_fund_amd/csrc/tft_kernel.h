@@ -54,6 +54,8 @@ struct LinearTftArgs {
     int* status;             // B (never null inside the library: the context supplies one)
     double* dbg;             // B x DBG_STRIDE or null
     const int* sample_idx;   // null, or B x N int32 indices into ONE shared scene at `corresp` (config 4: minimal samples)
+    double* init_p;          // null, or B x 27: initial parameters of the Pi methods (debug / building-block output)
+    double* init_x;          // with init_p: B x 6N initial observation estimates
 };
 
 // Inverse-iteration cap before a triplet is handed to the Jacobi fix-up pass: 300 iterations (~0.13 M
