@@ -165,13 +165,14 @@ def ReprError(ProjM, Corresp, Points3D=None):
 
 
 def AngError(R_t_true, R_t_est):
-    """auxiliar_functions/AngError.m:21-28 (no clamping of acos argument)."""
+    """auxiliar_functions/AngError.m:21-28.  The acos argument is not clamped: when rounding pushes it above 1
+    MATLAB's acos returns a purely imaginary number and abs() its magnitude (a tiny angle), restated here with the
+    complex arccos."""
     R_true, t_true = R_t_true[:, 0:3], R_t_true[:, 3]
     R_est, t_est = R_t_est[:, 0:3], R_t_est[:, 3]
-    with np.errstate(invalid='ignore'):
-        rot_err = abs(180 * np.arccos((np.trace(R_true.T @ R_est) - 1) / 2) / np.pi)
-        t_err = abs(180 * np.arccos(np.dot(t_est / np.linalg.norm(t_est),
-                                           t_true / np.linalg.norm(t_true))) / np.pi)
+    rot_err = float(abs(180 * np.arccos(complex((np.trace(R_true.T @ R_est) - 1) / 2)) / np.pi))
+    t_err = float(abs(180 * np.arccos(complex(np.dot(t_est / np.linalg.norm(t_est),
+                                                       t_true / np.linalg.norm(t_true)))) / np.pi))
     return rot_err, t_err
 
 
