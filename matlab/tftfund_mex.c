@@ -3,7 +3,7 @@
  *
  *   [R_t_2, R_t_3, Reconst, T, iter] = tftfund_mex(method, Corresp, CalM)
  *
- * method : 'linear_tft' | 'linear_f' | 'ressl_tft' | 'nordberg_tft' | 'faugpapa_tft' | 'optim_f'
+ * method : 'linear_tft' | 'linear_f' | 'ressl_tft' | 'nordberg_tft' | 'faugpapa_tft' | 'optim_f' | 'pi' | 'picol'
  *          (one entry per tff_<method>_pose_batch_host symbol)
  * Corresp: 6 x N double, or 6 x N x B for a batch of B triplets
  * CalM   : 9 x 3 double (shared) or 9 x 3 x B
@@ -53,6 +53,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     else if (!strcmp(method, "nordberg_tft")) fn = tff_nordberg_tft_pose_batch_host;
     else if (!strcmp(method, "faugpapa_tft")) fn = tff_faugpapa_tft_pose_batch_host;
     else if (!strcmp(method, "optim_f")) fn = tff_optim_f_pose_batch_host;
+    else if (!strcmp(method, "pi")) fn = tff_pi_pose_batch_host;
+    else if (!strcmp(method, "picol")) fn = tff_picol_pose_batch_host;
     else mexErrMsgIdAndTxt("tftfund:method", "unknown method '%s'", method);
     if (!mxIsDouble(prhs[1]) || mxIsComplex(prhs[1]) || !mxIsDouble(prhs[2]) || mxIsComplex(prhs[2]))
         mexErrMsgIdAndTxt("tftfund:type", "Corresp and CalM must be real double");
@@ -88,6 +90,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (rc != 0) mexErrMsgIdAndTxt("tftfund:hip", "%s: %s", method, tff_last_error());
     if (B == 1 && status[0] == TFF_ST_TOO_FEW)
         mexErrMsgIdAndTxt("tftfund:tooFew", "not enough correspondences for %s (N = %d)", method, (int)N);
+    if (B == 1 && status[0] == TFF_ST_NO_PARAM)
+        mexErrMsgIdAndTxt("tftfund:noParam", "The minimal param could not be found");
     if (B == 1 && status[0] == TFF_ST_NO_POSE)
         mexErrMsgIdAndTxt("tftfund:noPose", "no pose candidate with non-negative cheirality score");
     plhs[0] = aRt2;
