@@ -214,7 +214,7 @@ __device__ inline int gauss_helmert_f_wave(PoseLds* w, OptimFLds* g, double* xi,
         double chk = 0.0;
         for (int e = lane; e < n * ld; e += WAVE) chk += g->M[e];
         if (!(fabs(wave_sum(chk)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
-        if (!wave_solve_pivoted(g->M, n, g->dt)) { *st = ST_RANK; break; }   // :67
+        if (!wave_solve_gj<n>(g->M, g->dt)) { *st = ST_RANK; break; }        // :67
         wave_sync();
         double dt[9];
 #pragma unroll

@@ -274,44 +274,46 @@ __device__ inline void gh_sweep(const GhWork& g, int N) {
     }
 }
 
-// Solve the n x n system held as an augmented n x (n+1) matrix in LDS by Gaussian elimination
-// with partial pivoting.  x -> sol[0..n).  Returns false when a pivot is negligible.
-__device__ inline bool wave_solve_pivoted(double* M, int n, double* sol) {
+// Solve the n x n system held as an augmented n x (n+1) matrix in LDS (x -> sol[0..n), false when a pivot is
+// negligible).  The matrix lives in registers: lane r owns row r (compile-time n <= 64), Gauss-Jordan elimination
+// with partial pivoting and no physical row exchange -- the pivot row of column k is the not-yet-used lane with
+// the largest |a[k]|, broadcast by v_readlane; at the end the lane that served as pivot of column k holds x_k.
+// ~n^2 readlanes + n^2/2 FMAs per lane and no LDS traffic inside the loop.
+template <int n>
+__device__ inline bool wave_solve_gj(const double* M, double* sol) {
+    constexpr int ld = n + 1;
     const int lane = lane_id();
-    const int ld = n + 1;
+    const bool valid = lane < n;
+    double a[ld];
+    {
+        const double* row = M + (valid ? lane : 0) * ld;
+#pragma unroll
+        for (int c = 0; c < ld; ++c) a[c] = row[c];
+    }
     double amax = 0.0;
-    for (int e = lane; e < n * n; e += WAVE) { const double v = fabs(M[(e / n) * ld + e % n]); amax = (v > amax) ? v : amax; }
+#pragma unroll
+    for (int c = 0; c < n; ++c) amax = (valid && fabs(a[c]) > amax) ? fabs(a[c]) : amax;
     amax = wave_max(amax);
     bool ok = amax > 0.0 && amax < 1e300;
-    const int lr = lane & 7, lc = lane >> 3;
-#pragma unroll 1
-    for (int k = 0; k < n; ++k) {
-        const double v = (lane >= k && lane < n) ? fabs(M[lane * ld + k]) : -1.0;
-        const double best = wave_max(v);
-        int pr = (v == best && lane >= k && lane < n) ? lane : 64;
+    bool active = valid;
+    double x = 0.0;
+    int mycol = 0;
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { const int o = wave_shfl_xor_i(pr, m); pr = (o < pr) ? o : pr; }
+    for (int k = 0; k < n; ++k) {
+        const double v = active ? fabs(a[k]) : -1.0;
+        const double best = wave_max(v);
         if (!(best > 1e-10 * amax)) ok = false;
-        if (pr >= 64) pr = k;
-        wave_sync();
-        if (pr != k && lane <= n) { const double a = M[k * ld + lane], b = M[pr * ld + lane]; M[k * ld + lane] = b; M[pr * ld + lane] = a; }
-        wave_sync();
-        const double ipiv = 1.0 / M[k * ld + k];
-        wave_sync();
-        for (int r = k + 1 + lr; r < n; r += 8) {
-            const double fct = M[r * ld + k] * ipiv;
-            for (int c = k + 1 + lc; c <= n; c += 8) M[r * ld + c] -= fct * M[k * ld + c];
-        }
-        wave_sync();
+        int p = wave_first_lane(active && v == best);                        // wave-uniform
+        p = (p < 64) ? p : 0;
+        const double ipiv = 1.0 / wave_bcast(a[k], p);
+        const bool elim = valid && lane != p;
+        const double f = elim ? a[k] * ipiv : 0.0;
+#pragma unroll
+        for (int c = k + 1; c < ld; ++c) a[c] -= f * wave_bcast(a[c], p);
+        if (lane == p) { active = false; mycol = k; x = ipiv; }             // x_k = rhs / pivot once the other columns are cleared
     }
-#pragma unroll 1
-    for (int k = n - 1; k >= 0; --k) {                                       // back substitution on the last column
-        const double xk = M[k * ld + n] / M[k * ld + k];
-        wave_sync();
-        if (lane == 0) sol[k] = xk;
-        if (lane < k) M[lane * ld + n] -= M[lane * ld + k] * xk;
-        wave_sync();
-    }
+    if (valid) sol[mycol] = a[n] * x;
+    wave_sync();
     return ok;
 }
 
@@ -652,6 +654,70 @@ struct ResslModel {
     }
 };
 
+// inverse of a symmetric positive definite E x E block through its Cholesky factor (per lane), packed lower triangle out.
+// false when a pivot is not positive.
+template <int E>
+__device__ __forceinline__ bool spd_inverse_packed(const double (&W)[E][E], double* Wp) {
+    double L[E][E], id[E];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        double d = W[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        ok = ok && (d > 0.0);
+        id[j] = rsqrt(d);
+#pragma unroll
+        for (int i = j + 1; i < E; ++i) {
+            double s = W[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            L[i][j] = s * id[j];
+        }
+    }
+    double Li[E][E];                                                         // inv(L), lower triangular
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        Li[j][j] = id[j];
+#pragma unroll
+        for (int i = j + 1; i < E; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = j; k < i; ++k) s += L[i][k] * Li[k][j];
+            Li[i][j] = -s * id[i];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < E; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {                                       // inv(W) = inv(L)' inv(L)
+            double s = 0.0;
+#pragma unroll
+            for (int k = a; k < E; ++k) s += Li[k][a] * Li[k][b];
+            Wp[a * (a + 1) / 2 + b] = s;
+        }
+    return ok;
+}
+
+// w = -f - B (x - xi) (Gauss_Helmert.m:58); stores W+ (10) and W+ w (4) of correspondence i
+__device__ __forceinline__ void gh_store_point(const GhWork& g, const PoseLds* w, const double* pts, int i, const double (&o)[6],
+                                               const double (&f)[4], const double (&B)[4][6], const double (&Wp)[10]) {
+    const Pt6 x = premap(load_pt(pts, i), w->nrm);
+    double wv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        double s = -f[a];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s -= B[a][k] * (x.v[k] - o[k]);
+        wv[a] = s;
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) g.pp[14 * i + k] = Wp[k];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+        g.pp[14 * i + 10 + a] = wp_at(Wp, a, 0) * wv[0] + wp_at(Wp, a, 1) * wv[1] + wp_at(Wp, a, 2) * wv[2] + wp_at(Wp, a, 3) * wv[3];
+}
+
 // Gauss_Helmert.m:38-83 for a trilinearity model.  xi holds x0 on entry.  Returns iterations; status via *st.
 template <class Model>
 __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, const double* pts, int N, int* st, double* dbg) {
@@ -668,67 +734,93 @@ __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, co
     int it = 0;
 #pragma unroll 1
     for (it = 1; it <= GH_IT_MAX; ++it) {
+        if (it == 1) phase_stamp(dbg, 40);
         model.eval(g);                                                       // func(xi, ti, yi)   (:50)
+        if (it == 1) phase_stamp(dbg, 41);
         double T[27];
         load_uniform27(g.Tc, T);
-        // ---- W = B B', its largest eigenvalue -> pinv tolerance   (:52,:57) ----
-        double smax = 0.0;
+        // ---- W = B B' (:52): finite check and a bound on its largest eigenvalue (lambda_max <= |W|_F) ----
+        double f2max = 0.0;
         bool finite = true;
         for (int i = lane; i < N; i += WAVE) {
-            double o[6], f[4], B[4][6], W[4][4], V[4][4];
+            double o[6], f[4], B[4][6], W[4][4];
 #pragma unroll
             for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
             tril_block(T, o, f, B);
             block_W(B, W);
-            double chk = 0.0;
+            double chk = 0.0, fro2 = 0.0;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) chk += W[a][0] + W[a][1] + W[a][2] + W[a][3];
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { chk += W[a][b]; fro2 += W[a][b] * W[a][b]; }
             finite = finite && (fabs(chk) <= 1.79e308);
-            jacobi4<false>(W, V);
-#pragma unroll
-            for (int a = 0; a < 4; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+            f2max = (fro2 > f2max) ? fro2 : f2max;
         }
-        smax = wave_max(smax);
-        if (wave_any(!finite) || !(smax <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
-        const double tolW = 4.0 * (double)N * eps_of(smax);
-        // ---- per block: W+ = pinv(W + 1e-12 I) + 1e-12 I,  w = -f - B (x - xi)   (:57-58) ----
-        for (int i = lane; i < N; i += WAVE) {
-            double o[6], f[4], B[4][6], W[4][4], V[4][4];
+        f2max = wave_max(f2max);
+        if (wave_any(!finite) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
+        // pinv(W + 1e-12 I) (:57) truncates singular values <= 4N eps(lambda_max).  Every eigenvalue of W + 1e-12 I is
+        // >= 1e-12, so while that tolerance is safely below 1e-12 (N up to a few hundred) nothing is truncated and
+        // pinv is the plain inverse of each 4x4 block: Cholesky per lane.  Otherwise: exact path through the per-block
+        // eigen-decompositions (Jacobi), which reproduces the truncation.
+        bool fast = 4.0 * (double)N * eps_of(sqrt(f2max)) < 0.9e-12;
+        if (it == 1) phase_stamp(dbg, 42);
+        if (fast) {
+            bool bad = false;
+            for (int i = lane; i < N; i += WAVE) {
+                double o[6], f[4], B[4][6], W[4][4], Wp[10];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
-            tril_block(T, o, f, B);
-            block_W(B, W);
-            jacobi4<true>(W, V);
-            double inv[4];
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                tril_block(T, o, f, B);
+                block_W(B, W);
+                bad = !spd_inverse_packed<4>(W, Wp) || bad;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) inv[a] = (W[a][a] > tolW) ? 1.0 / W[a][a] : 0.0;
-            double Wp[10];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b <= a; ++b)
-                    Wp[a * (a + 1) / 2 + b] = V[a][0] * inv[0] * V[b][0] + V[a][1] * inv[1] * V[b][1] + V[a][2] * inv[2] * V[b][2]
-                                              + V[a][3] * inv[3] * V[b][3] + ((a == b) ? 1e-12 : 0.0);
-            const Pt6 x = premap(load_pt(pts, i), w->nrm);
-            double wv[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                double s = -f[a];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) s -= B[a][k] * (x.v[k] - o[k]);
-                wv[a] = s;
+                for (int a = 0; a < 4; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
+                gh_store_point(g, w, pts, i, o, f, B, Wp);
             }
+            if (wave_any(bad)) fast = false;                                 // numerically indefinite block: take the exact path
+        }
+        if (!fast) {
+            double smax = 0.0;
+            for (int i = lane; i < N; i += WAVE) {
+                double o[6], f[4], B[4][6], W[4][4], V[4][4];
 #pragma unroll
-            for (int k = 0; k < 10; ++k) g.pp[14 * i + k] = Wp[k];
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                tril_block(T, o, f, B);
+                block_W(B, W);
+                jacobi4<false>(W, V);
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-                g.pp[14 * i + 10 + a] = wp_at(Wp, a, 0) * wv[0] + wp_at(Wp, a, 1) * wv[1] + wp_at(Wp, a, 2) * wv[2] + wp_at(Wp, a, 3) * wv[3];
+                for (int a = 0; a < 4; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+            }
+            smax = wave_max(smax);
+            const double tolW = 4.0 * (double)N * eps_of(smax);
+            // per block: W+ = pinv(W + 1e-12 I) + 1e-12 I   (:57)
+            for (int i = lane; i < N; i += WAVE) {
+                double o[6], f[4], B[4][6], W[4][4], V[4][4];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                tril_block(T, o, f, B);
+                block_W(B, W);
+                jacobi4<true>(W, V);
+                double inv[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) inv[a] = (W[a][a] > tolW) ? 1.0 / W[a][a] : 0.0;
+                double Wp[10];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b <= a; ++b)
+                        Wp[a * (a + 1) / 2 + b] = V[a][0] * inv[0] * V[b][0] + V[a][1] * inv[1] * V[b][1] + V[a][2] * inv[2] * V[b][2]
+                                                  + V[a][3] * inv[3] * V[b][3] + ((a == b) ? 1e-12 : 0.0);
+                gh_store_point(g, w, pts, i, o, f, B, Wp);
+            }
         }
         wave_sync();
+        if (it == 1) phase_stamp(dbg, 43);
         // ---- Ghat = sum Ap' W+ Ap and ghat = sum Ap' W+ w   (:59-62) ----
         gh_sweep<0>(g, N); gh_sweep<1>(g, N); gh_sweep<2>(g, N); gh_sweep<3>(g, N); gh_sweep<4>(g, N);
         gh_sweep<5>(g, N); gh_sweep<6>(g, N); gh_sweep<7>(g, N); gh_sweep<8>(g, N); gh_sweep<9>(g, N);
         wave_sync();
+        if (it == 1) phase_stamp(dbg, 44);
         for (int e = lane; e < 729; e += WAVE) {                             // Ghat[(q,i1),(q',i1')] = H[6 tri(q,q') + hht(i1,i1')]
             const int r = e / 27, cc = e % 27;
             const int q = r % 9, i1 = r / 9, qq = cc % 9, i1p = cc / 9;
@@ -766,9 +858,10 @@ __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, co
         double chkM = 0.0;
         for (int e = lane; e < n * ld; e += WAVE) chkM += g.M[e];
         if (!(fabs(wave_sum(chkM)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
+        if (it == 1) phase_stamp(dbg, 45);
         // aux = pinv(M + 1e-12 I) * b   (:67)
         if (Model::REDUNDANT_CONSTRAINTS) wave_pinv_solve_sym(g.M, g.V, n, g.dt, g.Y);
-        else if (!wave_solve_pivoted(g.M, n, g.dt)) { *st = ST_RANK; break; }
+        else if (!wave_solve_gj<Model::U + Model::C>(g.M, g.dt)) { *st = ST_RANK; break; }
         wave_sync();
         if (lane < 27) {                                                     // dT = D dt
             double a = 0.0;
@@ -779,6 +872,7 @@ __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, co
         wave_sync();
         double dTr[27];
         load_uniform27(g.dT, dTr);
+        if (it == 1) phase_stamp(dbg, 46);
         // ---- v = -B' W+ (A dt - w)   (:69) ----
         double obj = 0.0, diff = 0.0;
         for (int i = lane; i < N; i += WAVE) {
@@ -811,6 +905,7 @@ __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, co
         diff = wave_sum(diff);
         const double dtk = (lane < u) ? g.dt[lane] : 0.0;
         const double ndt2 = wave_sum(dtk * dtk);
+        if (it == 1) phase_stamp(dbg, 47);
         if (dbg && lane == 0 && it <= 8) { dbg[96 + 3 * (it - 1)] = obj; dbg[97 + 3 * (it - 1)] = ndt2; dbg[98 + 3 * (it - 1)] = diff; }
         if (sqrt(ndt2) < GH_TOL && sqrt(diff) < GH_TOL) break;               // :71-73 (dy is empty)
         if (obj > objFunc) break;                                            // :75-76, factor = 1

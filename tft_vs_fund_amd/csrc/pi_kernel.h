@@ -570,6 +570,32 @@ __device__ __forceinline__ void pi_sweeps(const PiWork& g, const double (&pi)[27
     if constexpr (S < 15) pi_sweeps<Model, S + 1>(g, pi, N);
 }
 
+// w = -f - B (x - xi) (Gauss_Helmert.m:58); stores W+ (packed) and W+ w of correspondence i
+template <int E>
+__device__ __forceinline__ void pi_store_point(const PiWork& g, const PoseLds* w, const double* pts, int i, const double (&o)[6],
+                                               const PiPoint<E>& pt, const double* Wp) {
+    constexpr int PP = pi_pp(E), NW = E * (E + 1) / 2;
+    const Pt6 x = premap(load_pt(pts, i), w->nrm);
+    double wv[E];
+#pragma unroll
+    for (int a = 0; a < E; ++a) {
+        double s = -pt.f[a];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s -= pt.B[a][k] * (x.v[k] - o[k]);
+        wv[a] = s;
+    }
+    double* pw = g.pp + (long)PP * i;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) pw[k] = Wp[k];
+#pragma unroll
+    for (int a = 0; a < E; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < E; ++b) s += sym_at<E>(Wp, a, b) * wv[b];
+        pw[NW + a] = s;
+    }
+}
+
 // Gauss_Helmert.m:38-83 for a Pi model.  xi holds x0 on entry.  Returns iterations; status via *st.
 template <class Model>
 __device__ inline int gauss_helmert_pi_wave(PoseLds* w, PiWork& g, const double* pts, int N, int* st, double* dbg) {
@@ -588,69 +614,81 @@ __device__ inline int gauss_helmert_pi_wave(PoseLds* w, PiWork& g, const double*
     for (it = 1; it <= GH_IT_MAX; ++it) {
         double pi[27];
         load_uniform27(g.p, pi);
-        // ---- W = B B', its largest eigenvalue -> pinv tolerance   (:52,:57) ----
-        double smax = 0.0;
+        // ---- W = B B' (:52): finite check and a bound on its largest eigenvalue; fast / exact pinv as in gh_kernel.h ----
+        double f2max = 0.0;
         bool finite = true;
         for (int i = lane; i < N; i += WAVE) {
-            double o[6], W[E][E], V[E][E];
+            double o[6], W[E][E];
 #pragma unroll
             for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
             PiPoint<E> pt;
             pi_eval<Model, true>(pi, o, pt);
             pi_block_W<E>(pt.B, W);
-            double chk = 0.0;
+            double chk = 0.0, fro2 = 0.0;
 #pragma unroll
             for (int a = 0; a < E; ++a)
 #pragma unroll
-                for (int b = 0; b < E; ++b) chk += W[a][b];
+                for (int b = 0; b < E; ++b) { chk += W[a][b]; fro2 += W[a][b] * W[a][b]; }
             finite = finite && (fabs(chk) <= 1.79e308);
-            jacobi_small<E, false>(W, V);
-#pragma unroll
-            for (int a = 0; a < E; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+            f2max = (fro2 > f2max) ? fro2 : f2max;
         }
-        smax = wave_max(smax);
-        if (wave_any(!finite) || !(smax <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
-        const double tolW = (double)E * (double)N * eps_of(smax);
-        // ---- per block: W+ = pinv(W + 1e-12 I) + 1e-12 I,  w = -f - B (x - xi)   (:57-58) ----
-        for (int i = lane; i < N; i += WAVE) {
-            double o[6], W[E][E], V[E][E];
+        f2max = wave_max(f2max);
+        if (wave_any(!finite) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
+        bool fast = (double)E * (double)N * eps_of(sqrt(f2max)) < 0.9e-12;
+        if (fast) {
+            bool bad = false;
+            for (int i = lane; i < N; i += WAVE) {
+                double o[6], W[E][E], Wp[NW];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
-            PiPoint<E> pt;
-            pi_eval<Model, true>(pi, o, pt);
-            pi_block_W<E>(pt.B, W);
-            jacobi_small<E, true>(W, V);
-            double inv[E];
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                PiPoint<E> pt;
+                pi_eval<Model, true>(pi, o, pt);
+                pi_block_W<E>(pt.B, W);
+                bad = !spd_inverse_packed<E>(W, Wp) || bad;
 #pragma unroll
-            for (int a = 0; a < E; ++a) inv[a] = (W[a][a] > tolW) ? 1.0 / W[a][a] : 0.0;
-            double Wp[NW];
-#pragma unroll
-            for (int a = 0; a < E; ++a)
-#pragma unroll
-                for (int b = 0; b <= a; ++b) {
-                    double s = (a == b) ? 1e-12 : 0.0;
-#pragma unroll
-                    for (int k = 0; k < E; ++k) s += V[a][k] * inv[k] * V[b][k];
-                    Wp[a * (a + 1) / 2 + b] = s;
-                }
-            const Pt6 x = premap(load_pt(pts, i), w->nrm);
-            double wv[E];
-#pragma unroll
-            for (int a = 0; a < E; ++a) {
-                double s = -pt.f[a];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) s -= pt.B[a][k] * (x.v[k] - o[k]);
-                wv[a] = s;
+                for (int a = 0; a < E; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
+                pi_store_point<E>(g, w, pts, i, o, pt, Wp);
             }
-            double* pw = g.pp + (long)PP * i;
+            if (wave_any(bad)) fast = false;
+        }
+        if (!fast) {
+            double smax = 0.0;
+            for (int i = lane; i < N; i += WAVE) {
+                double o[6], W[E][E], V[E][E];
 #pragma unroll
-            for (int k = 0; k < NW; ++k) pw[k] = Wp[k];
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                PiPoint<E> pt;
+                pi_eval<Model, true>(pi, o, pt);
+                pi_block_W<E>(pt.B, W);
+                jacobi_small<E, false>(W, V);
 #pragma unroll
-            for (int a = 0; a < E; ++a) {
-                double s = 0.0;
+                for (int a = 0; a < E; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+            }
+            smax = wave_max(smax);
+            const double tolW = (double)E * (double)N * eps_of(smax);
+            // per block: W+ = pinv(W + 1e-12 I) + 1e-12 I   (:57)
+            for (int i = lane; i < N; i += WAVE) {
+                double o[6], W[E][E], V[E][E];
 #pragma unroll
-                for (int b = 0; b < E; ++b) s += sym_at<E>(Wp, a, b) * wv[b];
-                pw[NW + a] = s;
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                PiPoint<E> pt;
+                pi_eval<Model, true>(pi, o, pt);
+                pi_block_W<E>(pt.B, W);
+                jacobi_small<E, true>(W, V);
+                double inv[E];
+#pragma unroll
+                for (int a = 0; a < E; ++a) inv[a] = (W[a][a] > tolW) ? 1.0 / W[a][a] : 0.0;
+                double Wp[NW];
+#pragma unroll
+                for (int a = 0; a < E; ++a)
+#pragma unroll
+                    for (int b = 0; b <= a; ++b) {
+                        double s = (a == b) ? 1e-12 : 0.0;
+#pragma unroll
+                        for (int k = 0; k < E; ++k) s += V[a][k] * inv[k] * V[b][k];
+                        Wp[a * (a + 1) / 2 + b] = s;
+                    }
+                pi_store_point<E>(g, w, pts, i, o, pt, Wp);
             }
         }
         wave_sync();
@@ -690,7 +728,7 @@ __device__ inline int gauss_helmert_pi_wave(PoseLds* w, PiWork& g, const double*
         if (!(fabs(wave_sum(chkM)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
         // aux = pinv(M + 1e-12 I) b   (:67)
         if (Model::PINV_KKT) wave_pinv_solve_sym(g.M, g.V, n, g.dt, g.V + n * n);
-        else if (!wave_solve_pivoted(g.M, n, g.dt)) { *st = ST_RANK; break; }
+        else if (!wave_solve_gj<n>(g.M, g.dt)) { *st = ST_RANK; break; }
         wave_sync();
         double dt[27];
         load_uniform27(g.dt, dt);

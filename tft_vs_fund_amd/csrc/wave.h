@@ -108,11 +108,41 @@ __device__ __forceinline__ double wave_sum(double v) {
     return (r0 + r1) + (r2 + r3);
 }
 #endif
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
+#ifdef TFF_CPU_EMU
+__device__ inline double wave_max(double v) {
     for (int m = 32; m >= 1; m >>= 1) { double o = wave_shfl_xor(v, m); v = (o > v) ? o : v; }
     return v;
 }
+// lowest lane whose predicate holds (64 if none); wave-uniform
+__device__ inline int wave_first_lane(bool p) {
+    int c = p ? lane_id() : 64;
+    for (int m = 32; m >= 1; m >>= 1) { const int o = wave_shfl_xor_i(c, m); c = (o < c) ? o : c; }
+    return c;
+}
+#else
+// as dpp_mov, but lanes whose source falls outside the row keep their own value
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_keep(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max(double v) {
+    double o;
+    o = dpp_mov_keep<0x111>(v); v = (o > v) ? o : v;       // row_shr:1
+    o = dpp_mov_keep<0x112>(v); v = (o > v) ? o : v;       // row_shr:2
+    o = dpp_mov_keep<0x114>(v); v = (o > v) ? o : v;       // row_shr:4
+    o = dpp_mov_keep<0x118>(v); v = (o > v) ? o : v;       // row_shr:8   -> lane 15 of every row holds the row maximum
+    const double r0 = wave_bcast(v, 15), r1 = wave_bcast(v, 31), r2 = wave_bcast(v, 47), r3 = wave_bcast(v, 63);
+    const double a = (r0 > r1) ? r0 : r1, b = (r2 > r3) ? r2 : r3;
+    return (a > b) ? a : b;
+}
+__device__ __forceinline__ int wave_first_lane(bool p) {
+    const unsigned long long m = __ballot(p);
+    return m ? (__ffsll((long long)m) - 1) : 64;
+}
+#endif
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += wave_shfl_xor_i(v, m);
