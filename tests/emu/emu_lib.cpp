@@ -3,6 +3,7 @@
 // logic is covered by `pytest -m "not gpu"` and can be run under sanitizers.
 // Never linked into libtftfund.so.
 #define TFF_CPU_EMU 1
+#include <vector>
 #include "../../tft_vs_fund_amd/csrc/launch.h"
 
 // Same two-pass structure as the C ABI: inverse-iteration kernel, then the
@@ -62,6 +63,28 @@ extern "C" int emu_pi_pose_debug(int collinear, const double* corresp, const dou
                         corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status, nullptr, init_p, init_x);
     return emu_pose(tff::k_pi_tft_pose<tff::PiModel, false>, tff::k_pi_tft_pose<tff::PiModel, true>, tff::pi_lds_bytes<tff::PiModel>, false,
                     corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status, nullptr, init_p, init_x);
+}
+// Gauss-Helmert methods through the three-launch workgroup path (gh_wg_kernel.h): model 0 Ressl, 1 Nordberg, 2 FaugPapa
+template <class Model>
+static int emu_gh_wg_impl(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                          double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status) {
+    std::vector<double> rec((size_t)B * tff::GH_REC_DOUBLES), topt((size_t)B * 27);
+    tff::GhWgArgs a{corresp, calm, calm_stride, B, N, (flags & ~tff::FLAG_JACOBI) | (reconst ? tff::FLAG_RECONST : 0), rec.data(), topt.data(),
+                    Rt2, Rt3, T, reconst, iter, status, nullptr};
+    emu::launch(tff::k_gh_linear<false>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, a.flags, false), a);
+    tff::GhWgArgs m = a;
+    m.flags |= tff::FLAG_ONLY_RETRY;
+    emu::launch(tff::k_gh_linear<true>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
+    const size_t lds = (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, N)) * sizeof(double);
+    emu::launch(tff::k_gh_block<Model>, tff::pose_grid(B), tff::GH_WG_THREADS, lds, a);
+    emu::launch(tff::k_gh_finish, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
+    return 0;
+}
+extern "C" int emu_gh_wg_pose(int model, const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                              double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status) {
+    if (model == 0) return emu_gh_wg_impl<tff::ResslModel>(corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status);
+    if (model == 1) return emu_gh_wg_impl<tff::NordbergModel>(corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status);
+    return emu_gh_wg_impl<tff::FaugPapaModel>(corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status);
 }
 // building block: linearF / optimF per view pair (tff_linear_f_batch_dev)
 extern "C" int emu_linear_f(const double* corresp, long B, int N, int refine, double* F21, double* F31, int* iter, int* status) {

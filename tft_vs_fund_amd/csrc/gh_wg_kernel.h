@@ -1,0 +1,424 @@
+// Gauss-Helmert methods (Ressl, Nordberg, FaugPapa) as three launches, with a WORKGROUP of four wavefronts per
+// triplet for the iteration itself:
+//
+//   k_gh_linear<JAC>   one wavefront per triplet (2 waves / SIMD): Normalize2Ddata x3 + linearTFT
+//                      (ResslTFTPoseEstimation.m:48-53) -> a 64-double record per triplet (t, a, epipoles, normalisations)
+//   k_gh_block<Model>  256 threads per triplet: model set-up, initial observations (projective triangulation +
+//                      reprojection, :72-75), Gauss_Helmert.m:38-83 -> optimised tensor (27 doubles)
+//   k_gh_finish        one wavefront per triplet: transform_TFT, R_t_from_TFT, Reconst (:96-103)
+//
+// Why: the per-correspondence state of the iteration (xi, W+, W+w: 20 N doubles) plus the normal-equation workspace
+// take ~58 KB of LDS at N = 200.  With one wavefront per triplet (k_gh_tft_pose in gh_kernel.h) that allows two
+// wavefronts per CU -- two of the four SIMDs idle, the other two running a lone wave at ~8 cycles per dependent
+// instruction.  Four wavefronts sharing one triplet's LDS put 8 waves on a CU (2 per SIMD) and split the
+// per-correspondence sweeps four ways; the wave-serial steps (parameter Jacobian, KKT solve) run on one wave of
+// the group, chosen by blockIdx so that they spread over the SIMDs.
+//
+// Same arithmetic per correspondence as gh_kernel.h (shared device functions); sums over correspondences are
+// grouped per wavefront and then added, so results differ from the single-wave kernel by rounding only
+// (TFF_OPT_KERNEL = 1 selects the single-wave kernel for A/B runs).
+#pragma once
+#include "gh_kernel.h"
+
+namespace tff {
+
+constexpr int GH_WG_WAVES = 4;
+constexpr int GH_WG_THREADS = 64 * GH_WG_WAVES;
+constexpr int GH_REC_DOUBLES = 64;        // t 27 | pa 18 | epi 6 | nrm 9 | pad
+
+__host__ __device__ inline int gh_wg_lds_doubles(int u, int c, int N) {
+    return gh_lds_doubles(u, c, N) + GH_WG_WAVES * 298 + 16;                 // + per-wave partial sums + reduction slots
+}
+
+struct GhWgArgs {
+    const double* corresp; const double* calm; long calm_stride; long B; int N; int flags;
+    double* rec;             // B x GH_REC_DOUBLES (k_gh_linear out, k_gh_block / k_gh_finish in)
+    double* topt;            // B x 27 (k_gh_block out, k_gh_finish in): optimised tensor in the normalised frame
+    double* Rt2; double* Rt3; double* T; double* reconst; int* iter; int* status; double* dbg;
+};
+
+template <bool JAC>
+__global__ void __launch_bounds__(64, 2) k_gh_linear(const GhWgArgs a) {
+    TFF_DYNAMIC_LDS(double, smem);
+    PoseLds* w = reinterpret_cast<PoseLds*>(smem);
+    constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
+    JacobiLds* jw = JAC ? reinterpret_cast<JacobiLds*>(smem + base) : nullptr;
+    double* lds_pts = smem + base + (JAC ? ((JACOBI_LDS_DOUBLES + 1) & ~1) : 0);
+    const int lane = lane_id();
+    for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
+        if ((a.flags & FLAG_ONLY_RETRY) && a.status[b] != ST_RETRY) continue;
+        const int N = a.N;
+        const double* pts = a.corresp + b * 6 * (long)N;
+        wave_sync();
+        if (a.flags & FLAG_STAGE_LDS) { stage_points(pts, lds_pts, N); pts = lds_pts; }
+        int status = ST_OK;
+        if (N < 7) {
+            status = ST_TOO_FEW;
+        } else {
+            normalise3(pts, N, w->nrm);
+            if (!linear_tft_wave<JAC>(w, jw, pts, N, true, nullptr)) {
+                status = ST_RETRY;
+            } else {
+                double* r = a.rec + b * GH_REC_DOUBLES;
+                if (lane < 27) r[lane] = w->t[lane];
+                if (lane < 18) r[27 + lane] = w->pa[lane];
+                if (lane < 6) r[45 + lane] = w->epi[lane];
+                if (lane < 9) r[51 + lane] = w->nrm[lane];
+            }
+        }
+        if (lane == 0) { a.status[b] = status; if (a.iter) a.iter[b] = 0; }
+    }
+}
+
+// ---- block-level helpers (256 threads) -------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    v = wave_sum(v);
+    if (lane_id() == 0) red[wave_in_block()] = v;
+    __syncthreads();
+    const double r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ double block_max(double v, double* red) {
+    v = wave_max(v);
+    if (lane_id() == 0) red[wave_in_block()] = v;
+    __syncthreads();
+    const double a = (red[0] > red[1]) ? red[0] : red[1], b = (red[2] > red[3]) ? red[2] : red[3];
+    __syncthreads();
+    return (a > b) ? a : b;
+}
+__device__ __forceinline__ bool block_any(bool p, double* red) { return block_sum(p ? 1.0 : 0.0, red) != 0.0; }
+
+// one accumulation sweep over this wavefront's correspondences -> Hp (this wave's 298 partial sums)
+template <int CH>
+__device__ inline void gh_sweep_part(const GhWork& g, double* Hp, int N) {
+    const int lane = lane_id();
+    double acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+#pragma unroll 1
+    for (int i = threadIdx.x; i < N; i += GH_WG_THREADS) {
+        GhPoint pt;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pt.o[k] = g.xi[6 * i + k];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) pt.Wp[k] = g.pp[14 * i + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pt.ww[k] = g.pp[14 * i + 10 + k];
+        if constexpr (CH < 9) {
+            const double hh[6] = {pt.o[0] * pt.o[0], pt.o[0] * pt.o[1], pt.o[0], pt.o[1] * pt.o[1], pt.o[1], 1.0};
+            gh_accum_chunk<CH>(pt, hh, acc);
+        } else {
+            gh_accum_rhs(pt, acc);
+        }
+    }
+    const double tot = wave_reduce_scatter<32>(acc);
+    const int idx = reduce32_index(lane);
+    if ((lane & 1) == 0) {
+        if (CH < 9) { if (idx < 30) Hp[30 * CH + idx] = tot; }
+        else if (idx < 27) Hp[270 + idx] = tot;
+    }
+}
+
+// x_est: reprojection of the projective triangulation with P1 (Pfin[0]), P2 (P[0]), P3 (P[1])   (ResslTFT...m:72-75)
+__device__ inline void gh_block_reproject(PoseLds* w, const double* pts, int N, double* xi) {
+    double PA[12], PB[12], PC[12];
+    load_uniform12(w->Pfin[0], PA);
+    load_uniform12(w->P[0], PB);
+    load_uniform12(w->P[1], PC);
+#pragma unroll 1
+    for (int i = threadIdx.x; i < N; i += GH_WG_THREADS) {
+        const Pt6 p = premap(load_pt(pts, i), w->nrm);
+        double S[4][4], X[4];
+        tri_zero(S);
+        tri_accum(S, PA, p.v[0], p.v[1]);
+        tri_accum(S, PB, p.v[2], p.v[3]);
+        tri_accum(S, PC, p.v[4], p.v[5]);
+        spd_min_eigvec<4>(S, X, 40);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const double (&P)[12] = (v == 0) ? PA : ((v == 1) ? PB : PC);
+            const double aa = P[0] * X[0] + P[1] * X[1] + P[2] * X[2] + P[3] * X[3];
+            const double bb = P[4] * X[0] + P[5] * X[1] + P[6] * X[2] + P[7] * X[3];
+            const double cc = P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11] * X[3];
+            xi[6 * (long)i + 2 * v] = aa / cc;
+            xi[6 * (long)i + 2 * v + 1] = bb / cc;
+        }
+    }
+}
+
+// Gauss_Helmert.m:38-83, one workgroup per problem.  `own`: the wavefront that runs the wave-serial steps.
+template <class Model>
+__device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* Hpart, double* red, Model& model, int own, const double* pts, int N,
+                                          int* st, bool exact_pinv) {
+    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    constexpr int u = Model::U, c = Model::C, n = u + c, ld = n + 1;
+    const bool owner = wave == own;
+    double objFunc = 0.0;                                                    // v0' v0, v0 = x0 - x   (:45-46)
+    for (int i = tid; i < N; i += GH_WG_THREADS) {
+        const Pt6 x = premap(load_pt(pts, i), w->nrm);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { const double d = g.xi[6 * i + k] - x.v[k]; objFunc += d * d; }
+    }
+    objFunc = block_sum(objFunc, red);
+    int it = 0;
+#pragma unroll 1
+    for (it = 1; it <= GH_IT_MAX; ++it) {
+        if (owner) model.eval(g);                                            // func(xi, ti, yi)   (:50): Tc, D, constraint rows
+        __syncthreads();
+        double T[27];
+        load_uniform27(g.Tc, T);
+        // ---- W = B B' (:52): finite check, bound on the largest eigenvalue; see gh_kernel.h for the two pinv paths ----
+        double f2max = 0.0;
+        bool finite = true;
+        for (int i = tid; i < N; i += GH_WG_THREADS) {
+            double o[6], f[4], B[4][6], W[4][4];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+            tril_block(T, o, f, B);
+            block_W(B, W);
+            double chk = 0.0, fro2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { chk += W[a][b]; fro2 += W[a][b] * W[a][b]; }
+            finite = finite && (fabs(chk) <= 1.79e308);
+            f2max = (fro2 > f2max) ? fro2 : f2max;
+        }
+        f2max = block_max(f2max, red);
+        if (block_any(!finite, red) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
+        bool fast = !exact_pinv && 4.0 * (double)N * eps_of(sqrt(f2max)) < 0.9e-12;
+        if (fast) {
+            bool bad = false;
+            for (int i = tid; i < N; i += GH_WG_THREADS) {
+                double o[6], f[4], B[4][6], W[4][4], Wp[10];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                tril_block(T, o, f, B);
+                block_W(B, W);
+                bad = !spd_inverse_packed<4>(W, Wp) || bad;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
+                gh_store_point(g, w, pts, i, o, f, B, Wp);
+            }
+            if (block_any(bad, red)) fast = false;
+        }
+        if (!fast) {
+            double smax = 0.0;
+            for (int i = tid; i < N; i += GH_WG_THREADS) {
+                double o[6], f[4], B[4][6], W[4][4], V[4][4];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                tril_block(T, o, f, B);
+                block_W(B, W);
+                jacobi4<false>(W, V);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+            }
+            smax = block_max(smax, red);
+            const double tolW = 4.0 * (double)N * eps_of(smax);
+            for (int i = tid; i < N; i += GH_WG_THREADS) {
+                double o[6], f[4], B[4][6], W[4][4], V[4][4];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                tril_block(T, o, f, B);
+                block_W(B, W);
+                jacobi4<true>(W, V);
+                double inv[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) inv[a] = (W[a][a] > tolW) ? 1.0 / W[a][a] : 0.0;
+                double Wp[10];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b <= a; ++b)
+                        Wp[a * (a + 1) / 2 + b] = V[a][0] * inv[0] * V[b][0] + V[a][1] * inv[1] * V[b][1] + V[a][2] * inv[2] * V[b][2]
+                                                  + V[a][3] * inv[3] * V[b][3] + ((a == b) ? 1e-12 : 0.0);
+                gh_store_point(g, w, pts, i, o, f, B, Wp);
+            }
+        }
+        // ---- Ghat, ghat: every wavefront sweeps its correspondences (each thread re-reads only what it stored) ----
+        double* Hp = Hpart + 298 * wave;
+        gh_sweep_part<0>(g, Hp, N); gh_sweep_part<1>(g, Hp, N); gh_sweep_part<2>(g, Hp, N); gh_sweep_part<3>(g, Hp, N); gh_sweep_part<4>(g, Hp, N);
+        gh_sweep_part<5>(g, Hp, N); gh_sweep_part<6>(g, Hp, N); gh_sweep_part<7>(g, Hp, N); gh_sweep_part<8>(g, Hp, N); gh_sweep_part<9>(g, Hp, N);
+        __syncthreads();
+        for (int e = tid; e < 297; e += GH_WG_THREADS) g.H[e] = (Hpart[e] + Hpart[298 + e]) + (Hpart[2 * 298 + e] + Hpart[3 * 298 + e]);
+        __syncthreads();
+        for (int e = tid; e < 729; e += GH_WG_THREADS) {                     // Ghat[(q,i1),(q',i1')] = H[6 tri(q,q') + hht(i1,i1')]
+            const int r = e / 27, cc = e % 27;
+            const int q = r % 9, i1 = r / 9, qq = cc % 9, i1p = cc / 9;
+            const int hi = (q > qq) ? q : qq, lo = (q > qq) ? qq : q;
+            g.G[e] = g.H[6 * (hi * (hi + 1) / 2 + lo) + hht_index(i1, i1p)];
+        }
+        __syncthreads();
+        if (Model::IDENTITY_D) {                                             // A = Ap: A'WA = Ghat, A'Ww = ghat
+            for (int e = tid; e < 729 + 27; e += GH_WG_THREADS) {
+                if (e < 729) g.M[(e / 27) * ld + e % 27] = g.G[e] + ((e / 27 == e % 27) ? 1e-12 : 0.0);
+                else g.M[(e - 729) * ld + n] = g.H[270 + e - 729];
+            }
+        } else {
+            for (int e = tid; e < 27 * u; e += GH_WG_THREADS) {              // Y = Ghat D
+                const int r = e / u, pcol = e % u;
+                double acc = 0.0;
+                for (int k = 0; k < 27; ++k) acc += g.G[r * 27 + k] * g.D[k * u + pcol];
+                g.Y[e] = acc;
+            }
+            __syncthreads();
+            for (int e = tid; e < u * u + u; e += GH_WG_THREADS) {           // M = [D'Y + 1e-12 I ...], b = [D' ghat; -g]
+                const int pr = e / u, pc = e % u;
+                double acc = 0.0;
+                if (e < u * u) {
+                    for (int k = 0; k < 27; ++k) acc += g.D[k * u + pr] * g.Y[k * u + pc];
+                    g.M[pr * ld + pc] = acc + ((pr == pc) ? 1e-12 : 0.0);
+                } else {
+                    for (int k = 0; k < 27; ++k) acc += g.D[k * u + pc] * g.H[270 + k];
+                    g.M[pc * ld + n] = acc;
+                }
+            }
+        }
+        if (tid < c) g.M[(u + tid) * ld + u + tid] = 1e-12;
+        __syncthreads();
+        double chkM = 0.0;
+        for (int e = tid; e < n * ld; e += GH_WG_THREADS) chkM += g.M[e];
+        if (!(fabs(block_sum(chkM, red)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
+        // aux = pinv(M + 1e-12 I) * b   (:67), then dT = D dt: wave-serial, on the owner wavefront
+        if (owner) {
+            bool ok = true;
+            if (Model::REDUNDANT_CONSTRAINTS) wave_pinv_solve_sym(g.M, g.V, n, g.dt, g.Y);
+            else ok = wave_solve_gj<n>(g.M, g.dt);
+            wave_sync();
+            if (lane < 27) {
+                double acc = 0.0;
+                if (Model::IDENTITY_D) acc = g.dt[lane];
+                else for (int k = 0; k < u; ++k) acc += g.D[lane * u + k] * g.dt[k];
+                g.dT[lane] = acc;
+            }
+            if (lane == 0) red[8] = ok ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        if (red[8] == 0.0) { *st = ST_RANK; break; }
+        double dTr[27];
+        load_uniform27(g.dT, dTr);
+        // ---- v = -B' W+ (A dt - w)   (:69) ----
+        double obj = 0.0, diff = 0.0;
+        for (int i = tid; i < N; i += GH_WG_THREADS) {
+            double o[6], f[4], B[4][6], Ad[4];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+            tril_block(T, o, f, B);
+            {
+                double m[3][3], t1[3][3], t2[3][3];
+                tril_slices(dTr, o, m, t1, t2);
+                tril_quad(m, o[2], o[3], o[4], o[5], Ad);                    // Ap_i (D dt)
+            }
+            double Wp[10], r[4];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) Wp[k] = g.pp[14 * i + k];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                r[a] = wp_at(Wp, a, 0) * Ad[0] + wp_at(Wp, a, 1) * Ad[1] + wp_at(Wp, a, 2) * Ad[2] + wp_at(Wp, a, 3) * Ad[3] - g.pp[14 * i + 10 + a];
+            const Pt6 x = premap(load_pt(pts, i), w->nrm);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const double v = -(B[0][k] * r[0] + B[1][k] * r[1] + B[2][k] * r[2] + B[3][k] * r[3]);
+                g.pp[14 * i + k] = v;
+                obj += v * v;
+                const double d = o[k] - x.v[k] - v;
+                diff += d * d;
+            }
+        }
+        obj = block_sum(obj, red);
+        diff = block_sum(diff, red);
+        double ndt2 = 0.0;
+        for (int k = 0; k < u; ++k) ndt2 += g.dt[k] * g.dt[k];               // same order on every thread
+        if (sqrt(ndt2) < GH_TOL && sqrt(diff) < GH_TOL) break;               // :71-73 (dy is empty)
+        if (obj > objFunc) break;                                            // :75-76, factor = 1
+        objFunc = obj;                                                       // :78
+        for (int i = tid; i < N; i += GH_WG_THREADS) {                       // xi = x + v; ti = ti + dt   (:80)
+            const Pt6 x = premap(load_pt(pts, i), w->nrm);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) g.xi[6 * i + k] = x.v[k] + g.pp[14 * i + k];
+        }
+        if (tid < u) g.p[tid] += g.dt[tid];
+        __syncthreads();
+    }
+    __syncthreads();
+    return (it > GH_IT_MAX) ? GH_IT_MAX : it;                                // :82
+}
+
+template <class Model>
+__global__ void __launch_bounds__(GH_WG_THREADS, 1) k_gh_block(const GhWgArgs a) {
+    TFF_DYNAMIC_LDS(double, smem);
+    PoseLds* w = reinterpret_cast<PoseLds*>(smem);
+    constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
+    double* ghbase = smem + base;
+    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
+        __syncthreads();
+        if (a.status[b] != ST_OK) continue;                                  // block-uniform (too few points, or left for nobody: see launch)
+        const int N = a.N;
+        const double* pts = a.corresp + b * 6 * (long)N;
+        GhWork g = gh_carve(ghbase, Model::U, Model::C, N);
+        double* Hpart = ghbase + gh_lds_doubles(Model::U, Model::C, N);
+        double* red = Hpart + GH_WG_WAVES * 298;
+        const int own = (int)(b & (GH_WG_WAVES - 1));
+        const double* r = a.rec + b * GH_REC_DOUBLES;
+        if (tid < 27) w->t[tid] = r[tid];
+        if (tid < 18) w->pa[tid] = r[27 + tid];
+        if (tid < 6) w->epi[tid] = r[45 + tid];
+        if (tid < 9) w->nrm[tid] = r[51 + tid];
+        __syncthreads();
+        Model model;
+        if (wave == own) model.init(w, g);                                   // initial parameters; cameras P1, P2, P3 of the linear solution
+        __syncthreads();
+        gh_block_reproject(w, pts, N, g.xi);
+        __syncthreads();
+        int gst = ST_OK;
+        const int iters = gauss_helmert_block<Model>(w, g, Hpart, red, model, own, pts, N, &gst, (a.flags & FLAG_GH_EXACT) != 0);
+        if (wave == own) {
+            model.eval(g);                                                   // T from p_opt   (:87-94)
+            if (lane < 27) a.topt[b * 27 + lane] = g.Tc[lane];
+            if (lane == 0) {
+                if (a.iter) a.iter[b] = iters;
+                int s = gst;
+                if (gh_model_bad(model)) s = ST_RANK;
+                if (s != ST_OK) a.status[b] = -s;                            // negative: reported after k_gh_finish has produced the outputs
+            }
+        }
+    }
+}
+
+// transform_TFT + R_t_from_TFT + Reconst for the optimised tensor   (ResslTFTPoseEstimation.m:96-103)
+__global__ void __launch_bounds__(64, 2) k_gh_finish(const GhWgArgs a) {
+    TFF_DYNAMIC_LDS(double, smem);
+    PoseLds* w = reinterpret_cast<PoseLds*>(smem);
+    const int lane = lane_id();
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const int N = a.N;
+        const double* pts = a.corresp + b * 6 * (long)N;
+        wave_sync();
+        const int s0 = a.status[b];
+        if (s0 > 0) {                                                        // ST_TOO_FEW (or an unresolved retry): no outputs
+            if (lane < 12) { a.Rt2[b * 12 + lane] = qnan; a.Rt3[b * 12 + lane] = qnan; }
+            if (lane < 27) a.T[b * 27 + lane] = qnan;
+            if (a.reconst) for (int i = lane; i < 3 * N; i += WAVE) a.reconst[b * 3 * (long)N + i] = qnan;
+            continue;
+        }
+        if (lane < 27) { w->calm[lane] = a.calm[b * a.calm_stride + lane]; w->t[lane] = a.topt[b * 27 + lane]; }
+        if (lane < 9) w->nrm[lane] = a.rec[b * GH_REC_DOUBLES + 51 + lane];
+        wave_sync();
+        transform_tft_inverse(w->t, w->T1, w->Lp, [w](int v) { return normal_matrix(w->nrm, v); });
+        int status = rt_from_tft_wave(w, pts, N, nullptr);
+        if (s0 < 0) status = -s0;
+        write_poses(w, a.Rt2 + b * 12, a.Rt3 + b * 12);
+        if (lane < 27) a.T[b * 27 + lane] = w->T1[lane];
+        if (a.reconst) final_reconst(w, pts, N, a.reconst + b * 3 * (long)N);
+        double chk = (lane < 12) ? w->Rt[0][lane] : ((lane < 24) ? w->Rt[1][lane - 12] : ((lane < 51) ? w->T1[lane - 24] : 0.0));
+        const bool bad = !(fabs(chk) <= 1.79e308);
+        if (wave_any(bad) && status == ST_OK) status = ST_NONFINITE;
+        if (lane == 0) a.status[b] = status;
+    }
+}
+
+}  // namespace tff

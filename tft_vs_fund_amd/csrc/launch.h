@@ -5,6 +5,7 @@
 #include "gh_kernel.h"
 #include "blocks_kernel.h"
 #include "pi_kernel.h"
+#include "gh_wg_kernel.h"
 
 namespace tff {
 

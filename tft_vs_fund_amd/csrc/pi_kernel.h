@@ -598,7 +598,7 @@ __device__ __forceinline__ void pi_store_point(const PiWork& g, const PoseLds* w
 
 // Gauss_Helmert.m:38-83 for a Pi model.  xi holds x0 on entry.  Returns iterations; status via *st.
 template <class Model>
-__device__ inline int gauss_helmert_pi_wave(PoseLds* w, PiWork& g, const double* pts, int N, int* st, double* dbg) {
+__device__ inline int gauss_helmert_pi_wave(PoseLds* w, PiWork& g, const double* pts, int N, int* st, double* dbg, bool exact_pinv) {
     constexpr int E = Model::E, C = Model::C, u = 27, n = u + C, ld = n + 1, PP = pi_pp(E), NW = E * (E + 1) / 2;
     const int lane = lane_id();
     double objFunc = 0.0;                                                    // v0' v0, v0 = x0 - x   (:45-46)
@@ -634,7 +634,7 @@ __device__ inline int gauss_helmert_pi_wave(PoseLds* w, PiWork& g, const double*
         }
         f2max = wave_max(f2max);
         if (wave_any(!finite) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
-        bool fast = (double)E * (double)N * eps_of(sqrt(f2max)) < 0.9e-12;
+        bool fast = !exact_pinv && (double)E * (double)N * eps_of(sqrt(f2max)) < 0.9e-12;
         if (fast) {
             bool bad = false;
             for (int i = lane; i < N; i += WAVE) {
@@ -835,7 +835,7 @@ __global__ void __launch_bounds__(64, 1) k_pi_tft_pose(const LinearTftArgs a) {
                         if (lane < 27) a.init_p[b * 27 + lane] = g.p[lane];
                         for (int e = lane; e < 6 * N; e += WAVE) a.init_x[b * 6 * (long)N + e] = g.xi[e];
                     }
-                    iters = gauss_helmert_pi_wave<Model>(w, g, pts, N, &gst, dbg);  // :90
+                    iters = gauss_helmert_pi_wave<Model>(w, g, pts, N, &gst, dbg, (a.flags & FLAG_GH_EXACT) != 0);  // :90
                     wave_sync();
                     if (lane == 0) Model::cameras(g.p, w);                   // :94-100
                     wave_sync();
