@@ -75,7 +75,7 @@ static int emu_gh_wg_impl(const double* corresp, const double* calm, long calm_s
     tff::GhWgArgs m = a;
     m.flags |= tff::FLAG_ONLY_RETRY;
     emu::launch(tff::k_gh_linear<true>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
-    const size_t lds = (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, N)) * sizeof(double);
+    const size_t lds = (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, N, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double);
     emu::launch(tff::k_gh_block<Model>, tff::pose_grid(B), tff::GH_WG_THREADS, lds, a);
     emu::launch(tff::k_gh_finish, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
     return 0;

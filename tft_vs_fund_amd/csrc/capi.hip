@@ -174,7 +174,7 @@ int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_
 template <class Model, class KFused, class KFusedJac>
 int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    if (c->kernel_variant != 0 || dbg || c->solver != 0)
+    if (c->kernel_variant != 0 || c->solver != 0)
         return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     if (B == 0) return 0;
@@ -187,7 +187,7 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
     if (int r = c->gh_rec.reserve((size_t)B * tff::GH_REC_DOUBLES * sizeof(double))) return r;
     if (int r = c->gh_topt.reserve((size_t)B * 27 * sizeof(double))) return r;
     tff::GhWgArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr), (double*)c->gh_rec.p, (double*)c->gh_topt.p,
-                    Rt2, Rt3, T, reconst, iter, status, nullptr};
+                    Rt2, Rt3, T, reconst, iter, status, dbg};
     {   // linear stage + Jacobi fix-up over the triplets it marked ST_RETRY
         tff::GhWgArgs m = a;
         m.flags = staged_flags(c, N, a.flags, false);
@@ -202,7 +202,7 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
         TFF_HIP(hipGetLastError());
     }
     {
-        const size_t lds = (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, N)) * sizeof(double);
+        const size_t lds = (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, N, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double);
         if (int r = ensure_lds(tff::k_gh_block<Model>, lds)) return r;
         hipLaunchKernelGGL(tff::k_gh_block<Model>, dim3(tff::pose_grid(B)), dim3(tff::GH_WG_THREADS), lds, c->stream, a);
         TFF_HIP(hipGetLastError());
@@ -380,6 +380,11 @@ int tff_nordberg_tft_pose_batch_dev(tff_ctx* c, const double* corresp, const dou
                                      int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
                                      int32_t* status) {
     return launch_nordberg_tft(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, nullptr);
+}
+int tff_nordberg_tft_pose_batch_debug_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                                           int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                                           int32_t* status, double* dbg) {
+    return launch_nordberg_tft(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 int tff_nordberg_tft_pose_batch_host(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
                                       int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,

@@ -26,8 +26,45 @@ constexpr int GH_WG_WAVES = 4;
 constexpr int GH_WG_THREADS = 64 * GH_WG_WAVES;
 constexpr int GH_REC_DOUBLES = 64;        // t 27 | pa 18 | epi 6 | nrm 9 | pad
 
-__host__ __device__ inline int gh_wg_lds_doubles(int u, int c, int N) {
-    return gh_lds_doubles(u, c, N) + GH_WG_WAVES * 298 + 16;                 // + per-wave partial sums + reduction slots
+// LDS of k_gh_block after the PoseLds header: p, dt, Tc, dT, D, H, Y, M, V (n^2 + n for the pseudo-inverse models, else 112), xi (6N), W+ (10N),
+// reduction slots.  Ghat (729) lives in PoseLds::Lp (the linear stage's Cholesky factor is not needed here); the per-wavefront
+// partial sums of the sweeps live in Lp[0..595] (waves 0, 1), Y (wave 2) and H itself (wave 3), all dead at that point; W+ w is
+// recomputed where needed.  Ressl at N = 200: 50.4 KB with the header -> three workgroups per CU.
+__host__ __device__ inline int gh_wg_lds_doubles(int u, int c, int N, bool pinv) {
+    const int n = u + c;
+    return 2 * ((u + 1) & ~1) + 2 * c + 28 + 28 + 27 * u + 298 + ((27 * u > 298) ? 27 * u : 298) + n * (n + 1) + (pinv ? n * n + n : 112) + 6 * N + 10 * N + 16 + 8;
+}
+__device__ inline GhWork gh_wg_carve(double* base, PoseLds* w, int u, int c, int N, bool pinv, double** red) {
+    GhWork g;
+    const int n = u + c;
+    double* q = base;
+    g.p = q; q += (u + 1) & ~1;
+    g.dt = q; q += ((u + 1) & ~1) + 2 * c;
+    g.Tc = q; q += 28;
+    g.dT = q; q += 28;
+    g.D = q; q += 27 * u;
+    g.G = w->Lp;
+    g.H = q; q += 298;
+    g.Y = q; q += (27 * u > 298) ? 27 * u : 298;
+    g.M = q; q += n * (n + 1);
+    g.V = q; q += pinv ? n * n + n : 112;                                  // other models: 108 doubles of scratch (Nordberg's rotations)
+    g.xi = q; q += 6 * N;
+    g.pp = q; q += 10 * N;
+    *red = q;
+    g.u = u; g.c = c;
+    return g;
+}
+// w = -f - B (x - xi)   (Gauss_Helmert.m:58)
+__device__ __forceinline__ void gh_w_vector(const PoseLds* w, const double* pts, int i, const double (&o)[6], const double (&f)[4],
+                                            const double (&B)[4][6], double (&wv)[4]) {
+    const Pt6 x = premap(load_pt(pts, i), w->nrm);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        double s = -f[a];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s -= B[a][k] * (x.v[k] - o[k]);
+        wv[a] = s;
+    }
 }
 
 struct GhWgArgs {
@@ -91,7 +128,7 @@ __device__ __forceinline__ bool block_any(bool p, double* red) { return block_su
 
 // one accumulation sweep over this wavefront's correspondences -> Hp (this wave's 298 partial sums)
 template <int CH>
-__device__ inline void gh_sweep_part(const GhWork& g, double* Hp, int N) {
+__device__ inline void gh_sweep_part(const GhWork& g, double* Hp, int N, const double (&T)[27], const PoseLds* w, const double* pts) {
     const int lane = lane_id();
     double acc[32];
 #pragma unroll
@@ -102,9 +139,15 @@ __device__ inline void gh_sweep_part(const GhWork& g, double* Hp, int N) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) pt.o[k] = g.xi[6 * i + k];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) pt.Wp[k] = g.pp[14 * i + k];
+        for (int k = 0; k < 10; ++k) pt.Wp[k] = g.pp[10 * i + k];
+        if constexpr (CH == 9) {                                             // W+ w is not stored: recompute w from the observations
+            double f[4], B[4][6], wv[4];
+            tril_block(T, pt.o, f, B);
+            gh_w_vector(w, pts, i, pt.o, f, B, wv);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pt.ww[k] = g.pp[14 * i + 10 + k];
+            for (int a = 0; a < 4; ++a)
+                pt.ww[a] = wp_at(pt.Wp, a, 0) * wv[0] + wp_at(pt.Wp, a, 1) * wv[1] + wp_at(pt.Wp, a, 2) * wv[2] + wp_at(pt.Wp, a, 3) * wv[3];
+        }
         if constexpr (CH < 9) {
             const double hh[6] = {pt.o[0] * pt.o[0], pt.o[0] * pt.o[1], pt.o[0], pt.o[1] * pt.o[1], pt.o[1], 1.0};
             gh_accum_chunk<CH>(pt, hh, acc);
@@ -149,11 +192,12 @@ __device__ inline void gh_block_reproject(PoseLds* w, const double* pts, int N, 
 
 // Gauss_Helmert.m:38-83, one workgroup per problem.  `own`: the wavefront that runs the wave-serial steps.
 template <class Model>
-__device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* Hpart, double* red, Model& model, int own, const double* pts, int N,
-                                          int* st, bool exact_pinv) {
+__device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Model& model, int own, const double* pts, int N,
+                                          int* st, bool exact_pinv, double* dbg) {
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
     constexpr int u = Model::U, c = Model::C, n = u + c, ld = n + 1;
     const bool owner = wave == own;
+    double* sdbg = owner ? dbg : nullptr;                                    // phase stamps of the first iteration (debug entry point)
     double objFunc = 0.0;                                                    // v0' v0, v0 = x0 - x   (:45-46)
     for (int i = tid; i < N; i += GH_WG_THREADS) {
         const Pt6 x = premap(load_pt(pts, i), w->nrm);
@@ -164,8 +208,10 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* Hpart, 
     int it = 0;
 #pragma unroll 1
     for (it = 1; it <= GH_IT_MAX; ++it) {
+        if (it == 1) phase_stamp(sdbg, 40);
         if (owner) model.eval(g);                                            // func(xi, ti, yi)   (:50): Tc, D, constraint rows
         __syncthreads();
+        if (it == 1) phase_stamp(sdbg, 41);
         double T[27];
         load_uniform27(g.Tc, T);
         // ---- W = B B' (:52): finite check, bound on the largest eigenvalue; see gh_kernel.h for the two pinv paths ----
@@ -188,6 +234,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* Hpart, 
         f2max = block_max(f2max, red);
         if (block_any(!finite, red) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
         bool fast = !exact_pinv && 4.0 * (double)N * eps_of(sqrt(f2max)) < 0.9e-12;
+        if (it == 1) phase_stamp(sdbg, 42);
         if (fast) {
             bool bad = false;
             for (int i = tid; i < N; i += GH_WG_THREADS) {
@@ -199,7 +246,8 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* Hpart, 
                 bad = !spd_inverse_packed<4>(W, Wp) || bad;
 #pragma unroll
                 for (int a = 0; a < 4; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
-                gh_store_point(g, w, pts, i, o, f, B, Wp);
+#pragma unroll
+                for (int k = 0; k < 10; ++k) g.pp[10 * i + k] = Wp[k];
             }
             if (block_any(bad, red)) fast = false;
         }
@@ -234,15 +282,31 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* Hpart, 
                     for (int b = 0; b <= a; ++b)
                         Wp[a * (a + 1) / 2 + b] = V[a][0] * inv[0] * V[b][0] + V[a][1] * inv[1] * V[b][1] + V[a][2] * inv[2] * V[b][2]
                                                   + V[a][3] * inv[3] * V[b][3] + ((a == b) ? 1e-12 : 0.0);
-                gh_store_point(g, w, pts, i, o, f, B, Wp);
+#pragma unroll
+                for (int k = 0; k < 10; ++k) g.pp[10 * i + k] = Wp[k];
             }
         }
+        if (it == 1) phase_stamp(sdbg, 43);
         // ---- Ghat, ghat: every wavefront sweeps its correspondences (each thread re-reads only what it stored) ----
-        double* Hp = Hpart + 298 * wave;
-        gh_sweep_part<0>(g, Hp, N); gh_sweep_part<1>(g, Hp, N); gh_sweep_part<2>(g, Hp, N); gh_sweep_part<3>(g, Hp, N); gh_sweep_part<4>(g, Hp, N);
-        gh_sweep_part<5>(g, Hp, N); gh_sweep_part<6>(g, Hp, N); gh_sweep_part<7>(g, Hp, N); gh_sweep_part<8>(g, Hp, N); gh_sweep_part<9>(g, Hp, N);
+        double* Hp = (wave == 0) ? w->Lp : ((wave == 1) ? w->Lp + 298 : ((wave == 2) ? g.Y : g.H));   // dead storage, see gh_wg_lds_doubles
+        gh_sweep_part<0>(g, Hp, N, T, w, pts); gh_sweep_part<1>(g, Hp, N, T, w, pts); gh_sweep_part<2>(g, Hp, N, T, w, pts);
+        gh_sweep_part<3>(g, Hp, N, T, w, pts); gh_sweep_part<4>(g, Hp, N, T, w, pts); gh_sweep_part<5>(g, Hp, N, T, w, pts);
+        gh_sweep_part<6>(g, Hp, N, T, w, pts); gh_sweep_part<7>(g, Hp, N, T, w, pts); gh_sweep_part<8>(g, Hp, N, T, w, pts);
+        gh_sweep_part<9>(g, Hp, N, T, w, pts);
         __syncthreads();
-        for (int e = tid; e < 297; e += GH_WG_THREADS) g.H[e] = (Hpart[e] + Hpart[298 + e]) + (Hpart[2 * 298 + e] + Hpart[3 * 298 + e]);
+        if (it == 1) phase_stamp(sdbg, 44);
+        double hsum[2] = {0.0, 0.0};                                         // 297 sums over 256 threads; H is also wave 3's partial
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + k * GH_WG_THREADS;
+            if (e < 297) hsum[k] = (w->Lp[e] + w->Lp[298 + e]) + (g.Y[e] + g.H[e]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + k * GH_WG_THREADS;
+            if (e < 297) g.H[e] = hsum[k];
+        }
         __syncthreads();
         for (int e = tid; e < 729; e += GH_WG_THREADS) {                     // Ghat[(q,i1),(q',i1')] = H[6 tri(q,q') + hht(i1,i1')]
             const int r = e / 27, cc = e % 27;
@@ -281,10 +345,11 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* Hpart, 
         double chkM = 0.0;
         for (int e = tid; e < n * ld; e += GH_WG_THREADS) chkM += g.M[e];
         if (!(fabs(block_sum(chkM, red)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
+        if (it == 1) phase_stamp(sdbg, 45);
         // aux = pinv(M + 1e-12 I) * b   (:67), then dT = D dt: wave-serial, on the owner wavefront
         if (owner) {
             bool ok = true;
-            if (Model::REDUNDANT_CONSTRAINTS) wave_pinv_solve_sym(g.M, g.V, n, g.dt, g.Y);
+            if (Model::REDUNDANT_CONSTRAINTS) wave_pinv_solve_sym(g.M, g.V, n, g.dt, g.V + n * n);
             else ok = wave_solve_gj<n>(g.M, g.dt);
             wave_sync();
             if (lane < 27) {
@@ -299,6 +364,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* Hpart, 
         if (red[8] == 0.0) { *st = ST_RANK; break; }
         double dTr[27];
         load_uniform27(g.dT, dTr);
+        if (it == 1) phase_stamp(sdbg, 46);
         // ---- v = -B' W+ (A dt - w)   (:69) ----
         double obj = 0.0, diff = 0.0;
         for (int i = tid; i < N; i += GH_WG_THREADS) {
@@ -311,17 +377,24 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* Hpart, 
                 tril_slices(dTr, o, m, t1, t2);
                 tril_quad(m, o[2], o[3], o[4], o[5], Ad);                    // Ap_i (D dt)
             }
-            double Wp[10], r[4];
+            double Wp[10], r[4], wv[4];
 #pragma unroll
-            for (int k = 0; k < 10; ++k) Wp[k] = g.pp[14 * i + k];
+            for (int k = 0; k < 10; ++k) Wp[k] = g.pp[10 * i + k];
+            const Pt6 x = premap(load_pt(pts, i), w->nrm);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                double sw = -f[a];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sw -= B[a][k] * (x.v[k] - o[k]);
+                wv[a] = Ad[a] - sw;                                          // A dt - w
+            }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
-                r[a] = wp_at(Wp, a, 0) * Ad[0] + wp_at(Wp, a, 1) * Ad[1] + wp_at(Wp, a, 2) * Ad[2] + wp_at(Wp, a, 3) * Ad[3] - g.pp[14 * i + 10 + a];
-            const Pt6 x = premap(load_pt(pts, i), w->nrm);
+                r[a] = wp_at(Wp, a, 0) * wv[0] + wp_at(Wp, a, 1) * wv[1] + wp_at(Wp, a, 2) * wv[2] + wp_at(Wp, a, 3) * wv[3];
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 const double v = -(B[0][k] * r[0] + B[1][k] * r[1] + B[2][k] * r[2] + B[3][k] * r[3]);
-                g.pp[14 * i + k] = v;
+                g.pp[10 * i + k] = v;
                 obj += v * v;
                 const double d = o[k] - x.v[k] - v;
                 diff += d * d;
@@ -329,6 +402,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* Hpart, 
         }
         obj = block_sum(obj, red);
         diff = block_sum(diff, red);
+        if (it == 1) phase_stamp(sdbg, 47);
         double ndt2 = 0.0;
         for (int k = 0; k < u; ++k) ndt2 += g.dt[k] * g.dt[k];               // same order on every thread
         if (sqrt(ndt2) < GH_TOL && sqrt(diff) < GH_TOL) break;               // :71-73 (dy is empty)
@@ -337,7 +411,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* Hpart, 
         for (int i = tid; i < N; i += GH_WG_THREADS) {                       // xi = x + v; ti = ti + dt   (:80)
             const Pt6 x = premap(load_pt(pts, i), w->nrm);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) g.xi[6 * i + k] = x.v[k] + g.pp[14 * i + k];
+            for (int k = 0; k < 6; ++k) g.xi[6 * i + k] = x.v[k] + g.pp[10 * i + k];
         }
         if (tid < u) g.p[tid] += g.dt[tid];
         __syncthreads();
@@ -347,7 +421,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* Hpart, 
 }
 
 template <class Model>
-__global__ void __launch_bounds__(GH_WG_THREADS, 1) k_gh_block(const GhWgArgs a) {
+__global__ void __launch_bounds__(GH_WG_THREADS, 2) k_gh_block(const GhWgArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
     PoseLds* w = reinterpret_cast<PoseLds*>(smem);
     constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
@@ -358,9 +432,8 @@ __global__ void __launch_bounds__(GH_WG_THREADS, 1) k_gh_block(const GhWgArgs a)
         if (a.status[b] != ST_OK) continue;                                  // block-uniform (too few points, or left for nobody: see launch)
         const int N = a.N;
         const double* pts = a.corresp + b * 6 * (long)N;
-        GhWork g = gh_carve(ghbase, Model::U, Model::C, N);
-        double* Hpart = ghbase + gh_lds_doubles(Model::U, Model::C, N);
-        double* red = Hpart + GH_WG_WAVES * 298;
+        double* red;
+        GhWork g = gh_wg_carve(ghbase, w, Model::U, Model::C, N, Model::REDUNDANT_CONSTRAINTS, &red);
         const int own = (int)(b & (GH_WG_WAVES - 1));
         const double* r = a.rec + b * GH_REC_DOUBLES;
         if (tid < 27) w->t[tid] = r[tid];
@@ -369,12 +442,18 @@ __global__ void __launch_bounds__(GH_WG_THREADS, 1) k_gh_block(const GhWgArgs a)
         if (tid < 9) w->nrm[tid] = r[51 + tid];
         __syncthreads();
         Model model;
+        double* sdbg = (a.dbg && wave == own) ? a.dbg + b * DBG_STRIDE : nullptr;
+        phase_stamp(sdbg, 36);
         if (wave == own) model.init(w, g);                                   // initial parameters; cameras P1, P2, P3 of the linear solution
         __syncthreads();
+        phase_stamp(sdbg, 37);
         gh_block_reproject(w, pts, N, g.xi);
         __syncthreads();
+        phase_stamp(sdbg, 38);
         int gst = ST_OK;
-        const int iters = gauss_helmert_block<Model>(w, g, Hpart, red, model, own, pts, N, &gst, (a.flags & FLAG_GH_EXACT) != 0);
+        const int iters = gauss_helmert_block<Model>(w, g, red, model, own, pts, N, &gst, (a.flags & FLAG_GH_EXACT) != 0,
+                                                       a.dbg ? a.dbg + b * DBG_STRIDE : nullptr);
+        phase_stamp(sdbg, 39);
         if (wave == own) {
             model.eval(g);                                                   // T from p_opt   (:87-94)
             if (lane < 27) a.topt[b * 27 + lane] = g.Tc[lane];

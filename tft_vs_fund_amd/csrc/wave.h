@@ -191,56 +191,61 @@ template <> struct Group<32> {
 };
 
 // Reduce K (= 32) per-lane values over the 64 lanes with a halving
-// ("transposing") butterfly: K-1+1 shuffles instead of 6K.  On return lane l
+// ("transposing") butterfly: K-1+1 exchanges instead of 6K.  On return lane l
 // holds the full 64-lane sum of value index  reduce32_index(l).
+#ifdef TFF_CPU_EMU
+__device__ inline double xchg_sum(double lo_val, double hi_val, int mask) {   // lane keeps one, sends the other to lane ^ mask
+    const bool up = (lane_id() & mask) != 0;
+    const double keep = up ? hi_val : lo_val, send = up ? lo_val : hi_val;
+    return keep + wave_shfl_xor(send, mask);
+}
+template <int MASK> __device__ inline double halve_sum(double a, double b) { return xchg_sum(a, b, MASK); }
+#else
+// v_permlane32_swap / v_permlane16_swap (gfx950) do the keep/send exchange of one halving step in place:
+// swap(a, b) -> r0 = {a on the lower half-blocks, b's lower half-blocks moved up}, r1 = {a's upper half-blocks moved
+// down, b on the upper half-blocks}; r0 + r1 is a[l] + a[l ^ mask] where bit `mask` of l is clear and
+// b[l] + b[l ^ mask] where it is set.  No select, no LDS crossbar.
+template <int MASK>
+__device__ __forceinline__ double halve_sum(double a, double b) {
+    const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    if constexpr (MASK == 32) {
+        const auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    } else if constexpr (MASK == 16) {
+        const auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    } else {
+        const bool up = (lane_id() & MASK) != 0;
+        const double keep = up ? b : a, send = up ? a : b;
+        double got;
+        if constexpr (MASK == 8) got = dpp_mov<0x128>(send);                 // row_ror:8 = lane ^ 8 inside a row of 16
+        else if constexpr (MASK == 4) { const double dn = dpp_mov<0x114>(send), upv = dpp_mov<0x104>(send); got = up ? dn : upv; }   // row_shr:4 / row_shl:4
+        else if constexpr (MASK == 2) got = dpp_mov<0x4E>(send);             // quad_perm [2,3,0,1]
+        else got = dpp_mov<0xB1>(send);                                      // quad_perm [1,0,3,2]
+        return keep + got;
+    }
+}
+#endif
 template <int K>
 __device__ __forceinline__ double wave_reduce_scatter(double (&v)[K]) {
     static_assert(K == 32, "tuned for 32 values on a 64-lane wave");
-    const int lane = lane_id();
-    // stage xor 32: 32 -> 16 values
-    {
-        const bool up = (lane & 32) != 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            double keep = up ? v[i + 16] : v[i];
-            double send = up ? v[i] : v[i + 16];
-            v[i] = keep + wave_shfl_xor(send, 32);
-        }
-    }
-    {
-        const bool up = (lane & 16) != 0;
+    for (int i = 0; i < 16; ++i) v[i] = halve_sum<32>(v[i], v[i + 16]);      // 32 -> 16 values
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            double keep = up ? v[i + 8] : v[i];
-            double send = up ? v[i] : v[i + 8];
-            v[i] = keep + wave_shfl_xor(send, 16);
-        }
-    }
-    {
-        const bool up = (lane & 8) != 0;
+    for (int i = 0; i < 8; ++i) v[i] = halve_sum<16>(v[i], v[i + 8]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            double keep = up ? v[i + 4] : v[i];
-            double send = up ? v[i] : v[i + 4];
-            v[i] = keep + wave_shfl_xor(send, 8);
-        }
-    }
-    {
-        const bool up = (lane & 4) != 0;
+    for (int i = 0; i < 4; ++i) v[i] = halve_sum<8>(v[i], v[i + 4]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            double keep = up ? v[i + 2] : v[i];
-            double send = up ? v[i] : v[i + 2];
-            v[i] = keep + wave_shfl_xor(send, 4);
-        }
-    }
-    {
-        const bool up = (lane & 2) != 0;
-        double keep = up ? v[1] : v[0];
-        double send = up ? v[0] : v[1];
-        v[0] = keep + wave_shfl_xor(send, 2);
-    }
+    for (int i = 0; i < 2; ++i) v[i] = halve_sum<4>(v[i], v[i + 2]);
+    v[0] = halve_sum<2>(v[0], v[1]);
+#ifdef TFF_CPU_EMU
     v[0] += wave_shfl_xor(v[0], 1);
+#else
+    v[0] += dpp_mov<0xB1>(v[0]);
+#endif
     return v[0];
 }
 // value index owned by `lane` after wave_reduce_scatter<32>
