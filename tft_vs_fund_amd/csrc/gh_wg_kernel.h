@@ -421,7 +421,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
 }
 
 template <class Model>
-__global__ void __launch_bounds__(GH_WG_THREADS, 2) k_gh_block(const GhWgArgs a) {
+__global__ void __launch_bounds__(GH_WG_THREADS, 3) k_gh_block(const GhWgArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
     PoseLds* w = reinterpret_cast<PoseLds*>(smem);
     constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
