@@ -26,13 +26,13 @@ constexpr int GH_WG_WAVES = 4;
 constexpr int GH_WG_THREADS = 64 * GH_WG_WAVES;
 constexpr int GH_REC_DOUBLES = 64;        // t 27 | pa 18 | epi 6 | nrm 9 | pad
 
-// LDS of k_gh_block after the PoseLds header: p, dt, Tc, dT, D, H, Y, M, V (n^2 + n for the pseudo-inverse models, else 112), xi (6N), W+ (10N),
+// LDS of k_gh_block after the PoseLds header: p, dt, Tc, dT, D, H, Y, M, V (n^2 + 4n + 8 for the pseudo-inverse models: eigenvectors + the pair table of block_jacobi_sym, else 112), xi (6N), W+ (10N),
 // reduction slots.  Ghat (729) lives in PoseLds::Lp (the linear stage's Cholesky factor is not needed here); the per-wavefront
 // partial sums of the sweeps live in Lp[0..595] (waves 0, 1), Y (wave 2) and H itself (wave 3), all dead at that point; W+ w is
 // recomputed where needed.  Ressl at N = 200: 50.4 KB with the header -> three workgroups per CU.
 __host__ __device__ inline int gh_wg_lds_doubles(int u, int c, int N, bool pinv) {
     const int n = u + c;
-    return 2 * ((u + 1) & ~1) + 2 * c + 28 + 28 + 27 * u + 298 + ((27 * u > 298) ? 27 * u : 298) + n * (n + 1) + (pinv ? n * n + n : 112) + 6 * N + 10 * N + 16 + 8;
+    return 2 * ((u + 1) & ~1) + 2 * c + 28 + 28 + 27 * u + 298 + ((27 * u > 298) ? 27 * u : 298) + n * (n + 1) + (pinv ? n * n + 4 * n + 8 : 112) + 6 * N + 10 * N + 16 + 8;
 }
 __device__ inline GhWork gh_wg_carve(double* base, PoseLds* w, int u, int c, int N, bool pinv, double** red) {
     GhWork g;
@@ -47,7 +47,7 @@ __device__ inline GhWork gh_wg_carve(double* base, PoseLds* w, int u, int c, int
     g.H = q; q += 298;
     g.Y = q; q += (27 * u > 298) ? 27 * u : 298;
     g.M = q; q += n * (n + 1);
-    g.V = q; q += pinv ? n * n + n : 112;                                  // other models: 108 doubles of scratch (Nordberg's rotations)
+    g.V = q; q += pinv ? n * n + 4 * n + 8 : 112;                                  // other models: 108 doubles of scratch (Nordberg's rotations)
     g.xi = q; q += 6 * N;
     g.pp = q; q += 10 * N;
     *red = q;
@@ -125,6 +125,105 @@ __device__ __forceinline__ double block_max(double v, double* red) {
     return (a > b) ? a : b;
 }
 __device__ __forceinline__ bool block_any(bool p, double* red) { return block_sum(p ? 1.0 : 0.0, red) != 0.0; }
+
+// Jacobi eigen-decomposition of the symmetric n x n matrix A (LDS, leading dimension lda; diagonal -> eigenvalues, V -> eigenvectors)
+// by the whole workgroup: round-robin (tournament) ordering, m/2 disjoint rotations per round (m = n rounded up to even), each round
+//   (a) one thread per pair computes (c, s) with the thresholds of wave_jacobi_sym,
+//   (b) column phase: A <- A J, V <- V J   (pairs x rows work items),
+//   (c) row phase:    A <- J' A            (pairs x columns work items).
+// `cs`: 4 * (m/2) doubles of LDS scratch (p, q, c, s per pair), then one slot for the rotation counter.
+__device__ inline int block_jacobi_sym(double* A, const int lda, double* V, const int ldv, const int n, double* cs) {
+    const int tid = threadIdx.x;
+    const int m = (n + 1) & ~1, half = m / 2;
+    for (int e = tid; e < n * n; e += GH_WG_THREADS) V[(e / n) * ldv + e % n] = (e / n == e % n) ? 1.0 : 0.0;
+    double tr = 0.0;
+    for (int k = 0; k < n; ++k) tr += fabs(A[k * lda + k]);                  // same on every thread
+    const double absfloor = 1e-22 * tr + 1e-300;
+    double* counter = cs + 4 * half;
+    __syncthreads();
+    int sweep = 0;
+#pragma unroll 1
+    for (; sweep < 40; ++sweep) {
+        if (tid == 0) *counter = 0.0;
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < m - 1; ++r) {
+            if (tid < half) {                                                // (a) the pair of this thread in round r
+                int p, q;
+                if (tid == 0) { p = m - 1; q = r; }
+                else { p = (r + tid) % (m - 1); q = (r - tid + (m - 1)) % (m - 1); }
+                if (p > q) { const int t = p; p = q; q = t; }
+                double c = 1.0, s = 0.0;
+                if (q < n) {                                                 // q == n: the phantom index of an odd n
+                    const double apq = A[p * lda + q], app = A[p * lda + p], aqq = A[q * lda + q];
+                    if (fabs(apq) > 1.1e-16 * sqrt(fabs(app * aqq)) && fabs(apq) > absfloor) {
+                        const double tau = (aqq - app) / (2.0 * apq);
+                        const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c = rsqrt(1.0 + t * t); s = t * c;
+                        *counter = 1.0;                                      // benign race: every writer stores the same value
+                    }
+                }
+                cs[4 * tid] = (double)p; cs[4 * tid + 1] = (double)q; cs[4 * tid + 2] = c; cs[4 * tid + 3] = s;
+            }
+            __syncthreads();
+            for (int e = tid; e < half * n; e += GH_WG_THREADS) {            // (b) columns p, q of A and V, row `row`
+                const int pr = e / n, row = e % n;
+                const double s = cs[4 * pr + 3];
+                if (s != 0.0) {
+                    const int p = (int)cs[4 * pr], q = (int)cs[4 * pr + 1];
+                    const double c = cs[4 * pr + 2];
+                    const double arp = A[row * lda + p], arq = A[row * lda + q];
+                    A[row * lda + p] = c * arp - s * arq;
+                    A[row * lda + q] = s * arp + c * arq;
+                    const double vrp = V[row * ldv + p], vrq = V[row * ldv + q];
+                    V[row * ldv + p] = c * vrp - s * vrq;
+                    V[row * ldv + q] = s * vrp + c * vrq;
+                }
+            }
+            __syncthreads();
+            for (int e = tid; e < half * n; e += GH_WG_THREADS) {            // (c) rows p, q of A, column `col`
+                const int pr = e / n, col = e % n;
+                const double s = cs[4 * pr + 3];
+                if (s != 0.0) {
+                    const int p = (int)cs[4 * pr], q = (int)cs[4 * pr + 1];
+                    const double c = cs[4 * pr + 2];
+                    const double apc = A[p * lda + col], aqc = A[q * lda + col];
+                    A[p * lda + col] = c * apc - s * aqc;
+                    A[q * lda + col] = s * apc + c * aqc;
+                }
+            }
+            __syncthreads();
+        }
+        if (*counter == 0.0) break;
+        __syncthreads();
+    }
+    return sweep;
+}
+
+// x = pinv(M) b through the eigen-decomposition (see wave_pinv_solve_sym), by the whole workgroup.
+// scratch: n coefficients, then the pair table of block_jacobi_sym.
+__device__ inline void block_pinv_solve_sym(double* M, double* V, int n, double* sol, double* scratch) {
+    const int tid = threadIdx.x;
+    const int ld = n + 1;
+    block_jacobi_sym(M, ld, V, n, n, scratch + ((n + 1) & ~1));
+    __syncthreads();
+    double amax = 0.0;
+    for (int k = 0; k < n; ++k) { const double l = fabs(M[k * ld + k]); amax = (l > amax) ? l : amax; }
+    const double tol = (double)n * eps_of(amax);
+    if (tid < n) {
+        const double lam = M[tid * ld + tid];
+        double d = 0.0;
+        for (int r = 0; r < n; ++r) d += V[r * n + tid] * M[r * ld + n];
+        scratch[tid] = (fabs(lam) > tol) ? d / lam : 0.0;
+    }
+    __syncthreads();
+    if (tid < n) {
+        double x = 0.0;
+        for (int k = 0; k < n; ++k) x += V[tid * n + k] * scratch[k];
+        sol[tid] = x;
+    }
+    __syncthreads();
+}
 
 // one accumulation sweep over this wavefront's correspondences -> Hp (this wave's 298 partial sums)
 template <int CH>
@@ -346,13 +445,13 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         for (int e = tid; e < n * ld; e += GH_WG_THREADS) chkM += g.M[e];
         if (!(fabs(block_sum(chkM, red)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
         if (it == 1) phase_stamp(sdbg, 45);
-        // aux = pinv(M + 1e-12 I) * b   (:67), then dT = D dt: wave-serial, on the owner wavefront
+        // aux = pinv(M + 1e-12 I) * b   (:67): truncated pseudo-inverse by the workgroup, or Gauss-Jordan on the owner wavefront
+        if (Model::REDUNDANT_CONSTRAINTS) block_pinv_solve_sym(g.M, g.V, n, g.dt, g.V + n * n);
         if (owner) {
             bool ok = true;
-            if (Model::REDUNDANT_CONSTRAINTS) wave_pinv_solve_sym(g.M, g.V, n, g.dt, g.V + n * n);
-            else ok = wave_solve_gj<n>(g.M, g.dt);
+            if (!Model::REDUNDANT_CONSTRAINTS) ok = wave_solve_gj<n>(g.M, g.dt);
             wave_sync();
-            if (lane < 27) {
+            if (lane < 27) {                                                 // dT = D dt
                 double acc = 0.0;
                 if (Model::IDENTITY_D) acc = g.dt[lane];
                 else for (int k = 0; k < u; ++k) acc += g.D[lane * u + k] * g.dt[k];
