@@ -122,6 +122,9 @@ int tff_nordberg_tft_pose_batch_host(tff_ctx* ctx, const double* corresp, const 
 int tff_faugpapa_tft_pose_batch_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
                                     int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
                                     int32_t* iter, int32_t* status);
+int tff_faugpapa_tft_pose_batch_debug_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                                          int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                          int32_t* iter, int32_t* status, double* dbg);
 int tff_faugpapa_tft_pose_batch_host(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
                                      int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
                                      int32_t* iter, int32_t* status);

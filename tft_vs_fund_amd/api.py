@@ -124,7 +124,7 @@ EXPORTED_SYMBOLS = [
     "tff_linear_tft_pose_batch_dev", "tff_linear_tft_pose_batch_host", "tff_linear_tft_pose_batch_debug_dev",
     "tff_linear_f_pose_batch_dev", "tff_linear_f_pose_batch_host",
     "tff_ressl_tft_pose_batch_dev", "tff_ressl_tft_pose_batch_host", "tff_ressl_tft_pose_batch_debug_dev",
-    "tff_faugpapa_tft_pose_batch_dev", "tff_faugpapa_tft_pose_batch_host",
+    "tff_faugpapa_tft_pose_batch_dev", "tff_faugpapa_tft_pose_batch_host", "tff_faugpapa_tft_pose_batch_debug_dev",
     "tff_nordberg_tft_pose_batch_dev", "tff_nordberg_tft_pose_batch_host", "tff_nordberg_tft_pose_batch_debug_dev",
     "tff_optim_f_pose_batch_dev", "tff_optim_f_pose_batch_host",
     "tff_pi_pose_batch_dev", "tff_pi_pose_batch_host", "tff_picol_pose_batch_dev", "tff_picol_pose_batch_host",

@@ -396,6 +396,11 @@ int tff_faugpapa_tft_pose_batch_dev(tff_ctx* c, const double* corresp, const dou
                                      int32_t* status) {
     return launch_faugpapa_tft(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, nullptr);
 }
+int tff_faugpapa_tft_pose_batch_debug_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                                           int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                                           int32_t* status, double* dbg) {
+    return launch_faugpapa_tft(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+}
 int tff_faugpapa_tft_pose_batch_host(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
                                       int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
                                       int32_t* status) {

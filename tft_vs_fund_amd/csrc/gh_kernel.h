@@ -412,7 +412,7 @@ struct FaugPapaModel {
 __device__ inline void wave_pinv_solve_sym(double* M, double* V, int n, double* sol, double* coef) {
     const int lane = lane_id();
     const int ld = n + 1;
-    wave_jacobi_sym(M, ld, V, n, n);
+    wave_jacobi_sym(M, ld, V, n, n, true);
     const double lam = (lane < n) ? M[lane * ld + lane] : 0.0;
     const double amax = wave_max(fabs(lam));
     const double tol = (double)n * eps_of(amax);

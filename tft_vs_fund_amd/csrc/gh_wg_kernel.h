@@ -128,13 +128,14 @@ __device__ __forceinline__ bool block_any(bool p, double* red) { return block_su
 
 // Jacobi eigen-decomposition of the symmetric n x n matrix A (LDS, leading dimension lda; diagonal -> eigenvalues, V -> eigenvectors)
 // by the whole workgroup: round-robin (tournament) ordering, m/2 disjoint rotations per round (m = n rounded up to even), each round
-//   (a) one thread per pair computes (c, s) with the thresholds of wave_jacobi_sym,
+//   (a) one thread per pair computes (c, s) (thresholds: see below),
 //   (b) column phase: A <- A J, V <- V J   (pairs x rows work items),
 //   (c) row phase:    A <- J' A            (pairs x columns work items).
 // `cs`: 4 * (m/2) doubles of LDS scratch (p, q, c, s per pair), then one slot for the rotation counter.
-__device__ inline int block_jacobi_sym(double* A, const int lda, double* V, const int ldv, const int n, double* cs) {
+template <int n>
+__device__ inline int block_jacobi_sym(double* A, const int lda, double* V, const int ldv, double* cs) {
     const int tid = threadIdx.x;
-    const int m = (n + 1) & ~1, half = m / 2;
+    constexpr int m = (n + 1) & ~1, half = m / 2;
     for (int e = tid; e < n * n; e += GH_WG_THREADS) V[(e / n) * ldv + e % n] = (e / n == e % n) ? 1.0 : 0.0;
     double tr = 0.0;
     for (int k = 0; k < n; ++k) tr += fabs(A[k * lda + k]);                  // same on every thread
@@ -156,7 +157,10 @@ __device__ inline int block_jacobi_sym(double* A, const int lda, double* V, cons
                 double c = 1.0, s = 0.0;
                 if (q < n) {                                                 // q == n: the phantom index of an odd n
                     const double apq = A[p * lda + q], app = A[p * lda + p], aqq = A[q * lda + q];
-                    if (fabs(apq) > 1.1e-16 * sqrt(fabs(app * aqq)) && fabs(apq) > absfloor) {
+                    // threshold relative to the LARGER diagonal entry: couplings between a large eigenvalue and the (near-)null space of a
+                    // singular KKT matrix settle at rounding level and are left alone (error in the small eigenvalue ~ apq^2 / gap)
+                    const double big = (fabs(app) > fabs(aqq)) ? fabs(app) : fabs(aqq);
+                    if (fabs(apq) > 1.1e-16 * big && fabs(apq) > absfloor) {
                         const double tau = (aqq - app) / (2.0 * apq);
                         const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
                         c = rsqrt(1.0 + t * t); s = t * c;
@@ -167,7 +171,7 @@ __device__ inline int block_jacobi_sym(double* A, const int lda, double* V, cons
             }
             __syncthreads();
             for (int e = tid; e < half * n; e += GH_WG_THREADS) {            // (b) columns p, q of A and V, row `row`
-                const int pr = e / n, row = e % n;
+                const int row = e / half, pr = e % half;                     // neighbouring threads: same row, different pairs (LDS banks)
                 const double s = cs[4 * pr + 3];
                 if (s != 0.0) {
                     const int p = (int)cs[4 * pr], q = (int)cs[4 * pr + 1];
@@ -202,10 +206,12 @@ __device__ inline int block_jacobi_sym(double* A, const int lda, double* V, cons
 
 // x = pinv(M) b through the eigen-decomposition (see wave_pinv_solve_sym), by the whole workgroup.
 // scratch: n coefficients, then the pair table of block_jacobi_sym.
-__device__ inline void block_pinv_solve_sym(double* M, double* V, int n, double* sol, double* scratch) {
+template <int n>
+__device__ inline void block_pinv_solve_sym(double* M, double* V, double* sol, double* scratch, double* dbg = nullptr) {
     const int tid = threadIdx.x;
-    const int ld = n + 1;
-    block_jacobi_sym(M, ld, V, n, n, scratch + ((n + 1) & ~1));
+    constexpr int ld = n + 1;
+    const int sweeps = block_jacobi_sym<n>(M, ld, V, n, scratch + ((n + 1) & ~1));
+    if (dbg && tid == 0) dbg[79] = (double)sweeps;
     __syncthreads();
     double amax = 0.0;
     for (int k = 0; k < n; ++k) { const double l = fabs(M[k * ld + k]); amax = (l > amax) ? l : amax; }
@@ -446,7 +452,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         if (!(fabs(block_sum(chkM, red)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
         if (it == 1) phase_stamp(sdbg, 45);
         // aux = pinv(M + 1e-12 I) * b   (:67): truncated pseudo-inverse by the workgroup, or Gauss-Jordan on the owner wavefront
-        if (Model::REDUNDANT_CONSTRAINTS) block_pinv_solve_sym(g.M, g.V, n, g.dt, g.V + n * n);
+        if (Model::REDUNDANT_CONSTRAINTS) block_pinv_solve_sym<n>(g.M, g.V, g.dt, g.V + n * n, (it == 1) ? dbg : nullptr);
         if (owner) {
             bool ok = true;
             if (!Model::REDUNDANT_CONSTRAINTS) ok = wave_solve_gj<n>(g.M, g.dt);

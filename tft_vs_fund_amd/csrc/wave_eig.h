@@ -119,7 +119,7 @@ __device__ __forceinline__ bool eig_converged(double resid2) { return resid2 == 
 // its diagonal ends up holding the eigenvalues) with the eigenvectors accumulated in the columns of
 // V (leading dimension ldv).  n <= 64 (one lane per row).  Rotation (p,q): the lanes update the
 // column pair of A and V, then the row pair of A.  Works for indefinite matrices (KKT systems).
-__device__ inline int wave_jacobi_sym(double* A, const int lda, double* V, const int ldv, const int n) {
+__device__ inline int wave_jacobi_sym(double* A, const int lda, double* V, const int ldv, const int n, const bool kkt = false) {
     const int lane = lane_id();
     for (int e = lane; e < n * n; e += WAVE) V[(e / n) * ldv + e % n] = (e / n == e % n) ? 1.0 : 0.0;
     const double absfloor = 1e-22 * wave_sum(lane < n ? fabs(A[lane * lda + lane]) : 0.0) + 1e-300;
@@ -135,7 +135,10 @@ __device__ inline int wave_jacobi_sym(double* A, const int lda, double* V, const
                 const double apq = A[p * lda + q], app = A[p * lda + p], aqq = A[q * lda + q];
                 // relative threshold (de Rijk): keeps small eigenvalues accurate,
                 // plus an absolute floor so rounding noise under a zero eigenvalue is not chased
-                if (!(fabs(apq) > 1.1e-16 * sqrt(fabs(app * aqq)) && fabs(apq) > absfloor)) continue;   // wave-uniform
+                // kkt: singular indefinite matrices (pseudo-inverse of a KKT system): threshold relative to the larger diagonal entry,
+                // otherwise couplings between a large eigenvalue and the null space are rotated for ever at rounding level
+                const double ref = kkt ? ((fabs(app) > fabs(aqq)) ? fabs(app) : fabs(aqq)) : sqrt(fabs(app * aqq));
+                if (!(fabs(apq) > 1.1e-16 * ref && fabs(apq) > absfloor)) continue;   // wave-uniform
                 ++rotations;
                 const double tau = (aqq - app) / (2.0 * apq);
                 const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
