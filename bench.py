@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--ncorr", type=int, default=200)
     ap.add_argument("--cpu-sample", type=int, default=0, help="triplets timed on the CPU (default: 16 per host core, at least 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the LinearF / Ressl secondary metrics (1 GPU, rank 0)")
     args = ap.parse_args()
 
     import torch
@@ -140,6 +141,26 @@ def main():
     n_bad = int((status != 0).sum().item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
 
+    # secondary metrics of SURVEY 8(d) on the same resident batch (rank 0, a few untimed-by-the-contract steps each)
+    secondary = {}
+    if rank == 0 and world == 1 and not args.no_secondary:
+        it32 = torch.zeros(B, dtype=torch.int32, device=dev)
+        for name, fn in (("LinearFPoseEstimation", lib.tff_linear_f_pose_batch_dev), ("ResslTFTPoseEstimation", lib.tff_ressl_tft_pose_batch_dev)):
+            r = recs[0]
+            call = lambda: fn(ctx.handle, p(d_C), p(d_calm), 0, B, N, p(r, 0), p(r, 12 * B), p(r, 24 * B), None,
+                              ctypes.c_void_p(it32.data_ptr()), ctypes.c_void_p(status.data_ptr()))
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(10):
+                rc = call()
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            secondary[name] = {"value": B / (e0.elapsed_time(e1) / 10 * 1e-3), "unit": "triplet-hypotheses/s", "ms_per_batch": e0.elapsed_time(e1) / 10,
+                               "failed_triplets": int((status != 0).sum().item()), "mean_iterations": float(it32.double().mean().item())}
+
     if rank == 0:
         total = world * B * args.steps
         value = total / elapsed
@@ -166,6 +187,8 @@ def main():
                          "traffic": traffic, "kernel": "k_linear_tft_pose", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg},
         }
+        if secondary:
+            out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample or max(1024, 16 * (os.cpu_count() or 1))
             out["cpu_baseline"] = cpu_baseline(C, CalM, min(sample, B))

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_r1b; rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 3"
+CMD="python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 3"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1

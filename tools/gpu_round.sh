@@ -9,7 +9,7 @@ timeout 600 python bench.py > gpurun_out/bench.log 2>&1; tail -1 gpurun_out/benc
 timeout 300 python tools/phase_profile.py > gpurun_out/phase.log 2>&1; cat gpurun_out/phase.log
 if [ "$1" == "prof" ]; then
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- python3 $R/bench.py --no-cpu-baseline --steps 20 > $R/gpurun_out/prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 20 > $R/gpurun_out/prof.log 2>&1
 cd $R
 for f in $(find gpurun_out/prof -name '*kernel_stats.csv'); do head -3 $f | cut -c1-200; done
 fi
