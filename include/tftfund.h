@@ -49,7 +49,7 @@ typedef struct tff_ctx tff_ctx;
 #define TFF_ST_NONFINITE 2  /* NaN/Inf in the result: Gauss_Helmert.m:53-55,63-65 */
 #define TFF_ST_NO_POSE 3    /* no candidate with score >= 0: R_f unassigned in R_t_from_TFT.m:91-104 */
 #define TFF_ST_NO_PARAM 5   /* PiColPoseEstimation.m:84-89: error('The minimal param could not be found') */
-#define TFF_ST_RANK 4       /* Gauss-Helmert: KKT system numerically rank deficient (pinv would truncate, Gauss_Helmert.m:67) */
+#define TFF_ST_RANK 4       /* Nordberg: rank-deficient P2/P3 of the linear solution (projective fix-up of NordbergTFT...m:56-62 not applied) */
 
 /* error codes (besides -hipError_t) */
 #define TFF_E_INVALID (-10001)

@@ -861,7 +861,7 @@ __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, co
         if (it == 1) phase_stamp(dbg, 45);
         // aux = pinv(M + 1e-12 I) * b   (:67)
         if (Model::REDUNDANT_CONSTRAINTS) wave_pinv_solve_sym(g.M, g.V, n, g.dt, g.Y);
-        else if (!wave_solve_gj<Model::U + Model::C>(g.M, g.dt)) { *st = ST_RANK; break; }
+        else if (!wave_solve_gj<Model::U + Model::C>(g.M, g.dt)) wave_pinv_solve_sym(g.M, g.V, n, g.dt, g.Y);   // singular: pinv truncates
         wave_sync();
         if (lane < 27) {                                                     // dT = D dt
             double a = 0.0;

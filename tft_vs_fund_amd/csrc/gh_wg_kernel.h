@@ -466,7 +466,18 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
             if (lane == 0) red[8] = ok ? 1.0 : 0.0;
         }
         __syncthreads();
-        if (red[8] == 0.0) { *st = ST_RANK; break; }
+        if (!Model::REDUNDANT_CONSTRAINTS && red[8] == 0.0) {
+            // numerically singular KKT matrix (degenerate geometry): pinv truncates, so does the eigen-decomposition path.
+            // Eigenvectors go to Y and the pair table to H, both dead by now.
+            block_pinv_solve_sym<n>(g.M, g.Y, g.dt, g.H);
+            if (owner && lane < 27) {
+                double acc = 0.0;
+                if (Model::IDENTITY_D) acc = g.dt[lane];
+                else for (int k = 0; k < u; ++k) acc += g.D[lane * u + k] * g.dt[k];
+                g.dT[lane] = acc;
+            }
+            __syncthreads();
+        }
         double dTr[27];
         load_uniform27(g.dT, dTr);
         if (it == 1) phase_stamp(sdbg, 46);

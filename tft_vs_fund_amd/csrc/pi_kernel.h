@@ -30,14 +30,15 @@ struct PiWork {
     double* dt;     // n        KKT solution
     double* H;      // 405 + 27 accumulated sums: H[9 e + 3 k + k'], e = tri(b, b'); then rhs[27]
     double* M;      // n x (n+1) augmented KKT matrix
-    double* V;      // n x n    eigenvectors of the KKT matrix, then n coefficients (models with PINV_KKT only)
+    double* V;      // n x n    eigenvectors of the KKT matrix, then n coefficients (pseudo-inverse path)
     double* xi;     // 6N       current estimates of the observations
     double* pp;     // PP * N   per correspondence: W+ (packed lower), W+ w; later v (6)
 };
 __host__ __device__ constexpr int pi_pp(int E) { return E * (E + 1) / 2 + E; }
 __host__ __device__ inline int pi_lds_doubles(int E, int C, int N, bool pinv_kkt) {
     const int n = 27 + C;
-    return 28 + ((n + 1) & ~1) + 432 + ((n * (n + 1) + 1) & ~1) + (pinv_kkt ? ((n * n + n + 1) & ~1) : 0) + 6 * N + pi_pp(E) * N + 8;
+    (void)pinv_kkt;                                                          // V is always there: the fall-back of the elimination needs it too
+    return 28 + ((n + 1) & ~1) + 432 + ((n * (n + 1) + 1) & ~1) + ((n * n + n + 1) & ~1) + 6 * N + pi_pp(E) * N + 8;
 }
 __device__ inline PiWork pi_carve(double* base, int E, int C, int N, bool pinv_kkt) {
     PiWork g;
@@ -47,7 +48,8 @@ __device__ inline PiWork pi_carve(double* base, int E, int C, int N, bool pinv_k
     g.dt = q; q += (n + 1) & ~1;
     g.H = q; q += 432;
     g.M = q; q += (n * (n + 1) + 1) & ~1;
-    g.V = q; q += pinv_kkt ? ((n * n + n + 1) & ~1) : 0;
+    (void)pinv_kkt;
+    g.V = q; q += (n * n + n + 1) & ~1;
     g.xi = q; q += 6 * N;
     g.pp = q;
     return g;
@@ -727,8 +729,9 @@ __device__ inline int gauss_helmert_pi_wave(PoseLds* w, PiWork& g, const double*
         for (int e = lane; e < n * ld; e += WAVE) chkM += g.M[e];
         if (!(fabs(wave_sum(chkM)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
         // aux = pinv(M + 1e-12 I) b   (:67)
-        if (Model::PINV_KKT) wave_pinv_solve_sym(g.M, g.V, n, g.dt, g.V + n * n);
-        else if (!wave_solve_gj<n>(g.M, g.dt)) { *st = ST_RANK; break; }
+        // Gauss-Jordan when the matrix is regular (then pinv is the inverse); the eigen-decomposition path reproduces the
+        // truncation otherwise (degenerate geometry, e.g. collinear centres under the generic parameterisation)
+        if (Model::PINV_KKT || !wave_solve_gj<n>(g.M, g.dt)) wave_pinv_solve_sym(g.M, g.V, n, g.dt, g.V + n * n);
         wave_sync();
         double dt[27];
         load_uniform27(g.dt, dt);
