@@ -49,7 +49,7 @@ typedef struct tff_ctx tff_ctx;
 #define TFF_ST_NONFINITE 2  /* NaN/Inf in the result: Gauss_Helmert.m:53-55,63-65 */
 #define TFF_ST_NO_POSE 3    /* no candidate with score >= 0: R_f unassigned in R_t_from_TFT.m:91-104 */
 #define TFF_ST_NO_PARAM 5   /* PiColPoseEstimation.m:84-89: error('The minimal param could not be found') */
-#define TFF_ST_RANK 4       /* Nordberg: rank-deficient P2/P3 of the linear solution (projective fix-up of NordbergTFT...m:56-62 not applied) */
+#define TFF_ST_RANK 4       /* Nordberg: P2(:,1:3) or P3(:,1:3) of rank < 2 (NordbergTFT...m:58,60 would fail: null() returns two columns) */
 
 /* error codes (besides -hipError_t) */
 #define TFF_E_INVALID (-10001)
@@ -106,7 +106,7 @@ int tff_ressl_tft_pose_batch_debug_dev(tff_ctx* ctx, const double* corresp, cons
 
 /* NordbergTFTPoseEstimation (TFT_methods/NordbergTFTPoseEstimation.m:47-222): three orthogonal matrices in
  * axis-angle form + a 10-entry sparse tensor (19 parameters, 1 constraint), Gauss-Helmert refinement.
- * The projective fix-up for rank-deficient P2/P3 (:56-62) is reported as TFF_ST_RANK, not applied. */
+ * The projective fix-up for rank-deficient P2/P3 (:56-62) is applied (rank by sigma_3 = |det| / (sigma_1 sigma_2)). */
 int tff_nordberg_tft_pose_batch_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
                                     int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
                                     int32_t* iter, int32_t* status);

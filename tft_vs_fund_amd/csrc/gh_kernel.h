@@ -436,7 +436,7 @@ struct NordbergModel {
     static constexpr int U = 19, C = 1;
     static constexpr bool IDENTITY_D = false;
     static constexpr bool REDUNDANT_CONSTRAINTS = false;
-    int bad;                                                                 // rank-deficient P2/P3 fix-up (:56-62) not implemented
+    int bad;                                                                 // P2 or P3 of rank < 2: H(4,1:3) = null(.)' is an error in the reference (:56-62)
 
     __device__ static __forceinline__ void sparse_pos(int k, int& c, int& d, int& j) {
         // param_ind = [1,7,10,12,16,19:22,25] (1-based, column-major 3x3x3)   (:82)
@@ -486,11 +486,29 @@ struct NordbergModel {
             Mat3 A, B;
             double a[3], b[3];
             for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) { A.m[r][c] = w->P[0][4 * r + c]; B.m[r][c] = w->P[1][4 * r + c]; } a[r] = w->P[0][4 * r + 3]; b[r] = w->P[1][4 * r + 3]; }
-            // rank(P3(:,1:3)) < 3 or rank(P2(:,1:3)) < 3 (:57-61): generic tensors never hit it; reported, not silently mishandled
-            const double dA = mat3_det(A), dB = mat3_det(B);
-            double nA = 0, nB = 0;
-            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { nA += A.m[r][c] * A.m[r][c]; nB += B.m[r][c] * B.m[r][c]; }
-            const int deficient = (!(fabs(dA) > 1e-13 * nA * sqrt(nA))) || (!(fabs(dB) > 1e-13 * nB * sqrt(nB)));
+            // H = eye(4); H(4,1:3) = null(P3(:,1:3))' if rank(P3(:,1:3)) < 3, else the same with P2   (:56-62).
+            // rank(X) < 3 <=> sigma_3 <= 3 eps(sigma_1), with sigma_3 = |det X| / (sigma_1 sigma_2) (the squared-matrix
+            // Jacobi of svd3 cannot resolve a singular value that small).  P*H = [P(:,1:3) + P(:,4) n', P(:,4)]; P1*H = P1.
+            int deficient = 0;
+            {
+                Mat3 Us, Vs;
+                double svB[3], svA[3];
+                svd3(B, Us, Vs, svB);
+                const bool defB = !(fabs(mat3_det(B)) > 3.0 * eps_of(svB[0]) * svB[0] * svB[1]);
+                svd3(A, Us, Vs, svA);
+                const bool defA = !(fabs(mat3_det(A)) > 3.0 * eps_of(svA[0]) * svA[0] * svA[1]);
+                if (defB || defA) {
+                    double nv[3];
+                    null3(defB ? B : A, nv);
+                    for (int r = 0; r < 3; ++r)
+                        for (int c = 0; c < 3; ++c) { A.m[r][c] += a[r] * nv[c]; B.m[r][c] += b[r] * nv[c]; }
+                    for (int r = 0; r < 3; ++r)
+                        for (int c = 0; c < 3; ++c) { w->P[0][4 * r + c] = A.m[r][c]; w->P[1][4 * r + c] = B.m[r][c]; }
+                    // a null space of dimension > 1 makes H(4,1:3) = null(.)' a MATLAB error: reported
+                    const double s2 = defB ? svB[1] : svA[1], s1 = defB ? svB[0] : svA[0];
+                    deficient = !(s2 > 3.0 * eps_of(s1) * s1) ? 1 : 0;
+                }
+            }
             double r3[3], s3[3];
             matvec(mat3_inv(A), a, r3);                                      // r = A\a   (:65)
             matvec(mat3_inv(B), b, s3);                                      // s = B\b   (:66)
