@@ -70,7 +70,7 @@ static int emu_gh_wg_impl(const double* corresp, const double* calm, long calm_s
                           double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status) {
     std::vector<double> rec((size_t)B * tff::GH_REC_DOUBLES), topt((size_t)B * 27);
     tff::GhWgArgs a{corresp, calm, calm_stride, B, N, (flags & ~tff::FLAG_JACOBI) | (reconst ? tff::FLAG_RECONST : 0), rec.data(), topt.data(),
-                    Rt2, Rt3, T, reconst, iter, status, nullptr};
+                    Rt2, Rt3, T, reconst, iter, status, nullptr, nullptr, 0};
     emu::launch(tff::k_gh_linear<false>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, a.flags, false), a);
     tff::GhWgArgs m = a;
     m.flags |= tff::FLAG_ONLY_RETRY;

@@ -585,6 +585,35 @@ def test_singular_kkt_takes_the_pinv_path(gpu_ctx):
         assert np.abs(np.einsum("bij,bkj->bik", R, R) - np.eye(3)).max() < 1e-9
 
 
+def test_iterative_methods_at_large_n_use_the_global_workspace(gpu_ctx):
+    """N = 1500: the per-correspondence state of the iterative methods (up to 26 N doubles) exceeds the 160 KB of LDS and lives in
+    a global workspace instead; pinv(W) really truncates at this N (tolerance 4N eps(lambda_max) > 1e-12: eigen-decomposition path).
+    Ressl is checked against the block-structured restatement (the dense oracle would pinv a 6000 x 6000 matrix)."""
+    from oracle import gh_block_oracle as G
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    B, N = 6, 1500
+    C, CalM, Rt0, _ = generate_scene_batch(B, N, noise=1.0, seed=321)
+    errs = {}
+    for method in ("ResslTFTPoseEstimation", "NordbergTFTPoseEstimation", "FaugPapaTFTPoseEstimation", "PiPoseEstimation", "OptimFPoseEstimation"):
+        out = gpu_ctx.pose_batch(method, C, CalM, reconst=True)
+        assert np.all(out["status"] == 0), method
+        R = out["R_t_3"][:, :, :3]
+        c = (np.einsum("ij,bij->b", Rt0[1][:, :3], R) - 1) / 2
+        errs[method] = np.degrees(np.arccos(np.clip(c, -1, 1))).mean()
+        assert errs[method] < 0.3, (method, errs[method])                    # sigma = 1 px at N = 1500: ~0.1 degree
+        if method == "ResslTFTPoseEstimation":
+            for b in range(2):
+                R2, R3, Rec, T, it = G.ResslTFTPoseEstimation_blocks(C[b].T.copy(), CalM)
+                dit = int(out["iter"][b]) - it
+                assert abs(dit) <= 5
+                tol = 1e-4 if dit == 0 else 2e-3
+                assert rel_err_T(out["T"][b], T) < tol and rel_err(out["R_t_3"][b], R3) < tol
+    lin = gpu_ctx.pose_batch("LinearTFTPoseEstimation", C, CalM, reconst=False)
+    Rl = lin["R_t_3"][:, :, :3]
+    cl = (np.einsum("ij,bij->b", Rt0[1][:, :3], Rl) - 1) / 2
+    assert errs["ResslTFTPoseEstimation"] <= np.degrees(np.arccos(np.clip(cl, -1, 1))).mean() * 1.05
+
+
 def test_paired_kernel_variant_agrees(gpu_ctx):
     """TFF_OPT_KERNEL = 1 (two triplets per workgroup, half-wavefront middle section) against the default kernel."""
     import torch

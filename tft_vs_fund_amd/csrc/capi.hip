@@ -49,7 +49,7 @@ struct tff_ctx {
     hipStream_t stream = nullptr;
     int solver = 0;
     int stage = -1;
-    DevBuf in, calm, out, idx, scratch_status, gh_rec, gh_topt;
+    DevBuf in, calm, out, idx, scratch_status, gh_rec, gh_topt, spill;
     const int32_t* sample_idx = nullptr;   // set around a *_sampled_dev call
     double* init_p = nullptr; double* init_x = nullptr;   // set around tff_pi_pose_batch_debug_dev
     int kernel_variant = 0;                // TFF_OPT_KERNEL
@@ -69,6 +69,23 @@ template <class K>
 int ensure_lds(K kernel, size_t bytes) {
     if (bytes > 160 * 1024) return fail(TFF_E_INVALID, "N too large for the 160 KiB LDS workspace of this method");
     if (bytes > 64 * 1024) TFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+// Iterative methods at large N: when the per-correspondence state does not fit the 160 KB of LDS it goes to a global
+// workspace, one slice per resident block (the kernels loop over the batch with a grid stride).  lds_full / lds_fixed: the
+// kernel's LDS request with and without the per-correspondence part.  Returns the LDS bytes to launch with.
+constexpr size_t LDS_LIMIT = 160 * 1024;
+int plan_spill(tff_ctx* c, size_t lds_full, size_t lds_fixed, unsigned* grid, double** spill, long* stride, size_t* lds) {
+    *spill = nullptr; *stride = 0; *lds = lds_full;
+    if (lds_full <= LDS_LIMIT) return 0;
+    if (lds_fixed > LDS_LIMIT) return fail(TFF_E_INVALID, "LDS workspace of this method exceeds 160 KiB");
+    const size_t per_block = lds_full - lds_fixed;
+    size_t blocks = ((size_t)512 << 20) / per_block;
+    if (blocks < 256) blocks = 256;
+    if (*grid > blocks) *grid = (unsigned)blocks;
+    if (int r = c->spill.reserve((size_t)*grid * per_block)) return r;
+    *spill = (double*)c->spill.p; *stride = (long)(per_block / sizeof(double)); *lds = lds_fixed;
     return 0;
 }
 
@@ -106,16 +123,19 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, bool may_stage
     if (c->solver == 0) {
         tff::LinearTftArgs m = a;
         m.flags = may_stage ? staged_flags(c, N, a.flags, false) : a.flags;
-        const size_t lds = ldsfn(N, m.flags, false);
+        unsigned grid = tff::pose_grid(B);
+        size_t lds;
+        if (int r = plan_spill(c, ldsfn(N, m.flags, false), ldsfn(0, m.flags, false), &grid, &m.spill, &m.spill_stride, &lds)) return r;
         if (int r = ensure_lds(kmain, lds)) return r;
-        hipLaunchKernelGGL(kmain, dim3(tff::pose_grid(B)), dim3(64), lds, c->stream, m);
+        hipLaunchKernelGGL(kmain, dim3(grid), dim3(64), lds, c->stream, m);
         TFF_HIP(hipGetLastError());
         a.flags |= tff::FLAG_ONLY_RETRY;
     }
     if (may_stage) a.flags = staged_flags(c, N, a.flags, true);
-    const size_t lds = ldsfn(N, a.flags, true);
+    unsigned grid = (c->solver == 0) ? (unsigned)(B < 8192 ? B : 8192) : tff::pose_grid(B);
+    size_t lds;
+    if (int r = plan_spill(c, ldsfn(N, a.flags, true), ldsfn(0, a.flags, true), &grid, &a.spill, &a.spill_stride, &lds)) return r;
     if (int r = ensure_lds(kjac, lds)) return r;
-    const unsigned grid = (c->solver == 0) ? (unsigned)(B < 8192 ? B : 8192) : tff::pose_grid(B);
     hipLaunchKernelGGL(kjac, dim3(grid), dim3(64), lds, c->stream, a);
     TFF_HIP(hipGetLastError());
     return 0;
@@ -187,7 +207,7 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
     if (int r = c->gh_rec.reserve((size_t)B * tff::GH_REC_DOUBLES * sizeof(double))) return r;
     if (int r = c->gh_topt.reserve((size_t)B * 27 * sizeof(double))) return r;
     tff::GhWgArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr), (double*)c->gh_rec.p, (double*)c->gh_topt.p,
-                    Rt2, Rt3, T, reconst, iter, status, dbg};
+                    Rt2, Rt3, T, reconst, iter, status, dbg, nullptr, 0};
     {   // linear stage + Jacobi fix-up over the triplets it marked ST_RETRY
         tff::GhWgArgs m = a;
         m.flags = staged_flags(c, N, a.flags, false);
@@ -202,9 +222,13 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
         TFF_HIP(hipGetLastError());
     }
     {
-        const size_t lds = (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, N, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double);
+        auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
+        tff::GhWgArgs m = a;
+        unsigned grid = tff::pose_grid(B);
+        size_t lds;
+        if (int r = plan_spill(c, wg_lds(N), wg_lds(0), &grid, &m.spill, &m.spill_stride, &lds)) return r;
         if (int r = ensure_lds(tff::k_gh_block<Model>, lds)) return r;
-        hipLaunchKernelGGL(tff::k_gh_block<Model>, dim3(tff::pose_grid(B)), dim3(tff::GH_WG_THREADS), lds, c->stream, a);
+        hipLaunchKernelGGL(tff::k_gh_block<Model>, dim3(grid), dim3(tff::GH_WG_THREADS), lds, c->stream, m);
         TFF_HIP(hipGetLastError());
     }
     {
@@ -306,7 +330,7 @@ void tff_ctx_destroy(tff_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own) { (void)hipStreamSynchronize(c->own); (void)hipStreamDestroy(c->own); }
-    c->in.release(); c->calm.release(); c->out.release(); c->idx.release(); c->scratch_status.release(); c->gh_rec.release(); c->gh_topt.release();
+    c->in.release(); c->calm.release(); c->out.release(); c->idx.release(); c->scratch_status.release(); c->gh_rec.release(); c->gh_topt.release(); c->spill.release();
     delete c;
 }
 

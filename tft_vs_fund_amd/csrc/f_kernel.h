@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(64, 2) k_f_pose(const LinearTftArgs a) {
     JacobiLds* jw = JAC ? reinterpret_cast<JacobiLds*>(smem + base) : nullptr;
     double* extra = smem + base + (JAC ? ((JACOBI_LDS_DOUBLES + 1) & ~1) : 0);
     OptimFLds* og = (METHOD == 1) ? reinterpret_cast<OptimFLds*>(extra) : nullptr;
-    double* oxi = extra + ((OPTIMF_FIXED_DOUBLES + 1) & ~1);                 // METHOD 1: xi (4N), then v (4N)
+    double* oxi = a.spill ? a.spill + blockIdx.x * a.spill_stride : extra + ((OPTIMF_FIXED_DOUBLES + 1) & ~1);   // METHOD 1: xi (4N), then v (4N); large N: global
     double* lds_pts = (METHOD == 1) ? oxi + 8 * a.N + 2 : extra;             // staged correspondences (METHOD 0, or sampled)
     const int lane = lane_id();
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {

@@ -956,7 +956,8 @@ __global__ void __launch_bounds__(64, 1) k_gh_tft_pose(const LinearTftArgs a) {
         double* dbg = a.dbg ? a.dbg + b * DBG_STRIDE : nullptr;
         const double* pts = a.corresp + b * 6 * (long)N;                     // re-read through L2 (LDS is taken by the GH workspace)
         wave_sync();
-        GhWork g = gh_carve(ghbase, Model::U, Model::C, N);
+        GhWork g = gh_carve(ghbase, Model::U, Model::C, a.spill ? 0 : N);
+        if (a.spill) { g.xi = a.spill + blockIdx.x * a.spill_stride; g.pp = g.xi + 6 * (long)N; }   // large N: per-correspondence state in global memory
         if (lane < 27) w->calm[lane] = a.calm[b * a.calm_stride + lane];
         int status = ST_OK, iters = 0;
         if (N < 7) {

@@ -72,6 +72,7 @@ struct GhWgArgs {
     double* rec;             // B x GH_REC_DOUBLES (k_gh_linear out, k_gh_block / k_gh_finish in)
     double* topt;            // B x 27 (k_gh_block out, k_gh_finish in): optimised tensor in the normalised frame
     double* Rt2; double* Rt3; double* T; double* reconst; int* iter; int* status; double* dbg;
+    double* spill; long spill_stride;   // see LinearTftArgs
 };
 
 template <bool JAC>
@@ -549,7 +550,8 @@ __global__ void __launch_bounds__(GH_WG_THREADS, 3) k_gh_block(const GhWgArgs a)
         const int N = a.N;
         const double* pts = a.corresp + b * 6 * (long)N;
         double* red;
-        GhWork g = gh_wg_carve(ghbase, w, Model::U, Model::C, N, Model::REDUNDANT_CONSTRAINTS, &red);
+        GhWork g = gh_wg_carve(ghbase, w, Model::U, Model::C, a.spill ? 0 : N, Model::REDUNDANT_CONSTRAINTS, &red);
+        if (a.spill) { g.xi = a.spill + blockIdx.x * a.spill_stride; g.pp = g.xi + 6 * (long)N; }
         const int own = (int)(b & (GH_WG_WAVES - 1));
         const double* r = a.rec + b * GH_REC_DOUBLES;
         if (tid < 27) w->t[tid] = r[tid];

@@ -813,7 +813,8 @@ __global__ void __launch_bounds__(64, 1) k_pi_tft_pose(const LinearTftArgs a) {
         double* dbg = a.dbg ? a.dbg + b * DBG_STRIDE : nullptr;
         const double* pts = a.corresp + b * 6 * (long)N;
         wave_sync();
-        PiWork g = pi_carve(ghbase, Model::E, Model::C, N, Model::PINV_KKT);
+        PiWork g = pi_carve(ghbase, Model::E, Model::C, a.spill ? 0 : N, Model::PINV_KKT);
+        if (a.spill) { g.xi = a.spill + blockIdx.x * a.spill_stride; g.pp = g.xi + 6 * (long)N; }   // large N: per-correspondence state in global memory
         if (lane < 27) w->calm[lane] = a.calm[b * a.calm_stride + lane];
         int status = ST_OK, iters = 0;
         const double qnan = __longlong_as_double(0x7ff8000000000000LL);

@@ -56,6 +56,8 @@ struct LinearTftArgs {
     const int* sample_idx;   // null, or B x N int32 indices into ONE shared scene at `corresp` (config 4: minimal samples)
     double* init_p;          // null, or B x 27: initial parameters of the Pi methods (debug / building-block output)
     double* init_x;          // with init_p: B x 6N initial observation estimates
+    double* spill;           // null, or global workspace for the per-correspondence state of the iterative methods when it does not
+    long spill_stride;       //   fit the 160 KB of LDS (large N): gridDim.x blocks of spill_stride doubles
 };
 
 // Inverse-iteration cap before a triplet is handed to the Jacobi fix-up pass: 300 iterations (~0.13 M
