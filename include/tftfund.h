@@ -213,6 +213,16 @@ int tff_linear_tft_batch_dev(tff_ctx* ctx, const double* corresp, int64_t B, int
 int tff_linear_f_batch_dev(tff_ctx* ctx, const double* corresp, int64_t B, int32_t N, int32_t refine, double* F21,
                            double* F31, int32_t* iter, int32_t* status);
 
+/* BundleAdjustment (Optimization/BundleAdjustment.m:49-216) for three views: refines the poses (Rt2_in, Rt3_in: B x 12,
+ * camera 1 = [I|0]) and the space points (reconst0: B x 3N, or NULL to triangulate them first, :59-77) by Levenberg-Marquardt on
+ * the reprojection residual in per-view normalised coordinates.  Outputs: poses with |t2| = 1, points (NULL to skip),
+ * successful LM iterations, repr_err = norm of the final residual vector (normalised units, as BundleAdjustment.m:105).
+ * MATLAB's lsqnonlin is closed source: the loop follows its documented LM defaults (see csrc/ba_kernel.h); results are
+ * comparable at the converged optimum.  All correspondences must be visible in all three views. */
+int tff_bundle_adjust_batch_dev(tff_ctx* ctx, const double* calm, int64_t calm_stride, const double* Rt2_in,
+                                const double* Rt3_in, const double* corresp, int64_t B, int32_t N, const double* reconst0,
+                                double* Rt2, double* Rt3, double* reconst, int32_t* iter, double* repr_err, int32_t* status);
+
 /* Minimal-sample hypotheses (BASELINE.json config 4): hypothesis b = the n correspondences
  * sample_idx[b*n .. b*n+n) of one shared scene (6 x Ns); n >= 7 (TFT) / 8 (F); shared CalM (27). */
 int tff_linear_tft_pose_sampled_dev(tff_ctx* ctx, const double* scene, int32_t Ns, const double* calm,

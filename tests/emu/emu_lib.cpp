@@ -86,6 +86,12 @@ extern "C" int emu_gh_wg_pose(int model, const double* corresp, const double* ca
     if (model == 1) return emu_gh_wg_impl<tff::NordbergModel>(corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status);
     return emu_gh_wg_impl<tff::FaugPapaModel>(corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status);
 }
+extern "C" int emu_bundle_adjust(const double* calm, long calm_stride, const double* Rt2_in, const double* Rt3_in, const double* corresp, long B, int N,
+                                 const double* reconst0, double* Rt2, double* Rt3, double* reconst, int* iter, double* repr_err, int* status) {
+    tff::BaArgs a{calm, calm_stride, Rt2_in, Rt3_in, corresp, B, N, reconst0, Rt2, Rt3, reconst, iter, repr_err, status};
+    emu::launch(tff::k_bundle_adjust, tff::pose_grid(B), 64, tff::ba_lds_bytes(N), a);
+    return 0;
+}
 // building block: linearF / optimF per view pair (tff_linear_f_batch_dev)
 extern "C" int emu_linear_f(const double* corresp, long B, int N, int refine, double* F21, double* F31, int* iter, int* status) {
     tff::LinearFOnlyArgs a{corresp, B, N, 0, F21, F31, iter, status};

@@ -15,7 +15,7 @@ the literal numpy/LAPACK restatement of the .m files -- run on
 
 Run from the repo root (needs /root/reference for the EPFL part only):
     python tests/golden/make_golden.py
-Outputs: synthetic_linear.npz, synthetic_gh.npz, epfl.npz, optimf.npz, pi.npz  (inputs +
+Outputs: synthetic_linear.npz, synthetic_gh.npz, epfl.npz, optimf.npz, pi.npz, ba.npz  (inputs +
 expected outputs; no reference source text).  optimf.npz (OptimFPoseEstimation)
 covers synthetic scenes and the 100-correspondence EPFL samples of epfl.npz; pi.npz holds
 PiPoseEstimation on the same kinds of input and PiColPoseEstimation on scenes with collinear
@@ -176,6 +176,42 @@ def make_pi():
     np.savez_compressed(os.path.join(HERE, "pi.npz"), **data)
 
 
+BA_CASES = [(12, 1.0, 71, 3), (12, 3.0, 72, 2), (50, 1.0, 73, 3), (100, 1.0, 74, 2), (200, 1.0, 75, 2), (30, 0.0, 76, 2)]
+
+
+def make_ba():
+    """BundleAdjustment (oracle/ba_oracle.py) started from LinearTFTPoseEstimation's output, with and without Reconst0;
+    plus the EPFL samples (first 50 correspondences of each 100-sample, as experiments_real.m refines on a subset)."""
+    from oracle import ba_oracle as BA
+    data = {}
+    for ci, (N, sigma, seed, B) in enumerate(BA_CASES):
+        C, CalM, Rt0, _ = generate_scene_batch(B, N, noise=sigma, seed=seed)
+        pre = "c%d_" % ci
+        data[pre + "Corresp"] = C
+        data[pre + "CalM"] = CalM
+        data[pre + "meta"] = np.array([N, sigma, seed, B], dtype=np.float64)
+        acc = {k: [] for k in ("Rt2_in", "Rt3_in", "Rec_in", "Rt2", "Rt3", "Rec", "iter", "err", "Rt2_tri", "Rt3_tri", "iter_tri", "err_tri")}
+        for b in range(B):
+            R2, R3, Rec, T, _ = O.LinearTFTPoseEstimation(C[b].T.copy(), CalM)
+            R_t_0 = np.vstack([np.eye(3, 4), R2, R3])
+            Rt, Recn, it, err = BA.BundleAdjustment(CalM, R_t_0, C[b].T.copy(), Rec)
+            Rtt, _, itt, errt = BA.BundleAdjustment(CalM, R_t_0, C[b].T.copy(), None)
+            for k, v in zip(acc, (R2, R3, Rec, Rt[3:6], Rt[6:9], Recn, it, err, Rtt[3:6], Rtt[6:9], itt, errt)):
+                acc[k].append(v)
+        for k, v in acc.items():
+            data[pre + k] = np.array(v) if k.startswith(("iter", "err")) else np.stack(v)
+        print("ba case", ci, N, sigma, acc["iter"], acc["iter_tri"], flush=True)
+    g = np.load(os.path.join(HERE, "epfl.npz"))
+    for n in range(int(g["count"])):
+        pre = "t%d_" % n
+        Cs = g[pre + "sample"][:, :50].copy()
+        R_t_0 = np.vstack([np.eye(3, 4), g[pre + "tft_Rt2"], g[pre + "tft_Rt3"]])
+        Rt, Recn, it, err = BA.BundleAdjustment(g[pre + "CalM"], R_t_0, Cs, None)
+        data[pre + "ba_Rt2"] = Rt[3:6]; data[pre + "ba_Rt3"] = Rt[6:9]; data[pre + "ba_iter"] = np.array(it); data[pre + "ba_err"] = np.array(err)
+        print("ba epfl", n, it, err, flush=True)
+    np.savez_compressed(os.path.join(HERE, "ba.npz"), **data)
+
+
 def _read_camera(path):
     """Data/readCalibrationOrientation_EPFL.m: K (3 rows), skip, R' (3 rows), C, size."""
     with open(path) as f:
@@ -239,7 +275,7 @@ def make_epfl():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["linear", "gh", "epfl", "optimf", "pi"]
+    what = sys.argv[1:] or ["linear", "gh", "epfl", "optimf", "pi", "ba"]
     if "linear" in what:
         make_synthetic_linear()
     if "gh" in what:
@@ -250,3 +286,5 @@ if __name__ == "__main__":
         make_optimf()
     if "pi" in what:
         make_pi()
+    if "ba" in what:
+        make_ba()

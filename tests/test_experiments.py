@@ -67,6 +67,18 @@ def test_synthetic_sweep_matches_oracle_metrics(gpu_ctx):
             assert abs(res["t_err"][i][m] - np.mean(tr)) <= tol * np.mean(tr) + (0 if linear else 0.02), (N, name)
             assert abs(res["iter"][i][m] - np.mean(its)) <= (0 if linear else 1.5), (N, name)
             assert 0 < res["time"][i][m] < 1.0
+            # second column of the reference's arrays: after BundleAdjustment (experiments.m:127-141)
+            assert np.isfinite(res["rot_err_ba"][i][m]) and res["iter_ba"][i][m] >= 1 and 0 < res["time_ba"][i][m] < 1.0
+            if name == "LinearTFTPoseEstimation":
+                from oracle import ba_oracle as BA
+                rot_ba, rep_ba = [], []
+                for b in range(n_sim):
+                    R2, R3, Rec, T, it = O.LinearTFTPoseEstimation(C[b].T.copy(), CalM)
+                    Rt, _, _, err = BA.BundleAdjustment(CalM, np.vstack([np.eye(3, 4), R2, R3]), C[b].T.copy(), Rec)
+                    a2, _ = O.AngError(Rt0[0], Rt[3:6]); a3, _ = O.AngError(Rt0[1], Rt[6:9])
+                    rot_ba.append((a2 + a3) / 2); rep_ba.append(err)
+                assert abs(res["rot_err_ba"][i][m] - np.mean(rot_ba)) <= 1e-6 * np.mean(rot_ba)
+                assert abs(res["repr_err_ba"][i][m] - np.mean(rep_ba)) <= 1e-6 * np.mean(rep_ba)
 
 
 @pytest.mark.gpu
@@ -95,6 +107,7 @@ def test_real_sweep_on_epfl_fixture(gpu_ctx, golden_dir):
         ressl_dev.append(abs(res["repr_err"][n][1] - float(g[pre + "ressl_repr_all"])) / float(g[pre + "ressl_repr_all"]))
         assert res["repr_err"][n][5] == 0                                     # PiCol is not run on real data (experiments_real.m:62)
         assert all(np.isfinite(res["rot_err"][n][m]) and res["rot_err"][n][m] < 5 for m in (0, 1, 2, 3, 4, 6, 7))
+        assert all(np.isfinite(res["rot_err_ba"][n][m]) and res["rot_err_ba"][n][m] < 5 and res["iter_ba"][n][m] >= 1 for m in (0, 1, 2, 3, 4, 6, 7))
     # Gauss-Helmert on real matches: statistical parity.  Where the KKT matrix is ill-conditioned (fountain triplet 4: cond 1e6) the
     # 1e12-weighted rounding noise of A'Ww dominates the weak directions of the first step in ANY implementation,
     # and the "objective rose" exit then fires at a different iteration: most triplets agree to a few %, a minority does not.

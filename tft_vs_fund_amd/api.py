@@ -92,6 +92,7 @@ def load_library(path=None):
             "tff_rt_from_tft_batch_dev": [V, V, V, I64, V, I64, I32, V, V, V],
             "tff_linear_tft_batch_dev": [V, V, I64, I32, V, V, V, V],
             "tff_linear_f_batch_dev": [V, V, I64, I32, I32, V, V, V, V],
+            "tff_bundle_adjust_batch_dev": [V, V, I64, V, V, V, I64, I32, V, V, V, V, V, V, V],
             "tff_pi_pose_batch_debug_dev": [V, I32, V, V, I64, I64, I32, V, V, V, V, V, V, V, V],
             "tff_linear_tft_pose_sampled_dev": [V, V, I32, V, V, I64, I32, V, V, V, V],
             "tff_linear_f_pose_sampled_dev": [V, V, I32, V, V, I64, I32, V, V, V, V],
@@ -130,7 +131,7 @@ EXPORTED_SYMBOLS = [
     "tff_pi_pose_batch_dev", "tff_pi_pose_batch_host", "tff_picol_pose_batch_dev", "tff_picol_pose_batch_host",
     "tff_pi_pose_batch_debug_dev",
     "tff_triangulate_batch_dev", "tff_repr_error_batch_dev", "tff_inlier_count_batch_dev", "tff_transform_tft_batch_dev",
-    "tff_rt_from_tft_batch_dev", "tff_linear_tft_batch_dev", "tff_linear_f_batch_dev", "tff_linear_tft_pose_sampled_dev", "tff_linear_f_pose_sampled_dev",
+    "tff_rt_from_tft_batch_dev", "tff_linear_tft_batch_dev", "tff_linear_f_batch_dev", "tff_bundle_adjust_batch_dev", "tff_linear_tft_pose_sampled_dev", "tff_linear_f_pose_sampled_dev",
 ]
 
 
@@ -374,6 +375,29 @@ class Context:
                                                          self._p(it), self._p(st)), "tff_linear_f_batch_dev")
         return F21.reshape(B, 3, 3).transpose(1, 2), F31.reshape(B, 3, 3).transpose(1, 2), it, st
 
+    def bundle_adjust(self, calm, R_t_2, R_t_3, corresp, reconst0=None):
+        """BundleAdjustment for B triplets: calm (9,3) or (B,9,3); R_t_2, R_t_3 (B,3,4); corresp (B,N,6); reconst0 (B,3,N) or None.
+        -> dict(R_t_2, R_t_3 (B,3,4), Reconst (B,3,N), iter, repr_err, status)."""
+        self._begin()
+        corresp = self._t(corresp); B, N, _ = corresp.shape
+        dev = corresp.device
+        calm = self._t(calm)
+        if calm.dim() == 2:
+            calm_cm, stride = calm.t().contiguous().reshape(27), 0
+        else:
+            calm_cm, stride = calm.transpose(1, 2).contiguous().reshape(B * 27), 27
+        r2 = self._cams_cm(self._t(R_t_2)); r3 = self._cams_cm(self._t(R_t_3))
+        x0 = self._t(reconst0).transpose(1, 2).contiguous() if reconst0 is not None else None
+        o2 = torch.empty((B, 12), dtype=torch.float64, device=dev); o3 = torch.empty_like(o2)
+        rec = torch.empty((B, N, 3), dtype=torch.float64, device=dev)
+        it = torch.zeros(B, dtype=torch.int32, device=dev); st = torch.zeros_like(it)
+        err = torch.empty(B, dtype=torch.float64, device=dev)
+        _check(self.lib, self.lib.tff_bundle_adjust_batch_dev(self.handle, self._p(calm_cm), stride, self._p(r2), self._p(r3), self._p(corresp), B, N,
+                                                              self._p(x0), self._p(o2), self._p(o3), self._p(rec), self._p(it), self._p(err), self._p(st)),
+               "tff_bundle_adjust_batch_dev")
+        return dict(R_t_2=o2.reshape(B, 4, 3).transpose(1, 2), R_t_3=o3.reshape(B, 4, 3).transpose(1, 2), Reconst=rec.transpose(1, 2),
+                    iter=it, repr_err=err, status=st)
+
     def pose_sampled(self, method, scene, calm, sample_idx):
         """Minimal-sample hypotheses (config 4): scene (Ns, 6), sample_idx (B, n) int32 -> R_t_2, R_t_3 (B,3,4), T, status."""
         self._begin()
@@ -459,3 +483,17 @@ def PiPoseEstimation(Corresp, CalM):
 def PiColPoseEstimation(Corresp, CalM):
     """Drop-in for TFT_methods/PiColPoseEstimation.m (collinear camera centres; iter = Gauss-Helmert iterations)."""
     return _single("PiColPoseEstimation", Corresp, CalM)
+
+
+def BundleAdjustment(CalM, R_t_0, Corresp, Reconst0=None):
+    """Drop-in for Optimization/BundleAdjustment.m with M = 3 views and R_t_0(1:3,:) = eye(3,4): CalM 9x3, R_t_0 9x4,
+    Corresp 6xN, Reconst0 3xN or None -> R_t (9x4), Reconst (3xN), iter, repr_err."""
+    CalM = np.asarray(CalM, dtype=np.float64); R_t_0 = np.asarray(R_t_0, dtype=np.float64); Corresp = np.asarray(Corresp, dtype=np.float64)
+    if R_t_0.shape != (9, 4) or not np.allclose(R_t_0[0:3], np.eye(3, 4)):
+        raise ValueError("R_t_0 must be 9x4 with camera 1 = [I|0]")
+    if np.isnan(Corresp).any():
+        raise ValueError("correspondences missing in some view (NaN) are not supported")
+    out = default_context().bundle_adjust(CalM, R_t_0[3:6][None], R_t_0[6:9][None], np.ascontiguousarray(Corresp.T)[None],
+                                          None if Reconst0 is None else np.asarray(Reconst0, dtype=np.float64)[None])
+    R_t = np.vstack([np.eye(3, 4), out["R_t_2"][0].cpu().numpy(), out["R_t_3"][0].cpu().numpy()])
+    return R_t, out["Reconst"][0].cpu().numpy(), int(out["iter"][0]), float(out["repr_err"][0])

@@ -573,6 +573,23 @@ int tff_linear_tft_batch_dev(tff_ctx* c, const double* corresp, int64_t B, int32
     return 0;
 }
 
+// BundleAdjustment for three views: refines (R_t_2, R_t_3) and the points
+int tff_bundle_adjust_batch_dev(tff_ctx* c, const double* calm, int64_t calm_stride, const double* Rt2_in, const double* Rt3_in,
+                                const double* corresp, int64_t B, int32_t N, const double* reconst0, double* Rt2, double* Rt3,
+                                double* reconst, int32_t* iter, double* repr_err, int32_t* status) {
+    if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
+    if (B == 0) return 0;
+    if (!Rt2_in || !Rt3_in || !Rt2 || !Rt3) return fail(TFF_E_INVALID, "null pose pointer");
+    if (N < 1) return fail(TFF_E_INVALID, "bundle adjustment needs at least one correspondence");
+    TFF_HIP(hipSetDevice(c->device));
+    const size_t lds = tff::ba_lds_bytes(N);
+    if (int r = ensure_lds(tff::k_bundle_adjust, lds)) return r;
+    tff::BaArgs a{calm, (long)calm_stride, Rt2_in, Rt3_in, corresp, (long)B, N, reconst0, Rt2, Rt3, reconst, iter, repr_err, status};
+    hipLaunchKernelGGL(tff::k_bundle_adjust, dim3(tff::pose_grid(B)), dim3(64), lds, c->stream, a);
+    TFF_HIP(hipGetLastError());
+    return 0;
+}
+
 // linearF (refine = 0) / optimF (refine = 1) for the view pairs (1,2) and (1,3)
 int tff_linear_f_batch_dev(tff_ctx* c, const double* corresp, int64_t B, int32_t N, int32_t refine, double* F21, double* F31,
                            int32_t* iter, int32_t* status) {

@@ -15,8 +15,10 @@ AngError over both poses (:117-120), mean iterations, time per triplet (GPU time
 
 Differences, stated: MATLAB's rng stream cannot be reproduced, scenes come from the Philox generator of
 scenes.py (the reference draws N+100 points and keeps a random N: the same distribution as drawing N);
-the bundle-adjustment columns (experiments.m:127-141, index 2 of the reference's result arrays) are not
-produced (not built).
+the bundle-adjustment columns (experiments.m:127-141, index 2 of the reference's result arrays) are
+produced by `Context.bundle_adjust` under the keys `*_ba` (repr_err_ba is BundleAdjustment.m:105's residual norm in
+normalised units, as the reference records it; its optimiser is MATLAB's closed-source lsqnonlin, so iteration counts
+are those of this repo's Levenberg-Marquardt loop).
 
   python -m tft_vs_fund_amd.experiments --option noise --n-sim 20 --out noise.json
   python -m tft_vs_fund_amd.experiments --real tests/golden/epfl.npz --out real.json
@@ -87,7 +89,13 @@ def _cameras(CalM, R2, R3):
     return P
 
 
-def evaluate_batch(ctx, method, C, CalM, R_t0, device=True):
+def _scatter(ok, values):
+    out = np.full(ok.shape[0], np.inf)
+    out[ok] = values
+    return out
+
+
+def evaluate_batch(ctx, method, C, CalM, R_t0, device=True, with_ba=False):
     """All scenes of one interval value through one method.  Returns the per-triplet metrics."""
     B, N, _ = C.shape
     timer = None
@@ -108,16 +116,32 @@ def evaluate_batch(ctx, method, C, CalM, R_t0, device=True):
     r3, t3 = AngError_batch(R_t0[1], np.where(ok[:, None, None], R3, dummy))
     rot = np.where(ok, (r2 + r3) / 2, np.inf)
     tr = np.where(ok, (t2 + t3) / 2, np.inf)
-    return dict(repr_err=repr_err, rot_err=rot, t_err=tr, iter=out["iter"].astype(np.float64), ok=ok, seconds_per_triplet=sec)
+    res = dict(repr_err=repr_err, rot_err=rot, t_err=tr, iter=out["iter"].astype(np.float64), ok=ok, seconds_per_triplet=sec)
+    if with_ba and ok.any() and hasattr(ctx, "bundle_adjust"):
+        # BundleAdjustment(CalM, [eye(3,4); R_t_2; R_t_3], Corresp, Reconst)   (experiments.m:127-129)
+        call = lambda: ctx.bundle_adjust(CalM, R2[ok], R3[ok], C[ok], out["Reconst"][ok])
+        if device:
+            import torch
+            ba, ba_sec = _cuda_timer(torch)(call)
+        else:
+            t0 = time.perf_counter(); ba = call(); ba_sec = time.perf_counter() - t0
+        bR2, bR3 = _np(ba["R_t_2"]), _np(ba["R_t_3"])
+        a2, b2 = AngError_batch(R_t0[0], bR2); a3, b3 = AngError_batch(R_t0[1], bR3)                # :134-137
+        full = lambda v: _scatter(ok, v)
+        res.update(repr_err_ba=full(_np(ba["repr_err"])), rot_err_ba=full((a2 + a3) / 2), t_err_ba=full((b2 + b3) / 2),
+                   iter_ba=full(_np(ba["iter"]).astype(np.float64)), seconds_per_triplet_ba=ba_sec / max(int(ok.sum()), 1))
+    return res
 
 
 def synthetic_sweep(ctx, option="noise", n_sim=20, N=12, noise=1.0, f=50.0, angle=0.0, interval=None, methods=None,
-                    seed0=1, device=True):
+                    seed0=1, device=True, with_ba=True):
     """experiments.m:28-125 for one `option`.  Returns a dict of (len(interval) x 8) lists (means over the simulations
     that returned a pose; `failed` counts the others), inf where the reference records inf (too few points)."""
     interval = list(INTERVALS[option] if interval is None else interval)
     mt = methods_to_test(option) if methods is None else list(methods)
     keys = ("repr_err", "rot_err", "t_err", "iter", "time")
+    if with_ba:
+        keys = keys + tuple(k + "_ba" for k in keys)
     res = {k: np.zeros((len(interval), len(METHODS))) for k in keys}
     failed = np.zeros((len(interval), len(METHODS)), dtype=np.int64)
     for i, val in enumerate(interval):
@@ -137,16 +161,20 @@ def synthetic_sweep(ctx, option="noise", n_sim=20, N=12, noise=1.0, f=50.0, angl
                 for k in keys:
                     res[k][i, m] = np.inf
                 continue
-            ev = evaluate_batch(ctx, METHODS[m], C, CalM, R_t0, device)
+            ev = evaluate_batch(ctx, METHODS[m], C, CalM, R_t0, device, with_ba)
             ok = ev["ok"]
             failed[i, m] = int((~ok).sum())
             for k in ("repr_err", "rot_err", "t_err", "iter"):
                 res[k][i, m] = float(np.mean(ev[k][ok])) if ok.any() else np.inf
+                if with_ba:
+                    res[k + "_ba"][i, m] = float(np.mean(ev[k + "_ba"][ok])) if (ok.any() and k + "_ba" in ev) else np.inf
             res["time"][i, m] = ev["seconds_per_triplet"]
+            if with_ba:
+                res["time_ba"][i, m] = ev.get("seconds_per_triplet_ba", np.inf)
     out = dict(option=option, interval=[float(v) for v in interval], methods=METHODS, methods_tested=[METHODS[m] for m in mt],
                n_sim=n_sim, N=N, noise=noise, focal=f, angle=angle, failed=failed.tolist(),
                note="means over the simulations that returned a pose; time = seconds per triplet of the batched call; "
-                    "no bundle-adjustment columns")
+                    "*_ba: after BundleAdjustment (repr_err_ba in normalised units, as experiments.m:131 records it)")
     out.update({k: v.tolist() for k, v in res.items()})
     return out
 
@@ -186,12 +214,13 @@ def load_epfl_dataset(path_to_data, n_triplets):
     return trips
 
 
-def real_sweep(ctx, triplets, initial_sample_size=100, repr_err_th=1.0, methods=None, seed0=1):
+def real_sweep(ctx, triplets, initial_sample_size=100, repr_err_th=1.0, methods=None, seed0=1, bundle_adj_size=50):
     """experiments_real.m:76-138 over `triplets` (dicts with Corresp 6xN, CalM, R_t0).  Per triplet and method:
     ReprError over all inliers (re-triangulated, :130-131), AngError, iterations, time."""
     mt = [0, 1, 2, 3, 4, 6, 7] if methods is None else list(methods)                               # :62
     T = len(triplets)
     keys = ("repr_err", "rot_err", "t_err", "iter", "time")
+    keys = keys + tuple(k + "_ba" for k in keys)
     res = {k: np.zeros((T, len(METHODS))) for k in keys}
     info = []
     for it, tr in enumerate(triplets):
@@ -208,6 +237,8 @@ def real_sweep(ctx, triplets, initial_sample_size=100, repr_err_th=1.0, methods=
         sel = np.sort(rng.choice(N, size=min(initial_sample_size, N), replace=False))
         Cs = np.ascontiguousarray(Ci[:, sel].T)[None]
         Call = np.ascontiguousarray(Ci.T)[None]
+        ref = np.sort(rng.choice(sel, size=min(bundle_adj_size, sel.size), replace=False))          # :106-108 (ref_sample out of init_sample)
+        Cref = np.ascontiguousarray(Ci[:, ref].T)[None]
         info.append(dict(name=tr.get("name", str(it)), matches=int(Corresp.shape[1]), inliers=int(N), sample=int(sel.size),
                          repr_err_gt=float(_np(ctx.repr_error(P0[None], Call))[0])))
         for m in mt:
@@ -226,8 +257,20 @@ def real_sweep(ctx, triplets, initial_sample_size=100, repr_err_th=1.0, methods=
             r2, t2 = AngError_batch(R_t0[0], out["R_t_2"]); r3, t3 = AngError_batch(R_t0[1], out["R_t_3"])
             res["rot_err"][it, m] = float((r2[0] + r3[0]) / 2); res["t_err"][it, m] = float((t2[0] + t3[0]) / 2)
             res["iter"][it, m] = float(out["iter"][0]); res["time"][it, m] = sec
+            # BundleAdjustment(CalM, [eye(3,4); R_t_2; R_t_3], Corresp_ref) -- no initial points   (:140-142)
+            ba, ba_sec = _cuda_timer(torch)(lambda: ctx.bundle_adjust(CalM, out["R_t_2"], out["R_t_3"], Cref, None))
+            if int(_np(ba["status"])[0]) != 0:
+                for k in keys[5:]:
+                    res[k][it, m] = np.inf
+                continue
+            bR2, bR3 = _np(ba["R_t_2"]), _np(ba["R_t_3"])
+            res["repr_err_ba"][it, m] = float(_np(ctx.repr_error(_cameras(CalM, bR2, bR3), Call))[0])    # :145-147
+            r2, t2 = AngError_batch(R_t0[0], bR2); r3, t3 = AngError_batch(R_t0[1], bR3)
+            res["rot_err_ba"][it, m] = float((r2[0] + r3[0]) / 2); res["t_err_ba"][it, m] = float((t2[0] + t3[0]) / 2)
+            res["iter_ba"][it, m] = float(_np(ba["iter"])[0]); res["time_ba"][it, m] = ba_sec
     out = dict(methods=METHODS, methods_tested=[METHODS[m] for m in mt], triplets=info,
-               note="one row per triplet; time = seconds of the single-triplet call; no bundle-adjustment columns")
+               note="one row per triplet; time = seconds of the single-triplet call; *_ba: after BundleAdjustment on a 50-correspondence "
+                    "subset of the sample, ReprError again over all inliers (experiments_real.m:140-153)")
     out.update({k: v.tolist() for k, v in res.items()})
     return out
 
