@@ -222,6 +222,9 @@ int tff_linear_f_batch_dev(tff_ctx* ctx, const double* corresp, int64_t B, int32
 int tff_bundle_adjust_batch_dev(tff_ctx* ctx, const double* calm, int64_t calm_stride, const double* Rt2_in,
                                 const double* Rt3_in, const double* corresp, int64_t B, int32_t N, const double* reconst0,
                                 double* Rt2, double* Rt3, double* reconst, int32_t* iter, double* repr_err, int32_t* status);
+int tff_bundle_adjust_batch_host(tff_ctx* ctx, const double* calm, int64_t calm_stride, const double* Rt2_in,
+                                 const double* Rt3_in, const double* corresp, int64_t B, int32_t N, const double* reconst0,
+                                 double* Rt2, double* Rt3, double* reconst, int32_t* iter, double* repr_err, int32_t* status);
 
 /* Minimal-sample hypotheses (BASELINE.json config 4): hypothesis b = the n correspondences
  * sample_idx[b*n .. b*n+n) of one shared scene (6 x Ns); n >= 7 (TFT) / 8 (F); shared CalM (27). */

@@ -93,6 +93,7 @@ def load_library(path=None):
             "tff_linear_tft_batch_dev": [V, V, I64, I32, V, V, V, V],
             "tff_linear_f_batch_dev": [V, V, I64, I32, I32, V, V, V, V],
             "tff_bundle_adjust_batch_dev": [V, V, I64, V, V, V, I64, I32, V, V, V, V, V, V, V],
+            "tff_bundle_adjust_batch_host": [V, V, I64, V, V, V, I64, I32, V, V, V, V, V, V, V],
             "tff_pi_pose_batch_debug_dev": [V, I32, V, V, I64, I64, I32, V, V, V, V, V, V, V, V],
             "tff_linear_tft_pose_sampled_dev": [V, V, I32, V, V, I64, I32, V, V, V, V],
             "tff_linear_f_pose_sampled_dev": [V, V, I32, V, V, I64, I32, V, V, V, V],
@@ -131,7 +132,7 @@ EXPORTED_SYMBOLS = [
     "tff_pi_pose_batch_dev", "tff_pi_pose_batch_host", "tff_picol_pose_batch_dev", "tff_picol_pose_batch_host",
     "tff_pi_pose_batch_debug_dev",
     "tff_triangulate_batch_dev", "tff_repr_error_batch_dev", "tff_inlier_count_batch_dev", "tff_transform_tft_batch_dev",
-    "tff_rt_from_tft_batch_dev", "tff_linear_tft_batch_dev", "tff_linear_f_batch_dev", "tff_bundle_adjust_batch_dev", "tff_linear_tft_pose_sampled_dev", "tff_linear_f_pose_sampled_dev",
+    "tff_rt_from_tft_batch_dev", "tff_linear_tft_batch_dev", "tff_linear_f_batch_dev", "tff_bundle_adjust_batch_dev", "tff_bundle_adjust_batch_host", "tff_linear_tft_pose_sampled_dev", "tff_linear_f_pose_sampled_dev",
 ]
 
 

@@ -590,6 +590,41 @@ int tff_bundle_adjust_batch_dev(tff_ctx* c, const double* calm, int64_t calm_str
     return 0;
 }
 
+// host-pointer variant: H2D, launch, D2H, synchronise (what the MEX shim calls)
+int tff_bundle_adjust_batch_host(tff_ctx* c, const double* calm, int64_t calm_stride, const double* Rt2_in, const double* Rt3_in,
+                                 const double* corresp, int64_t B, int32_t N, const double* reconst0, double* Rt2, double* Rt3,
+                                 double* reconst, int32_t* iter, double* repr_err, int32_t* status) {
+    if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
+    if (B == 0) return 0;
+    if (!Rt2_in || !Rt3_in || !Rt2 || !Rt3) return fail(TFF_E_INVALID, "null pose pointer");
+    TFF_HIP(hipSetDevice(c->device));
+    const size_t nin = (size_t)B * 6 * (size_t)N * sizeof(double), npt = (size_t)B * 3 * (size_t)N * sizeof(double);
+    const size_t ncal = (calm_stride ? (size_t)B : 1) * 27 * sizeof(double), npose = (size_t)B * 12 * sizeof(double);
+    if (int r = c->in.reserve(nin + npt + 2 * npose)) return r;
+    if (int r = c->calm.reserve(ncal)) return r;
+    if (int r = c->out.reserve(2 * npose + npt + (size_t)B * sizeof(double))) return r;
+    if (int r = c->idx.reserve((size_t)B * 2 * sizeof(int32_t))) return r;
+    char* din = (char*)c->in.p;
+    double* d_C = (double*)din; double* d_X0 = (double*)(din + nin); double* d_r2 = (double*)(din + nin + npt); double* d_r3 = (double*)(din + nin + npt + npose);
+    char* dout = (char*)c->out.p;
+    double* d_o2 = (double*)dout; double* d_o3 = (double*)(dout + npose); double* d_rec = (double*)(dout + 2 * npose); double* d_err = (double*)(dout + 2 * npose + npt);
+    int32_t* d_it = (int32_t*)c->idx.p; int32_t* d_st = d_it + B;
+    TFF_HIP(hipMemcpyAsync(d_C, corresp, nin, hipMemcpyHostToDevice, c->stream));
+    if (reconst0) TFF_HIP(hipMemcpyAsync(d_X0, reconst0, npt, hipMemcpyHostToDevice, c->stream));
+    TFF_HIP(hipMemcpyAsync(d_r2, Rt2_in, npose, hipMemcpyHostToDevice, c->stream));
+    TFF_HIP(hipMemcpyAsync(d_r3, Rt3_in, npose, hipMemcpyHostToDevice, c->stream));
+    TFF_HIP(hipMemcpyAsync(c->calm.p, calm, ncal, hipMemcpyHostToDevice, c->stream));
+    if (int r = tff_bundle_adjust_batch_dev(c, (double*)c->calm.p, calm_stride, d_r2, d_r3, d_C, B, N, reconst0 ? d_X0 : nullptr, d_o2, d_o3, d_rec, d_it, d_err, d_st)) return r;
+    TFF_HIP(hipMemcpyAsync(Rt2, d_o2, npose, hipMemcpyDeviceToHost, c->stream));
+    TFF_HIP(hipMemcpyAsync(Rt3, d_o3, npose, hipMemcpyDeviceToHost, c->stream));
+    if (reconst) TFF_HIP(hipMemcpyAsync(reconst, d_rec, npt, hipMemcpyDeviceToHost, c->stream));
+    if (iter) TFF_HIP(hipMemcpyAsync(iter, d_it, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (repr_err) TFF_HIP(hipMemcpyAsync(repr_err, d_err, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (status) TFF_HIP(hipMemcpyAsync(status, d_st, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    TFF_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 // linearF (refine = 0) / optimF (refine = 1) for the view pairs (1,2) and (1,3)
 int tff_linear_f_batch_dev(tff_ctx* c, const double* corresp, int64_t B, int32_t N, int32_t refine, double* F21, double* F31,
                            int32_t* iter, int32_t* status) {

@@ -32,3 +32,21 @@ for name, stem, variant in variants:
         ms = e0.elapsed_time(e1) / K
         print("%-26s reconst=%d  %8.3f ms/batch  %.3e triplets/s  bad=%d  mean iter %.2f" % (
             name, with_rec, ms, B / ms * 1e3, int((st != 0).sum()), float(it.double().mean())), flush=True)
+# BundleAdjustment from the linear TFT poses (N = 100 as experiments_real.m's samples, and the configs[1] batch)
+for Bb, Nb in ((10000, 100), (B, N)):
+    Cb, CalMb, _, _ = generate_scene_batch(Bb, Nb, noise=1.0, seed=2)
+    db = torch.from_numpy(Cb).cuda(); cb = torch.from_numpy(CalMb).cuda()
+    ctx.set_kernel_variant(0)
+    lin = ctx.pose_batch("LinearTFTPoseEstimation", db, cb, reconst=True)
+    r2, r3, x0 = lin["R_t_2"].contiguous(), lin["R_t_3"].contiguous(), lin["Reconst"].contiguous()
+    for _ in range(3):
+        out = ctx.bundle_adjust(cb, r2, r3, db, x0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        out = ctx.bundle_adjust(cb, r2, r3, db, x0)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print("%-26s N=%-4d    %8.3f ms/batch  %.3e triplets/s  bad=%d  mean iter %.2f" % ("BundleAdjustment", Nb, ms, Bb / ms * 1e3, int((out["status"] != 0).sum()),
+                                                                                    float(out["iter"].double().mean())), flush=True)
