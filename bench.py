@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=10000)
     ap.add_argument("--ncorr", type=int, default=200)
-    ap.add_argument("--cpu-sample", type=int, default=0, help="triplets timed on the CPU (default: 16 per host core, at least 1024)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="triplets timed on the CPU (default: 40 per host core, at least 1024, at most the batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the LinearF / Ressl secondary metrics (1 GPU, rank 0)")
     args = ap.parse_args()
@@ -190,7 +190,7 @@ def main():
         if secondary:
             out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
-            sample = args.cpu_sample or max(1024, 16 * (os.cpu_count() or 1))
+            sample = args.cpu_sample or max(1024, 40 * (os.cpu_count() or 1))   # ~10 s of wall time on the box's host cores
             out["cpu_baseline"] = cpu_baseline(C, CalM, min(sample, B))
         print(json.dumps(out), flush=True)
     if world > 1:
