@@ -65,6 +65,30 @@ extern "C" int emu_pi_pose_debug(int collinear, const double* corresp, const dou
                     corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status, nullptr, init_p, init_x);
 }
 // Gauss-Helmert methods through the three-launch workgroup path (gh_wg_kernel.h): model 0 Ressl, 1 Nordberg, 2 FaugPapa
+template <class KBlock>
+static int emu_wg_run(KBlock kblock, size_t lds_block, const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                      double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status) {
+    std::vector<double> rec((size_t)B * tff::GH_REC_DOUBLES), topt((size_t)B * 27);
+    tff::GhWgArgs a{corresp, calm, calm_stride, B, N, (flags & ~tff::FLAG_JACOBI) | (reconst ? tff::FLAG_RECONST : 0), rec.data(), topt.data(),
+                    Rt2, Rt3, T, reconst, iter, status, nullptr, nullptr, 0};
+    emu::launch(tff::k_gh_linear<false>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, a.flags, false), a);
+    tff::GhWgArgs m = a;
+    m.flags |= tff::FLAG_ONLY_RETRY;
+    emu::launch(tff::k_gh_linear<true>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
+    emu::launch(kblock, tff::pose_grid(B), tff::GH_WG_THREADS, lds_block, a);
+    emu::launch(tff::k_gh_finish, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
+    return 0;
+}
+// Pi / PiCol through the workgroup path (pi_wg_kernel.h)
+extern "C" int emu_pi_wg_pose(int collinear, const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                              double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status) {
+    const size_t pre = (size_t)((tff::POSE_LDS_DOUBLES + 1) & ~1);
+    if (collinear)
+        return emu_wg_run(tff::k_pi_block<tff::PiColModel>, (pre + tff::pi_wg_lds_doubles(tff::PiColModel::E, tff::PiColModel::C, N)) * sizeof(double),
+                          corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status);
+    return emu_wg_run(tff::k_pi_block<tff::PiModel>, (pre + tff::pi_wg_lds_doubles(tff::PiModel::E, tff::PiModel::C, N)) * sizeof(double),
+                      corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status);
+}
 template <class Model>
 static int emu_gh_wg_impl(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
                           double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status) {

@@ -159,6 +159,23 @@ def test_gh_workgroup_path_matches_fused_kernel(emu):
     assert st[0] == 1 and np.all(np.isnan(T))
 
 
+@pytest.mark.parametrize("collinear,angle", [(0, None), (1, 180)])
+def test_pi_workgroup_path_matches_fused_kernel(emu, collinear, angle):
+    """k_pi_block (four wavefronts per triplet, pi_wg_kernel.h) against the fused single-wavefront Pi kernels."""
+    B, N = 1, 14
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=61, angle=angle)
+    calm = calm_colmajor(CalM)
+    Rt2 = np.zeros((B, 12)); Rt3 = np.zeros((B, 12)); T = np.zeros((B, 27)); Rec = np.zeros((B, N, 3))
+    it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32)
+    emu.emu_pi_wg_pose(ctypes.c_int(collinear), _p(C), _p(calm), ctypes.c_long(0), ctypes.c_long(B), ctypes.c_int(N), ctypes.c_int(0),
+                       _p(Rt2), _p(Rt3), _p(T), _p(Rec), _p(it), _p(st))
+    ref = run_linear_tft(emu, C, CalM, entry="emu_picol_pose" if collinear else "emu_pi_pose")
+    assert st[0] == 0 and ref["status"][0] == 0 and abs(int(it[0]) - int(ref["iter"][0])) <= 5
+    tol = (2e-3 if it[0] == ref["iter"][0] else 1e-2) * (10 if collinear else 1)
+    assert rel_err_T(T.reshape(3, 3, 3).transpose(2, 1, 0), ref["T"][0]) < tol
+    assert rel_err(Rt3.reshape(4, 3).T, ref["R_t_3"][0]) < tol and rel_err(Rec[0].T, ref["Reconst"][0]) < 10 * tol
+
+
 def run_pi_debug(lib, collinear, C, CalM, flags=0):
     B, N, _ = C.shape
     calm = calm_colmajor(CalM)

@@ -189,13 +189,12 @@ int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_
                        reconst, iter, status, dbg);
 }
 
-// Gauss-Helmert methods: three launches, a workgroup of four wavefronts per triplet for the iteration (gh_wg_kernel.h).
-// TFF_OPT_KERNEL = 1, a debug buffer, or TFF_OPT_SOLVER = 1 select the fused single-wavefront kernel (gh_kernel.h).
-template <class Model, class KFused, class KFusedJac>
-int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
+// Iterative TFT methods: three launches, a workgroup of four wavefronts per triplet for the iteration (gh_wg_kernel.h,
+// pi_wg_kernel.h): k_gh_linear (+ Jacobi fix-up), the block kernel, k_gh_finish.  wg_lds(n): LDS bytes of the block kernel for n
+// correspondences held in LDS.
+template <class KBlock, class LdsFn>
+int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    if (c->kernel_variant != 0 || c->solver != 0)
-        return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     if (B == 0) return 0;
     if (!Rt2 || !Rt3 || !T) return fail(TFF_E_INVALID, "null output pointer");
@@ -222,13 +221,12 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
         TFF_HIP(hipGetLastError());
     }
     {
-        auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
         tff::GhWgArgs m = a;
         unsigned grid = tff::pose_grid(B);
         size_t lds;
         if (int r = plan_spill(c, wg_lds(N), wg_lds(0), &grid, &m.spill, &m.spill_stride, &lds)) return r;
-        if (int r = ensure_lds(tff::k_gh_block<Model>, lds)) return r;
-        hipLaunchKernelGGL(tff::k_gh_block<Model>, dim3(grid), dim3(tff::GH_WG_THREADS), lds, c->stream, m);
+        if (int r = ensure_lds(kblock, lds)) return r;
+        hipLaunchKernelGGL(kblock, dim3(grid), dim3(tff::GH_WG_THREADS), lds, c->stream, m);
         TFF_HIP(hipGetLastError());
     }
     {
@@ -237,6 +235,24 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
         TFF_HIP(hipGetLastError());
     }
     return 0;
+}
+// TFF_OPT_KERNEL = 1 or TFF_OPT_SOLVER = 1 select the fused single-wavefront kernels (gh_kernel.h, pi_kernel.h).
+template <class Model, class KFused, class KFusedJac>
+int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
+              double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+    if (c->kernel_variant != 0 || c->solver != 0)
+        return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
+    return launch_wg(c, tff::k_gh_block<Model>, wg_lds, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+}
+template <class Model>
+int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
+                    double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+    if (c->kernel_variant != 0 || c->solver != 0 || c->init_p)               // the debug outputs (init_p, init_x) come from the fused kernel
+        return launch_pose(c, tff::k_pi_tft_pose<Model, false>, tff::k_pi_tft_pose<Model, true>, tff::pi_lds_bytes<Model>, false,
+                           corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::pi_wg_lds_doubles(Model::E, Model::C, n)) * sizeof(double); };
+    return launch_wg(c, tff::k_pi_block<Model>, wg_lds, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 int launch_ressl_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
@@ -255,13 +271,11 @@ int launch_faugpapa_tft(tff_ctx* c, const double* corresp, const double* calm, i
 }
 int launch_pi(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    return launch_pose(c, tff::k_pi_tft_pose<tff::PiModel, false>, tff::k_pi_tft_pose<tff::PiModel, true>,
-                       tff::pi_lds_bytes<tff::PiModel>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    return launch_pi_model<tff::PiModel>(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 int launch_picol(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                  double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    return launch_pose(c, tff::k_pi_tft_pose<tff::PiColModel, false>, tff::k_pi_tft_pose<tff::PiColModel, true>,
-                       tff::pi_lds_bytes<tff::PiColModel>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    return launch_pi_model<tff::PiColModel>(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 
 typedef int (*pose_launcher)(tff_ctx*, const double*, const double*, int64_t, int64_t, int32_t, double*, double*, double*, double*,

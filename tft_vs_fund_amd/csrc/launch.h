@@ -6,6 +6,7 @@
 #include "blocks_kernel.h"
 #include "pi_kernel.h"
 #include "gh_wg_kernel.h"
+#include "pi_wg_kernel.h"
 #include "ba_kernel.h"
 
 namespace tff {

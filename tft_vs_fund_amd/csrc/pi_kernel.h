@@ -509,14 +509,14 @@ __device__ __forceinline__ double sym_at(const double* Wp, int a, int b) { retur
 
 // one accumulation sweep: S < 15: block pairs e = 3S .. 3S+2 of A'WA; S == 15: A'Ww
 template <class Model, int S>
-__device__ inline void pi_sweep(const PiWork& g, const double (&pi)[27], int N) {
+__device__ inline void pi_sweep(const PiWork& g, const double (&pi)[27], int N, int first, int step, double* Hp) {
     constexpr int E = Model::E, PP = pi_pp(E), NW = E * (E + 1) / 2;
     const int lane = lane_id();
     double acc[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.0;
 #pragma unroll 1
-    for (int i = lane; i < N; i += WAVE) {
+    for (int i = first; i < N; i += step) {
         double o[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
@@ -564,12 +564,13 @@ __device__ inline void pi_sweep(const PiWork& g, const double (&pi)[27], int N) 
     }
     const double tot = wave_reduce_scatter<32>(acc);
     const int idx = reduce32_index(lane);
-    if ((lane & 1) == 0 && idx < 27) g.H[27 * S + idx] = tot;
+    if ((lane & 1) == 0 && idx < 27) Hp[27 * S + idx] = tot;
 }
+// all 16 sweeps over the correspondences first, first + step, ...; sums of this wavefront -> Hp[0..431]
 template <class Model, int S>
-__device__ __forceinline__ void pi_sweeps(const PiWork& g, const double (&pi)[27], int N) {
-    pi_sweep<Model, S>(g, pi, N);
-    if constexpr (S < 15) pi_sweeps<Model, S + 1>(g, pi, N);
+__device__ __forceinline__ void pi_sweeps(const PiWork& g, const double (&pi)[27], int N, int first, int step, double* Hp) {
+    pi_sweep<Model, S>(g, pi, N, first, step, Hp);
+    if constexpr (S < 15) pi_sweeps<Model, S + 1>(g, pi, N, first, step, Hp);
 }
 
 // w = -f - B (x - xi) (Gauss_Helmert.m:58); stores W+ (packed) and W+ w of correspondence i
@@ -695,7 +696,7 @@ __device__ inline int gauss_helmert_pi_wave(PoseLds* w, PiWork& g, const double*
         }
         wave_sync();
         // ---- A'WA and A'Ww   (:59-62) ----
-        pi_sweeps<Model, 0>(g, pi, N);
+        pi_sweeps<Model, 0>(g, pi, N, lane, WAVE, g.H);
         wave_sync();
         for (int e = lane; e < n * ld; e += WAVE) g.M[e] = 0.0;
         wave_sync();

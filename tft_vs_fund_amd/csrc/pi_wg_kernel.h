@@ -1,0 +1,277 @@
+// PiPoseEstimation / PiColPoseEstimation with a workgroup of four wavefronts per triplet for the Gauss-Helmert iteration:
+// the layout of gh_wg_kernel.h (k_gh_linear -> k_pi_block<Model> -> k_gh_finish) applied to the Pi models of pi_kernel.h.
+// Per-correspondence passes are strided over the 256 threads, the 16 accumulation sweeps are reduced per wavefront and the four
+// partials added in a fixed order (they live in the eigenvector storage V and in H, both dead at that point), the 36 x 36 KKT
+// system is solved by one wavefront (wave_solve_gj) and the truncated pseudo-inverse (PiCol always, Pi when the elimination
+// meets a negligible pivot) by the whole workgroup (block_pinv_solve_sym).  TFF_OPT_KERNEL = 1 selects the fused kernel.
+#pragma once
+#include "pi_kernel.h"
+#include "gh_wg_kernel.h"
+
+namespace tff {
+
+__host__ __device__ inline int pi_wg_lds_doubles(int E, int C, int N) { return pi_lds_doubles(E, C, N, true) + 16; }
+
+template <class Model>
+__device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red, int own, const double* pts, int N, int* st, bool exact_pinv) {
+    constexpr int E = Model::E, C = Model::C, u = 27, n = u + C, ld = n + 1, PP = pi_pp(E), NW = E * (E + 1) / 2;
+    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    const bool owner = wave == own;
+    double objFunc = 0.0;                                                    // v0' v0, v0 = x0 - x   (:45-46)
+    for (int i = tid; i < N; i += GH_WG_THREADS) {
+        const Pt6 x = premap(load_pt(pts, i), w->nrm);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { const double d = g.xi[6 * i + k] - x.v[k]; objFunc += d * d; }
+    }
+    objFunc = block_sum(objFunc, red);
+    int it = 0;
+#pragma unroll 1
+    for (it = 1; it <= GH_IT_MAX; ++it) {
+        double pi[27];
+        load_uniform27(g.p, pi);
+        double f2max = 0.0;
+        bool finite = true;
+        for (int i = tid; i < N; i += GH_WG_THREADS) {
+            double o[6], W[E][E];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+            PiPoint<E> pt;
+            pi_eval<Model, true>(pi, o, pt);
+            pi_block_W<E>(pt.B, W);
+            double chk = 0.0, fro2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < E; ++a)
+#pragma unroll
+                for (int b = 0; b < E; ++b) { chk += W[a][b]; fro2 += W[a][b] * W[a][b]; }
+            finite = finite && (fabs(chk) <= 1.79e308);
+            f2max = (fro2 > f2max) ? fro2 : f2max;
+        }
+        f2max = block_max(f2max, red);
+        if (block_any(!finite, red) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
+        bool fast = !exact_pinv && (double)E * (double)N * eps_of(sqrt(f2max)) < 0.9e-12;
+        if (fast) {
+            bool bad = false;
+            for (int i = tid; i < N; i += GH_WG_THREADS) {
+                double o[6], W[E][E], Wp[NW];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                PiPoint<E> pt;
+                pi_eval<Model, true>(pi, o, pt);
+                pi_block_W<E>(pt.B, W);
+                bad = !spd_inverse_packed<E>(W, Wp) || bad;
+#pragma unroll
+                for (int a = 0; a < E; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
+                pi_store_point<E>(g, w, pts, i, o, pt, Wp);
+            }
+            if (block_any(bad, red)) fast = false;
+        }
+        if (!fast) {
+            double smax = 0.0;
+            for (int i = tid; i < N; i += GH_WG_THREADS) {
+                double o[6], W[E][E], V[E][E];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                PiPoint<E> pt;
+                pi_eval<Model, true>(pi, o, pt);
+                pi_block_W<E>(pt.B, W);
+                jacobi_small<E, false>(W, V);
+#pragma unroll
+                for (int a = 0; a < E; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+            }
+            smax = block_max(smax, red);
+            const double tolW = (double)E * (double)N * eps_of(smax);
+            for (int i = tid; i < N; i += GH_WG_THREADS) {
+                double o[6], W[E][E], V[E][E];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                PiPoint<E> pt;
+                pi_eval<Model, true>(pi, o, pt);
+                pi_block_W<E>(pt.B, W);
+                jacobi_small<E, true>(W, V);
+                double inv[E];
+#pragma unroll
+                for (int a = 0; a < E; ++a) inv[a] = (W[a][a] > tolW) ? 1.0 / W[a][a] : 0.0;
+                double Wp[NW];
+#pragma unroll
+                for (int a = 0; a < E; ++a)
+#pragma unroll
+                    for (int b = 0; b <= a; ++b) {
+                        double s = (a == b) ? 1e-12 : 0.0;
+#pragma unroll
+                        for (int k = 0; k < E; ++k) s += V[a][k] * inv[k] * V[b][k];
+                        Wp[a * (a + 1) / 2 + b] = s;
+                    }
+                pi_store_point<E>(g, w, pts, i, o, pt, Wp);
+            }
+        }
+        // ---- A'WA and A'Ww: per-wavefront partial sums in V (waves 0..2) and H (wave 3), then added in a fixed order ----
+        double* Hp = (wave < 3) ? g.V + 432 * wave : g.H;
+        pi_sweeps<Model, 0>(g, pi, N, tid, GH_WG_THREADS, Hp);
+        __syncthreads();
+        double hs[2] = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + k * GH_WG_THREADS;
+            if (e < 432) hs[k] = (g.V[e] + g.V[432 + e]) + (g.V[864 + e] + g.H[e]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + k * GH_WG_THREADS;
+            if (e < 432) g.H[e] = hs[k];
+        }
+        for (int e = tid; e < n * ld; e += GH_WG_THREADS) g.M[e] = 0.0;
+        __syncthreads();
+        for (int e = tid; e < 729 + 27; e += GH_WG_THREADS) {
+            if (e < 729) {
+                const int r = e / 27, cc = e % 27;
+                const int b = r / 3, k = r % 3, bp = cc / 3, kk = cc % 3;
+                const double v = (b >= bp) ? g.H[9 * (b * (b + 1) / 2 + bp) + 3 * k + kk] : g.H[9 * (bp * (bp + 1) / 2 + b) + 3 * kk + k];
+                g.M[r * ld + cc] = v + ((r == cc) ? 1e-12 : 0.0);
+            } else {
+                g.M[(e - 729) * ld + n] = g.H[405 + e - 729];
+            }
+        }
+        if (tid < C) {                                                       // constraints g, C   (KKT borders)
+            const int b = Model::cb(tid, 0), bp = Model::cb(tid, 1), row = u + tid;
+            double gv = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                const double pb = g.p[3 * b + k], pbp = g.p[3 * bp + k];
+                gv += pb * pbp;
+                if (b == bp) { g.M[row * ld + 3 * b + k] = 2.0 * pb; g.M[(3 * b + k) * ld + row] = 2.0 * pb; }
+                else {
+                    g.M[row * ld + 3 * b + k] = pbp; g.M[(3 * b + k) * ld + row] = pbp;
+                    g.M[row * ld + 3 * bp + k] = pb; g.M[(3 * bp + k) * ld + row] = pb;
+                }
+            }
+            g.M[row * ld + n] = -(gv - ((b == bp) ? 1.0 : 0.0));
+            g.M[row * ld + row] = 1e-12;
+        }
+        __syncthreads();
+        double chkM = 0.0;
+        for (int e = tid; e < n * ld; e += GH_WG_THREADS) chkM += g.M[e];
+        if (!(fabs(block_sum(chkM, red)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
+        // aux = pinv(M + 1e-12 I) b   (:67)
+        bool need_pinv = Model::PINV_KKT;
+        if (!Model::PINV_KKT) {
+            if (owner) { const bool ok = wave_solve_gj<n>(g.M, g.dt); if (lane == 0) red[8] = ok ? 1.0 : 0.0; }
+            __syncthreads();
+            need_pinv = red[8] == 0.0;
+        }
+        if (need_pinv) block_pinv_solve_sym<n>(g.M, g.V, g.dt, g.H);          // eigenvectors -> V, pair table -> H (both dead by now)
+        __syncthreads();
+        double dt[27];
+        load_uniform27(g.dt, dt);
+        // ---- v = -B' W+ (A dt - w)   (:69) ----
+        double obj = 0.0, diff = 0.0;
+        for (int i = tid; i < N; i += GH_WG_THREADS) {
+            double o[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+            PiPoint<E> pt;
+            pi_eval<Model, true>(pi, o, pt);
+            Model::a_quirk(pt.c);
+            double q[9];
+#pragma unroll
+            for (int b = 0; b < 9; ++b) q[b] = dt[3 * b] * o[2 * (b / 3)] + dt[3 * b + 1] * o[2 * (b / 3) + 1] + dt[3 * b + 2];
+            double Ad[E];
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                double s = 0.0;
+#pragma unroll
+                for (int b = 0; b < 9; ++b)
+                    if (Model::nz(r, b)) s += pt.c[r][b] * q[b];
+                Ad[r] = s;
+            }
+            double* pw = g.pp + (long)PP * i;
+            double rr[E];
+#pragma unroll
+            for (int a = 0; a < E; ++a) {
+                double s = -pw[NW + a];
+#pragma unroll
+                for (int b = 0; b < E; ++b) s += sym_at<E>(pw, a, b) * Ad[b];
+                rr[a] = s;
+            }
+            const Pt6 x = premap(load_pt(pts, i), w->nrm);
+            double vv[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                double s = 0.0;
+#pragma unroll
+                for (int a = 0; a < E; ++a) s -= pt.B[a][k] * rr[a];
+                vv[k] = s;
+                obj += s * s;
+                const double d = o[k] - x.v[k] - s;
+                diff += d * d;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pw[k] = vv[k];
+        }
+        obj = block_sum(obj, red);
+        diff = block_sum(diff, red);
+        double ndt2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) ndt2 += dt[k] * dt[k];
+        if (sqrt(ndt2) < GH_TOL && sqrt(diff) < GH_TOL) break;               // :71-73
+        if (obj > objFunc) break;                                            // :75-76
+        objFunc = obj;
+        for (int i = tid; i < N; i += GH_WG_THREADS) {                       // xi = x + v; ti = ti + dt   (:80)
+            const Pt6 x = premap(load_pt(pts, i), w->nrm);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) g.xi[6 * i + k] = x.v[k] + g.pp[(long)PP * i + k];
+        }
+        if (tid < u) g.p[tid] += g.dt[tid];
+        __syncthreads();
+    }
+    __syncthreads();
+    return (it > GH_IT_MAX) ? GH_IT_MAX : it;
+}
+
+template <class Model>
+__global__ void __launch_bounds__(GH_WG_THREADS, 2) k_pi_block(const GhWgArgs a) {
+    TFF_DYNAMIC_LDS(double, smem);
+    PoseLds* w = reinterpret_cast<PoseLds*>(smem);
+    constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
+    double* ghbase = smem + base;
+    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
+        __syncthreads();
+        if (a.status[b] != ST_OK) continue;
+        const int N = a.N;
+        const double* pts = a.corresp + b * 6 * (long)N;
+        PiWork g = pi_carve(ghbase, Model::E, Model::C, a.spill ? 0 : N, true);
+        double* red = g.pp + (long)pi_pp(Model::E) * (a.spill ? 0 : N);
+        if (a.spill) { g.xi = a.spill + blockIdx.x * a.spill_stride; g.pp = g.xi + 6 * (long)N; }
+        const int own = (int)(b & (GH_WG_WAVES - 1));
+        const double* r = a.rec + b * GH_REC_DOUBLES;
+        if (tid < 27) w->t[tid] = r[tid];
+        if (tid < 18) w->pa[tid] = r[27 + tid];
+        if (tid < 6) w->epi[tid] = r[45 + tid];
+        if (tid < 9) w->nrm[tid] = r[51 + tid];
+        __syncthreads();
+        if (wave == own && lane == 0) red[9] = (double)Model::init(w, g.p);  // Pi matrices from the linear cameras; cameras for x_est
+        __syncthreads();
+        const int ist = (int)red[9];
+        if (ist != ST_OK) {                                                  // 'The minimal param could not be found'
+            if (tid == 0) a.status[b] = ist;
+            continue;
+        }
+        gh_block_reproject(w, pts, N, g.xi);                                 // x_est   (PiPoseEstimation.m:80-83)
+        __syncthreads();
+        int gst = ST_OK;
+        const int iters = gauss_helmert_pi_block<Model>(w, g, red, own, pts, N, &gst, (a.flags & FLAG_GH_EXACT) != 0);
+        if (wave == own) {
+            if (lane == 0) Model::cameras(g.p, w);                           // :94-100
+            wave_sync();
+            tft_from_cameras(w, w->t);                                       // T = TFT_from_P(P1,P2,P3)
+            wave_sync();
+            if (lane < 27) a.topt[b * 27 + lane] = w->t[lane];
+            if (lane == 0) {
+                if (a.iter) a.iter[b] = iters;
+                if (gst != ST_OK) a.status[b] = -gst;
+            }
+        }
+    }
+}
+
+}  // namespace tff
