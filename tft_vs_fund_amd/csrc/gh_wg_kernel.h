@@ -130,13 +130,14 @@ __device__ __forceinline__ bool block_any(bool p, double* red) { return block_su
 // Jacobi eigen-decomposition of the symmetric n x n matrix A (LDS, leading dimension lda; diagonal -> eigenvalues, V -> eigenvectors)
 // by the whole workgroup: round-robin (tournament) ordering, m/2 disjoint rotations per round (m = n rounded up to even), each round
 //   (a) one thread per pair computes (c, s) (thresholds: see below),
-//   (b) column phase: A <- A J, V <- V J   (pairs x rows work items),
-//   (c) row phase:    A <- J' A            (pairs x columns work items).
+//   (b) A <- J' A J by 2 x 2 blocks (pair I x pair J: four entries read, both rotations applied, four written) and V <- V J by
+//       (row, pair) items -- one phase, two barriers per round.
 // `cs`: 4 * (m/2) doubles of LDS scratch (p, q, c, s per pair), then one slot for the rotation counter.
 template <int n>
 __device__ inline int block_jacobi_sym(double* A, const int lda, double* V, const int ldv, double* cs) {
     const int tid = threadIdx.x;
     constexpr int m = (n + 1) & ~1, half = m / 2;
+    constexpr int NBLK = (half * half + GH_WG_THREADS - 1) / GH_WG_THREADS, NVIT = (half * n + GH_WG_THREADS - 1) / GH_WG_THREADS;
     for (int e = tid; e < n * n; e += GH_WG_THREADS) V[(e / n) * ldv + e % n] = (e / n == e % n) ? 1.0 : 0.0;
     double tr = 0.0;
     for (int k = 0; k < n; ++k) tr += fabs(A[k * lda + k]);                  // same on every thread
@@ -171,31 +172,48 @@ __device__ inline int block_jacobi_sym(double* A, const int lda, double* V, cons
                 cs[4 * tid] = (double)p; cs[4 * tid + 1] = (double)q; cs[4 * tid + 2] = c; cs[4 * tid + 3] = s;
             }
             __syncthreads();
-            for (int e = tid; e < half * n; e += GH_WG_THREADS) {            // (b) columns p, q of A and V, row `row`
-                const int row = e / half, pr = e % half;                     // neighbouring threads: same row, different pairs (LDS banks)
-                const double s = cs[4 * pr + 3];
-                if (s != 0.0) {
-                    const int p = (int)cs[4 * pr], q = (int)cs[4 * pr + 1];
-                    const double c = cs[4 * pr + 2];
-                    const double arp = A[row * lda + p], arq = A[row * lda + q];
-                    A[row * lda + p] = c * arp - s * arq;
-                    A[row * lda + q] = s * arp + c * arq;
-                    const double vrp = V[row * ldv + p], vrq = V[row * ldv + q];
-                    V[row * ldv + p] = c * vrp - s * vrq;
-                    V[row * ldv + q] = s * vrp + c * vrq;
-                }
+            // (b) all loads of this thread's items first, then the arithmetic, then the stores (the items of a round are disjoint)
+            double a00[NBLK], a01[NBLK], a10[NBLK], a11[NBLK], cI[NBLK], sI[NBLK], cJ[NBLK], sJ[NBLK];
+            int pI[NBLK], qI[NBLK], pJ[NBLK], qJ[NBLK];
+#pragma unroll
+            for (int k = 0; k < NBLK; ++k) {
+                const int blk = tid + k * GH_WG_THREADS;
+                const int I = (blk < half * half) ? blk / half : 0, J = (blk < half * half) ? blk % half : 0;
+                pI[k] = (int)cs[4 * I]; qI[k] = (int)cs[4 * I + 1]; cI[k] = cs[4 * I + 2]; sI[k] = (blk < half * half) ? cs[4 * I + 3] : 0.0;
+                pJ[k] = (int)cs[4 * J]; qJ[k] = (int)cs[4 * J + 1]; cJ[k] = cs[4 * J + 2]; sJ[k] = (blk < half * half) ? cs[4 * J + 3] : 0.0;
+                const bool vi = qI[k] < n, vj = qJ[k] < n;
+                a00[k] = A[pI[k] * lda + pJ[k]];
+                a01[k] = vj ? A[pI[k] * lda + qJ[k]] : 0.0;
+                a10[k] = vi ? A[qI[k] * lda + pJ[k]] : 0.0;
+                a11[k] = (vi && vj) ? A[qI[k] * lda + qJ[k]] : 0.0;
             }
-            __syncthreads();
-            for (int e = tid; e < half * n; e += GH_WG_THREADS) {            // (c) rows p, q of A, column `col`
-                const int pr = e / n, col = e % n;
-                const double s = cs[4 * pr + 3];
-                if (s != 0.0) {
-                    const int p = (int)cs[4 * pr], q = (int)cs[4 * pr + 1];
-                    const double c = cs[4 * pr + 2];
-                    const double apc = A[p * lda + col], aqc = A[q * lda + col];
-                    A[p * lda + col] = c * apc - s * aqc;
-                    A[q * lda + col] = s * apc + c * aqc;
-                }
+            double vp[NVIT], vq[NVIT], vc[NVIT], vs[NVIT];
+            int vrow[NVIT], vpi[NVIT], vqi[NVIT];
+#pragma unroll
+            for (int k = 0; k < NVIT; ++k) {
+                const int e = tid + k * GH_WG_THREADS;
+                const bool in = e < half * n;
+                const int row = in ? e / half : 0, pr = in ? e % half : 0;   // neighbouring threads: same row, different pairs (LDS banks)
+                vrow[k] = row; vpi[k] = (int)cs[4 * pr]; vqi[k] = (int)cs[4 * pr + 1]; vc[k] = cs[4 * pr + 2]; vs[k] = in ? cs[4 * pr + 3] : 0.0;
+                vp[k] = V[row * ldv + vpi[k]];
+                vq[k] = (vs[k] != 0.0) ? V[row * ldv + vqi[k]] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < NBLK; ++k) {
+                if (sI[k] == 0.0 && sJ[k] == 0.0) continue;
+                const double b00 = cI[k] * a00[k] - sI[k] * a10[k], b01 = cI[k] * a01[k] - sI[k] * a11[k];     // rows: J_I' A
+                const double b10 = sI[k] * a00[k] + cI[k] * a10[k], b11 = sI[k] * a01[k] + cI[k] * a11[k];
+                const bool vi = qI[k] < n, vj = qJ[k] < n;
+                A[pI[k] * lda + pJ[k]] = cJ[k] * b00 - sJ[k] * b01;                                              // columns: (.) J_J
+                if (vj) A[pI[k] * lda + qJ[k]] = sJ[k] * b00 + cJ[k] * b01;
+                if (vi) A[qI[k] * lda + pJ[k]] = cJ[k] * b10 - sJ[k] * b11;
+                if (vi && vj) A[qI[k] * lda + qJ[k]] = sJ[k] * b10 + cJ[k] * b11;
+            }
+#pragma unroll
+            for (int k = 0; k < NVIT; ++k) {
+                if (vs[k] == 0.0) continue;
+                V[vrow[k] * ldv + vpi[k]] = vc[k] * vp[k] - vs[k] * vq[k];
+                V[vrow[k] * ldv + vqi[k]] = vs[k] * vp[k] + vc[k] * vq[k];
             }
             __syncthreads();
         }
