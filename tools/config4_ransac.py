@@ -21,12 +21,14 @@ def main():
     ap.add_argument("--method", default="tft")
     ap.add_argument("--scene", type=int, default=400)
     ap.add_argument("--outliers", type=float, default=0.25)
+    ap.add_argument("--variant", type=int, default=0, help="TFF_OPT_KERNEL (1: paired kernel, A/B)")
     args = ap.parse_args()
     from tft_vs_fund_amd import api, dist as tdist
     from tft_vs_fund_amd.scenes import generate_scene_batch
     rank, world, local = tdist.init_from_env("cuda")
     torch.cuda.set_device(local)
     ctx = api.Context(local)
+    ctx.set_kernel_variant(args.variant)
     C, CalM, Rt0, _ = generate_scene_batch(1, args.scene, noise=0.5, seed=7)
     scene = C[0].copy()
     rng = np.random.default_rng(1)
