@@ -166,13 +166,22 @@ def main():
         value = total / elapsed
         alg = algorithmic_bytes_per_triplet(N) * B
         achieved = alg / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, valu = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get("hbm_bytes_per_launch")
+                # the bound that actually binds: fp64 vector issue.  Counters from the committed rocprofv3 PMC passes;
+                # the issue-limited rate = SIMDs x clock / (4 cycles per wave64 VALU instruction) / instructions per triplet.
+                ipt = pj.get("valu_instructions_per_triplet")
+                if ipt:
+                    simds, clock_hz = 256 * 4, 2.4e9
+                    valu = {"instructions_per_triplet": ipt, "busy_fraction": pj.get("valu_busy_fraction"),
+                            "issue_limited_triplets_per_s": simds * clock_hz / 4.0 / ipt, "source": "profiles/pmc_latest.json (rocprofv3 --pmc, same command)"}
+                    valu["frac_of_issue_limit"] = (B / (kern_ms * 1e-3)) / valu["issue_limited_triplets_per_s"]
             except Exception:
-                traffic = None
+                traffic, valu = None, None
         out = {
             "metric": "triplet-hypotheses/sec (linearTFT+R,t) at N=200 corresp.",
             "value": value, "unit": "triplet-hypotheses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -187,6 +196,8 @@ def main():
                          "traffic": traffic, "kernel": "k_linear_tft_pose", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg},
         }
+        if valu:
+            out["fp64_valu"] = valu
         if secondary:
             out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:

@@ -301,7 +301,7 @@ __device__ inline bool wave_solve_gj(const double* M, double* sol) {
 #pragma unroll
     for (int k = 0; k < n; ++k) {
         const double v = active ? fabs(a[k]) : -1.0;
-        const double best = wave_max(v);
+        const double best = (n <= 32) ? wave_max32_finite(v) : wave_max(v);  // rows live in lanes 0..n-1
         if (!(best > 1e-10 * amax)) ok = false;
         int p = wave_first_lane(active && v == best);                        // wave-uniform
         p = (p < 64) ? p : 0;

@@ -113,6 +113,7 @@ __device__ inline double wave_max(double v) {
     for (int m = 32; m >= 1; m >>= 1) { double o = wave_shfl_xor(v, m); v = (o > v) ? o : v; }
     return v;
 }
+__device__ inline double wave_max32_finite(double v) { return wave_max((lane_id() < 32) ? v : -1.7e308); }
 // lowest lane whose predicate holds (64 if none); wave-uniform
 __device__ inline int wave_first_lane(bool p) {
     int c = p ? lane_id() : 64;
@@ -141,6 +142,14 @@ __device__ __forceinline__ double wave_max(double v) {
 __device__ __forceinline__ int wave_first_lane(bool p) {
     const unsigned long long m = __ballot(p);
     return m ? (__ffsll((long long)m) - 1) : 64;
+}
+// maximum over lanes 0..31 only, v_max_f64 per stage (NaNs are dropped: for pivot searches over finite data)
+__device__ __forceinline__ double wave_max32_finite(double v) {
+    v = fmax(v, dpp_mov_keep<0x111>(v));
+    v = fmax(v, dpp_mov_keep<0x112>(v));
+    v = fmax(v, dpp_mov_keep<0x114>(v));
+    v = fmax(v, dpp_mov_keep<0x118>(v));
+    return fmax(wave_bcast(v, 15), wave_bcast(v, 31));
 }
 #endif
 __device__ __forceinline__ int wave_sum_i(int v) {
