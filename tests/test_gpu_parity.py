@@ -134,6 +134,37 @@ def test_edge_cases(gpu_ctx):
     assert out["status"][0] == 0 and out["status"][1] in (2, 3)
 
 
+@pytest.mark.parametrize("method", ["LinearFPoseEstimation", "OptimFPoseEstimation", "ResslTFTPoseEstimation", "NordbergTFTPoseEstimation",
+                                    "FaugPapaTFTPoseEstimation", "PiPoseEstimation", "PiColPoseEstimation"])
+def test_bad_inputs_are_reported_per_triplet(gpu_ctx, method):
+    """NaN coordinates, a degenerate triplet (every correspondence identical) and too few points: reported through `status` for that
+    triplet only (MATLAB would throw or return NaN), the other triplets of the batch are unaffected, nothing hangs."""
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    C, CalM, _, _ = generate_scene_batch(4, 24, noise=1.0, seed=21)
+    ref = gpu_ctx.pose_batch(method, C, CalM, reconst=True)
+    Cb = C.copy()
+    Cb[1, 5, 3] = np.nan
+    Cb[2, :, :] = Cb[2, 0:1, :]
+    out = gpu_ctx.pose_batch(method, Cb, CalM, reconst=True)
+    assert out["status"][1] != 0 and out["status"][2] != 0
+    for b in (0, 3):
+        assert out["status"][b] == ref["status"][b]
+        if ref["status"][b] == 0:
+            assert np.array_equal(out["R_t_3"][b], ref["R_t_3"][b]) and np.array_equal(out["T"][b], ref["T"][b])
+    few = gpu_ctx.pose_batch(method, C[:, :6], CalM, reconst=True)
+    assert np.all(few["status"] == 1) and np.all(np.isnan(few["T"]))
+
+
+def test_bundle_adjust_bad_inputs(gpu_ctx):
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    C, CalM, _, _ = generate_scene_batch(3, 20, noise=1.0, seed=22)
+    lin = gpu_ctx.pose_batch("LinearTFTPoseEstimation", C, CalM, reconst=True)
+    Cb = C.copy(); Cb[1, 2, 0] = np.nan
+    out = gpu_ctx.bundle_adjust(CalM, lin["R_t_2"], lin["R_t_3"], Cb, lin["Reconst"])
+    st = out["status"].cpu().numpy()
+    assert st[1] != 0 and st[0] == 0 and st[2] == 0
+
+
 def test_full_size_properties(gpu_ctx):
     """B=10 000, N=200 (BASELINE.json configs[1]) through the device-pointer ABI."""
     import torch
