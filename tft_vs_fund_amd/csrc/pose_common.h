@@ -265,12 +265,84 @@ __device__ __forceinline__ void compose_camera_from_pose(const Mat3& K, const do
         for (int c = 0; c < 4; ++c) P[4 * r + c] = K.m[r][0] * Rt[c] + K.m[r][1] * Rt[4 + c] + K.m[r][2] * Rt[8 + c];
 }
 
+// Cheirality vote of one pose candidate (R_t_from_TFT.m:96-101): sum_n sign(X1(3)) + sign(X2(3)), X1 the two-view DLT point of
+// correspondence n (cameras Pfin[0] = K1 [I|0] and camB), X2 = [R t] X1.  Only the two SIGNS are consumed, so this is a slimmed copy
+// of tri_pass: the first camera's fourth column is zero by construction; the point is the least-squares solution with X(4) = 1,
+//     X(1:3) = -inv(S(1:3,1:3)) S(1:3,4)
+// read off the Cholesky factor of S = A'A (its last row is the forward solve, one 3 x 3 back substitution finishes it) -- the
+// inhomogeneous form of the same DLT system, within lambda_4/lambda_3 (~1e-6 for correspondences consistent with the candidate)
+// of the singular vector the reference takes, which cannot move the sign of a depth that is O(1) in these units.  No fourth pivot,
+// no normalisation, no iteration: 60 % of the instructions of the general pass.  `Rt`: candidate pose, row-major 3x4.
+__device__ __attribute__((noinline)) int tri_vote(PoseLds* w, const double* pts, int N, int view, const double* camB, const double* Rt) {
+    const int lane = lane_id();
+    double PA[9], PB[12], R3[4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) PA[3 * r + c] = wave_uniform(w->Pfin[0][4 * r + c]);
+    load_uniform12(camB, PB);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) R3[c] = wave_uniform(Rt[8 + c]);
+    int score = 0;
+    Pt6 pnext = load_pt(pts, (lane < N) ? lane : 0);
+#pragma unroll 1
+    for (int i = lane; i < N; i += WAVE) {
+        const Pt6 p = pnext;
+        if (i + WAVE < N) pnext = load_pt(pts, i + WAVE);
+        const double x1 = p.v[0], y1 = p.v[1], x2 = (view == 1) ? p.v[2] : p.v[4], y2 = (view == 1) ? p.v[3] : p.v[5];
+        double a0[3], a1[3], b0[4], b1[4];                                  // rows [0 -1 y; 1 0 -x] * P   (triangulation3D.m:58-59)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a0[c] = y1 * PA[6 + c] - PA[3 + c]; a1[c] = PA[c] - x1 * PA[6 + c]; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { b0[c] = y2 * PB[8 + c] - PB[4 + c]; b1[c] = PB[c] - x2 * PB[8 + c]; }
+        double S[4][3];                                                      // lower triangle of A'A, columns 0..2 (S[3][3] is not needed)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (c > r) continue;
+                double v = b0[r] * b0[c] + b1[r] * b1[c];
+                if (r < 3) v += a0[r] * a0[c] + a1[r] * a1[c];
+                S[r][c] = v;
+            }
+        // Cholesky of S + delta I as in spd_min_eigvec (the shift only conditions the factorisation)
+        const double tr = S[0][0] + S[1][1] + S[2][2] + (b0[3] * b0[3] + b1[3] * b1[3]);
+        const double delta = 1e-14 * tr, pfloor = 1e-3 * delta + 1e-300;
+        double L[4][3], inv[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double d = S[j][j] + delta;
+#pragma unroll
+            for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+            d = (d > pfloor) ? d : pfloor;
+            inv[j] = rsqrt(d);
+#pragma unroll
+            for (int r = j + 1; r < 4; ++r) {
+                double sv = S[r][j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) sv -= L[r][k] * L[j][k];
+                L[r][j] = sv * inv[j];
+            }
+        }
+        double z[3];                                                         // L11' z = -L(4,1:3)'
+#pragma unroll
+        for (int r = 2; r >= 0; --r) {
+            double sum = -L[3][r];
+#pragma unroll
+            for (int k = r + 1; k < 3; ++k) sum -= L[k][r] * z[k];
+            z[r] = sum * inv[r];
+        }
+        const double z2 = R3[0] * z[0] + R3[1] * z[1] + R3[2] * z[2] + R3[3];
+        score += (int)sgn(z[2]) + (int)sgn(z2);                             // X(4) = 1 > 0
+    }
+    return wave_sum_i(score);
+}
+
 // One pass over the correspondences of the triplet, one lane per correspondence:
 // DLT triangulation (triangulation3D.m:51-63) from camera Pfin[0] = K1 [I|0], camera
 // `camB` and (mode TRI_RECONST) camera `aux`, then a mode-specific epilogue.
 // A single non-inlined copy serves the cheirality vote, the t3 scale and Reconst
 // (code size: see the instruction-cache note in wave_eig.h).
-//   TRI_VOTE    : aux = candidate pose [R|t] (row-major 3x4); returns sum_n sign(X1(3)) + sign(X2(3))
 //   TRI_SCALE   : aux = [K3*R3 | u3 = K3*t3]; num/den of R_t_from_TFT.m:72-73 -> w->pa[0..1]
 //   TRI_RECONST : aux = third camera; dehomogenised points -> `out` (3 x N column-major)
 //   TRI_REPROJECT : aux = third camera; the three reprojections of the homogeneous point ->
@@ -300,16 +372,7 @@ __device__ __attribute__((noinline)) int tri_pass(PoseLds* w, const double* pts,
         tri_accum(S, PB, (view == 1) ? p.v[2] : p.v[4], (view == 1) ? p.v[3] : p.v[5]);
         if (mode == TRI_RECONST || mode == TRI_REPROJECT) tri_accum(S, AX, p.v[4], p.v[5]);
         double X[4];
-        // The vote only consumes the SIGNS of two depths: from the least-squares start (error ~ lambda4/lambda3
-        // ~ 1e-7) one inverse iteration (-> ~1e-14) is plenty; the other modes iterate to convergence.
-        spd_min_eigvec<4>(S, X, (mode == TRI_VOTE) ? 1 : 40);
-        if (mode == TRI_VOTE) {
-            // sign(X1(3)) + sign(X2(3)) with X1 = X./X(4), X2 = [R t]*X1   (R_t_from_TFT.m:98-100): signs only, no division
-            const double s4 = sgn(X[3]);
-            const double z2 = AX[8] * X[0] + AX[9] * X[1] + AX[10] * X[2] + AX[11] * X[3];
-            score += (int)(sgn(X[2]) * s4) + (int)(sgn(z2) * s4);
-            continue;
-        }
+        spd_min_eigvec<4>(S, X, 40);
         if (mode == TRI_REPROJECT2) {
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
@@ -353,7 +416,6 @@ __device__ __attribute__((noinline)) int tri_pass(PoseLds* w, const double* pts,
             out[3 * (long)i + 2] = X2;
         }
     }
-    if (mode == TRI_VOTE) return wave_sum_i(score);
     if (mode == TRI_SCALE) {
         num = wave_sum(num);
         den = wave_sum(den);
@@ -424,8 +486,8 @@ __device__ inline int recover_vote(PoseLds* w, const double* pts, int N, double*
     int status = ST_OK;
 #pragma unroll 1
     for (int call = 0; call < 2; ++call) {
-        const int sR = tri_pass(w, pts, N, TRI_VOTE, call + 1, w->P[2 * call], w->candRt[2 * call], nullptr);
-        const int sRp = tri_pass(w, pts, N, TRI_VOTE, call + 1, w->P[2 * call + 1], w->candRt[2 * call + 1], nullptr);
+        const int sR = tri_vote(w, pts, N, call + 1, w->P[2 * call], w->candRt[2 * call]);
+        const int sRp = tri_vote(w, pts, N, call + 1, w->P[2 * call + 1], w->candRt[2 * call + 1]);
         // reference order: k=1 (R,t), k=2 (R,-t), k=3 (Rp,-t), k=4 (Rp,t)   (:92-104)
         const int score[4] = {sR, -sR, -sRp, sRp};
         int seen = 0, pick = -1;
