@@ -236,8 +236,18 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, bool want_P,
             x = wave_jacobi_min_eigvec(jw->A, jw->V, 15, 15, &it2);
             it2 += 1000;
         } else {
+            // start from the unconstrained solution projected onto range(E): tp0 = Up' t (9 non-zeros per basis vector).  The
+            // constrained tensor differs from it at noise level, which saves one of the four inverse iterations.
+            double tp0 = 0.0;
+            if (lane < 15) {
+                const int i = lane / 5, m = lane % 5, jj = (m < 3) ? 0 : m - 2, kk = (m < 3) ? m : 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) tp0 += w->Q[3 * j + jj] * w->Q[9 + 3 * k + kk] * w->t[j + 3 * k + 9 * i];
+            }
             double r2;
-            x = wave_min_eigvec_reg<15, G>(g, diag, w->Lp, EIG_MAXIT, &it2, &r2);
+            x = wave_min_eigvec_reg<15, G>(g, diag, w->Lp, EIG_MAXIT, &it2, &r2, true, tp0);
             ok = ok && eig_converged(r2);
         }
         if (lane < 15) w->tp[lane] = x;

@@ -30,9 +30,10 @@ __device__ __forceinline__ int tri_index(int r, int c) { return (r * (r + 1)) / 
 // Lp: n*n doubles of LDS.  On return lane r (< n) holds component r of the
 // unit eigenvector of the smallest eigenvalue; *iters = iterations used,
 // *resid2 = 0 when the iteration converged, else the last squared step.
+// has_start / start: optional initial guess (component `lane` on lane `lane`), default the uniform vector.
 template <int n, int G = 64>
 __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, double* Lp, const int maxit,
-                                             int* iters, double* resid2) {
+                                             int* iters, double* resid2, const bool has_start = false, const double start = 0.0) {
     using Grp = Group<G>;                                   // one lane group per matrix (the whole wave, or one half of it)
     const int lane = Grp::lane();
     const double tr = Grp::sum(lane < n ? diag : 0.0);
@@ -65,6 +66,11 @@ __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, 
     wave_sync();
     const int rl = (lane < n) ? lane : 0;
     double x = (lane < n) ? rsqrt((double)n) : 0.0;
+    if (has_start) {                                        // caller's guess (lane r: component r); a zero / non-finite guess falls back
+        const double s0 = (lane < n) ? start : 0.0;
+        const double nn0 = Grp::sum(s0 * s0);
+        if (nn0 > 1e-300 && nn0 < 1e300) x = s0 * rsqrt(nn0);
+    }
     double rprev2 = 1.0, res = 1.0;
     int it = 0;
     bool done = false;                                      // per group; the loop itself is wave-uniform
