@@ -116,5 +116,12 @@ def test_gpu_bundle_adjustment_full_size_and_wrapper(gpu_ctx):
     R_t_0 = np.vstack([np.eye(3, 4), lin["R_t_2"][0].cpu().numpy(), lin["R_t_3"][0].cpu().numpy()])
     R_t, Rec, it1, err1 = api.BundleAdjustment(CalM, R_t_0, C[0].T.copy(), lin["Reconst"][0].cpu().numpy())
     assert it1 == it[0] and abs(err1 - float(out["repr_err"][0])) < 1e-12 and rel_err(R_t[6:9], out["R_t_3"][0].cpu().numpy()) < 1e-12
+    # a first camera other than [I|0]: the wrapper changes coordinates as BundleAdjustment.m:80-86 does
+    a = 0.3
+    G = np.eye(4); G[:3, :3] = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]]); G[:3, 3] = [0.2, -0.1, 0.4]
+    R_t_g = np.vstack([R_t_0[3 * j:3 * j + 3] @ G for j in range(3)])
+    Xg = np.linalg.inv(G) @ np.vstack([lin["Reconst"][0].cpu().numpy(), np.ones(N)])
+    R_t2, Rec2, it2, err2 = api.BundleAdjustment(CalM, R_t_g, C[0].T.copy(), Xg[:3])
+    assert it2 == it1 and abs(err2 - err1) < 1e-9 * err1 and rel_err(R_t2, R_t) < 1e-8
     with pytest.raises(ValueError):
-        api.BundleAdjustment(CalM, np.vstack([R_t_0[3:6], R_t_0[3:9]]), C[0].T.copy())
+        api.BundleAdjustment(CalM, R_t_0[0:6], C[0].T.copy())

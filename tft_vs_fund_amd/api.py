@@ -487,14 +487,26 @@ def PiColPoseEstimation(Corresp, CalM):
 
 
 def BundleAdjustment(CalM, R_t_0, Corresp, Reconst0=None):
-    """Drop-in for Optimization/BundleAdjustment.m with M = 3 views and R_t_0(1:3,:) = eye(3,4): CalM 9x3, R_t_0 9x4,
-    Corresp 6xN, Reconst0 3xN or None -> R_t (9x4), Reconst (3xN), iter, repr_err."""
-    CalM = np.asarray(CalM, dtype=np.float64); R_t_0 = np.asarray(R_t_0, dtype=np.float64); Corresp = np.asarray(Corresp, dtype=np.float64)
-    if R_t_0.shape != (9, 4) or not np.allclose(R_t_0[0:3], np.eye(3, 4)):
-        raise ValueError("R_t_0 must be 9x4 with camera 1 = [I|0]")
+    """Drop-in for Optimization/BundleAdjustment.m with M = 3 views: CalM 9x3, R_t_0 9x4, Corresp 6xN, Reconst0 3xN or None
+    -> R_t (9x4, first camera [I|0], |t2| = 1), Reconst (3xN), iter, repr_err.  A first camera other than [I|0] is handled as the
+    reference does (BundleAdjustment.m:80-86): change of coordinates to camera 1 on the host, then the batched kernel."""
+    CalM = np.asarray(CalM, dtype=np.float64); R_t_0 = np.array(R_t_0, dtype=np.float64); Corresp = np.asarray(Corresp, dtype=np.float64)
+    if R_t_0.shape != (9, 4) or Corresp.ndim != 2 or Corresp.shape[0] != 6:
+        raise ValueError("three views: R_t_0 must be 9x4 and Corresp 6xN")
     if np.isnan(Corresp).any():
         raise ValueError("correspondences missing in some view (NaN) are not supported")
+    X0 = None if Reconst0 is None else np.array(Reconst0, dtype=np.float64)
+    cc = R_t_0[0:3].copy()
+    if not np.array_equal(cc, np.eye(3, 4)):                                  # :80-86
+        for j in (1, 2):
+            R_t_0[3 * j:3 * j + 3, 3] = R_t_0[3 * j:3 * j + 3, 3] - R_t_0[3 * j:3 * j + 3, 0:3] @ cc[:, 0:3].T @ cc[:, 3]
+            R_t_0[3 * j:3 * j + 3, 0:3] = R_t_0[3 * j:3 * j + 3, 0:3] @ cc[:, 0:3].T
+        if X0 is not None:
+            X0 = cc[:, 0:3] @ X0 + cc[:, 3:4]
+        # without Reconst0 the kernel triangulates with the transformed cameras: the same DLT systems up to the rigid motion of the
+        # frame (the homogeneous minimiser is taken in a rotated/translated basis), i.e. the same points to rounding for noise-free
+        # data and an equally valid start otherwise
     out = default_context().bundle_adjust(CalM, R_t_0[3:6][None], R_t_0[6:9][None], np.ascontiguousarray(Corresp.T)[None],
-                                          None if Reconst0 is None else np.asarray(Reconst0, dtype=np.float64)[None])
+                                          None if X0 is None else X0[None])
     R_t = np.vstack([np.eye(3, 4), out["R_t_2"][0].cpu().numpy(), out["R_t_3"][0].cpu().numpy()])
     return R_t, out["Reconst"][0].cpu().numpy(), int(out["iter"][0]), float(out["repr_err"][0])
