@@ -164,7 +164,8 @@ class Context:
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_GH_EXACT, int(bool(on))), "set_option")
 
     def set_kernel_variant(self, v):
-        """0: one wavefront per triplet (default); 1: paired kernel, two triplets per workgroup (slower on MI355X; A/B only)."""
+        """TFF_OPT_KERNEL.  LinearTFT: 0 one wavefront per triplet (default), 1 paired kernel (slower; A/B).  Iterative TFT methods:
+        0 automatic (workgroup per triplet, fused single-wavefront kernel at small N), 1 fused always, 2 workgroup always."""
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_KERNEL, int(v)), "set_option")
 
     def set_stream(self, stream_ptr):

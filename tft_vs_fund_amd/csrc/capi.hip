@@ -2,6 +2,7 @@
 // CPU path behind these entry points: without a HIP device they fail loudly.
 #include <hip/hip_runtime.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include <cstdio>
 #include <cstring>
@@ -147,7 +148,7 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, bool may_stage
 // sequential triangular solves), kept for A/B measurements.
 int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    if (c->solver != 0 || c->kernel_variant == 0)
+    if (c->solver != 0 || c->kernel_variant != 1)
         return launch_pose(c, tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, true, corresp, calm, calm_stride,
                            B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
@@ -240,7 +241,11 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, const double* corresp, co
 template <class Model, class KFused, class KFusedJac>
 int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    if (c->kernel_variant != 0 || c->solver != 0)
+    // small N: the fused kernel's LDS footprint lets more wavefronts share a CU than the workgroup layout can use (measured crossover
+    // at N ~ 32 for Ressl, ~ 48 for Nordberg; FaugPapa's eigen-decomposition always wants the workgroup)
+    const int crossover = std::is_same<Model, tff::ResslModel>::value ? 32 : 48;
+    const bool small = !Model::REDUNDANT_CONSTRAINTS && N < crossover && c->kernel_variant == 0 && !dbg;
+    if (c->kernel_variant == 1 || c->solver != 0 || small)
         return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
     return launch_wg(c, tff::k_gh_block<Model>, wg_lds, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
@@ -248,7 +253,8 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
 template <class Model>
 int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    if (c->kernel_variant != 0 || c->solver != 0 || c->init_p)               // the debug outputs (init_p, init_x) come from the fused kernel
+    const bool small = !Model::PINV_KKT && N < 112 && c->kernel_variant == 0;   // measured crossover for Pi at N ~ 110
+    if (c->kernel_variant == 1 || c->solver != 0 || c->init_p || small)      // the debug outputs (init_p, init_x) come from the fused kernel
         return launch_pose(c, tff::k_pi_tft_pose<Model, false>, tff::k_pi_tft_pose<Model, true>, tff::pi_lds_bytes<Model>, false,
                            corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::pi_wg_lds_doubles(Model::E, Model::C, n)) * sizeof(double); };
@@ -366,7 +372,7 @@ int tff_ctx_set_option(tff_ctx* c, int option, long value) {
         case TFF_OPT_SOLVER: if (value != 0 && value != 1) return fail(TFF_E_INVALID, "solver must be 0 or 1"); c->solver = (int)value; return 0;
         case TFF_OPT_STAGE_LDS: if (value < -1 || value > 1) return fail(TFF_E_INVALID, "stage_lds must be -1, 0 or 1"); c->stage = (int)value; return 0;
         case TFF_OPT_GH_EXACT: c->gh_exact = value != 0; return 0;
-        case TFF_OPT_KERNEL: if (value != 0 && value != 1) return fail(TFF_E_INVALID, "kernel must be 0 or 1"); c->kernel_variant = (int)value; return 0;
+        case TFF_OPT_KERNEL: if (value < 0 || value > 2) return fail(TFF_E_INVALID, "kernel must be 0, 1 or 2"); c->kernel_variant = (int)value; return 0;
         default: return fail(TFF_E_INVALID, "unknown option");
     }
 }
