@@ -162,3 +162,31 @@ extern "C" int emu_linear_tft_pose_pair(const double* corresp, const double* cal
     emu::launch(tff::k_linear_tft_pose<true>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, a.flags, true), a);
     return 1;
 }
+
+// wave_eigh_ql / wave_pinv_solve_sym on caller-supplied symmetric matrices (one wavefront per matrix):
+// Maug B x n x (n+1) row-major (column n = right-hand side) -> lam B x n, vecs B x n x n (row j = eigenvector of lam[j]), sol B x n
+namespace {
+struct EighArgs { const double* Maug; int n; double* lam; double* vecs; double* sol; };
+__global__ void k_emu_eigh(EighArgs a) {
+    TFF_DYNAMIC_LDS(double, lds);
+    const int n = a.n, ld = n + 1, lane = tff::lane_id();
+    const long b = blockIdx.x;
+    double* M = lds; double* ZT = M + n * ld; double* scr = ZT + n * n; double* M2 = scr + 2 * n; double* sol = M2 + n * ld;
+    for (int e = lane; e < n * ld; e += 64) { M[e] = a.Maug[b * n * ld + e]; M2[e] = M[e]; }
+    tff::wave_sync();
+    int fail;
+    const double lam = tff::wave_eigh_ql(M, ld, ZT, n, n, scr, &fail);
+    if (lane < n) {
+        a.lam[b * n + lane] = fail ? 0.0 / 0.0 : lam;
+        for (int r = 0; r < n; ++r) a.vecs[(b * n + lane) * n + r] = ZT[tff::eig_row(n, lane) * n + r];
+    }
+    tff::wave_sync();
+    tff::wave_pinv_solve_sym(M2, ZT, n, sol, scr);
+    if (lane < n) a.sol[b * n + lane] = sol[lane];
+}
+}
+extern "C" int emu_eigh(const double* Maug, long B, int n, double* lam, double* vecs, double* sol) {
+    EighArgs a{Maug, n, lam, vecs, sol};
+    emu::launch(k_emu_eigh, tff::pose_grid(B), 64, sizeof(double) * (size_t)(2 * n * (n + 1) + n * n + 3 * n), a);
+    return 0;
+}

@@ -159,6 +159,58 @@ def test_gh_workgroup_path_matches_fused_kernel(emu):
     assert st[0] == 1 and np.all(np.isnan(T))
 
 
+def test_faugpapa_workgroup_path_matches_fused_kernel(emu):
+    """FaugPapa through k_gh_block: the pseudo-inverse workspace overlays D | H | Y there (gh_wg_carve) and the solve runs on one
+    wavefront of the four; against the fused single-wavefront kernel (separate workspace)."""
+    B, N = 1, 9
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=0.5, seed=77)
+    calm = calm_colmajor(CalM)
+    Rt2 = np.zeros((B, 12)); Rt3 = np.zeros((B, 12)); T = np.zeros((B, 27)); Rec = np.zeros((B, N, 3))
+    it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32)
+    emu.emu_gh_wg_pose(ctypes.c_int(2), _p(C), _p(calm), ctypes.c_long(0), ctypes.c_long(B), ctypes.c_int(N), ctypes.c_int(0),
+                       _p(Rt2), _p(Rt3), _p(T), _p(Rec), _p(it), _p(st))
+    ref = run_linear_tft(emu, C, CalM, entry="emu_faugpapa_tft_pose")
+    assert st[0] == 0 and ref["status"][0] == 0 and abs(int(it[0]) - int(ref["iter"][0])) <= 2
+    tol = 2e-3 if it[0] == ref["iter"][0] else 2e-2
+    assert rel_err_T(T.reshape(3, 3, 3).transpose(2, 1, 0), ref["T"][0]) < tol
+    assert rel_err(Rt3.reshape(4, 3).T, ref["R_t_3"][0]) < tol
+
+
+def test_wave_eigh_ql_against_lapack(emu):
+    """wave_eigh_ql (Householder tridiagonalisation + implicit QL on one wavefront) and the truncated pseudo-inverse built on it:
+    eigenvalues, orthogonality, residual and pinv(M) b against numpy on generic, singular and KKT-graded matrices."""
+    rng = np.random.default_rng(0)
+    for n in (12, 39):                                                                       # the sizes in use are 20 ... 39; pinv's n * eps margin is thin below ~10
+        cases = []
+        if n < 39:
+            G = rng.standard_normal((n, n - 3)); cases.append(G @ G.T)                     # singular: three eigenvalues truncated
+            cases.append(np.diag(rng.standard_normal(n)))
+        u = (2 * n) // 3; c = n - u                                                        # [N C'; C 1e-12 I], N ~ 1e13 and rank deficient
+        J = rng.standard_normal((u - 1, u)); K = np.zeros((n, n))
+        K[:u, :u] = 1e13 * J.T @ J; K[u:, :u] = rng.standard_normal((c, u)); K[:u, u:] = K[u:, :u].T; K[u:, u:] = 1e-12 * np.eye(c)
+        cases.append(K)
+        Ms = np.stack(cases); bs = rng.standard_normal((len(cases), n))
+        Maug = np.concatenate([Ms, bs[:, :, None]], axis=2).copy()
+        lam = np.zeros((len(cases), n)); vecs = np.zeros((len(cases), n, n)); sol = np.zeros((len(cases), n))
+        emu.emu_eigh(_p(Maug), ctypes.c_long(len(cases)), ctypes.c_int(n), _p(lam), _p(vecs), _p(sol))
+        for i, M in enumerate(Ms):
+            nrm = np.linalg.norm(M, 2)
+            w, VV = np.linalg.eigh(M)
+            V = vecs[i].T
+            assert np.abs(np.sort(lam[i]) - w).max() < 1e-14 * nrm
+            assert np.abs(V.T @ V - np.eye(n)).max() < 1e-13
+            assert np.abs(M @ V - V * lam[i]).max() < 1e-14 * nrm
+            tol = n * np.spacing(np.abs(w).max())
+            if np.min(np.abs(np.abs(w) - tol)) > 0.5 * tol:                                # no eigenvalue sits at the truncation threshold
+                keep = np.abs(w) > tol
+                xref = VV[:, keep] @ ((VV[:, keep].T @ bs[i]) / w[keep])
+                # graded KKT case: eigenvalues of O(1) next to |M| ~ 1e13 carry an absolute error eps * |M| ~ 1e-3 in ANY backward-stable
+                # solver (LAPACK included), which is what the multiplier block sees; the parameter block does not
+                head = n if i < len(cases) - 1 else (2 * n) // 3
+                assert np.abs(sol[i][:head] - xref[:head]).max() < 1e-9 * np.abs(xref).max()
+                assert np.abs(sol[i] - xref).max() < 2e-2 * np.abs(xref).max()
+
+
 @pytest.mark.parametrize("collinear,angle", [(0, None), (1, 180)])
 def test_pi_workgroup_path_matches_fused_kernel(emu, collinear, angle):
     """k_pi_block (four wavefronts per triplet, pi_wg_kernel.h) against the fused single-wavefront Pi kernels."""
@@ -194,7 +246,7 @@ def test_pi_kernels_match_oracle_under_their_sign_convention(emu, method, collin
     conventions the reference leaves open (tests/helpers.py), and from there results agree to the Gauss-Helmert
     noise level (1e12-weighted normal equations, see test_gpu_parity.py)."""
     from helpers import oracle_in_kernel_convention
-    B = 1 if collinear else 2                                               # the 38x38 Jacobi pseudo-inverse is slow under emulation
+    B = 1 if collinear else 2                                               # the 38x38 pseudo-inverse is slow under emulation
     C, CalM, Rt0, _ = generate_scene_batch(B, N, noise=sigma, seed=900 + N, angle=angle)
     out = run_pi_debug(emu, collinear, C, CalM)
     assert np.all(out["status"] == 0)

@@ -77,9 +77,13 @@ int ensure_lds(K kernel, size_t bytes) {
 // workspace, one slice per resident block (the kernels loop over the batch with a grid stride).  lds_full / lds_fixed: the
 // kernel's LDS request with and without the per-correspondence part.  Returns the LDS bytes to launch with.
 constexpr size_t LDS_LIMIT = 160 * 1024;
-int plan_spill(tff_ctx* c, size_t lds_full, size_t lds_fixed, unsigned* grid, double** spill, long* stride, size_t* lds) {
+// occupancy_cap > 0: the kernel is bound by a wave-serial step (the pseudo-inverse of the KKT matrix on one wavefront), so workgroups
+// per CU are what counts: spill also when that lets more of them (up to the cap its registers allow) share the CU's LDS.
+int plan_spill(tff_ctx* c, size_t lds_full, size_t lds_fixed, unsigned* grid, double** spill, long* stride, size_t* lds, int occupancy_cap = 0) {
     *spill = nullptr; *stride = 0; *lds = lds_full;
-    if (lds_full <= LDS_LIMIT) return 0;
+    auto per_cu = [&](size_t bytes) { const size_t k = LDS_LIMIT / (bytes + 512); return (int)(k < (size_t)occupancy_cap ? k : (size_t)occupancy_cap); };
+    const bool for_occupancy = occupancy_cap > 0 && lds_fixed < lds_full && per_cu(lds_fixed) > per_cu(lds_full);
+    if (lds_full <= LDS_LIMIT && !for_occupancy) return 0;
     if (lds_fixed > LDS_LIMIT) return fail(TFF_E_INVALID, "LDS workspace of this method exceeds 160 KiB");
     const size_t per_block = lds_full - lds_fixed;
     size_t blocks = ((size_t)512 << 20) / per_block;
@@ -194,7 +198,7 @@ int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_
 // pi_wg_kernel.h): k_gh_linear (+ Jacobi fix-up), the block kernel, k_gh_finish.  wg_lds(n): LDS bytes of the block kernel for n
 // correspondences held in LDS.
 template <class KBlock, class LdsFn>
-int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
+int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     if (B == 0) return 0;
@@ -225,7 +229,7 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, const double* corresp, co
         tff::GhWgArgs m = a;
         unsigned grid = tff::pose_grid(B);
         size_t lds;
-        if (int r = plan_spill(c, wg_lds(N), wg_lds(0), &grid, &m.spill, &m.spill_stride, &lds)) return r;
+        if (int r = plan_spill(c, wg_lds(N), wg_lds(0), &grid, &m.spill, &m.spill_stride, &lds, occupancy_cap)) return r;
         if (int r = ensure_lds(kblock, lds)) return r;
         hipLaunchKernelGGL(kblock, dim3(grid), dim3(tff::GH_WG_THREADS), lds, c->stream, m);
         TFF_HIP(hipGetLastError());
@@ -248,7 +252,7 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
     if (c->kernel_variant == 1 || c->solver != 0 || small)
         return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
-    return launch_wg(c, tff::k_gh_block<Model>, wg_lds, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    return launch_wg(c, tff::k_gh_block<Model>, wg_lds, Model::REDUNDANT_CONSTRAINTS ? 4 : 0, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 template <class Model>
 int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
@@ -258,7 +262,7 @@ int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64
         return launch_pose(c, tff::k_pi_tft_pose<Model, false>, tff::k_pi_tft_pose<Model, true>, tff::pi_lds_bytes<Model>, false,
                            corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::pi_wg_lds_doubles(Model::E, Model::C, n)) * sizeof(double); };
-    return launch_wg(c, tff::k_pi_block<Model>, wg_lds, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    return launch_wg(c, tff::k_pi_block<Model>, wg_lds, Model::PINV_KKT ? 4 : 0, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 int launch_ressl_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {

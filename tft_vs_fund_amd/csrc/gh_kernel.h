@@ -407,24 +407,26 @@ struct FaugPapaModel {
 };
 
 // x = pinv(M) b for the symmetric n x n matrix held (with b as column n) in the augmented n x (n+1) array:
-// eigen-decomposition M = V L V', singular values |lambda_k|, MATLAB's pinv tolerance n * eps(max |lambda|),
+// eigen-decomposition M = V L V' (wave_eigh_ql), singular values |lambda_k|, MATLAB's pinv tolerance n * eps(max |lambda|),
 // x = sum_{|lambda_k| > tol} v_k (v_k' b) / lambda_k.  Needed when the constraints are redundant (KKT singular).
-__device__ inline void wave_pinv_solve_sym(double* M, double* V, int n, double* sol, double* coef) {
+// ZT: n * n doubles (eigenvectors, one per row), scr: 2 n doubles.  One wavefront.
+__device__ inline void wave_pinv_solve_sym(double* M, double* ZT, int n, double* sol, double* scr) {
     const int lane = lane_id();
     const int ld = n + 1;
-    wave_jacobi_sym(M, ld, V, n, n, true);
-    const double lam = (lane < n) ? M[lane * ld + lane] : 0.0;
-    const double amax = wave_max(fabs(lam));
+    int fail;
+    const double lam = wave_eigh_ql(M, ld, ZT, n, n, scr, &fail);
+    const double amax = wave_max((lane < n) ? fabs(lam) : 0.0);
     const double tol = (double)n * eps_of(amax);
     if (lane < n) {
+        const double* vk = ZT + eig_row(n, lane) * n;
         double d = 0.0;
-        for (int r = 0; r < n; ++r) d += V[r * n + lane] * M[r * ld + n];
-        coef[lane] = (fabs(lam) > tol) ? d / lam : 0.0;
+        for (int r = 0; r < n; ++r) d += vk[r] * M[r * ld + n];
+        scr[lane] = (fabs(lam) > tol) ? d / lam : 0.0;
     }
     wave_sync();
     if (lane < n) {
         double x = 0.0;
-        for (int k = 0; k < n; ++k) x += V[lane * n + k] * coef[k];
+        for (int k = 0; k < n; ++k) x += ZT[eig_row(n, k) * n + lane] * scr[k];
         sol[lane] = x;
     }
     wave_sync();

@@ -26,13 +26,14 @@ constexpr int GH_WG_WAVES = 4;
 constexpr int GH_WG_THREADS = 64 * GH_WG_WAVES;
 constexpr int GH_REC_DOUBLES = 64;        // t 27 | pa 18 | epi 6 | nrm 9 | pad
 
-// LDS of k_gh_block after the PoseLds header: p, dt, Tc, dT, D, H, Y, M, V (n^2 + 4n + 8 for the pseudo-inverse models: eigenvectors + the pair table of block_jacobi_sym, else 112), xi (6N), W+ (10N),
-// reduction slots.  Ghat (729) lives in PoseLds::Lp (the linear stage's Cholesky factor is not needed here); the per-wavefront
+// LDS of k_gh_block after the PoseLds header: p, dt, Tc, dT, D, H, Y, M, V (112 doubles of scratch), xi (6N), W+ (10N), reduction slots.
+// `pinv` (FaugPapa: D is the identity and never stored): the eigenvectors + scratch of the pseudo-inverse (n^2 + 2n) overlay D | H | Y,
+// all dead during the solve, which keeps the fixed part under 40 KB -> four workgroups per CU once xi / W+ are spilled.  Ghat (729) lives in PoseLds::Lp (the linear stage's Cholesky factor is not needed here); the per-wavefront
 // partial sums of the sweeps live in Lp[0..595] (waves 0, 1), Y (wave 2) and H itself (wave 3), all dead at that point; W+ w is
 // recomputed where needed.  Ressl at N = 200: 50.4 KB with the header -> three workgroups per CU.
 __host__ __device__ inline int gh_wg_lds_doubles(int u, int c, int N, bool pinv) {
     const int n = u + c;
-    return 2 * ((u + 1) & ~1) + 2 * c + 28 + 28 + 27 * u + 298 + ((27 * u > 298) ? 27 * u : 298) + n * (n + 1) + (pinv ? n * n + 4 * n + 8 : 112) + 6 * N + 10 * N + 16 + 8;
+    return 2 * ((u + 1) & ~1) + 2 * c + 28 + 28 + 27 * u + 298 + ((27 * u > 298) ? 27 * u : 298) + n * (n + 1) + 112 + 6 * N + 10 * N + 16 + 8;
 }
 __device__ inline GhWork gh_wg_carve(double* base, PoseLds* w, int u, int c, int N, bool pinv, double** red) {
     GhWork g;
@@ -47,7 +48,7 @@ __device__ inline GhWork gh_wg_carve(double* base, PoseLds* w, int u, int c, int
     g.H = q; q += 298;
     g.Y = q; q += (27 * u > 298) ? 27 * u : 298;
     g.M = q; q += n * (n + 1);
-    g.V = q; q += pinv ? n * n + 4 * n + 8 : 112;                                  // other models: 108 doubles of scratch (Nordberg's rotations)
+    g.V = pinv ? g.D : q; q += 112;                                                // 108 doubles of scratch (Nordberg's rotations)
     g.xi = q; q += 6 * N;
     g.pp = q; q += 10 * N;
     *red = q;
@@ -127,126 +128,13 @@ __device__ __forceinline__ double block_max(double v, double* red) {
 }
 __device__ __forceinline__ bool block_any(bool p, double* red) { return block_sum(p ? 1.0 : 0.0, red) != 0.0; }
 
-// Jacobi eigen-decomposition of the symmetric n x n matrix A (LDS, leading dimension lda; diagonal -> eigenvalues, V -> eigenvectors)
-// by the whole workgroup: round-robin (tournament) ordering, m/2 disjoint rotations per round (m = n rounded up to even), each round
-//   (a) one thread per pair computes (c, s) (thresholds: see below),
-//   (b) A <- J' A J by 2 x 2 blocks (pair I x pair J: four entries read, both rotations applied, four written) and V <- V J by
-//       (row, pair) items -- one phase, two barriers per round.
-// `cs`: 4 * (m/2) doubles of LDS scratch (p, q, c, s per pair), then one slot for the rotation counter.
+// x = pinv(M) b through the eigen-decomposition (wave_pinv_solve_sym) on the wavefront `own` of the workgroup; the others wait.
+// (A workgroup-parallel cyclic Jacobi was measured here first: 11 sweeps x 39 rounds x 2 barriers on the 39 x 39 matrix, 1.5 ms per
+// solve; tridiagonalisation + QL on one wavefront does a tenth of the arithmetic and leaves the CU to the other workgroups.)
+// scratch: 2 n doubles.
 template <int n>
-__device__ inline int block_jacobi_sym(double* A, const int lda, double* V, const int ldv, double* cs) {
-    const int tid = threadIdx.x;
-    constexpr int m = (n + 1) & ~1, half = m / 2;
-    constexpr int NBLK = (half * half + GH_WG_THREADS - 1) / GH_WG_THREADS, NVIT = (half * n + GH_WG_THREADS - 1) / GH_WG_THREADS;
-    for (int e = tid; e < n * n; e += GH_WG_THREADS) V[(e / n) * ldv + e % n] = (e / n == e % n) ? 1.0 : 0.0;
-    double tr = 0.0;
-    for (int k = 0; k < n; ++k) tr += fabs(A[k * lda + k]);                  // same on every thread
-    const double absfloor = 1e-22 * tr + 1e-300;
-    double* counter = cs + 4 * half;
-    __syncthreads();
-    int sweep = 0;
-#pragma unroll 1
-    for (; sweep < 40; ++sweep) {
-        if (tid == 0) *counter = 0.0;
-        __syncthreads();
-#pragma unroll 1
-        for (int r = 0; r < m - 1; ++r) {
-            if (tid < half) {                                                // (a) the pair of this thread in round r
-                int p, q;
-                if (tid == 0) { p = m - 1; q = r; }
-                else { p = (r + tid) % (m - 1); q = (r - tid + (m - 1)) % (m - 1); }
-                if (p > q) { const int t = p; p = q; q = t; }
-                double c = 1.0, s = 0.0;
-                if (q < n) {                                                 // q == n: the phantom index of an odd n
-                    const double apq = A[p * lda + q], app = A[p * lda + p], aqq = A[q * lda + q];
-                    // threshold relative to the LARGER diagonal entry: couplings between a large eigenvalue and the (near-)null space of a
-                    // singular KKT matrix settle at rounding level and are left alone (error in the small eigenvalue ~ apq^2 / gap)
-                    const double big = (fabs(app) > fabs(aqq)) ? fabs(app) : fabs(aqq);
-                    if (fabs(apq) > 1.1e-16 * big && fabs(apq) > absfloor) {
-                        const double tau = (aqq - app) / (2.0 * apq);
-                        const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                        c = rsqrt(1.0 + t * t); s = t * c;
-                        *counter = 1.0;                                      // benign race: every writer stores the same value
-                    }
-                }
-                cs[4 * tid] = (double)p; cs[4 * tid + 1] = (double)q; cs[4 * tid + 2] = c; cs[4 * tid + 3] = s;
-            }
-            __syncthreads();
-            // (b) all loads of this thread's items first, then the arithmetic, then the stores (the items of a round are disjoint)
-            double a00[NBLK], a01[NBLK], a10[NBLK], a11[NBLK], cI[NBLK], sI[NBLK], cJ[NBLK], sJ[NBLK];
-            int pI[NBLK], qI[NBLK], pJ[NBLK], qJ[NBLK];
-#pragma unroll
-            for (int k = 0; k < NBLK; ++k) {
-                const int blk = tid + k * GH_WG_THREADS;
-                const int I = (blk < half * half) ? blk / half : 0, J = (blk < half * half) ? blk % half : 0;
-                pI[k] = (int)cs[4 * I]; qI[k] = (int)cs[4 * I + 1]; cI[k] = cs[4 * I + 2]; sI[k] = (blk < half * half) ? cs[4 * I + 3] : 0.0;
-                pJ[k] = (int)cs[4 * J]; qJ[k] = (int)cs[4 * J + 1]; cJ[k] = cs[4 * J + 2]; sJ[k] = (blk < half * half) ? cs[4 * J + 3] : 0.0;
-                const bool vi = qI[k] < n, vj = qJ[k] < n;
-                a00[k] = A[pI[k] * lda + pJ[k]];
-                a01[k] = vj ? A[pI[k] * lda + qJ[k]] : 0.0;
-                a10[k] = vi ? A[qI[k] * lda + pJ[k]] : 0.0;
-                a11[k] = (vi && vj) ? A[qI[k] * lda + qJ[k]] : 0.0;
-            }
-            double vp[NVIT], vq[NVIT], vc[NVIT], vs[NVIT];
-            int vrow[NVIT], vpi[NVIT], vqi[NVIT];
-#pragma unroll
-            for (int k = 0; k < NVIT; ++k) {
-                const int e = tid + k * GH_WG_THREADS;
-                const bool in = e < half * n;
-                const int row = in ? e / half : 0, pr = in ? e % half : 0;   // neighbouring threads: same row, different pairs (LDS banks)
-                vrow[k] = row; vpi[k] = (int)cs[4 * pr]; vqi[k] = (int)cs[4 * pr + 1]; vc[k] = cs[4 * pr + 2]; vs[k] = in ? cs[4 * pr + 3] : 0.0;
-                vp[k] = V[row * ldv + vpi[k]];
-                vq[k] = (vs[k] != 0.0) ? V[row * ldv + vqi[k]] : 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < NBLK; ++k) {
-                if (sI[k] == 0.0 && sJ[k] == 0.0) continue;
-                const double b00 = cI[k] * a00[k] - sI[k] * a10[k], b01 = cI[k] * a01[k] - sI[k] * a11[k];     // rows: J_I' A
-                const double b10 = sI[k] * a00[k] + cI[k] * a10[k], b11 = sI[k] * a01[k] + cI[k] * a11[k];
-                const bool vi = qI[k] < n, vj = qJ[k] < n;
-                A[pI[k] * lda + pJ[k]] = cJ[k] * b00 - sJ[k] * b01;                                              // columns: (.) J_J
-                if (vj) A[pI[k] * lda + qJ[k]] = sJ[k] * b00 + cJ[k] * b01;
-                if (vi) A[qI[k] * lda + pJ[k]] = cJ[k] * b10 - sJ[k] * b11;
-                if (vi && vj) A[qI[k] * lda + qJ[k]] = sJ[k] * b10 + cJ[k] * b11;
-            }
-#pragma unroll
-            for (int k = 0; k < NVIT; ++k) {
-                if (vs[k] == 0.0) continue;
-                V[vrow[k] * ldv + vpi[k]] = vc[k] * vp[k] - vs[k] * vq[k];
-                V[vrow[k] * ldv + vqi[k]] = vs[k] * vp[k] + vc[k] * vq[k];
-            }
-            __syncthreads();
-        }
-        if (*counter == 0.0) break;
-        __syncthreads();
-    }
-    return sweep;
-}
-
-// x = pinv(M) b through the eigen-decomposition (see wave_pinv_solve_sym), by the whole workgroup.
-// scratch: n coefficients, then the pair table of block_jacobi_sym.
-template <int n>
-__device__ inline void block_pinv_solve_sym(double* M, double* V, double* sol, double* scratch, double* dbg = nullptr) {
-    const int tid = threadIdx.x;
-    constexpr int ld = n + 1;
-    const int sweeps = block_jacobi_sym<n>(M, ld, V, n, scratch + ((n + 1) & ~1));
-    if (dbg && tid == 0) dbg[79] = (double)sweeps;
-    __syncthreads();
-    double amax = 0.0;
-    for (int k = 0; k < n; ++k) { const double l = fabs(M[k * ld + k]); amax = (l > amax) ? l : amax; }
-    const double tol = (double)n * eps_of(amax);
-    if (tid < n) {
-        const double lam = M[tid * ld + tid];
-        double d = 0.0;
-        for (int r = 0; r < n; ++r) d += V[r * n + tid] * M[r * ld + n];
-        scratch[tid] = (fabs(lam) > tol) ? d / lam : 0.0;
-    }
-    __syncthreads();
-    if (tid < n) {
-        double x = 0.0;
-        for (int k = 0; k < n; ++k) x += V[tid * n + k] * scratch[k];
-        sol[tid] = x;
-    }
+__device__ inline void block_pinv_solve_sym(double* M, double* V, double* sol, double* scratch, const int own) {
+    if (wave_in_block() == own) wave_pinv_solve_sym(M, V, n, sol, scratch);
     __syncthreads();
 }
 
@@ -471,7 +359,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         if (!(fabs(block_sum(chkM, red)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
         if (it == 1) phase_stamp(sdbg, 45);
         // aux = pinv(M + 1e-12 I) * b   (:67): truncated pseudo-inverse by the workgroup, or Gauss-Jordan on the owner wavefront
-        if (Model::REDUNDANT_CONSTRAINTS) block_pinv_solve_sym<n>(g.M, g.V, g.dt, g.V + n * n, (it == 1) ? dbg : nullptr);
+        if (Model::REDUNDANT_CONSTRAINTS) block_pinv_solve_sym<n>(g.M, g.V, g.dt, g.V + n * n, own);
         if (owner) {
             bool ok = true;
             if (!Model::REDUNDANT_CONSTRAINTS) ok = wave_solve_gj<n>(g.M, g.dt);
@@ -487,8 +375,8 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         __syncthreads();
         if (!Model::REDUNDANT_CONSTRAINTS && red[8] == 0.0) {
             // numerically singular KKT matrix (degenerate geometry): pinv truncates, so does the eigen-decomposition path.
-            // Eigenvectors go to Y and the pair table to H, both dead by now.
-            block_pinv_solve_sym<n>(g.M, g.Y, g.dt, g.H);
+            // Eigenvectors go to Y and the scratch vectors to H, both dead by now.
+            block_pinv_solve_sym<n>(g.M, g.Y, g.dt, g.H, own);
             if (owner && lane < 27) {
                 double acc = 0.0;
                 if (Model::IDENTITY_D) acc = g.dt[lane];
@@ -556,7 +444,9 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
 }
 
 template <class Model>
-__global__ void __launch_bounds__(GH_WG_THREADS, 3) k_gh_block(const GhWgArgs a) {
+__global__ void __launch_bounds__(GH_WG_THREADS, Model::REDUNDANT_CONSTRAINTS ? 4 : 3) k_gh_block(const GhWgArgs a) {
+    static_assert(!Model::REDUNDANT_CONSTRAINTS || (Model::IDENTITY_D && 2 * 27 * Model::U + 298 >= (Model::U + Model::C) * (Model::U + Model::C + 2)),
+                  "pseudo-inverse workspace must fit D | H | Y");
     TFF_DYNAMIC_LDS(double, smem);
     PoseLds* w = reinterpret_cast<PoseLds*>(smem);
     constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;

@@ -262,7 +262,7 @@ struct PiColModel {
     // the reference's A(ind2+4,1:3) = +p1' (pi32'p2)(pi33'p3)   (:186), opposite to the derivative used in its B (:198)
     __device__ static __forceinline__ void a_quirk(double (&c)[5][9]) { c[3][0] = -c[3][0]; }
     // lane 0: PiColPoseEstimation.m:61-113
-    __device__ static inline int init(PoseLds* w, double* p) {
+    __device__ static __forceinline__ int init(PoseLds* w, double* p) {
         double P1[3][4], P2[3][4], P3[3][4];
         pi_linear_cameras(w, P1, P2, P3);
         double M[4][4];
@@ -732,7 +732,7 @@ __device__ inline int gauss_helmert_pi_wave(PoseLds* w, PiWork& g, const double*
         // aux = pinv(M + 1e-12 I) b   (:67)
         // Gauss-Jordan when the matrix is regular (then pinv is the inverse); the eigen-decomposition path reproduces the
         // truncation otherwise (degenerate geometry, e.g. collinear centres under the generic parameterisation)
-        if (Model::PINV_KKT || !wave_solve_gj<n>(g.M, g.dt)) wave_pinv_solve_sym(g.M, g.V, n, g.dt, g.V + n * n);
+        if (Model::PINV_KKT || !wave_solve_gj<n>(g.M, g.dt)) wave_pinv_solve_sym(g.M, g.V, n, g.dt, g.H);   // H is dead by now
         wave_sync();
         double dt[27];
         load_uniform27(g.dt, dt);

@@ -158,7 +158,7 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
             __syncthreads();
             need_pinv = red[8] == 0.0;
         }
-        if (need_pinv) block_pinv_solve_sym<n>(g.M, g.V, g.dt, g.H);          // eigenvectors -> V, pair table -> H (both dead by now)
+        if (need_pinv) block_pinv_solve_sym<n>(g.M, g.V, g.dt, g.H, own);     // eigenvectors -> V, scratch -> H (both dead by now)
         __syncthreads();
         double dt[27];
         load_uniform27(g.dt, dt);
@@ -228,7 +228,7 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
 }
 
 template <class Model>
-__global__ void __launch_bounds__(GH_WG_THREADS, 2) k_pi_block(const GhWgArgs a) {
+__global__ void __launch_bounds__(GH_WG_THREADS, Model::PINV_KKT ? 4 : 2) k_pi_block(const GhWgArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
     PoseLds* w = reinterpret_cast<PoseLds*>(smem);
     constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;

@@ -38,6 +38,9 @@ __device__ inline double wave_bcast(double v, int src) {
 __device__ inline int wave_shfl_xor_i(int v, int mask) { return (int)emu::exchange((uint64_t)(uint32_t)v, lane_id() ^ mask); }
 __device__ inline int wave_bcast_i(int v, int src) { return (int)emu::exchange((uint64_t)(uint32_t)v, src); }
 __device__ inline double wave_uniform(double v) { return v; }
+__device__ inline int wave_uniform_i(int v) { return v; }
+typedef double* lds_ptr;
+__device__ inline lds_ptr to_lds(double* p) { return p; }
 #else
 #define TFF_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 // Lanes of one wavefront exchange data through LDS without a workgroup
@@ -66,6 +69,11 @@ __device__ __forceinline__ double wave_uniform(double v) {
     hi = __builtin_amdgcn_readfirstlane(hi);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ int wave_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// A pointer into LDS that went through a non-inlined call is a generic pointer (flat_load / flat_store); casting it back to the
+// local address space restores ds_read / ds_write.
+typedef __attribute__((address_space(3))) double* lds_ptr;
+__device__ __forceinline__ lds_ptr to_lds(double* p) { return (lds_ptr)p; }
 #endif
 
 // Coarse phase stamps for the *_debug_dev entry points (shader clock, lane 0):

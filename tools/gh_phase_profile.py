@@ -23,8 +23,6 @@ dt = np.diff(st, axis=1)
 tot = st[:, 7] - st[:, 0]
 print("%s, variant %d, N = %d: first GH iteration %.0f cycles (mean iterations %.2f)" % (method, variant, N, tot.mean(), out["iter"].double().mean().item()))
 if variant == 0:
-    if dbg[:, 79].max() > 0:
-        print("  Jacobi sweeps of the first pseudo-inverse: mean %.1f max %d" % (dbg[:, 79].mean(), dbg[:, 79].max()))
     s4 = dbg[:, 116:120]
     print("  k_gh_block: model.init %.0f, reprojection %.0f, whole iteration loop %.0f cycles" % ((s4[:, 1] - s4[:, 0]).mean(), (s4[:, 2] - s4[:, 1]).mean(), (s4[:, 3] - s4[:, 2]).mean()))
 for k, nme in enumerate(names):
