@@ -39,14 +39,16 @@ struct Block {
 inline thread_local Idx tl_threadIdx, tl_blockIdx, tl_blockDim, tl_gridDim;
 inline thread_local Block* tl_block = nullptr;
 
+// One barrier per exchange: the slots are double-buffered by the parity of the lane's exchange count (every lane of a wavefront
+// executes the same sequence of exchanges), so slot set p is not rewritten before the barrier of the NEXT exchange, which no lane
+// passes until every lane has finished reading set p.
+inline thread_local unsigned tl_xchg = 0;
 inline uint64_t exchange(uint64_t v, int src) {
     Block& b = *tl_block;
-    unsigned t = tl_threadIdx.x, w = t >> 6;
-    b.slot[t] = v;
+    const unsigned t = tl_threadIdx.x, w = t >> 6, half = (tl_xchg++ & 1u) * b.nthreads;
+    b.slot[half + t] = v;
     b.wavebar[w]->arrive_and_wait();
-    uint64_t r = b.slot[(w << 6) + (unsigned(src) & 63u)];
-    b.wavebar[w]->arrive_and_wait();
-    return r;
+    return b.slot[half + (w << 6) + (unsigned(src) & 63u)];
 }
 inline void wave_barrier() { tl_block->wavebar[tl_threadIdx.x >> 6]->arrive_and_wait(); }
 inline void block_barrier() { tl_block->bar->arrive_and_wait(); }
@@ -60,7 +62,7 @@ void launch(F kernel, unsigned grid, unsigned block, size_t smem, A... args) {
         blk.nthreads = block;
         blk.bar = std::make_unique<std::barrier<>>(block);
         for (unsigned w = 0; w < block / 64; ++w) blk.wavebar.push_back(std::make_unique<std::barrier<>>(64));
-        blk.slot.assign(block, 0);
+        blk.slot.assign(2 * block, 0);
         blk.dyn.assign(smem + 16, 0);
         std::vector<std::thread> th;
         th.reserve(block);
@@ -71,6 +73,7 @@ void launch(F kernel, unsigned grid, unsigned block, size_t smem, A... args) {
                 tl_blockDim.x = block;
                 tl_gridDim.x = grid;
                 tl_block = &blk;
+                tl_xchg = 0;
                 kernel(args...);
             });
         }
