@@ -8,7 +8,7 @@ ctx = api.Context(0)
 for N in (12, 40, 64, 100, 130):
     C, CalM, _, _ = generate_scene_batch(20000, N, noise=1.0, seed=1)
     d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
-    for meth in ("ResslTFTPoseEstimation", "NordbergTFTPoseEstimation", "PiPoseEstimation", "FaugPapaTFTPoseEstimation"):
+    for meth in ("ResslTFTPoseEstimation", "NordbergTFTPoseEstimation", "PiPoseEstimation", "FaugPapaTFTPoseEstimation", "PiColPoseEstimation"):
         row = []
         for variant in (2, 1, 0):
             ctx.set_kernel_variant(variant)
