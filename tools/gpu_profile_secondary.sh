@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_secondary; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for m in LinearFPoseEstimation ResslTFTPoseEstimation NordbergTFTPoseEstimation FaugPapaTFTPoseEstimation PiPoseEstimation OptimFPoseEstimation; do
+for m in LinearFPoseEstimation ResslTFTPoseEstimation NordbergTFTPoseEstimation FaugPapaTFTPoseEstimation PiPoseEstimation PiColPoseEstimation OptimFPoseEstimation; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$m -- python3 $R/tools/bench_one.py $m 10 > $OUT/$m.log 2>&1
   f=$(find $OUT/$m -name "*kernel_stats.csv" | head -1)
   grep -E "^\"Name\"|tff::" $f > $OUT/${m}_kernel_stats.csv
