@@ -245,9 +245,9 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
 template <class Model, class KFused, class KFusedJac>
 int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    // small N: the fused kernel's LDS footprint lets more wavefronts share a CU than the workgroup layout can use (measured crossover
-    // at N ~ 32 for Ressl, ~ 48 for Nordberg; FaugPapa's eigen-decomposition always wants the workgroup)
-    const int crossover = std::is_same<Model, tff::ResslModel>::value ? 32 : 48;
+    // small N: the fused kernel's LDS footprint lets more wavefronts share a CU than the workgroup layout can use (measured: Nordberg
+    // below N ~ 48; Ressl never since the sweeps are dealt to the wavefronts; FaugPapa's eigen-decomposition always wants the workgroup)
+    const int crossover = std::is_same<Model, tff::ResslModel>::value ? 0 : 48;
     const bool small = !Model::REDUNDANT_CONSTRAINTS && N < crossover && c->kernel_variant == 0 && !dbg;
     if (c->kernel_variant == 1 || c->solver != 0 || small)
         return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
@@ -257,7 +257,7 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
 template <class Model>
 int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    const bool small = !Model::PINV_KKT && N < 112 && c->kernel_variant == 0;   // measured crossover for Pi at N ~ 110
+    const bool small = !Model::PINV_KKT && N < 96 && c->kernel_variant == 0;    // measured crossover for Pi at N ~ 100
     if (c->kernel_variant == 1 || c->solver != 0 || c->init_p || small)      // the debug outputs (init_p, init_x) come from the fused kernel
         return launch_pose(c, tff::k_pi_tft_pose<Model, false>, tff::k_pi_tft_pose<Model, true>, tff::pi_lds_bytes<Model>, false,
                            corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);

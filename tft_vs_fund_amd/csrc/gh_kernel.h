@@ -409,12 +409,14 @@ struct FaugPapaModel {
 // x = pinv(M) b for the symmetric n x n matrix held (with b as column n) in the augmented n x (n+1) array:
 // eigen-decomposition M = V L V' (wave_eigh_ql), singular values |lambda_k|, MATLAB's pinv tolerance n * eps(max |lambda|),
 // x = sum_{|lambda_k| > tol} v_k (v_k' b) / lambda_k.  Needed when the constraints are redundant (KKT singular).
-// ZT: n * n doubles (eigenvectors, one per row), scr: 2 n doubles.  One wavefront.
+// ZT: n * n doubles (eigenvectors, one per row), scr: 2 n doubles.  One wavefront.  INLINE: the workgroup kernels, whose register
+// budget (launch bounds) must cover the solver.
+template <bool INLINE = false>
 __device__ inline void wave_pinv_solve_sym(double* M, double* ZT, int n, double* sol, double* scr) {
     const int lane = lane_id();
     const int ld = n + 1;
     int fail;
-    const double lam = wave_eigh_ql(M, ld, ZT, n, n, scr, &fail);
+    const double lam = INLINE ? wave_eigh_ql(M, ld, ZT, n, n, scr, &fail) : wave_eigh_ql_call(M, ld, ZT, n, n, scr, &fail);
     const double amax = wave_max((lane < n) ? fabs(lam) : 0.0);
     const double tol = (double)n * eps_of(amax);
     if (lane < n) {

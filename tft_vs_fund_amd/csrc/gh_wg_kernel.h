@@ -28,9 +28,10 @@ constexpr int GH_REC_DOUBLES = 64;        // t 27 | pa 18 | epi 6 | nrm 9 | pad
 
 // LDS of k_gh_block after the PoseLds header: p, dt, Tc, dT, D, H, Y, M, V (112 doubles of scratch), xi (6N), W+ (10N), reduction slots.
 // `pinv` (FaugPapa: D is the identity and never stored): the eigenvectors + scratch of the pseudo-inverse (n^2 + 2n) overlay D | H | Y,
-// all dead during the solve, which keeps the fixed part under 40 KB -> four workgroups per CU once xi / W+ are spilled.  Ghat (729) lives in PoseLds::Lp (the linear stage's Cholesky factor is not needed here); the per-wavefront
-// partial sums of the sweeps live in Lp[0..595] (waves 0, 1), Y (wave 2) and H itself (wave 3), all dead at that point; W+ w is
-// recomputed where needed.  Ressl at N = 200: 50.4 KB with the header -> three workgroups per CU.
+// all dead during the solve, which keeps the fixed part under 40 KB -> four workgroups per CU once xi / W+ are spilled.
+// Ghat (729) lives in PoseLds::Lp (the linear stage's Cholesky factor is not needed here); the ten sweeps write their sums straight
+// into H (each sweep runs on one wavefront over all correspondences); W+ w is recomputed where needed.
+// Ressl at N = 200: 50.4 KB with the header -> three workgroups per CU.
 __host__ __device__ inline int gh_wg_lds_doubles(int u, int c, int N, bool pinv) {
     const int n = u + c;
     return 2 * ((u + 1) & ~1) + 2 * c + 28 + 28 + 27 * u + 298 + ((27 * u > 298) ? 27 * u : 298) + n * (n + 1) + 112 + 6 * N + 10 * N + 16 + 8;
@@ -134,11 +135,11 @@ __device__ __forceinline__ bool block_any(bool p, double* red) { return block_su
 // scratch: 2 n doubles.
 template <int n>
 __device__ inline void block_pinv_solve_sym(double* M, double* V, double* sol, double* scratch, const int own) {
-    if (wave_in_block() == own) wave_pinv_solve_sym(M, V, n, sol, scratch);
+    if (wave_in_block() == own) wave_pinv_solve_sym<true>(M, V, n, sol, scratch);
     __syncthreads();
 }
 
-// one accumulation sweep over this wavefront's correspondences -> Hp (this wave's 298 partial sums)
+// one accumulation sweep (30 of the 297 sums) over ALL correspondences by the calling wavefront -> H
 template <int CH>
 __device__ inline void gh_sweep_part(const GhWork& g, double* Hp, int N, const double (&T)[27], const PoseLds* w, const double* pts) {
     const int lane = lane_id();
@@ -146,7 +147,7 @@ __device__ inline void gh_sweep_part(const GhWork& g, double* Hp, int N, const d
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.0;
 #pragma unroll 1
-    for (int i = threadIdx.x; i < N; i += GH_WG_THREADS) {
+    for (int i = lane; i < N; i += WAVE) {
         GhPoint pt;
 #pragma unroll
         for (int k = 0; k < 6; ++k) pt.o[k] = g.xi[6 * i + k];
@@ -299,27 +300,16 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
             }
         }
         if (it == 1) phase_stamp(sdbg, 43);
-        // ---- Ghat, ghat: every wavefront sweeps its correspondences (each thread re-reads only what it stored) ----
-        double* Hp = (wave == 0) ? w->Lp : ((wave == 1) ? w->Lp + 298 : ((wave == 2) ? g.Y : g.H));   // dead storage, see gh_wg_lds_doubles
-        gh_sweep_part<0>(g, Hp, N, T, w, pts); gh_sweep_part<1>(g, Hp, N, T, w, pts); gh_sweep_part<2>(g, Hp, N, T, w, pts);
-        gh_sweep_part<3>(g, Hp, N, T, w, pts); gh_sweep_part<4>(g, Hp, N, T, w, pts); gh_sweep_part<5>(g, Hp, N, T, w, pts);
-        gh_sweep_part<6>(g, Hp, N, T, w, pts); gh_sweep_part<7>(g, Hp, N, T, w, pts); gh_sweep_part<8>(g, Hp, N, T, w, pts);
-        gh_sweep_part<9>(g, Hp, N, T, w, pts);
+        // ---- Ghat, ghat: the ten sweeps are dealt to the four wavefronts, each sweep runs over ALL correspondences on one wavefront
+        //      (4 per lane at N = 200) and ends in one reduce-scatter: a quarter of the reductions of the per-wavefront-partial layout
+        //      and no combine step ----
+        __syncthreads();                                                     // xi, W+ of every correspondence are in place
+        if (wave == 0) { gh_sweep_part<0>(g, g.H, N, T, w, pts); gh_sweep_part<4>(g, g.H, N, T, w, pts); gh_sweep_part<8>(g, g.H, N, T, w, pts); }
+        else if (wave == 1) { gh_sweep_part<1>(g, g.H, N, T, w, pts); gh_sweep_part<5>(g, g.H, N, T, w, pts); gh_sweep_part<7>(g, g.H, N, T, w, pts); }
+        else if (wave == 2) { gh_sweep_part<2>(g, g.H, N, T, w, pts); gh_sweep_part<6>(g, g.H, N, T, w, pts); }
+        else { gh_sweep_part<3>(g, g.H, N, T, w, pts); gh_sweep_part<9>(g, g.H, N, T, w, pts); }   // 9: the right-hand side, recomputes w
         __syncthreads();
         if (it == 1) phase_stamp(sdbg, 44);
-        double hsum[2] = {0.0, 0.0};                                         // 297 sums over 256 threads; H is also wave 3's partial
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int e = tid + k * GH_WG_THREADS;
-            if (e < 297) hsum[k] = (w->Lp[e] + w->Lp[298 + e]) + (g.Y[e] + g.H[e]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int e = tid + k * GH_WG_THREADS;
-            if (e < 297) g.H[e] = hsum[k];
-        }
-        __syncthreads();
         for (int e = tid; e < 729; e += GH_WG_THREADS) {                     // Ghat[(q,i1),(q',i1')] = H[6 tri(q,q') + hht(i1,i1')]
             const int r = e / 27, cc = e % 27;
             const int q = r % 9, i1 = r / 9, qq = cc % 9, i1p = cc / 9;

@@ -568,6 +568,11 @@ __device__ inline void pi_sweep(const PiWork& g, const double (&pi)[27], int N, 
 }
 // all 16 sweeps over the correspondences first, first + step, ...; sums of this wavefront -> Hp[0..431]
 template <class Model, int S>
+__device__ __forceinline__ void pi_sweeps_strided(const PiWork& g, const double (&pi)[27], int N, int first, int step, double* Hp) {
+    pi_sweep<Model, S>(g, pi, N, first, step, Hp);
+    if constexpr (S + 4 < 16) pi_sweeps_strided<Model, S + 4>(g, pi, N, first, step, Hp);
+}
+template <class Model, int S>
 __device__ __forceinline__ void pi_sweeps(const PiWork& g, const double (&pi)[27], int N, int first, int step, double* Hp) {
     pi_sweep<Model, S>(g, pi, N, first, step, Hp);
     if constexpr (S < 15) pi_sweeps<Model, S + 1>(g, pi, N, first, step, Hp);

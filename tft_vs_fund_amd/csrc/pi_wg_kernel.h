@@ -104,22 +104,14 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
                 pi_store_point<E>(g, w, pts, i, o, pt, Wp);
             }
         }
-        // ---- A'WA and A'Ww: per-wavefront partial sums in V (waves 0..2) and H (wave 3), then added in a fixed order ----
-        double* Hp = (wave < 3) ? g.V + 432 * wave : g.H;
-        pi_sweeps<Model, 0>(g, pi, N, tid, GH_WG_THREADS, Hp);
+        // ---- A'WA and A'Ww: the sixteen sweeps are dealt to the four wavefronts (wave w: sweeps w, w + 4, w + 8, w + 12), each over ALL
+        //      correspondences and straight into H -- a quarter of the reductions of a per-wavefront-partial layout, no combine step ----
+        __syncthreads();                                                     // every correspondence's xi, W+ are in place
+        if (wave == 0) pi_sweeps_strided<Model, 0>(g, pi, N, lane, WAVE, g.H);
+        else if (wave == 1) pi_sweeps_strided<Model, 1>(g, pi, N, lane, WAVE, g.H);
+        else if (wave == 2) pi_sweeps_strided<Model, 2>(g, pi, N, lane, WAVE, g.H);
+        else pi_sweeps_strided<Model, 3>(g, pi, N, lane, WAVE, g.H);
         __syncthreads();
-        double hs[2] = {0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int e = tid + k * GH_WG_THREADS;
-            if (e < 432) hs[k] = (g.V[e] + g.V[432 + e]) + (g.V[864 + e] + g.H[e]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int e = tid + k * GH_WG_THREADS;
-            if (e < 432) g.H[e] = hs[k];
-        }
         for (int e = tid; e < n * ld; e += GH_WG_THREADS) g.M[e] = 0.0;
         __syncthreads();
         for (int e = tid; e < 729 + 27; e += GH_WG_THREADS) {

@@ -186,7 +186,7 @@ __device__ inline int wave_jacobi_sym(double* A, const int lda, double* V, const
 // On return lane j (< n) holds eigenvalue j and ROW eig_row(n, j) of ZT (leading dimension ldz) its unit eigenvector.
 // scr: 2 n doubles of LDS.  *fail = 1 if an eigenvalue needed more than 60 sweeps (never observed).
 __device__ __forceinline__ int eig_row(int n, int j) { return n - 1 - j; }
-__device__ inline double wave_eigh_ql(double* A_, const int lda, double* ZT_, const int ldz, const int n, double* scr_, int* fail) {
+__device__ __forceinline__ double wave_eigh_ql(double* A_, const int lda, double* ZT_, const int ldz, const int n, double* scr_, int* fail) {
     const lds_ptr A = to_lds(A_), ZT = to_lds(ZT_), scr = to_lds(scr_);
     const int lane = lane_id();
     const int rl = (lane < n) ? lane : 0;
@@ -296,6 +296,11 @@ __device__ inline double wave_eigh_ql(double* A_, const int lda, double* ZT_, co
     wave_sync();
     *fail = failed;
     return dq;
+}
+
+// Out-of-line copy for the single-wavefront kernels (rare fall-back there; inlined it would cost them a wave of occupancy).
+__device__ __attribute__((noinline)) double wave_eigh_ql_call(double* A, const int lda, double* ZT, const int ldz, const int n, double* scr, int* fail) {
+    return wave_eigh_ql(A, lda, ZT, ldz, n, scr, fail);
 }
 
 // eigenvector of the smallest eigenvalue (see wave_jacobi_sym); per lane r < n component r
