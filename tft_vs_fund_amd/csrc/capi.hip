@@ -60,8 +60,8 @@ struct tff_ctx {
 namespace {
 
 int base_flags(const tff_ctx* c, bool reconst) { return (reconst ? tff::FLAG_RECONST : 0) | (c->gh_exact ? tff::FLAG_GH_EXACT : 0); }
-int staged_flags(const tff_ctx* c, int N, int flags, bool jacobi) {
-    if (c->stage < 0) return tff::pose_auto_flags(N, flags, jacobi);
+int staged_flags(const tff_ctx* c, int N, int flags, bool jacobi, int max_n = tff::STAGE_MAX_N_TFT) {
+    if (c->stage < 0) return tff::pose_auto_flags(N, flags, jacobi, max_n);
     if (c->stage > 0) return flags | tff::FLAG_STAGE_LDS;
     return flags;
 }
@@ -77,8 +77,9 @@ int ensure_lds(K kernel, size_t bytes) {
 // workspace, one slice per resident block (the kernels loop over the batch with a grid stride).  lds_full / lds_fixed: the
 // kernel's LDS request with and without the per-correspondence part.  Returns the LDS bytes to launch with.
 constexpr size_t LDS_LIMIT = 160 * 1024;
-// occupancy_cap > 0: the kernel is bound by a wave-serial step (the pseudo-inverse of the KKT matrix on one wavefront), so workgroups
-// per CU are what counts: spill also when that lets more of them (up to the cap its registers allow) share the CU's LDS.
+// occupancy_cap > 0 (the workgroup kernels; the cap is what their registers allow): spill also when that lets more workgroups share
+// the CU's LDS -- their wave-serial steps (KKT solve, pseudo-inverse) make workgroups per CU what counts.  Measured
+// (tools/bench_n_sweep.py): Ressl 2.14 -> 3.26 M/s at N = 500, Pi 1.18 -> 1.79 M/s at N = 300, never slower.
 int plan_spill(tff_ctx* c, size_t lds_full, size_t lds_fixed, unsigned* grid, double** spill, long* stride, size_t* lds, int occupancy_cap = 0) {
     *spill = nullptr; *stride = 0; *lds = lds_full;
     auto per_cu = [&](size_t bytes) { const size_t k = LDS_LIMIT / (bytes + 512); return (int)(k < (size_t)occupancy_cap ? k : (size_t)occupancy_cap); };
@@ -108,7 +109,7 @@ int check_common(const tff_ctx* c, const void* corresp, const void* calm, int64_
 typedef size_t (*lds_fn)(int N, int flags, bool jacobi);
 
 template <class KMain, class KJac>
-int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, bool may_stage, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_n, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
                 int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     if (B == 0) return 0;
@@ -121,13 +122,13 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, bool may_stage
     tff::LinearTftArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr),
                          Rt2, Rt3, T, reconst, iter, status, dbg, c->sample_idx, c->init_p, c->init_x};
     if (c->sample_idx) {                   // gathered samples always live in LDS
-        if (!may_stage) return fail(TFF_E_INVALID, "sampled hypotheses are not supported by this method");
+        if (!stage_max_n) return fail(TFF_E_INVALID, "sampled hypotheses are not supported by this method");
         a.flags |= tff::FLAG_STAGE_LDS;
-        may_stage = false;
+        stage_max_n = 0;
     }
     if (c->solver == 0) {
         tff::LinearTftArgs m = a;
-        m.flags = may_stage ? staged_flags(c, N, a.flags, false) : a.flags;
+        m.flags = stage_max_n ? staged_flags(c, N, a.flags, false, stage_max_n) : a.flags;
         unsigned grid = tff::pose_grid(B);
         size_t lds;
         if (int r = plan_spill(c, ldsfn(N, m.flags, false), ldsfn(0, m.flags, false), &grid, &m.spill, &m.spill_stride, &lds)) return r;
@@ -136,7 +137,7 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, bool may_stage
         TFF_HIP(hipGetLastError());
         a.flags |= tff::FLAG_ONLY_RETRY;
     }
-    if (may_stage) a.flags = staged_flags(c, N, a.flags, true);
+    if (stage_max_n) a.flags = staged_flags(c, N, a.flags, true, stage_max_n);
     unsigned grid = (c->solver == 0) ? (unsigned)(B < 8192 ? B : 8192) : tff::pose_grid(B);
     size_t lds;
     if (int r = plan_spill(c, ldsfn(N, a.flags, true), ldsfn(0, a.flags, true), &grid, &a.spill, &a.spill_stride, &lds)) return r;
@@ -153,7 +154,7 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, bool may_stage
 int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     if (c->solver != 0 || c->kernel_variant != 1)
-        return launch_pose(c, tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, true, corresp, calm, calm_stride,
+        return launch_pose(c, tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, corresp, calm, calm_stride,
                            B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     if (B == 0) return 0;
@@ -185,12 +186,12 @@ int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int
 }
 int launch_linear_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    return launch_pose(c, tff::k_f_pose<false, 0>, tff::k_f_pose<true, 0>, tff::pose_lds_bytes, true, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
+    return launch_pose(c, tff::k_f_pose<false, 0>, tff::k_f_pose<true, 0>, tff::pose_lds_bytes, tff::STAGE_MAX_N_F, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
                        reconst, iter, status, dbg);
 }
 int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                    double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    return launch_pose(c, tff::k_f_pose<false, 1>, tff::k_f_pose<true, 1>, tff::optimf_lds_bytes, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
+    return launch_pose(c, tff::k_f_pose<false, 1>, tff::k_f_pose<true, 1>, tff::optimf_lds_bytes, 0, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
                        reconst, iter, status, dbg);
 }
 
@@ -250,19 +251,19 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
     const int crossover = std::is_same<Model, tff::ResslModel>::value ? 0 : 48;
     const bool small = !Model::REDUNDANT_CONSTRAINTS && N < crossover && c->kernel_variant == 0 && !dbg;
     if (c->kernel_variant == 1 || c->solver != 0 || small)
-        return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, false, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+        return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, 0, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
-    return launch_wg(c, tff::k_gh_block<Model>, wg_lds, Model::REDUNDANT_CONSTRAINTS ? 4 : 0, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    return launch_wg(c, tff::k_gh_block<Model>, wg_lds, Model::REDUNDANT_CONSTRAINTS ? 4 : 3, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 template <class Model>
 int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     const bool small = !Model::PINV_KKT && N < 96 && c->kernel_variant == 0;    // measured crossover for Pi at N ~ 100
     if (c->kernel_variant == 1 || c->solver != 0 || c->init_p || small)      // the debug outputs (init_p, init_x) come from the fused kernel
-        return launch_pose(c, tff::k_pi_tft_pose<Model, false>, tff::k_pi_tft_pose<Model, true>, tff::pi_lds_bytes<Model>, false,
+        return launch_pose(c, tff::k_pi_tft_pose<Model, false>, tff::k_pi_tft_pose<Model, true>, tff::pi_lds_bytes<Model>, 0,
                            corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::pi_wg_lds_doubles(Model::E, Model::C, n)) * sizeof(double); };
-    return launch_wg(c, tff::k_pi_block<Model>, wg_lds, Model::PINV_KKT ? 4 : 0, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    return launch_wg(c, tff::k_pi_block<Model>, wg_lds, Model::PINV_KKT ? 4 : 2, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 int launch_ressl_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {

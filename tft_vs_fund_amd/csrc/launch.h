@@ -18,10 +18,13 @@ inline size_t pose_lds_bytes(int N, int flags, bool jacobi) {
     if (flags & FLAG_STAGE_LDS) d += 6 * (size_t)N;
     return d * sizeof(double);
 }
-// stage the correspondences in LDS when the whole workspace stays within the
-// default 64 KiB dynamic-LDS window; beyond that, points are re-read through L2.
-inline int pose_auto_flags(int N, int flags, bool jacobi) {
-    if (pose_lds_bytes(N, flags | FLAG_STAGE_LDS, jacobi) <= 64 * 1024) flags |= FLAG_STAGE_LDS;
+// Stage the correspondences in LDS only while that does not cost occupancy: measured on MI355X (tools/bench_n_sweep.py, STAGE=0 / 1)
+// re-reading them through L2 / MALL wins from N ~ 220 for the trifocal kernel (26 vs 19 M/s at N = 300, 10.9 vs 4.4 M/s at
+// N = 1000, where the staged points would leave two wavefronts per CU) and from N ~ 64 for the fundamental-matrix kernel, whose
+// smaller register footprint allows more wavefronts than a staged LDS does (37.9 vs 30.4 M/s at N = 200).
+constexpr int STAGE_MAX_N_TFT = 200, STAGE_MAX_N_F = 48;
+inline int pose_auto_flags(int N, int flags, bool jacobi, int max_n = STAGE_MAX_N_TFT) {
+    if (N <= max_n && pose_lds_bytes(N, flags | FLAG_STAGE_LDS, jacobi) <= 64 * 1024) flags |= FLAG_STAGE_LDS;
     return flags;
 }
 // Gauss-Helmert kernels: correspondences are re-read through L2 (never staged); the LDS holds
