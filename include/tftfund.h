@@ -62,7 +62,7 @@ typedef struct tff_ctx tff_ctx;
 #define TFF_OPT_GH_EXACT 4  /* Gauss-Helmert methods: 1 = always form pinv(W) through per-block eigen-decompositions (default 0: Cholesky inverse while pinv cannot truncate) */
 #define TFF_OPT_KERNEL 3    /* Kernel variants.  LinearTFT: 0 one wavefront per triplet (default); 1 paired kernel, two triplets per workgroup (slower).
                              * Iterative TFT methods: 0 automatic (default: a 4-wavefront workgroup per triplet for the iteration, the fused
-                             * single-wavefront kernel below the measured crossover, N < 48 for Nordberg, N < 96 for Pi);
+                             * single-wavefront kernel below the measured crossover, N < 64 for Nordberg, N < 176 for Pi);
                              * 1 fused kernel always; 2 workgroup kernels always */
 #define TFF_DEBUG_STRIDE 128 /* doubles per triplet written by the *_debug_dev entry points */
 

@@ -105,11 +105,13 @@ int check_common(const tff_ctx* c, const void* corresp, const void* calm, int64_
 
 // Two launches on the context's stream: the inverse-iteration kernel for the whole
 // batch, then the Jacobi kernel over the (rare) triplets it marked ST_RETRY.
+// stage_max_n: largest N whose correspondences are staged in LDS (0: the kernel never stages); occupancy_cap: wavefronts per CU the
+// kernel's registers allow (0: the kernel has no per-correspondence LDS state to spill), see plan_spill.
 // With TFF_OPT_SOLVER = 1 only the Jacobi kernel runs, for every triplet.
 typedef size_t (*lds_fn)(int N, int flags, bool jacobi);
 
 template <class KMain, class KJac>
-int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_n, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_n, int occupancy_cap, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
                 int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     if (B == 0) return 0;
@@ -131,7 +133,7 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_
         m.flags = stage_max_n ? staged_flags(c, N, a.flags, false, stage_max_n) : a.flags;
         unsigned grid = tff::pose_grid(B);
         size_t lds;
-        if (int r = plan_spill(c, ldsfn(N, m.flags, false), ldsfn(0, m.flags, false), &grid, &m.spill, &m.spill_stride, &lds)) return r;
+        if (int r = plan_spill(c, ldsfn(N, m.flags, false), ldsfn(0, m.flags, false), &grid, &m.spill, &m.spill_stride, &lds, occupancy_cap)) return r;
         if (int r = ensure_lds(kmain, lds)) return r;
         hipLaunchKernelGGL(kmain, dim3(grid), dim3(64), lds, c->stream, m);
         TFF_HIP(hipGetLastError());
@@ -154,7 +156,7 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_
 int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     if (c->solver != 0 || c->kernel_variant != 1)
-        return launch_pose(c, tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, corresp, calm, calm_stride,
+        return launch_pose(c, tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, 0, corresp, calm, calm_stride,
                            B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     if (B == 0) return 0;
@@ -186,12 +188,12 @@ int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int
 }
 int launch_linear_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    return launch_pose(c, tff::k_f_pose<false, 0>, tff::k_f_pose<true, 0>, tff::pose_lds_bytes, tff::STAGE_MAX_N_F, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
+    return launch_pose(c, tff::k_f_pose<false, 0>, tff::k_f_pose<true, 0>, tff::pose_lds_bytes, tff::STAGE_MAX_N_F, 0, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
                        reconst, iter, status, dbg);
 }
 int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                    double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    return launch_pose(c, tff::k_f_pose<false, 1>, tff::k_f_pose<true, 1>, tff::optimf_lds_bytes, 0, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
+    return launch_pose(c, tff::k_f_pose<false, 1>, tff::k_f_pose<true, 1>, tff::optimf_lds_bytes, 0, 8, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
                        reconst, iter, status, dbg);
 }
 
@@ -247,20 +249,20 @@ template <class Model, class KFused, class KFusedJac>
 int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     // small N: the fused kernel's LDS footprint lets more wavefronts share a CU than the workgroup layout can use (measured: Nordberg
-    // below N ~ 48; Ressl never since the sweeps are dealt to the wavefronts; FaugPapa's eigen-decomposition always wants the workgroup)
-    const int crossover = std::is_same<Model, tff::ResslModel>::value ? 0 : 48;
+    // below N ~ 64; Ressl never since the sweeps are dealt to the wavefronts; FaugPapa's eigen-decomposition always wants the workgroup)
+    const int crossover = std::is_same<Model, tff::ResslModel>::value ? 0 : 64;
     const bool small = !Model::REDUNDANT_CONSTRAINTS && N < crossover && c->kernel_variant == 0 && !dbg;
     if (c->kernel_variant == 1 || c->solver != 0 || small)
-        return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, 0, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+        return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, 0, std::is_same<Model, tff::ResslModel>::value ? 8 : 4, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
     return launch_wg(c, tff::k_gh_block<Model>, wg_lds, Model::REDUNDANT_CONSTRAINTS ? 4 : 3, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 template <class Model>
 int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    const bool small = !Model::PINV_KKT && N < 96 && c->kernel_variant == 0;    // measured crossover for Pi at N ~ 100
+    const bool small = !Model::PINV_KKT && N < 176 && c->kernel_variant == 0;   // measured crossover for Pi at N ~ 180
     if (c->kernel_variant == 1 || c->solver != 0 || c->init_p || small)      // the debug outputs (init_p, init_x) come from the fused kernel
-        return launch_pose(c, tff::k_pi_tft_pose<Model, false>, tff::k_pi_tft_pose<Model, true>, tff::pi_lds_bytes<Model>, 0,
+        return launch_pose(c, tff::k_pi_tft_pose<Model, false>, tff::k_pi_tft_pose<Model, true>, tff::pi_lds_bytes<Model>, 0, 4,
                            corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::pi_wg_lds_doubles(Model::E, Model::C, n)) * sizeof(double); };
     return launch_wg(c, tff::k_pi_block<Model>, wg_lds, Model::PINV_KKT ? 4 : 2, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);

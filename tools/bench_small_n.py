@@ -5,10 +5,10 @@ import numpy as np, torch
 from tft_vs_fund_amd import api
 from tft_vs_fund_amd.scenes import generate_scene_batch
 ctx = api.Context(0)
-for N in (12, 40, 64, 100, 130):
+for N in [int(x) for x in os.environ.get("NS", "12,40,64,100,130").split(",")]:
     C, CalM, _, _ = generate_scene_batch(20000, N, noise=1.0, seed=1)
     d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
-    for meth in ("ResslTFTPoseEstimation", "NordbergTFTPoseEstimation", "PiPoseEstimation", "FaugPapaTFTPoseEstimation", "PiColPoseEstimation"):
+    for meth in os.environ.get("METHODS", "ResslTFTPoseEstimation,NordbergTFTPoseEstimation,PiPoseEstimation,FaugPapaTFTPoseEstimation,PiColPoseEstimation").split(","):
         row = []
         for variant in (2, 1, 0):
             ctx.set_kernel_variant(variant)
