@@ -6,6 +6,12 @@
 #include <vector>
 #include "../../tft_vs_fund_amd/csrc/launch.h"
 
+// Optional cap on the grid of every launch below (0 = none): exercises the grid-stride loops, in which one block takes several
+// batch items through the same LDS (stale state between items is what that catches).
+static unsigned g_grid_cap = 0;
+extern "C" void emu_set_grid_cap(int cap) { g_grid_cap = cap > 0 ? (unsigned)cap : 0u; }
+static unsigned emu_grid(long B) { const unsigned g = tff::pose_grid(B); return (g_grid_cap && g > g_grid_cap) ? g_grid_cap : g; }
+
 // Same two-pass structure as the C ABI: inverse-iteration kernel, then the
 // Jacobi fix-up over ST_RETRY triplets (or Jacobi for everything with FLAG_JACOBI).
 typedef size_t (*lds_fn)(int, int, bool);
@@ -18,7 +24,7 @@ static int emu_pose(KMain kmain, KJac kjac, lds_fn ldsfn, bool may_stage, const 
     const bool all_jacobi = (flags & tff::FLAG_JACOBI) != 0;
     if (!all_jacobi) {
         if (may_stage) a.flags = tff::pose_auto_flags(N, a.flags, false);
-        emu::launch(kmain, tff::pose_grid(B), 64, ldsfn(N, a.flags, false), a);
+        emu::launch(kmain, emu_grid(B), 64, ldsfn(N, a.flags, false), a);
         bool any = false;
         for (long b = 0; b < B; ++b) any = any || status[b] == tff::ST_RETRY;
         if (!any) return 0;
@@ -26,7 +32,7 @@ static int emu_pose(KMain kmain, KJac kjac, lds_fn ldsfn, bool may_stage, const 
     }
     a.flags &= ~tff::FLAG_STAGE_LDS;
     if (may_stage) a.flags = tff::pose_auto_flags(N, a.flags, true);
-    emu::launch(kjac, tff::pose_grid(B), 64, ldsfn(N, a.flags, true), a);
+    emu::launch(kjac, emu_grid(B), 64, ldsfn(N, a.flags, true), a);
     return all_jacobi ? 0 : 1;
 }
 
@@ -71,12 +77,12 @@ static int emu_wg_run(KBlock kblock, size_t lds_block, const double* corresp, co
     std::vector<double> rec((size_t)B * tff::GH_REC_DOUBLES), topt((size_t)B * 27);
     tff::GhWgArgs a{corresp, calm, calm_stride, B, N, (flags & ~tff::FLAG_JACOBI) | (reconst ? tff::FLAG_RECONST : 0), rec.data(), topt.data(),
                     Rt2, Rt3, T, reconst, iter, status, nullptr, nullptr, 0};
-    emu::launch(tff::k_gh_linear<false>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, a.flags, false), a);
+    emu::launch(tff::k_gh_linear<false>, emu_grid(B), 64, tff::pose_lds_bytes(N, a.flags, false), a);
     tff::GhWgArgs m = a;
     m.flags |= tff::FLAG_ONLY_RETRY;
-    emu::launch(tff::k_gh_linear<true>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
-    emu::launch(kblock, tff::pose_grid(B), tff::GH_WG_THREADS, lds_block, a);
-    emu::launch(tff::k_gh_finish, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
+    emu::launch(tff::k_gh_linear<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
+    emu::launch(kblock, emu_grid(B), tff::GH_WG_THREADS, lds_block, a);
+    emu::launch(tff::k_gh_finish, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
     return 0;
 }
 // Pi / PiCol through the workgroup path (pi_wg_kernel.h)
@@ -95,13 +101,13 @@ static int emu_gh_wg_impl(const double* corresp, const double* calm, long calm_s
     std::vector<double> rec((size_t)B * tff::GH_REC_DOUBLES), topt((size_t)B * 27);
     tff::GhWgArgs a{corresp, calm, calm_stride, B, N, (flags & ~tff::FLAG_JACOBI) | (reconst ? tff::FLAG_RECONST : 0), rec.data(), topt.data(),
                     Rt2, Rt3, T, reconst, iter, status, nullptr, nullptr, 0};
-    emu::launch(tff::k_gh_linear<false>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, a.flags, false), a);
+    emu::launch(tff::k_gh_linear<false>, emu_grid(B), 64, tff::pose_lds_bytes(N, a.flags, false), a);
     tff::GhWgArgs m = a;
     m.flags |= tff::FLAG_ONLY_RETRY;
-    emu::launch(tff::k_gh_linear<true>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
+    emu::launch(tff::k_gh_linear<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
     const size_t lds = (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, N, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double);
-    emu::launch(tff::k_gh_block<Model>, tff::pose_grid(B), tff::GH_WG_THREADS, lds, a);
-    emu::launch(tff::k_gh_finish, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
+    emu::launch(tff::k_gh_block<Model>, emu_grid(B), tff::GH_WG_THREADS, lds, a);
+    emu::launch(tff::k_gh_finish, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
     return 0;
 }
 extern "C" int emu_gh_wg_pose(int model, const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
@@ -113,20 +119,20 @@ extern "C" int emu_gh_wg_pose(int model, const double* corresp, const double* ca
 extern "C" int emu_bundle_adjust(const double* calm, long calm_stride, const double* Rt2_in, const double* Rt3_in, const double* corresp, long B, int N,
                                  const double* reconst0, double* Rt2, double* Rt3, double* reconst, int* iter, double* repr_err, int* status) {
     tff::BaArgs a{calm, calm_stride, Rt2_in, Rt3_in, corresp, B, N, reconst0, Rt2, Rt3, reconst, iter, repr_err, status};
-    emu::launch(tff::k_bundle_adjust, tff::pose_grid(B), 64, tff::ba_lds_bytes(N), a);
+    emu::launch(tff::k_bundle_adjust, emu_grid(B), 64, tff::ba_lds_bytes(N), a);
     return 0;
 }
 // building block: linearF / optimF per view pair (tff_linear_f_batch_dev)
 extern "C" int emu_linear_f(const double* corresp, long B, int N, int refine, double* F21, double* F31, int* iter, int* status) {
     tff::LinearFOnlyArgs a{corresp, B, N, 0, F21, F31, iter, status};
     if (refine) {
-        emu::launch(tff::k_linear_f<false, 1>, tff::pose_grid(B), 64, tff::optimf_lds_bytes(N, 0, false), a);
+        emu::launch(tff::k_linear_f<false, 1>, emu_grid(B), 64, tff::optimf_lds_bytes(N, 0, false), a);
         a.flags |= tff::FLAG_ONLY_RETRY;
-        emu::launch(tff::k_linear_f<true, 1>, tff::pose_grid(B), 64, tff::optimf_lds_bytes(N, 0, true), a);
+        emu::launch(tff::k_linear_f<true, 1>, emu_grid(B), 64, tff::optimf_lds_bytes(N, 0, true), a);
     } else {
-        emu::launch(tff::k_linear_f<false, 0>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
+        emu::launch(tff::k_linear_f<false, 0>, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
         a.flags |= tff::FLAG_ONLY_RETRY;
-        emu::launch(tff::k_linear_f<true, 0>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, 0, true), a);
+        emu::launch(tff::k_linear_f<true, 0>, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, true), a);
     }
     return 0;
 }
@@ -153,13 +159,13 @@ extern "C" int emu_linear_tft_pose_pair(const double* corresp, const double* cal
     if (reconst) a.flags |= tff::FLAG_RECONST;
     tff::LinearTftArgs m = a;
     m.flags = tff::pair_auto_flags(N, m.flags);
-    emu::launch(tff::k_linear_tft_pose_pair, tff::pose_grid((B + 1) / 2), 128, tff::pair_lds_bytes(N, m.flags, false), m);
+    emu::launch(tff::k_linear_tft_pose_pair, emu_grid((B + 1) / 2), 128, tff::pair_lds_bytes(N, m.flags, false), m);
     bool any = false;
     for (long b = 0; b < B; ++b) any = any || status[b] == tff::ST_RETRY;
     if (!any) return 0;
     a.flags |= tff::FLAG_ONLY_RETRY;
     a.flags = tff::pose_auto_flags(N, a.flags, true);
-    emu::launch(tff::k_linear_tft_pose<true>, tff::pose_grid(B), 64, tff::pose_lds_bytes(N, a.flags, true), a);
+    emu::launch(tff::k_linear_tft_pose<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, a.flags, true), a);
     return 1;
 }
 
@@ -187,6 +193,6 @@ __global__ void k_emu_eigh(EighArgs a) {
 }
 extern "C" int emu_eigh(const double* Maug, long B, int n, double* lam, double* vecs, double* sol) {
     EighArgs a{Maug, n, lam, vecs, sol};
-    emu::launch(k_emu_eigh, tff::pose_grid(B), 64, sizeof(double) * (size_t)(2 * n * (n + 1) + n * n + 3 * n), a);
+    emu::launch(k_emu_eigh, emu_grid(B), 64, sizeof(double) * (size_t)(2 * n * (n + 1) + n * n + 3 * n), a);
     return 0;
 }

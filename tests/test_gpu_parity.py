@@ -644,6 +644,25 @@ def test_iterative_methods_at_large_n_use_the_global_workspace(gpu_ctx):
                 tol = 1e-4 if dit == 0 else 2e-3
                 assert rel_err_T(out["T"][b], T) < tol and rel_err(out["R_t_3"][b], R3) < tol
 
+@pytest.mark.parametrize("method,N", [("OptimFPoseEstimation", 500), ("ResslTFTPoseEstimation", 500), ("NordbergTFTPoseEstimation", 400),
+                                      ("FaugPapaTFTPoseEstimation", 200), ("PiPoseEstimation", 300), ("PiColPoseEstimation", 200),
+                                      ("PiPoseEstimation", 64), ("OptimFPoseEstimation", 1500)])
+def test_spilled_batches_are_bit_identical_to_single_triplets(gpu_ctx, method, N):
+    """Configurations whose per-correspondence state lives in global spill slices (for occupancy, or because it exceeds the LDS):
+    every triplet of a batch -- neighbouring blocks running concurrently on adjacent slices -- must come out bit-identical to the same
+    triplet launched alone.  (A slice sized without the kernels' alignment pads once let OptimF's v overlap the next block's xi.)"""
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    # N = 1500: slices of 96 KB, the 512 MB workspace holds 5461 of them, so a batch of 6000 also runs the grid-stride loop (blocks
+    # out of step with their neighbours -- the condition under which an overlap shows)
+    B = 6000 if N == 1500 else 96
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=77 + N)
+    full = gpu_ctx.pose_batch(method, C, CalM, reconst=True)
+    for b in list(range(0, 6)) + [B // 2, B - 1]:
+        one = gpu_ctx.pose_batch(method, C[b:b + 1], CalM, reconst=True)
+        for k in ("T", "R_t_2", "R_t_3", "Reconst", "iter", "status"):
+            assert np.array_equal(np.asarray(full[k][b]), np.asarray(one[k][0]), equal_nan=True), (method, N, b, k)
+
+
 def test_paired_kernel_variant_agrees(gpu_ctx):
     """TFF_OPT_KERNEL = 1 (two triplets per workgroup, half-wavefront middle section) against the default kernel."""
     import torch

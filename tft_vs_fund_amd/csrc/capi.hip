@@ -86,7 +86,9 @@ int plan_spill(tff_ctx* c, size_t lds_full, size_t lds_fixed, unsigned* grid, do
     const bool for_occupancy = occupancy_cap > 0 && lds_fixed < lds_full && per_cu(lds_fixed) > per_cu(lds_full);
     if (lds_full <= LDS_LIMIT && !for_occupancy) return 0;
     if (lds_fixed > LDS_LIMIT) return fail(TFF_E_INVALID, "LDS workspace of this method exceeds 160 KiB");
-    const size_t per_block = lds_full - lds_fixed;
+    // + 16 doubles: the kernels carve their per-correspondence arrays with small alignment pads (e.g. OptimF's v = xi + 4N + 2), so a
+    // slice of exactly lds_full - lds_fixed bytes would let the tail of one block's arrays overlap the head of its neighbour's
+    const size_t per_block = lds_full - lds_fixed + 16 * sizeof(double);
     size_t blocks = ((size_t)512 << 20) / per_block;
     if (blocks < 256) blocks = 256;
     if (*grid > blocks) *grid = (unsigned)blocks;
