@@ -70,6 +70,21 @@ def test_paired_kernel_matches_oracle(emu, N, B, sigma):
         assert rel_err(out["R_t_3"][b], R3) < tol and rel_err(out["Reconst"][b], Rec) < tol
 
 
+@pytest.mark.parametrize("entry,N", [("emu_linear_tft_pose", 9), ("emu_linear_f_pose", 9), ("emu_optim_f_pose", 10), ("emu_ressl_tft_pose", 9)])
+def test_grid_stride_loop_leaves_no_state_between_triplets(emu, entry, N):
+    """One block taking several triplets through the same LDS (grid capped at 1) gives bit-identical results to one block per triplet."""
+    B = 3
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=40 + N)
+    ref = run_linear_tft(emu, C, CalM, entry=entry)
+    emu.emu_set_grid_cap(1)
+    try:
+        out = run_linear_tft(emu, C, CalM, entry=entry)
+    finally:
+        emu.emu_set_grid_cap(0)
+    for k in ("T", "R_t_2", "R_t_3", "Reconst", "iter", "status"):
+        assert np.array_equal(ref[k], out[k], equal_nan=True), (entry, k)
+
+
 def test_too_few_points_sets_status(emu):
     C, CalM, _, _ = generate_scene_batch(1, 6, noise=1.0, seed=1)
     out = run_linear_tft(emu, C, CalM)
