@@ -57,7 +57,8 @@ typedef struct tff_ctx tff_ctx;
 
 /* options for tff_ctx_set_option */
 #define TFF_OPT_SOLVER 1    /* 0: Cholesky inverse iteration with Jacobi fallback (default); 1: Jacobi sweeps only */
-#define TFF_OPT_STAGE_LDS 2 /* -1 auto (default), 0 re-read correspondences through L2, 1 stage them in LDS */
+#define TFF_OPT_STAGE_LDS 2 /* -1 auto (default: staged in LDS while that costs no occupancy, N <= 200 for the TFT kernels, N <= 48 for LinearF),
+                             * 0 re-read correspondences through L2, 1 stage them in LDS */
 
 #define TFF_OPT_GH_EXACT 4  /* Gauss-Helmert methods: 1 = always form pinv(W) through per-block eigen-decompositions (default 0: Cholesky inverse while pinv cannot truncate) */
 #define TFF_OPT_KERNEL 3    /* Kernel variants.  LinearTFT: 0 one wavefront per triplet (default); 1 paired kernel, two triplets per workgroup (slower).
