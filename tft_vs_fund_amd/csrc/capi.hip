@@ -195,7 +195,7 @@ int launch_linear_f(tff_ctx* c, const double* corresp, const double* calm, int64
 }
 int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                    double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    return launch_pose(c, tff::k_f_pose<false, 1>, tff::k_f_pose<true, 1>, tff::optimf_lds_bytes, 0, 8, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
+    return launch_pose(c, tff::k_f_pose<false, 1>, tff::k_f_pose<true, 1>, tff::optimf_lds_bytes, 0, 12, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
                        reconst, iter, status, dbg);
 }
 
