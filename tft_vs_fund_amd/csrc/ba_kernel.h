@@ -197,7 +197,7 @@ __device__ inline double ba_cost(const BaLds* L, const BaCams* cam, const double
     return wave_sum(S);
 }
 
-__global__ void __launch_bounds__(64, 2) k_bundle_adjust(const BaArgs a) {
+__global__ void __launch_bounds__(64, 1) k_bundle_adjust(const BaArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
     PoseLds* w = reinterpret_cast<PoseLds*>(smem);
     constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
