@@ -55,13 +55,15 @@ __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, 
             g[c] -= g[k] * lck;                             // L[r][c] -= L[r][k] L[c][k]   (meaningful for r >= c)
         }
     }
-    // Store L as a full n x n square (row-major, ld = n) with zeros above the diagonal and
-    // L_jj - 1 ON the diagonal: the solves below then need neither masked loads nor a
-    // per-step select, because on the pivot lane  y - (L_jj - 1) * (y / L_jj) = y / L_jj.
+    // Store the ROW-SCALED factor L' = D^-1 L (unit diagonal, D = diag(L)) as a full n x n square (row-major, ld = n) with zeros on
+    // and above the diagonal: the substitutions below then need no division, no masked load and no per-step select --
+    //   L y = x   <=>  L' y = D^-1 x,          L' z' = ... : L^T z = y  <=>  L'^T (D z) = y,
+    // one multiplication by 1 / L_jj before the forward and one after the backward sweep instead of one per step, and a dependent
+    // chain of readlane + fma per step.
     wave_sync();
     if (lane < n) {
 #pragma unroll
-        for (int c = 0; c < n; ++c) Lp[lane * n + c] = (c < lane) ? g[c] : ((c == lane) ? g[c] - 1.0 : 0.0);
+        for (int c = 0; c < n; ++c) Lp[lane * n + c] = (c < lane) ? g[c] * myinv : 0.0;
     }
     wave_sync();
     const int rl = (lane < n) ? lane : 0;
@@ -76,27 +78,28 @@ __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, 
     bool done = false;                                      // per group; the loop itself is wave-uniform
 #pragma unroll 1
     while (true) {
-        double y = x;
+        double y = x * myinv;
         {
-            double row[n];                                  // L[lane][j] (0 for j > lane)
+            double row[n];                                  // L'[lane][j] (0 for j >= lane)
 #pragma unroll
             for (int j = 0; j < n; ++j) row[j] = Lp[rl * n + j];
 #pragma unroll
-            for (int j = 0; j < n; ++j) {                   // forward  L y = x
-                const double yj = Grp::bcast(y * myinv, j);
+            for (int j = 0; j < n; ++j) {                   // forward  L' y = D^-1 x
+                const double yj = Grp::bcast(y, j);
                 y -= row[j] * yj;
             }
         }
         {
-            double col[n];                                  // L[j][lane] (0 for j < lane)
+            double col[n];                                  // L'[j][lane] (0 for j <= lane)
 #pragma unroll
             for (int j = 0; j < n; ++j) col[j] = Lp[j * n + rl];
 #pragma unroll
-            for (int j = n - 1; j >= 0; --j) {              // backward L' z = y
-                const double zj = Grp::bcast(y * myinv, j);
-                y -= col[j] * zj;
+            for (int j = n - 1; j >= 0; --j) {              // backward L'^T u = y,  u = D z
+                const double uj = Grp::bcast(y, j);
+                y -= col[j] * uj;
             }
         }
+        y *= myinv;
         if (lane >= n) y = 0.0;
         const double nn = Grp::sum(y * y);
         const double dot = Grp::sum(y * x);
