@@ -228,7 +228,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         double T[27];
         load_uniform27(g.Tc, T);
         // ---- W = B B' (:52): finite check, bound on the largest eigenvalue; see gh_kernel.h for the two pinv paths ----
-        double f2max = 0.0;
+        double f2max = 0.0;                                                  // max_i |W_i|_F^2
         bool finite = true;
         for (int i = tid; i < N; i += GH_WG_THREADS) {
             double o[6], f[4], B[4][6], W[4][4];
@@ -238,9 +238,10 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
             block_W(B, W);
             double chk = 0.0, fro2 = 0.0;
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 4; ++a) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) { chk += W[a][b]; fro2 += W[a][b] * W[a][b]; }
+            }
             finite = finite && (fabs(chk) <= 1.79e308);
             f2max = (fro2 > f2max) ? fro2 : f2max;
         }
@@ -265,18 +266,37 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
             if (block_any(bad, red)) fast = false;
         }
         if (!fast) {
-            double smax = 0.0;
+            // pinv's tolerance 4N eps(max_i lambda_max(W_i)) needs only the binade of that maximum: when the bounds above agree on it,
+            // the eigenvalue pass that would find the maximum is skipped
+            double umax = 0.0, lmax = 0.0;                                   // upper / lower bound on max_i lambda_max(W_i)
             for (int i = tid; i < N; i += GH_WG_THREADS) {
-                double o[6], f[4], B[4][6], W[4][4], V[4][4];
+                double o[6], f[4], B[4][6], W[4][4];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
                 tril_block(T, o, f, B);
                 block_W(B, W);
-                jacobi4<false>(W, V);
-#pragma unroll
-                for (int a = 0; a < 4; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+                double up, lo;
+                psd_lambda_max_bounds(W, up, lo);
+                umax = (up > umax) ? up : umax;
+                lmax = (lo > lmax) ? lo : lmax;
             }
-            smax = block_max(smax, red);
+            umax = block_max(umax, red);
+            lmax = block_max(lmax, red);
+            double smax = umax;
+            if (eps_of(lmax) != eps_of(umax)) {
+                smax = 0.0;
+                for (int i = tid; i < N; i += GH_WG_THREADS) {
+                    double o[6], f[4], B[4][6], W[4][4], V[4][4];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                    tril_block(T, o, f, B);
+                    block_W(B, W);
+                    jacobi4<false>(W, V);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+                }
+                smax = block_max(smax, red);
+            }
             const double tolW = 4.0 * (double)N * eps_of(smax);
             for (int i = tid; i < N; i += GH_WG_THREADS) {
                 double o[6], f[4], B[4][6], W[4][4], V[4][4];

@@ -660,19 +660,37 @@ __device__ inline int gauss_helmert_pi_wave(PoseLds* w, PiWork& g, const double*
             if (wave_any(bad)) fast = false;
         }
         if (!fast) {
-            double smax = 0.0;
+            // only the binade of max_i lambda_max(W_i) enters pinv's tolerance: skip the eigenvalue pass when cheap bounds agree on it
+            double umax = 0.0, lmax = 0.0;
             for (int i = lane; i < N; i += WAVE) {
-                double o[6], W[E][E], V[E][E];
+                double o[6], W[E][E], up, lo;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
                 PiPoint<E> pt;
                 pi_eval<Model, true>(pi, o, pt);
                 pi_block_W<E>(pt.B, W);
-                jacobi_small<E, false>(W, V);
-#pragma unroll
-                for (int a = 0; a < E; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+                psd_lambda_max_bounds(W, up, lo);
+                umax = (up > umax) ? up : umax;
+                lmax = (lo > lmax) ? lo : lmax;
             }
-            smax = wave_max(smax);
+            umax = wave_max(umax);
+            lmax = wave_max(lmax);
+            double smax = umax;
+            if (eps_of(lmax) != eps_of(umax)) {
+                smax = 0.0;
+                for (int i = lane; i < N; i += WAVE) {
+                    double o[6], W[E][E], V[E][E];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                    PiPoint<E> pt;
+                    pi_eval<Model, true>(pi, o, pt);
+                    pi_block_W<E>(pt.B, W);
+                    jacobi_small<E, false>(W, V);
+#pragma unroll
+                    for (int a = 0; a < E; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+                }
+                smax = wave_max(smax);
+            }
             const double tolW = (double)E * (double)N * eps_of(smax);
             // per block: W+ = pinv(W + 1e-12 I) + 1e-12 I   (:57)
             for (int i = lane; i < N; i += WAVE) {

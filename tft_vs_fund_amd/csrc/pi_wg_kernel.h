@@ -29,7 +29,7 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
     for (it = 1; it <= GH_IT_MAX; ++it) {
         double pi[27];
         load_uniform27(g.p, pi);
-        double f2max = 0.0;
+        double f2max = 0.0;                                                  // max_i |W_i|_F^2
         bool finite = true;
         for (int i = tid; i < N; i += GH_WG_THREADS) {
             double o[6], W[E][E];
@@ -40,9 +40,10 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
             pi_block_W<E>(pt.B, W);
             double chk = 0.0, fro2 = 0.0;
 #pragma unroll
-            for (int a = 0; a < E; ++a)
+            for (int a = 0; a < E; ++a) {
 #pragma unroll
                 for (int b = 0; b < E; ++b) { chk += W[a][b]; fro2 += W[a][b] * W[a][b]; }
+            }
             finite = finite && (fabs(chk) <= 1.79e308);
             f2max = (fro2 > f2max) ? fro2 : f2max;
         }
@@ -66,19 +67,38 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
             if (block_any(bad, red)) fast = false;
         }
         if (!fast) {
-            double smax = 0.0;
+            // only the binade of max_i lambda_max(W_i) enters pinv's tolerance: skip the eigenvalue pass when the bounds agree on it
+            double umax = 0.0, lmax = 0.0;                                   // upper / lower bound on max_i lambda_max(W_i)
             for (int i = tid; i < N; i += GH_WG_THREADS) {
-                double o[6], W[E][E], V[E][E];
+                double o[6], W[E][E];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
                 PiPoint<E> pt;
                 pi_eval<Model, true>(pi, o, pt);
                 pi_block_W<E>(pt.B, W);
-                jacobi_small<E, false>(W, V);
-#pragma unroll
-                for (int a = 0; a < E; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+                double up, lo;
+                psd_lambda_max_bounds(W, up, lo);
+                umax = (up > umax) ? up : umax;
+                lmax = (lo > lmax) ? lo : lmax;
             }
-            smax = block_max(smax, red);
+            umax = block_max(umax, red);
+            lmax = block_max(lmax, red);
+            double smax = umax;
+            if (eps_of(lmax) != eps_of(umax)) {
+                smax = 0.0;
+                for (int i = tid; i < N; i += GH_WG_THREADS) {
+                    double o[6], W[E][E], V[E][E];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                    PiPoint<E> pt;
+                    pi_eval<Model, true>(pi, o, pt);
+                    pi_block_W<E>(pt.B, W);
+                    jacobi_small<E, false>(W, V);
+#pragma unroll
+                    for (int a = 0; a < E; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+                }
+                smax = block_max(smax, red);
+            }
             const double tolW = (double)E * (double)N * eps_of(smax);
             for (int i = tid; i < N; i += GH_WG_THREADS) {
                 double o[6], W[E][E], V[E][E];

@@ -155,6 +155,67 @@ __device__ __forceinline__ int spd_min_eigvec(const double (&S)[n][n], double (&
     return it;
 }
 
+// Lower bound on the largest eigenvalue of a symmetric positive semi-definite E x E matrix: Rayleigh quotients of W e_k and
+// W^2 e_k (k: the largest diagonal entry), two matrix-vector products.  Within a few per cent of lambda_max when one eigenvalue
+// dominates, which is what decides the binade of pinv's tolerance without an eigen-decomposition (gh_wg_kernel.h).
+template <int E>
+__device__ __forceinline__ double psd_lambda_max_lower(const double (&W)[E][E]) {
+    int k = 0;
+    double d = W[0][0];
+#pragma unroll
+    for (int a = 1; a < E; ++a) if (W[a][a] > d) { d = W[a][a]; k = a; }
+    double v[E], w1[E], w2[E];
+#pragma unroll
+    for (int a = 0; a < E; ++a) {
+        v[a] = W[a][0];
+#pragma unroll
+        for (int c = 1; c < E; ++c) v[a] = (k == c) ? W[a][c] : v[a];
+    }
+    double vv = 0.0, vw = 0.0, ww = 0.0, wz = 0.0;
+#pragma unroll
+    for (int a = 0; a < E; ++a) {
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < E; ++c) acc += W[a][c] * v[c];
+        w1[a] = acc;
+        vv += v[a] * v[a]; vw += v[a] * acc; ww += acc * acc;
+    }
+#pragma unroll
+    for (int a = 0; a < E; ++a) {
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < E; ++c) acc += W[a][c] * w1[c];
+        w2[a] = acc;
+        wz += w1[a] * acc;
+    }
+    const double r1 = (vv > 0.0) ? vw / vv : 0.0, r2 = (ww > 0.0) ? wz / ww : 0.0;
+    const double r = (r1 > r2) ? r1 : r2;
+    return (r > d) ? r : d;
+}
+
+// Upper and lower bound on the largest eigenvalue of a symmetric positive semi-definite E x E matrix without an eigen-decomposition:
+// trace / Frobenius norm (Wolkowicz-Styan), |W|_F, |W|_F^2 / trace and the power-step Rayleigh quotients above.  MATLAB's
+// pinv / rank tolerance max(size) * eps(norm) depends only on the BINADE of the norm, which these bounds usually settle.
+template <int E>
+__device__ __forceinline__ void psd_lambda_max_bounds(const double (&W)[E][E], double& up, double& lo) {
+    double fro2 = 0.0, tr = 0.0;
+#pragma unroll
+    for (int a = 0; a < E; ++a) {
+        tr += W[a][a];
+#pragma unroll
+        for (int b = 0; b < E; ++b) fro2 += W[a][b] * W[a][b];
+    }
+    constexpr double n = (double)E;
+    const double m = tr / n, s2 = (fro2 - tr * m > 0.0) ? fro2 - tr * m : 0.0;
+    up = m + sqrt((n - 1.0) / n * s2);
+    lo = m + sqrt(s2 / (n * (n - 1.0)));
+    const double fr = sqrt(fro2), ray = (tr > 0.0) ? fro2 / tr : 0.0;
+    up = (fr < up) ? fr : up;
+    lo = (ray > lo) ? ray : lo;
+    const double pw = psd_lambda_max_lower(W);
+    lo = (pw > lo) ? pw : lo;
+}
+
 // --------------------------------------------------------------------------
 // Cyclic Jacobi eigen-decomposition of a symmetric 3x3 matrix (per lane).
 // A is overwritten by its diagonal form, V (columns) are the eigenvectors.
