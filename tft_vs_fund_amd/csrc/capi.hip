@@ -77,6 +77,8 @@ int ensure_lds(K kernel, size_t bytes) {
 // workspace, one slice per resident block (the kernels loop over the batch with a grid stride).  lds_full / lds_fixed: the
 // kernel's LDS request with and without the per-correspondence part.  Returns the LDS bytes to launch with.
 constexpr size_t LDS_LIMIT = 160 * 1024;
+// grid of the Jacobi fix-up pass: it scans the status array for ST_RETRY (almost always none), so it is sized to be resident in one go
+constexpr long FIXUP_GRID = 1024;
 // occupancy_cap > 0 (the workgroup kernels; the cap is what their registers allow): spill also when that lets more workgroups share
 // the CU's LDS -- their wave-serial steps (KKT solve, pseudo-inverse) make workgroups per CU what counts.  Measured
 // (tools/bench_n_sweep.py): Ressl 2.14 -> 3.26 M/s at N = 500, Pi 1.18 -> 1.79 M/s at N = 300, never slower.
@@ -142,7 +144,7 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_
         a.flags |= tff::FLAG_ONLY_RETRY;
     }
     if (stage_max_n) a.flags = staged_flags(c, N, a.flags, true, stage_max_n);
-    unsigned grid = (c->solver == 0) ? (unsigned)(B < 8192 ? B : 8192) : tff::pose_grid(B);
+    unsigned grid = (c->solver == 0) ? (unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID) : tff::pose_grid(B);
     size_t lds;
     if (int r = plan_spill(c, ldsfn(N, a.flags, true), ldsfn(0, a.flags, true), &grid, &a.spill, &a.spill_stride, &lds)) return r;
     if (int r = ensure_lds(kjac, lds)) return r;
@@ -184,7 +186,7 @@ int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int
     else a.flags = staged_flags(c, N, a.flags, true);
     const size_t lds = tff::pose_lds_bytes(N, a.flags, true);
     if (int r = ensure_lds(tff::k_linear_tft_pose<true>, lds)) return r;
-    hipLaunchKernelGGL(tff::k_linear_tft_pose<true>, dim3((unsigned)(B < 8192 ? B : 8192)), dim3(64), lds, c->stream, a);
+    hipLaunchKernelGGL(tff::k_linear_tft_pose<true>, dim3((unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID)), dim3(64), lds, c->stream, a);
     TFF_HIP(hipGetLastError());
     return 0;
 }
@@ -227,7 +229,7 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
         m.flags = staged_flags(c, N, a.flags, true) | tff::FLAG_ONLY_RETRY;
         lds = tff::pose_lds_bytes(N, m.flags, true);
         if (int r = ensure_lds(tff::k_gh_linear<true>, lds)) return r;
-        hipLaunchKernelGGL(tff::k_gh_linear<true>, dim3((unsigned)(B < 8192 ? B : 8192)), dim3(64), lds, c->stream, m);
+        hipLaunchKernelGGL(tff::k_gh_linear<true>, dim3((unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID)), dim3(64), lds, c->stream, m);
         TFF_HIP(hipGetLastError());
     }
     {
@@ -596,7 +598,7 @@ int tff_linear_tft_batch_dev(tff_ctx* c, const double* corresp, int64_t B, int32
         TFF_HIP(hipGetLastError());
         a.flags |= tff::FLAG_ONLY_RETRY;
     }
-    const unsigned grid = (c->solver == 0) ? (unsigned)(B < 8192 ? B : 8192) : tff::pose_grid(B);
+    const unsigned grid = (c->solver == 0) ? (unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID) : tff::pose_grid(B);
     hipLaunchKernelGGL(tff::k_linear_tft<true>, dim3(grid), dim3(64), tff::pose_lds_bytes(N, 0, true), c->stream, a);
     TFF_HIP(hipGetLastError());
     return 0;
@@ -667,7 +669,7 @@ int tff_linear_f_batch_dev(tff_ctx* c, const double* corresp, int64_t B, int32_t
         status = (int32_t*)c->scratch_status.p;
     }
     tff::LinearFOnlyArgs a{corresp, (long)B, N, 0, F21, F31, iter, status};
-    const unsigned fix_grid = (c->solver == 0) ? (unsigned)(B < 8192 ? B : 8192) : tff::pose_grid(B);
+    const unsigned fix_grid = (c->solver == 0) ? (unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID) : tff::pose_grid(B);
     if (refine) {
         if (c->solver == 0) {
             const size_t lds = tff::optimf_lds_bytes(N, 0, false);
