@@ -7,7 +7,7 @@ from oracle import tft_oracle as O
 from tft_vs_fund_amd import api
 from tft_vs_fund_amd.scenes import generate_scene_batch
 from helpers import rel_err_T, rel_err
-ctx = api.Context(0)
+ctx = api.Context(0, solver=os.environ.get("SOAK_SOLVER", "invit"))
 worst = {}
 count = {}
 t0 = time.time()
