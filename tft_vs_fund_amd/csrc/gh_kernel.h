@@ -721,6 +721,43 @@ __device__ __forceinline__ bool spd_inverse_packed(const double (&W)[E][E], doub
     return ok;
 }
 
+// pinv(W + 1e-12 I) under MATLAB's tolerance tolW for a positive semi-definite block whose ONLY eigenvalue below the tolerance is its
+// (shifted) null direction n -- the generic case of the rank-(E-1) weight blocks once 4N eps(|W|) exceeds 1e-12.  With
+// Wn = W + 1e-12 I + n n' (well conditioned, so its Cholesky inverse is accurate)
+//     pinv = Wn^-1 - n n' / (1 + 1e-12)
+// exactly, at a fifth of the cost of the Jacobi eigen-decomposition.  Returns false when the structure does not hold (no eigenvalue
+// under the tolerance, a second one, or a failed factorisation): the caller then takes the eigen-decomposition.
+template <int E>
+__device__ __forceinline__ bool pinv_one_null_packed(const double (&W)[E][E], const double tolW, double* Wp) {
+    double n[E];
+    spd_min_eigvec<E>(W, n, 40);
+    double lam = 0.0;
+#pragma unroll
+    for (int a = 0; a < E; ++a) {
+        double wn = 0.0;
+#pragma unroll
+        for (int c = 0; c < E; ++c) wn += W[a][c] * n[c];
+        lam += n[a] * wn;
+    }
+    if (!(lam + 1e-12 <= tolW)) return false;                                // nothing is truncated here (or NaN)
+    double Wn[E][E];
+#pragma unroll
+    for (int a = 0; a < E; ++a)
+#pragma unroll
+        for (int c = 0; c < E; ++c) Wn[a][c] = W[a][c] + n[a] * n[c] + ((a == c) ? 1e-12 : 0.0);
+    if (!spd_inverse_packed<E>(Wn, Wp)) return false;
+    double fro2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < E; ++a)
+#pragma unroll
+        for (int c = 0; c <= a; ++c) {
+            const double v = Wp[a * (a + 1) / 2 + c] - n[a] * n[c] / (1.0 + 1e-12);
+            Wp[a * (a + 1) / 2 + c] = v;
+            fro2 += (a == c) ? v * v : 2.0 * v * v;
+        }
+    return fro2 * tolW * tolW < 1.0;                                         // second-smallest eigenvalue >= 1 / |pinv|_F > tolW
+}
+
 // w = -f - B (x - xi) (Gauss_Helmert.m:58); stores W+ (10) and W+ w (4) of correspondence i
 __device__ __forceinline__ void gh_store_point(const GhWork& g, const PoseLds* w, const double* pts, int i, const double (&o)[6],
                                                const double (&f)[4], const double (&B)[4][6], const double (&Wp)[10]) {

@@ -700,20 +700,26 @@ __device__ inline int gauss_helmert_pi_wave(PoseLds* w, PiWork& g, const double*
                 PiPoint<E> pt;
                 pi_eval<Model, true>(pi, o, pt);
                 pi_block_W<E>(pt.B, W);
-                jacobi_small<E, true>(W, V);
-                double inv[E];
-#pragma unroll
-                for (int a = 0; a < E; ++a) inv[a] = (W[a][a] > tolW) ? 1.0 / W[a][a] : 0.0;
                 double Wp[NW];
+                // E = 4 (Pi): one truncated direction is the generic case, no eigen-decomposition then; measured slower for PiCol's 5 x 5 blocks
+                if (E == 4 && pinv_one_null_packed<E>(W, tolW, Wp)) {
 #pragma unroll
-                for (int a = 0; a < E; ++a)
+                    for (int a = 0; a < E; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
+                } else {
+                    jacobi_small<E, true>(W, V);
+                    double inv[E];
 #pragma unroll
-                    for (int b = 0; b <= a; ++b) {
-                        double s = (a == b) ? 1e-12 : 0.0;
+                    for (int a = 0; a < E; ++a) inv[a] = (W[a][a] > tolW) ? 1.0 / W[a][a] : 0.0;
 #pragma unroll
-                        for (int k = 0; k < E; ++k) s += V[a][k] * inv[k] * V[b][k];
-                        Wp[a * (a + 1) / 2 + b] = s;
-                    }
+                    for (int a = 0; a < E; ++a)
+#pragma unroll
+                        for (int b = 0; b <= a; ++b) {
+                            double s = (a == b) ? 1e-12 : 0.0;
+#pragma unroll
+                            for (int k = 0; k < E; ++k) s += V[a][k] * inv[k] * V[b][k];
+                            Wp[a * (a + 1) / 2 + b] = s;
+                        }
+                }
                 pi_store_point<E>(g, w, pts, i, o, pt, Wp);
             }
         }
