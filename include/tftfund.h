@@ -56,13 +56,16 @@ typedef struct tff_ctx tff_ctx;
 #define TFF_E_NOMEM (-10002)
 
 /* options for tff_ctx_set_option */
-#define TFF_OPT_SOLVER 1    /* 0: Cholesky inverse iteration with Jacobi fallback (default); 1: Jacobi sweeps only */
+#define TFF_OPT_SOLVER 1    /* 0 (default): fast tiers (Gram matrix + Cholesky inverse iteration, certified sign-only cheirality votes) with
+                             * the exact kernel (Householder QR of the explicit design matrix, one-sided Jacobi fall-backs: the accuracy
+                             * of the reference's svd() calls) over the triplets they could not finish or certify; 1: exact kernel for all */
+#define TFF_OPT_EXACT_BELOW 5 /* batches with N < value go to the exact kernel as a whole (default 12: minimal samples, where the two smallest
+                             * singular values of the design matrix often nearly coincide); 0 = only the flagged triplets */
 #define TFF_OPT_STAGE_LDS 2 /* -1 auto (default: staged in LDS while that costs no occupancy, N <= 200 for the TFT kernels, N <= 48 for LinearF),
                              * 0 re-read correspondences through L2, 1 stage them in LDS */
 
 #define TFF_OPT_GH_EXACT 4  /* Gauss-Helmert methods: 1 = always form pinv(W) through per-block eigen-decompositions (default 0: Cholesky inverse while pinv cannot truncate) */
-#define TFF_OPT_KERNEL 3    /* Kernel variants.  LinearTFT: 0 one wavefront per triplet (default); 1 paired kernel, two triplets per workgroup (slower).
-                             * Iterative TFT methods: 0 automatic (default: a 4-wavefront workgroup per triplet for the iteration, the fused
+#define TFF_OPT_KERNEL 3    /* Kernel variants of the iterative TFT methods: 0 automatic (default: a 4-wavefront workgroup per triplet for the iteration, the fused
                              * single-wavefront kernel below the measured crossover, N < 64 for Nordberg, N < 176 for Pi);
                              * 1 fused kernel always; 2 workgroup kernels always */
 #define TFF_DEBUG_STRIDE 128 /* doubles per triplet written by the *_debug_dev entry points */
@@ -95,7 +98,8 @@ int tff_linear_tft_pose_batch_debug_dev(tff_ctx* ctx, const double* corresp, con
 
 /* ResslTFTPoseEstimation (TFT_methods/ResslTFTPoseEstimation.m:47-177): linearTFT, Ressl's 20-parameter /
  * 2-constraint minimal parameterisation, Gauss-Helmert refinement (Optimization/Gauss_Helmert.m:38-83),
- * then transform_TFT -> R_t_from_TFT -> (Reconst).  iter = Gauss-Helmert iterations.  N <= ~900. */
+ * then transform_TFT -> R_t_from_TFT -> (Reconst).  iter = Gauss-Helmert iterations.  Any N (the per-correspondence state spills to a
+ * global workspace when it exceeds the LDS). */
 int tff_ressl_tft_pose_batch_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
                                  int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
                                  int32_t* iter, int32_t* status);

@@ -281,6 +281,17 @@ def linearTFT(p1, p2, p3, return_debug=False):
     return T, P1, P2, P3
 
 
+E_SVD_SIGNS = None      # test hook, see _recover_R_t_core
+_recover_call = 0
+
+
+def set_E_svd_signs(signs):
+    """signs: None, or a list of (sign U(:,3), sign V(:,3)) pairs, one per recover_R_t call of a method (two calls)."""
+    global E_SVD_SIGNS, _recover_call
+    E_SVD_SIGNS = signs
+    _recover_call = 0
+
+
 def _recover_R_t_core(E21, P1cam, K2, x1, x2, return_debug=False):
     """R_t_from_TFT.m:84-104 (== LinearFPoseEstimation.m:87-107 after E21 is
     formed).  Candidate order (R,t),(R,-t),(Rp,-t),(Rp,t); `>=` keeps the
@@ -288,6 +299,16 @@ def _recover_R_t_core(E21, P1cam, K2, x1, x2, return_debug=False):
     (None here; a MATLAB runtime error in the reference)."""
     W = np.array([[0., -1, 0], [1, 0, 0], [0, 0, 1]])
     U, _, V = _svd(E21)
+    # [U,~,V] = svd(E21): the signs of U(:,3) and V(:,3) (E21 has rank 2) are whatever the SVD routine returns; they
+    # permute the candidate order below, which decides TIES of the `>=` rule.  E_SVD_SIGNS lets a test replay the other
+    # conventions (entry `call` of the list for the call-th recover_R_t of a method; None = numpy's LAPACK as is).
+    global _recover_call
+    if E_SVD_SIGNS is not None:
+        su, sv = E_SVD_SIGNS[_recover_call % len(E_SVD_SIGNS)]
+        U = U.copy(); V = V.copy()
+        U[:, 2] *= su
+        V[:, 2] *= sv
+    _recover_call += 1
     R = U @ W @ V.T
     Rp = U @ W.T @ V.T
     R = R * _sign(np.linalg.det(R))

@@ -21,7 +21,7 @@ static int emu_pose(KMain kmain, KJac kjac, lds_fn ldsfn, bool may_stage, const 
                     double* init_p = nullptr, double* init_x = nullptr) {
     tff::LinearTftArgs a{corresp, calm, calm_stride, B, N, flags & ~tff::FLAG_JACOBI, Rt2, Rt3, T, reconst, iter, status, dbg, nullptr, init_p, init_x};
     if (reconst) a.flags |= tff::FLAG_RECONST;
-    const bool all_jacobi = (flags & tff::FLAG_JACOBI) != 0;
+    const bool all_jacobi = (flags & tff::FLAG_JACOBI) != 0 || N < tff::EXACT_BELOW_N;   // as the C ABI: minimal samples go to the exact kernel
     if (!all_jacobi) {
         if (may_stage) a.flags = tff::pose_auto_flags(N, a.flags, false);
         emu::launch(kmain, emu_grid(B), 64, ldsfn(N, a.flags, false), a);
@@ -150,23 +150,6 @@ extern "C" int emu_nordberg_tft_pose(const double* corresp, const double* calm, 
                                      double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
     return emu_pose(tff::k_gh_tft_pose<tff::NordbergModel, false>, tff::k_gh_tft_pose<tff::NordbergModel, true>,
                     tff::gh_lds_bytes<tff::NordbergModel>, false, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status, dbg);
-}
-
-// the paired kernel (TFF_OPT_KERNEL = 1): two triplets per 128-thread workgroup + Jacobi fix-up
-extern "C" int emu_linear_tft_pose_pair(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
-                                        double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
-    tff::LinearTftArgs a{corresp, calm, calm_stride, B, N, flags & ~tff::FLAG_JACOBI, Rt2, Rt3, T, reconst, iter, status, dbg, nullptr};
-    if (reconst) a.flags |= tff::FLAG_RECONST;
-    tff::LinearTftArgs m = a;
-    m.flags = tff::pair_auto_flags(N, m.flags);
-    emu::launch(tff::k_linear_tft_pose_pair, emu_grid((B + 1) / 2), 128, tff::pair_lds_bytes(N, m.flags, false), m);
-    bool any = false;
-    for (long b = 0; b < B; ++b) any = any || status[b] == tff::ST_RETRY;
-    if (!any) return 0;
-    a.flags |= tff::FLAG_ONLY_RETRY;
-    a.flags = tff::pose_auto_flags(N, a.flags, true);
-    emu::launch(tff::k_linear_tft_pose<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, a.flags, true), a);
-    return 1;
 }
 
 // wave_eigh_ql / wave_pinv_solve_sym on caller-supplied symmetric matrices (one wavefront per matrix):

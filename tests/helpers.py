@@ -69,3 +69,55 @@ def oracle_in_kernel_convention(method, Cb, CalM, init_p, init_x, tol=1e-8):
                 best = (d, (s2, s3))
     assert best[0] < tol, "no sign convention reproduces the kernel's start (best deviation %.2e)" % best[0]
     return fn(Cb, CalM, True, null=kernel_null_convention, cam_signs=best[1]), best[0]
+
+
+# ---- recover_R_t: conventions of svd(E) ------------------------------------------------------------------------
+def vote_patterns(v):
+    """The four orders in which the candidate scores [a,-a,-b,b] of recover_R_t (R_t_from_TFT.m:92-104) can come out,
+    depending on the signs svd(E) gives U(:,3) and V(:,3) (E has rank 2, both are free): flipping U(:,3) swaps R <-> Rp
+    and negates t, flipping V(:,3) swaps R <-> Rp."""
+    a, b = v[0], v[3]
+    return [[a, -a, -b, b], [-b, b, a, -a], [b, -b, -a, a], [-a, a, b, -b]]
+
+
+def votes_match(kernel_votes, oracle_votes):
+    k = [float(x) for x in kernel_votes]
+    return any(k == [float(x) for x in p] for p in vote_patterns(list(oracle_votes)))
+
+
+def has_vote_tie(v):
+    """True when the `>=` rule of recover_R_t has to break a tie between the two rotations (|a| == |b|): the winner then
+    depends on the sign convention of svd(E), which MATLAB does not specify."""
+    return abs(v[0]) == abs(v[3])
+
+
+def oracle_under_conventions(fn, Cb, CalM):
+    """Outputs of an oracle pose method under the 16 sign conventions of its two svd(E) calls; the default convention
+    (numpy's LAPACK as is) comes first."""
+    from oracle import tft_oracle as O
+    outs = []
+    try:
+        for s2 in ((1, 1), (-1, 1), (1, -1), (-1, -1)):
+            for s3 in ((1, 1), (-1, 1), (1, -1), (-1, -1)):
+                O.set_E_svd_signs(None if (s2 == (1, 1) and s3 == (1, 1)) else [s2, s3])
+                try:
+                    outs.append(fn(Cb, CalM))
+                except Exception:
+                    outs.append(None)
+    finally:
+        O.set_E_svd_signs(None)
+    return outs
+
+
+def pose_err(out_b, ref):
+    """max relative deviation of (T up to sign, R_t_2, R_t_3) from an oracle result tuple (R_t_2, R_t_3, Reconst, T, ...)."""
+    return max(rel_err_T(out_b["T"], ref[3]), rel_err(out_b["R_t_2"], ref[0]), rel_err(out_b["R_t_3"], ref[1]))
+
+
+def pose_err_any_convention(out_b, fn, Cb, CalM):
+    """(error against the default convention, error against the best of the 16 conventions).  The second is what a
+    triplet with a cheirality-vote tie is held to: its reference result is not unique."""
+    refs = oracle_under_conventions(fn, Cb, CalM)
+    e0 = pose_err(out_b, refs[0]) if refs[0] is not None else float("inf")
+    eb = min([pose_err(out_b, r) for r in refs if r is not None] or [float("inf")])
+    return e0, eb

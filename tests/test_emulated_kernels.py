@@ -57,19 +57,6 @@ def test_linear_tft_kernel_matches_oracle(emu, N, sigma, flags):
         assert sorted(np.abs(votes[0:4])) == [0, 0, 2 * N, 2 * N] or sigma > 0
 
 
-@pytest.mark.parametrize("N,B,sigma", [(9, 3, 1.0), (70, 2, 1.0)])
-def test_paired_kernel_matches_oracle(emu, N, B, sigma):
-    """The paired kernel (TFF_OPT_KERNEL = 1): two triplets per 128-thread workgroup, half-wavefront (Group<32>) middle section."""
-    C, CalM, Rt0, _ = generate_scene_batch(B, N, noise=sigma, seed=500 + N)
-    out = run_linear_tft(emu, C, CalM, 0, entry="emu_linear_tft_pose_pair")
-    assert np.all(out["status"] == 0)
-    for b in range(B):
-        R2, R3, Rec, T, _ = O.LinearTFTPoseEstimation(C[b].T.copy(), CalM)
-        tol = 1e-9 if N >= 12 else 1e-6
-        assert rel_err_T(out["T"][b], T) < tol and rel_err(out["R_t_2"][b], R2) < tol
-        assert rel_err(out["R_t_3"][b], R3) < tol and rel_err(out["Reconst"][b], Rec) < tol
-
-
 @pytest.mark.parametrize("entry,N", [("emu_linear_tft_pose", 9), ("emu_linear_f_pose", 9), ("emu_optim_f_pose", 10), ("emu_ressl_tft_pose", 9)])
 def test_grid_stride_loop_leaves_no_state_between_triplets(emu, entry, N):
     """One block taking several triplets through the same LDS (grid capped at 1) gives bit-identical results to one block per triplet."""

@@ -7,7 +7,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-from helpers import rel_err_T, rel_err   # noqa: E402
+from helpers import rel_err_T, rel_err, pose_err_any_convention   # noqa: E402
 
 TOL = 1e-9
 
@@ -138,18 +138,24 @@ def test_config4_minimal_hypotheses_and_inlier_counts(gpu_ctx):
         st = hyp["status"].cpu().numpy(); cnt = cnt.cpu().numpy()
         R2 = hyp["R_t_2"].cpu().numpy(); R3 = hyp["R_t_3"].cpu().numpy()
         assert np.all(st == 0)
-        checked = 0
+        # every sampled hypothesis must be the reference's, to 1e-6 (the exact kernel takes whole batches of minimal samples).
+        # A cheirality-vote tie between the two rotations is broken by the unspecified signs of svd(E): such a hypothesis
+        # must equal the reference under one of the sign conventions.
+        ties = 0
         for b in range(0, B, 6):
-            o2, o3, _, oT, _ = ofn(scene[idx[b]].T.copy(), CalM)
-            if not (rel_err(R2[b], o2) < 1e-6 and rel_err(R3[b], o3) < 1e-6):
-                continue                                                       # ill-conditioned minimal sample: skip the count check
+            Cb = scene[idx[b]].T.copy()
+            e0, eb = pose_err_any_convention({"T": hyp["T"][b].cpu().numpy(), "R_t_2": R2[b], "R_t_3": R3[b]}, ofn, Cb, CalM)
+            assert eb < 1e-6, (method, b, e0, eb)
+            if e0 >= 1e-6:
+                ties += 1
+                continue                                                       # tie: the count below belongs to another convention
+            o2, o3 = ofn(Cb, CalM)[0:2]
             Ps = [CalM[0:3] @ np.eye(3, 4), CalM[3:6] @ o2, CalM[6:9] @ o3]
             Rec = O.triangulation3D(Ps, scene.T.copy()); Rec = Rec[0:3] / Rec[3:4]
             res = O.project3Dpoints(Rec, Ps) - scene.T
             ref_cnt = int(np.sum(np.sum(np.abs(res) > 1.0, axis=0) == 0))
             assert abs(int(cnt[b]) - ref_cnt) <= 1                              # a residual within 1e-6 of the threshold may flip
-            checked += 1
-        assert checked >= B // 12
+        assert ties <= 2, (method, ties)
         # known answer: a sample without outliers gives the exact pose, so it counts exactly the uncorrupted correspondences
         clean = [b for b in range(B) if not np.intersect1d(idx[b], out_idx).size]
         assert len(clean) >= 3

@@ -15,7 +15,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-from helpers import rel_err_T, rel_err, golden_cases   # noqa: E402
+from helpers import rel_err_T, rel_err, golden_cases, votes_match   # noqa: E402
 
 TOL = 1e-9
 TOL_MINIMAL = 1e-6   # N < 12: minimal-sample geometry is ill-conditioned; the north_star bound applies
@@ -63,14 +63,11 @@ def test_linear_tft_golden_intermediates(gpu_ctx, golden_dir):
         for b in range(C.shape[0]):
             Tlin = dbg[b, 33:60].reshape(3, 3, 3, order="F")           # constrained linearTFT tensor
             assert rel_err_T(Tlin, g[pre + "dbg_lin_T"][b]) < (TOL if N >= 12 else TOL_MINIMAL)
-            # votes: the reference's candidate order may differ by the sign convention of U(:,3)
-            # ((R,t)<->(Rp,-t)); the multiset of scores and the winning score are convention-free
-            # The winning score and its mirror must match exactly.  The other pair belongs to the wrong rotation, whose two-view DLT
-            # systems are inconsistent: there the kernel's inhomogeneous solution (tri_vote) and the reference's singular vector may put
-            # a point on different sides of a camera -- a few votes at most, never the winner (N = 7 golden case: +-2 of 14).
+            # votes: ALL FOUR candidate scores equal the reference's (homogeneous DLT point per correspondence and candidate,
+            # R_t_from_TFT.m:96-101).  Their order depends on the signs svd(E) gives U(:,3) and V(:,3), which MATLAB leaves
+            # unspecified: one of the four possible orders must match entry by entry.
             for k, key in ((60, "dbg_votes2"), (64, "dbg_votes3")):
-                sk, so = sorted(dbg[b, k:k + 4]), sorted(g[pre + key][b])
-                assert sk[0] == so[0] and sk[3] == so[3] and sk[1] == -sk[2] and abs(sk[1] - so[1]) <= max(2, N // 25), (ci, b, sk, so)
+                assert votes_match(dbg[b, k:k + 4], g[pre + key][b]), (ci, b, dbg[b, k:k + 4], g[pre + key][b])
             assert abs(dbg[b, 68] - g[pre + "dbg_lam"][b]) < (TOL if N >= 12 else TOL_MINIMAL) * abs(g[pre + "dbg_lam"][b])
             assert int(g[pre + "dbg_rankE"][b]) == 15
 
@@ -663,36 +660,31 @@ def test_spilled_batches_are_bit_identical_to_single_triplets(gpu_ctx, method, N
             assert np.array_equal(np.asarray(full[k][b]), np.asarray(one[k][0]), equal_nan=True), (method, N, b, k)
 
 
-def test_jacobi_fixup_pass_finds_every_retry_in_a_large_batch(gpu_ctx):
-    """Minimal noisy samples: a few triplets per 10 000 do not converge in the inverse iteration (status ST_RETRY inside the library)
-    and are redone by the Jacobi kernel, whose fixed 1024-block grid strides over the status array.  None may be left behind."""
+def test_exact_fixup_pass_finds_every_retry_in_a_large_batch(gpu_ctx):
+    """Minimal noisy samples with the whole-batch routing switched off (TFF_OPT_EXACT_BELOW = 0): the fast tiers flag the triplets
+    they cannot finish or certify (status ST_RETRY inside the library) and the exact kernel, whose fixed 1024-block grid strides
+    over the status array, redoes them.  None may be left behind, and the result must not depend on the route."""
     import torch
     from tft_vs_fund_amd.scenes import generate_scene_batch
     B = 40000
     C, CalM, _, _ = generate_scene_batch(B, 7, noise=3.0, seed=5)
-    out = gpu_ctx.pose_batch("LinearTFTPoseEstimation", torch.from_numpy(C).cuda(), torch.from_numpy(CalM).cuda(), reconst=False, debug=True)
+    d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
+    gpu_ctx.set_exact_below(0)
+    try:
+        out = gpu_ctx.pose_batch("LinearTFTPoseEstimation", d, calm, reconst=False, debug=True)
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_exact_below(12)
     st = out["status"].cpu().numpy(); dbg = out["debug"].cpu().numpy()
     assert np.all(st == 0)
-    redone = dbg[:, 69] >= 1000                                            # the Jacobi solver stamps its sweep count + 1000
-    assert redone.sum() >= 1 and redone[1024:].sum() >= 1                  # the path ran, also beyond the first grid-full of triplets
+    redone = dbg[:, 69] >= 10000                                           # the exact kernel stamps its iteration count + 10000
+    assert 0 < redone.sum() < B and redone[1024:].sum() >= 1               # both routes ran, also beyond the first grid-full of triplets
     assert np.all(np.isfinite(out["T"].cpu().numpy()))
-
-
-def test_paired_kernel_variant_agrees(gpu_ctx):
-    """TFF_OPT_KERNEL = 1 (two triplets per workgroup, half-wavefront middle section) against the default kernel."""
-    import torch
-    from tft_vs_fund_amd.scenes import generate_scene_batch
-    C, CalM, _, _ = generate_scene_batch(513, 60, noise=1.0, seed=808)          # odd batch: the last workgroup has one triplet
-    d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
-    ref = gpu_ctx.pose_batch("LinearTFTPoseEstimation", d, calm, reconst=True)
-    gpu_ctx.set_kernel_variant(1)
-    try:
-        out = gpu_ctx.pose_batch("LinearTFTPoseEstimation", d, calm, reconst=True)
-    finally:
-        gpu_ctx.set_kernel_variant(0)
+    ref = gpu_ctx.pose_batch("LinearTFTPoseEstimation", d, calm, reconst=False)   # default: the whole batch through the exact kernel
     torch.cuda.synchronize()
-    assert int((out["status"] != 0).sum()) == 0
     T0 = ref["T"].cpu().numpy(); T1 = out["T"].cpu().numpy()
-    assert max(rel_err_T(T1[b], T0[b]) for b in range(513)) < 1e-9
-    assert rel_err(out["R_t_3"].cpu().numpy(), ref["R_t_3"].cpu().numpy()) < 1e-9
-    assert rel_err(out["Reconst"].cpu().numpy(), ref["Reconst"].cpu().numpy()) < 1e-8
+    eT = np.array([rel_err_T(T1[b], T0[b]) for b in range(0, B, 7)])
+    # the fast tiers that were NOT flagged agree with the exact kernel (that is what the flags are for)
+    assert np.quantile(eT, 0.999) < 1e-7 and eT.max() < 1e-5, (eT.max(), np.quantile(eT, 0.999))
+    e3 = np.abs(out["R_t_3"].cpu().numpy() - ref["R_t_3"].cpu().numpy()).reshape(B, -1).max(axis=1)
+    assert (e3 > 1e-6).mean() < 2e-3, (e3 > 1e-6).mean()                    # only cheirality ties / rounding-level sign decisions may differ

@@ -33,6 +33,7 @@ TFF_OPT_SOLVER = 1
 TFF_OPT_STAGE_LDS = 2
 TFF_OPT_KERNEL = 3
 TFF_OPT_GH_EXACT = 4
+TFF_OPT_EXACT_BELOW = 5
 DEBUG_STRIDE = 128
 
 ST_OK, ST_TOO_FEW, ST_NONFINITE, ST_NO_POSE, ST_RANK, ST_NO_PARAM = 0, 1, 2, 3, 4, 5
@@ -143,8 +144,9 @@ def _check(lib, rc, what):
 
 
 class Context:
-    """A tff_ctx: one device, one stream.  `solver`: 'invit' (Cholesky inverse
-    iteration with Jacobi fallback) or 'jacobi'."""
+    """A tff_ctx: one device, one stream.  `solver`: 'invit' (fast tiers -- Gram matrix + Cholesky inverse iteration,
+    certified sign-only votes -- with the exact kernel over what they cannot finish) or 'exact' (exact kernel for every
+    triplet: Householder QR of the explicit design matrix, one-sided Jacobi fall-backs; 'jacobi' is the old name)."""
 
     def __init__(self, device=0, solver="invit", stage_lds=-1, lib_path=None):
         self.lib = load_library(lib_path)
@@ -156,15 +158,20 @@ class Context:
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_STAGE_LDS, int(stage_lds)), "set_option")
 
     def set_solver(self, solver):
-        v = {"invit": 0, "jacobi": 1}[solver]
+        v = {"invit": 0, "jacobi": 1, "exact": 1}[solver]
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_SOLVER, v), "set_option")
+
+    def set_exact_below(self, n):
+        """TFF_OPT_EXACT_BELOW: batches with fewer than n correspondences per triplet go to the exact kernel as a whole
+        (default 12); 0 = only the triplets the fast tiers flag."""
+        _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_EXACT_BELOW, int(n)), "set_option")
 
     def set_gh_exact(self, on):
         """Gauss-Helmert methods: True = pinv(W) always through per-block eigen-decompositions (A/B; slower)."""
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_GH_EXACT, int(bool(on))), "set_option")
 
     def set_kernel_variant(self, v):
-        """TFF_OPT_KERNEL.  LinearTFT: 0 one wavefront per triplet (default), 1 paired kernel (slower; A/B).  Iterative TFT methods:
+        """TFF_OPT_KERNEL.  Iterative TFT methods:
         0 automatic (workgroup per triplet, fused single-wavefront kernel at small N), 1 fused always, 2 workgroup always."""
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_KERNEL, int(v)), "set_option")
 

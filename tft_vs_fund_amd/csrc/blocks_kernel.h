@@ -43,13 +43,8 @@ __global__ void __launch_bounds__(64, 4) k_triangulate(const TriangulateArgs a) 
 #pragma unroll 1
         for (int i = lane; i < a.N; i += WAVE) {
             const double* q = p + 2 * (long)a.M * i;
-            double S[4][4];
-            tri_zero(S);
-            tri_accum(S, P0, q[0], q[1]);
-            tri_accum(S, P1, q[2], q[3]);
-            if (a.M > 2) tri_accum(S, P2, q[4], q[5]);
             double X[4];
-            spd_min_eigvec<4>(S, X);
+            dlt_point<true>(P0, P1, P2, cam[0], cam[1], cam[2], a.M > 2, q[0], q[1], q[2], q[3], (a.M > 2) ? q[4] : 0.0, (a.M > 2) ? q[5] : 0.0, X);
 #pragma unroll
             for (int k = 0; k < 4; ++k) out[4 * (long)i + k] = X[k];
         }
@@ -104,12 +99,7 @@ __global__ void __launch_bounds__(64, 4) k_repr_error(const ReprErrorArgs a) {
                 const double* q = a.pts3d + (b * a.N + i) * 3;
                 X[0] = q[0]; X[1] = q[1]; X[2] = q[2]; X[3] = 1.0;
             } else {
-                double S[4][4];
-                tri_zero(S);
-                tri_accum(S, P[0], p.v[0], p.v[1]);
-                tri_accum(S, P[1], p.v[2], p.v[3]);
-                tri_accum(S, P[2], p.v[4], p.v[5]);
-                spd_min_eigvec<4>(S, X);
+                dlt_point<true>(P[0], P[1], P[2], cam[0], cam[1], cam[2], true, p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], p.v[5], X);
             }
             bool in = true;
 #pragma unroll

@@ -49,6 +49,7 @@ struct tff_ctx {
     hipStream_t own = nullptr;
     hipStream_t stream = nullptr;
     int solver = 0;
+    int exact_below = tff::EXACT_BELOW_N;   // TFF_OPT_EXACT_BELOW
     int stage = -1;
     DevBuf in, calm, out, idx, scratch_status, gh_rec, gh_topt, spill;
     const int32_t* sample_idx = nullptr;   // set around a *_sampled_dev call
@@ -132,7 +133,8 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_
         a.flags |= tff::FLAG_STAGE_LDS;
         stage_max_n = 0;
     }
-    if (c->solver == 0) {
+    const bool all_exact = c->solver != 0 || N < c->exact_below;
+    if (!all_exact) {
         tff::LinearTftArgs m = a;
         m.flags = stage_max_n ? staged_flags(c, N, a.flags, false, stage_max_n) : a.flags;
         unsigned grid = tff::pose_grid(B);
@@ -144,7 +146,7 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_
         a.flags |= tff::FLAG_ONLY_RETRY;
     }
     if (stage_max_n) a.flags = staged_flags(c, N, a.flags, true, stage_max_n);
-    unsigned grid = (c->solver == 0) ? (unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID) : tff::pose_grid(B);
+    unsigned grid = !all_exact ? (unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID) : tff::pose_grid(B);
     size_t lds;
     if (int r = plan_spill(c, ldsfn(N, a.flags, true), ldsfn(0, a.flags, true), &grid, &a.spill, &a.spill_stride, &lds)) return r;
     if (int r = ensure_lds(kjac, lds)) return r;
@@ -153,42 +155,11 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_
     return 0;
 }
 
-// LinearTFTPoseEstimation: one wavefront per triplet + Jacobi fix-up.  TFF_OPT_KERNEL = 1 selects the paired
-// kernel (two triplets per workgroup, half-wavefront middle section) instead -- measured slower on MI355X
-// (0.57-0.63 ms vs 0.47 ms per 10k x 200 batch: its per-half broadcasts ride the LDS crossbar inside the
-// sequential triangular solves), kept for A/B measurements.
+// LinearTFTPoseEstimation: one wavefront per triplet (fast tiers) + the exact kernel over what they could not finish.
 int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    if (c->solver != 0 || c->kernel_variant != 1)
-        return launch_pose(c, tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, 0, corresp, calm, calm_stride,
-                           B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
-    if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
-    if (B == 0) return 0;
-    if (!Rt2 || !Rt3 || !T) return fail(TFF_E_INVALID, "null output pointer");
-    TFF_HIP(hipSetDevice(c->device));
-    if (!status) {
-        if (int r = c->scratch_status.reserve((size_t)B * sizeof(int32_t))) return r;
-        status = (int32_t*)c->scratch_status.p;
-    }
-    tff::LinearTftArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr),
-                         Rt2, Rt3, T, reconst, iter, status, dbg, c->sample_idx, c->init_p, c->init_x};
-    {
-        tff::LinearTftArgs m = a;
-        if (c->sample_idx || c->stage > 0) m.flags |= tff::FLAG_STAGE_LDS;
-        else if (c->stage < 0) m.flags = tff::pair_auto_flags(N, m.flags);
-        const size_t lds = tff::pair_lds_bytes(N, m.flags, false);
-        if (int r = ensure_lds(tff::k_linear_tft_pose_pair, lds)) return r;
-        hipLaunchKernelGGL(tff::k_linear_tft_pose_pair, dim3(tff::pose_grid((B + 1) / 2)), dim3(128), lds, c->stream, m);
-        TFF_HIP(hipGetLastError());
-    }
-    a.flags |= tff::FLAG_ONLY_RETRY;
-    if (c->sample_idx) a.flags |= tff::FLAG_STAGE_LDS;
-    else a.flags = staged_flags(c, N, a.flags, true);
-    const size_t lds = tff::pose_lds_bytes(N, a.flags, true);
-    if (int r = ensure_lds(tff::k_linear_tft_pose<true>, lds)) return r;
-    hipLaunchKernelGGL(tff::k_linear_tft_pose<true>, dim3((unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID)), dim3(64), lds, c->stream, a);
-    TFF_HIP(hipGetLastError());
-    return 0;
+    return launch_pose(c, tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, 0, corresp, calm, calm_stride,
+                       B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 int launch_linear_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
@@ -219,17 +190,21 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
     if (int r = c->gh_topt.reserve((size_t)B * 27 * sizeof(double))) return r;
     tff::GhWgArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr), (double*)c->gh_rec.p, (double*)c->gh_topt.p,
                     Rt2, Rt3, T, reconst, iter, status, dbg, nullptr, 0};
-    {   // linear stage + Jacobi fix-up over the triplets it marked ST_RETRY
+    {   // linear stage: fast tiers, then the exact kernel over the triplets they marked ST_RETRY (minimal samples: exact kernel for all)
+        const bool all_exact = c->solver != 0 || N < c->exact_below;
         tff::GhWgArgs m = a;
-        m.flags = staged_flags(c, N, a.flags, false);
-        size_t lds = tff::pose_lds_bytes(N, m.flags, false);
-        if (int r = ensure_lds(tff::k_gh_linear<false>, lds)) return r;
-        hipLaunchKernelGGL(tff::k_gh_linear<false>, dim3(tff::pose_grid(B)), dim3(64), lds, c->stream, m);
-        TFF_HIP(hipGetLastError());
-        m.flags = staged_flags(c, N, a.flags, true) | tff::FLAG_ONLY_RETRY;
+        size_t lds;
+        if (!all_exact) {
+            m.flags = staged_flags(c, N, a.flags, false);
+            lds = tff::pose_lds_bytes(N, m.flags, false);
+            if (int r = ensure_lds(tff::k_gh_linear<false>, lds)) return r;
+            hipLaunchKernelGGL(tff::k_gh_linear<false>, dim3(tff::pose_grid(B)), dim3(64), lds, c->stream, m);
+            TFF_HIP(hipGetLastError());
+        }
+        m.flags = staged_flags(c, N, a.flags, true) | (all_exact ? 0 : tff::FLAG_ONLY_RETRY);
         lds = tff::pose_lds_bytes(N, m.flags, true);
         if (int r = ensure_lds(tff::k_gh_linear<true>, lds)) return r;
-        hipLaunchKernelGGL(tff::k_gh_linear<true>, dim3((unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID)), dim3(64), lds, c->stream, m);
+        hipLaunchKernelGGL(tff::k_gh_linear<true>, dim3(all_exact ? tff::pose_grid(B) : (unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID)), dim3(64), lds, c->stream, m);
         TFF_HIP(hipGetLastError());
     }
     {
@@ -381,6 +356,7 @@ int tff_ctx_set_option(tff_ctx* c, int option, long value) {
     if (!c) return fail(TFF_E_INVALID, "null context");
     switch (option) {
         case TFF_OPT_SOLVER: if (value != 0 && value != 1) return fail(TFF_E_INVALID, "solver must be 0 or 1"); c->solver = (int)value; return 0;
+        case TFF_OPT_EXACT_BELOW: if (value < 0 || value > (1L << 30)) return fail(TFF_E_INVALID, "exact_below must be >= 0"); c->exact_below = (int)value; return 0;
         case TFF_OPT_STAGE_LDS: if (value < -1 || value > 1) return fail(TFF_E_INVALID, "stage_lds must be -1, 0 or 1"); c->stage = (int)value; return 0;
         case TFF_OPT_GH_EXACT: c->gh_exact = value != 0; return 0;
         case TFF_OPT_KERNEL: if (value < 0 || value > 2) return fail(TFF_E_INVALID, "kernel must be 0, 1 or 2"); c->kernel_variant = (int)value; return 0;
@@ -593,12 +569,13 @@ int tff_linear_tft_batch_dev(tff_ctx* c, const double* corresp, int64_t B, int32
         status = (int32_t*)c->scratch_status.p;
     }
     tff::LinearTftOnlyArgs a{corresp, (long)B, N, 0, T, P2, P3, status};
-    if (c->solver == 0) {
+    const bool all_exact = c->solver != 0 || N < c->exact_below;
+    if (!all_exact) {
         hipLaunchKernelGGL(tff::k_linear_tft<false>, dim3(tff::pose_grid(B)), dim3(64), tff::pose_lds_bytes(N, 0, false), c->stream, a);
         TFF_HIP(hipGetLastError());
         a.flags |= tff::FLAG_ONLY_RETRY;
     }
-    const unsigned grid = (c->solver == 0) ? (unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID) : tff::pose_grid(B);
+    const unsigned grid = !all_exact ? (unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID) : tff::pose_grid(B);
     hipLaunchKernelGGL(tff::k_linear_tft<true>, dim3(grid), dim3(64), tff::pose_lds_bytes(N, 0, true), c->stream, a);
     TFF_HIP(hipGetLastError());
     return 0;
@@ -669,9 +646,10 @@ int tff_linear_f_batch_dev(tff_ctx* c, const double* corresp, int64_t B, int32_t
         status = (int32_t*)c->scratch_status.p;
     }
     tff::LinearFOnlyArgs a{corresp, (long)B, N, 0, F21, F31, iter, status};
-    const unsigned fix_grid = (c->solver == 0) ? (unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID) : tff::pose_grid(B);
+    const bool all_exact = c->solver != 0 || N < c->exact_below;
+    const unsigned fix_grid = !all_exact ? (unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID) : tff::pose_grid(B);
     if (refine) {
-        if (c->solver == 0) {
+        if (!all_exact) {
             const size_t lds = tff::optimf_lds_bytes(N, 0, false);
             if (int r = ensure_lds(tff::k_linear_f<false, 1>, lds)) return r;
             hipLaunchKernelGGL((tff::k_linear_f<false, 1>), dim3(tff::pose_grid(B)), dim3(64), lds, c->stream, a);
@@ -682,7 +660,7 @@ int tff_linear_f_batch_dev(tff_ctx* c, const double* corresp, int64_t B, int32_t
         if (int r = ensure_lds(tff::k_linear_f<true, 1>, lds)) return r;
         hipLaunchKernelGGL((tff::k_linear_f<true, 1>), dim3(fix_grid), dim3(64), lds, c->stream, a);
     } else {
-        if (c->solver == 0) {
+        if (!all_exact) {
             hipLaunchKernelGGL((tff::k_linear_f<false, 0>), dim3(tff::pose_grid(B)), dim3(64), tff::pose_lds_bytes(N, 0, false), c->stream, a);
             TFF_HIP(hipGetLastError());
             a.flags |= tff::FLAG_ONLY_RETRY;

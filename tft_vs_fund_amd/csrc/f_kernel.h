@@ -266,33 +266,52 @@ __device__ inline int gauss_helmert_f_wave(PoseLds* w, OptimFLds* g, double* xi,
 template <bool JAC>
 __device__ inline bool linear_f_wave(PoseLds* w, JacobiLds* jw, const double* pts, int N, double* dbg, bool unit_norm) {
     const int lane = lane_id();
-    accumulate_moments_f(w, pts, N);
+    if (!JAC) accumulate_moments_f(w, pts, N);
     bool ok = true;
 #pragma unroll 1
     for (int pair = 0; pair < 2; ++pair) {                                   // linearF(x1,x2), linearF(x1,x3)
-        double g[9], diag = 0.0, x;
-        const int r = (lane < 9) ? lane : 0, i = r / 3, j = r % 3;
-#pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            g[c] = w->mom[36 * pair + 6 * hht_index(i, c / 3) + hht_index(j, c % 3)];
-            diag = (c == r) ? g[c] : diag;
-        }
+        double x;
         int its = 0;
         if (JAC) {
-            if (lane < 9) for (int c = 0; c < 9; ++c) jw->A[lane * 9 + c] = g[c];
-            wave_sync();
-            x = wave_jacobi_min_eigvec(jw->A, jw->V, 9, 9, &its);
+            // exact tier: streaming QR of the N x 9 system itself (linearF.m:48-53; row = h1 (x) h2, position 3a + b), 55 rows per chunk
+            double g[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) g[c] = 0.0;
+#pragma unroll 1
+            for (int base = 0; base < N; base += 55) {
+                const int i = base + lane - 9;
+                if (lane >= 9) {
+                    const bool have = i < N;
+                    const Pt6 p = premap(premap(load_pt(pts, have ? i : 0), w->nrm), w->nrm2);
+                    const double h1[3] = {p.v[0], p.v[1], 1.0};
+                    const double h2[3] = {pair ? p.v[4] : p.v[2], pair ? p.v[5] : p.v[3], 1.0};
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int bb = 0; bb < 3; ++bb) g[3 * a + bb] = have ? h1[a] * h2[bb] : 0.0;
+                }
+                wave_qr_append<9>(g);
+            }
+            x = wave_qr_min_rsv<9>(g, jw->A, jw->V, w->Lp, EIG_MAXIT, &its);
+            its += 10000;
         } else {
-            double r2;
-            x = wave_min_eigvec_reg<9>(g, diag, w->Lp, EIG_MAXIT, &its, &r2);
-            ok = ok && eig_converged(r2);
+            double g[9], diag = 0.0;
+            const int r = (lane < 9) ? lane : 0, i = r / 3, j = r % 3;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                g[c] = w->mom[36 * pair + 6 * hht_index(i, c / 3) + hht_index(j, c % 3)];
+                diag = (c == r) ? g[c] : diag;
+            }
+            double r2, risk;
+            x = wave_min_eigvec_reg<9>(g, diag, w->Lp, EIG_MAXIT, &its, &r2, false, 0.0, &risk);
+            ok = ok && eig_converged(r2) && risk < GRAM_RISK_MAX;
         }
         if (dbg && lane == 0) dbg[69 + pair] = (double)its;
         // F = reshape(V(:,9),3,3): F(rr,cc) = v[rr + 3 cc]   (linearF.m:55); stored row-major
         if (lane < 9) w->Fm[9 * pair + 3 * (lane % 3) + lane / 3] = x;
         wave_sync();
     }
-    if (!ok) return false;
+    if (!ok) return false;                                                   // wave-uniform so far
     if (lane < 2) {                                                          // linearF.m:58-62: inner de-normalisation, rank 2
         const int v2 = lane + 1;
         Mat3 F;
@@ -302,7 +321,7 @@ __device__ inline bool linear_f_wave(PoseLds* w, JacobiLds* jw, const double* pt
             for (int c = 0; c < 3; ++c) F.m[r][c] = w->Fm[9 * lane + 3 * r + c];
         F = mat3_mul(mat3_mul(mat3_T(normal_matrix(w->nrm2, v2)), F), normal_matrix(w->nrm2, 0));
         double v3[3], fv[3];
-        null3(F, v3);
+        ok = null3<JAC>(F, v3);
 #pragma unroll
         for (int r = 0; r < 3; ++r) fv[r] = F.m[r][0] * v3[0] + F.m[r][1] * v3[1] + F.m[r][2] * v3[2];
         double nn = 0.0;
@@ -317,14 +336,17 @@ __device__ inline bool linear_f_wave(PoseLds* w, JacobiLds* jw, const double* pt
             for (int c = 0; c < 3; ++c) w->Fm[9 * lane + 3 * r + c] = F.m[r][c] * sc;
     }
     wave_sync();
-    return true;
+    return !wave_any(!ok);
 }
 
 // optimF.m:52-69 for both pairs: initial x_est by two-view triangulation with P1 = [I|0], P2 = [crossM(epi21) F, epi21],
 // then Gauss-Helmert on F(:).  w->Fm holds the unit-norm linear F (x-frame) on entry, the refined one on exit.  Returns it1 + it2.
-__device__ inline int optim_f_refine(PoseLds* w, OptimFLds* og, double* oxi, const double* pts, int N, int* gst) {
+// *ok (EXACT = false): cleared when a fast tier (null vector, DLT point) could not finish.
+template <bool EXACT = true>
+__device__ inline int optim_f_refine(PoseLds* w, OptimFLds* og, double* oxi, const double* pts, int N, int* gst, bool* ok = nullptr) {
     const int lane = lane_id();
     int iters = 0;
+    bool fine = true;
 #pragma unroll 1
     for (int pair = 0; pair < 2; ++pair) {
         if (lane == 0) {
@@ -332,7 +354,7 @@ __device__ inline int optim_f_refine(PoseLds* w, OptimFLds* og, double* oxi, con
             for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) F.m[r][c] = w->Fm[9 * pair + 3 * r + c];
             Ft = mat3_T(F);
             double e[3];
-            null3(Ft, e);                                                    // epi21 = U(:,3): left null vector   (optimF.m:53)
+            fine = null3<EXACT>(Ft, e) && fine;                              // epi21 = U(:,3): left null vector   (optimF.m:53)
             // P1 = [I|0] -> Pfin[0];  P2 = [crossM(epi21)*F, epi21] -> P[0]   (:54-55)
             for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) w->Pfin[0][4 * r + c] = (r == c) ? 1.0 : 0.0;
             for (int c = 0; c < 3; ++c) {
@@ -344,7 +366,8 @@ __device__ inline int optim_f_refine(PoseLds* w, OptimFLds* og, double* oxi, con
         }
         if (lane < 9) og->p[lane] = w->Fm[9 * pair + 3 * (lane % 3) + lane / 3];   // p = F(:) column-major   (:61)
         wave_sync();
-        tri_pass(w, pts, N, TRI_REPROJECT2, pair + 1, w->P[0], w->P[0], oxi, w->nrm);   // x_est   (:56-60)
+        fine = tri_pass<EXACT>(w, pts, N, TRI_REPROJECT2, pair + 1, w->P[0], w->P[0], oxi, w->nrm) && fine;   // x_est   (:56-60)
+        if (!EXACT && wave_any(!fine)) { if (ok) *ok = false; return iters; }                                  // the exact kernel redoes the triplet
         wave_sync();
         iters += gauss_helmert_f_wave(w, og, oxi, oxi + 4 * N + 2, pts, N, pair + 1, gst);   // :66
         wave_sync();
@@ -397,7 +420,8 @@ __global__ void __launch_bounds__(64, METHOD == 1 ? 3 : 2) k_f_pose(const Linear
             } else {
                 wave_sync();
                 int gst = ST_OK;
-                if (METHOD == 1) iters = optim_f_refine(w, og, oxi, pts, N, &gst);   // [F21,it1] = optimF(...), [F31,it2] = optimF(...)   (:48-49)
+                bool fine = true;
+                if (METHOD == 1) iters = optim_f_refine<JAC>(w, og, oxi, pts, N, &gst, &fine);   // [F21,it1] = optimF(...), [F31,it2] = optimF(...)   (:48-49)
                 double* Ein = w->Minv;
                 if (lane < 2) {
                     const int v2 = lane + 1;
@@ -410,7 +434,7 @@ __global__ void __launch_bounds__(64, METHOD == 1 ? 3 : 2) k_f_pose(const Linear
                     F = mat3_mul(mat3_mul(mat3_T(normal_matrix(w->nrm, v2)), F), normal_matrix(w->nrm, 0));
                     if (METHOD == 1) {                                       // optimF.m:75-76: rank 2 again
                         double v3[3], fv[3];
-                        null3(F, v3);
+                        fine = null3<JAC>(F, v3) && fine;
 #pragma unroll
                         for (int r = 0; r < 3; ++r) fv[r] = F.m[r][0] * v3[0] + F.m[r][1] * v3[1] + F.m[r][2] * v3[2];
 #pragma unroll
@@ -425,19 +449,28 @@ __global__ void __launch_bounds__(64, METHOD == 1 ? 3 : 2) k_f_pose(const Linear
                         for (int c = 0; c < 3; ++c) Ein[9 * lane + 3 * r + c] = E.m[r][c];
                 }
                 wave_sync();
-                status = recover_poses(w, Ein, pts, N, dbg);
-                if (gst != ST_OK) status = gst;
-                scale_t3(w, pts, N, dbg);
-                write_poses(w, a.Rt2 + b * 12, a.Rt3 + b * 12);
-                if (lane == 0) compose_camera_from_pose(load_K(w->calm, 2), w->Rt[1], w->Pfin[2]);   // K3 [R3 | lam t3]
-                wave_sync();
-                if (a.reconst) tri_pass(w, pts, N, TRI_RECONST, 1, w->Pfin[1], w->Pfin[2], a.reconst + b * 3 * (long)N);
-                tft_from_cameras(w, w->T1);
-                wave_sync();
-                if (lane < 27) a.T[b * 27 + lane] = w->T1[lane];
-                double chk = (lane < 12) ? w->Rt[0][lane] : ((lane < 24) ? w->Rt[1][lane - 12] : ((lane < 51) ? w->T1[lane - 24] : 0.0));
-                const bool bad = !(fabs(chk) <= 1.79e308);
-                if (wave_any(bad) && status == ST_OK) status = ST_NONFINITE;
+                fine = !wave_any(!fine);
+                if (fine) {
+                    status = recover_poses<JAC>(w, Ein, pts, N, dbg, &fine);
+                    if (gst != ST_OK) status = gst;
+                }
+                if (fine) fine = scale_t3<JAC>(w, pts, N, dbg);
+                if (fine) {
+                    if (lane == 0) compose_camera_from_pose(load_K(w->calm, 2), w->Rt[1], w->Pfin[2]);   // K3 [R3 | lam t3]
+                    wave_sync();
+                    if (a.reconst) fine = tri_pass<JAC>(w, pts, N, TRI_RECONST, 1, w->Pfin[1], w->Pfin[2], a.reconst + b * 3 * (long)N);
+                }
+                if (!fine) {
+                    status = ST_RETRY;                                       // a fast tier gave up: redone by k_f_pose<true, .>
+                } else {
+                    write_poses(w, a.Rt2 + b * 12, a.Rt3 + b * 12);
+                    tft_from_cameras(w, w->T1);
+                    wave_sync();
+                    if (lane < 27) a.T[b * 27 + lane] = w->T1[lane];
+                    double chk = (lane < 12) ? w->Rt[0][lane] : ((lane < 24) ? w->Rt[1][lane - 12] : ((lane < 51) ? w->T1[lane - 24] : 0.0));
+                    const bool bad = !(fabs(chk) <= 1.79e308);
+                    if (wave_any(bad) && status == ST_OK) status = ST_NONFINITE;
+                }
             }
         }
         if (lane == 0) {
@@ -487,7 +520,8 @@ __global__ void __launch_bounds__(64, 2) k_linear_f(const LinearFOnlyArgs a) {
             if (!linear_f_wave<JAC>(w, jw, pts, N, nullptr, REFINE != 0)) {
                 st = ST_RETRY;
             } else {
-                if (REFINE) iters = optim_f_refine(w, og, oxi, pts, N, &st);
+                bool fine = true;
+                if (REFINE) iters = optim_f_refine<JAC>(w, og, oxi, pts, N, &st, &fine);
                 if (lane < 2) {
                     Mat3 F;
 #pragma unroll
@@ -497,7 +531,7 @@ __global__ void __launch_bounds__(64, 2) k_linear_f(const LinearFOnlyArgs a) {
                     if (REFINE) {                                            // optimF.m:72-76: de-normalise, rank 2
                         F = mat3_mul(mat3_mul(mat3_T(normal_matrix(w->nrm, lane + 1)), F), normal_matrix(w->nrm, 0));
                         double v3[3], fv[3];
-                        null3(F, v3);
+                        fine = null3<JAC>(F, v3) && fine;
 #pragma unroll
                         for (int r = 0; r < 3; ++r) fv[r] = F.m[r][0] * v3[0] + F.m[r][1] * v3[1] + F.m[r][2] * v3[2];
 #pragma unroll
@@ -511,6 +545,7 @@ __global__ void __launch_bounds__(64, 2) k_linear_f(const LinearFOnlyArgs a) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) out[3 * c + r] = F.m[r][c];
                 }
+                if (wave_any(!fine)) st = ST_RETRY;
             }
         }
         if (lane == 0) {

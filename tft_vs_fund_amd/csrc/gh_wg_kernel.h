@@ -185,12 +185,8 @@ __device__ inline void gh_block_reproject(PoseLds* w, const double* pts, int N, 
 #pragma unroll 1
     for (int i = threadIdx.x; i < N; i += GH_WG_THREADS) {
         const Pt6 p = premap(load_pt(pts, i), w->nrm);
-        double S[4][4], X[4];
-        tri_zero(S);
-        tri_accum(S, PA, p.v[0], p.v[1]);
-        tri_accum(S, PB, p.v[2], p.v[3]);
-        tri_accum(S, PC, p.v[4], p.v[5]);
-        spd_min_eigvec<4>(S, X, 40);
+        double X[4];
+        dlt_point<true>(PA, PB, PC, w->Pfin[0], w->P[0], w->P[1], true, p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], p.v[5], X);
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
             const double (&P)[12] = (v == 0) ? PA : ((v == 1) ? PB : PC);

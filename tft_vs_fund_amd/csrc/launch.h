@@ -52,16 +52,9 @@ inline size_t optimf_lds_bytes(int N, int flags, bool jacobi) {
     if (flags & FLAG_STAGE_LDS) d += 6 * (size_t)N;
     return d * sizeof(double);
 }
-// paired kernel: two triplets (two waves) per workgroup
-inline size_t pair_lds_bytes(int N, int flags, bool /*jacobi*/) {
-    size_t d = (size_t)((POSE_LDS_DOUBLES + 1) & ~1);
-    if (flags & FLAG_STAGE_LDS) d += (size_t)((6 * N + 1) & ~1);
-    return 2 * d * sizeof(double);
-}
-inline int pair_auto_flags(int N, int flags) {
-    if (pair_lds_bytes(N, flags | FLAG_STAGE_LDS, false) <= 64 * 1024) flags |= FLAG_STAGE_LDS;
-    return flags;
-}
+// Batches of fewer correspondences per triplet than this go to the exact kernel as a whole (minimal samples: the two smallest singular
+// values of the design matrix nearly coincide too often for the flag-and-redo path to pay).  TFF_OPT_EXACT_BELOW overrides.
+constexpr int EXACT_BELOW_N = 12;
 inline unsigned pose_grid(long B) { return (unsigned)((B < (1L << 30)) ? (B > 0 ? B : 1) : (1L << 30)); }
 
 }  // namespace tff

@@ -6,6 +6,7 @@
 #include "wave.h"
 #include "small_la.h"
 #include "wave_eig.h"
+#include "wave_qr.h"
 
 namespace tff {
 
@@ -21,7 +22,7 @@ constexpr int ST_OK = 0;
 constexpr int ST_TOO_FEW = 1;         // N < 7 (TFT) / N < 8 (F): experiments.m:99, linearF.m:35
 constexpr int ST_NONFINITE = 2;       // NaN/Inf reached the outputs (Gauss_Helmert.m:53,63)
 constexpr int ST_NO_POSE = 3;         // no candidate with non-negative cheirality score (R_t_from_TFT.m:91-104)
-constexpr int ST_RETRY = 100;         // internal: inverse iteration did not converge; redone by the Jacobi fix-up pass
+constexpr int ST_RETRY = 100;         // internal: a fast tier could not finish or certify its result; the triplet is redone by the exact kernel
 
 constexpr int DBG_STRIDE = 128;       // doubles per triplet in the optional debug buffer
 
@@ -154,9 +155,11 @@ __device__ __forceinline__ Mat3 normal_matrix(const double* nrm, int v) {
 // ones, lanes 0/1 then the null vector of each stacked 3x3.  epi[0..2] = e21,
 // epi[3..5] = e31.  fix_sign: multiply by sign of the own third component
 // (R_t_from_TFT.m:50,55).
-template <int G>
-__device__ __attribute__((noinline)) void epipoles_from_tensor(const double* t, double* nullv, double* epi, bool fix_sign) {
+// Returns (per lane) false when a null-vector iteration hit its cap and EXACT = false left it unfinished.
+template <int G, bool EXACT = true>
+__device__ __attribute__((noinline)) bool epipoles_from_tensor(const double* t, double* nullv, double* epi, bool fix_sign) {
     const int lane = Group<G>::lane();
+    bool ok = true;
     if (lane < 6) {
         const int i = (lane < 3) ? lane : lane - 3;
         Mat3 M;
@@ -168,7 +171,7 @@ __device__ __attribute__((noinline)) void epipoles_from_tensor(const double* t, 
                 if (lane < 3) M.m[j][k] = v; else M.m[k][j] = v;             // T(:,:,i) or its transpose
             }
         double x[3];
-        null3(M, x);
+        ok = null3<EXACT>(M, x);
         nullv[3 * lane + 0] = x[0]; nullv[3 * lane + 1] = x[1]; nullv[3 * lane + 2] = x[2];
     }
     wave_sync();
@@ -179,12 +182,13 @@ __device__ __attribute__((noinline)) void epipoles_from_tensor(const double* t, 
 #pragma unroll
             for (int k = 0; k < 3; ++k) M.m[i][k] = nullv[9 * lane + 3 * i + k];
         double x[3];
-        null3(M, x);
+        ok = null3<EXACT>(M, x) && ok;
         if (fix_sign) { const double sg = sgn(x[2]); x[0] *= sg; x[1] *= sg; x[2] *= sg; }
         double* dst = (lane == 0) ? (epi + 3) : epi;                         // lane 0: right nulls -> e31; lane 1: left -> e21
         dst[0] = x[0]; dst[1] = x[1]; dst[2] = x[2];
     }
     wave_sync();
+    return ok;
 }
 
 // transform_TFT.m:42-49 with inverse = 1:  Tn(:,:,i) = inv(M2) (sum_j M1(j,i) To(:,:,j)) inv(M3).'
@@ -247,6 +251,106 @@ __device__ __forceinline__ void tri_zero(double (&S)[4][4]) {
         for (int j = 0; j < 4; ++j) S[i][j] = 0.0;
 }
 
+// Rows [0 -1 y; 1 0 -x] * P of one view's DLT block (triangulation3D.m:58-59), P row-major 3x4.
+__device__ __forceinline__ void dlt_rows(double* r0, double* r1, const double (&P)[12], double x, double y) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { r0[c] = y * P[8 + c] - P[4 + c]; r1[c] = P[c] - x * P[8 + c]; }
+}
+
+// Exact tier of the DLT point (see dlt_point): one-sided Jacobi (Hestenes) on the 2M x 4 matrix itself -- the reference's
+// [~,~,V] = svd(ls_matrix); V(:,4) at SVD accuracy, whatever the gap between the two smallest singular values.
+// Out of line and deliberately ROLLED (the matrices live in per-lane scratch memory, indexed dynamically): it runs for the rare
+// correspondences whose inverse iteration hits its cap, and a caller's register budget is the maximum over its callees --
+// unrolled into 40 live doubles it would cost every kernel that can reach it its occupancy.
+// cam*: row-major 3x4 cameras in LDS (camC ignored unless three).
+struct Vec4 { double v[4]; };
+__device__ __attribute__((noinline)) Vec4 dlt_point_exact(const double* camA, const double* camB, const double* camC, const int three,
+                                                          const double xa, const double ya, const double xb, const double yb,
+                                                          const double xc, const double yc) {
+    double M[6][4], V[4][4];
+    const int rows = three ? 6 : 4;
+#pragma unroll 1
+    for (int v = 0; v < 3; ++v) {
+        const double* P = (v == 0) ? camA : ((v == 1) ? camB : camC);
+        const double x = (v == 0) ? xa : ((v == 1) ? xb : xc), y = (v == 0) ? ya : ((v == 1) ? yb : yc);
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            const bool have = v < 2 || three;
+            M[2 * v][c] = have ? y * P[8 + c] - P[4 + c] : 0.0;              // [0 -1 y; 1 0 -x] * P   (triangulation3D.m:58-59)
+            M[2 * v + 1][c] = have ? P[c] - x * P[8 + c] : 0.0;
+        }
+    }
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i)
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+#pragma unroll 1
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        bool rotated = false;
+#pragma unroll 1
+        for (int p = 0; p < 3; ++p)
+#pragma unroll 1
+            for (int q = p + 1; q < 4; ++q) {
+                double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll 1
+                for (int r = 0; r < rows; ++r) { const double mp = M[r][p], mq = M[r][q]; al += mp * mp; be += mq * mq; ga += mp * mq; }
+                if (!(fabs(ga) > 1e-15 * sqrt(al * be))) continue;
+                rotated = true;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = rsqrt(1.0 + t * t), s = c * t;
+#pragma unroll 1
+                for (int r = 0; r < rows; ++r) { const double mp = M[r][p], mq = M[r][q]; M[r][p] = c * mp - s * mq; M[r][q] = s * mp + c * mq; }
+#pragma unroll 1
+                for (int r = 0; r < 4; ++r) { const double vp = V[r][p], vq = V[r][q]; V[r][p] = c * vp - s * vq; V[r][q] = s * vp + c * vq; }
+            }
+        if (!rotated) break;
+    }
+    int best = 0;
+    double bv = 0.0;
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        double nn = 0.0;
+#pragma unroll 1
+        for (int r = 0; r < rows; ++r) nn += M[r][c] * M[r][c];
+        if (c == 0 || nn < bv) { bv = nn; best = c; }
+    }
+    Vec4 X;
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) X.v[r] = V[r][best];
+    return X;
+}
+
+// The DLT point of one correspondence (triangulation3D.m:51-63): V(:,4) of the 2M x 4 system of cameras PA, PB and (three) PC,
+// unit norm, sign free.  Fast tier: Cholesky + inverse iteration on the 4 x 4 normal matrix, run until the iterate stops
+// moving.  When the two smallest singular values nearly coincide (inconsistent systems: minimal samples, wrong candidates) the
+// iteration cap is hit; then
+//   EXACT = true : the one-sided Jacobi on the matrix itself takes over (gap-independent, SVD accuracy), out of line;
+//   EXACT = false: the function only reports it (returns false) and the CALLER repeats its pass with EXACT = true -- the hot
+//                  per-correspondence loops then contain no call, which would make their (non-inlined) functions save and
+//                  restore ~35 registers on every entry.
+// PA.. hold the cameras as (wave-uniform) values, camA.. point to the same cameras in LDS (for the exact tier).
+template <bool EXACT>
+__device__ __forceinline__ bool dlt_point(const double (&PA)[12], const double (&PB)[12], const double (&PC)[12],
+                                          const double* camA, const double* camB, const double* camC, const bool three,
+                                          const double xa, const double ya, const double xb, const double yb, const double xc, const double yc,
+                                          double (&X)[4]) {
+    double S[4][4];
+    tri_zero(S);
+    tri_accum(S, PA, xa, ya);
+    tri_accum(S, PB, xb, yb);
+    if (three) tri_accum(S, PC, xc, yc);
+    bool conv;
+    spd_min_eigvec<4>(S, X, 40, &conv);
+    if (EXACT && !conv) {
+        Vec4 E; E = dlt_point_exact(camA, camB, camC, three ? 1 : 0, xa, ya, xb, yb, xc, yc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X[k] = E.v[k];
+        conv = true;
+    }
+    return conv;
+}
+
 // P = K [R | t]   (R row-major 9, t 3) -> row-major 3x4
 __device__ __forceinline__ void compose_camera(const Mat3& K, const double* R, const double* t, double* P) {
 #pragma unroll
@@ -265,25 +369,31 @@ __device__ __forceinline__ void compose_camera_from_pose(const Mat3& K, const do
         for (int c = 0; c < 4; ++c) P[4 * r + c] = K.m[r][0] * Rt[c] + K.m[r][1] * Rt[4 + c] + K.m[r][2] * Rt[8 + c];
 }
 
-// Cheirality vote of one pose candidate (R_t_from_TFT.m:96-101): sum_n sign(X1(3)) + sign(X2(3)), X1 the two-view DLT point of
-// correspondence n (cameras Pfin[0] = K1 [I|0] and camB), X2 = [R t] X1.  Only the two SIGNS are consumed, so this is a slimmed copy
-// of tri_pass: the first camera's fourth column is zero by construction; the point is the least-squares solution with X(4) = 1,
-//     X(1:3) = -inv(S(1:3,1:3)) S(1:3,4)
-// read off the Cholesky factor of S = A'A (its last row is the forward solve, one 3 x 3 back substitution finishes it) -- the
-// inhomogeneous form of the same DLT system, within lambda_4/lambda_3 (~1e-6 for correspondences consistent with the candidate)
-// of the singular vector the reference takes, which cannot move the sign of a depth that is O(1) in these units.  No fourth pivot,
-// no normalisation, no iteration: 60 % of the instructions of the general pass.  `Rt`: candidate pose, row-major 3x4.
-__device__ __attribute__((noinline)) int tri_vote(PoseLds* w, const double* pts, int N, int view, const double* camB, const double* Rt) {
+// Cheirality vote of one pose candidate (R_t_from_TFT.m:96-101): sum_n sign(X1(3)) + sign(X2(3)), X1 = X / X(4) with X the
+// homogeneous two-view DLT point of correspondence n (cameras Pfin[0] = K1 [I|0] and camB; V(:,4) of the 4 x 4 system,
+// triangulation3D.m:61-62), X2 = [R t] X1.  Only the two SIGNS are consumed, so the vote is two-tiered:
+//   * fast tier (tri_vote_fast): the inhomogeneous least-squares point z = -inv(S11) s (S = M'M = [S11 s; s' sigma]; X(4) = 1),
+//     read off the Cholesky factor with one 3 x 3 back substitution -- no fourth column, no normalisation, no iteration;
+//   * certificate: the singular vector satisfies X(1:3)/X(4) = -inv(S11 - mu I) s with mu = lambda_min(S) <= nu = lambda_min(S11)
+//     (interlacing), a continuous path from z (mu' = 0) along which every eigen-component of z grows by at most
+//     mu / (nu - mu); so |X(1:3)/X(4) - z| <= rho |z|, rho = m / (nu_low - m), with the computable bounds
+//     mu <= m = (Schur complement of S11) / (1 + |z|^2)  (Rayleigh quotient of (z,1)) and nu >= nu_low = 4 det(S11) / tr(S11)^2.
+//     Both depths are then sign-certain iff they exceed (2 rho + rounding) |z|  (the pose row R(3,:) has unit norm);
+//   * exact tier (tri_vote_exact), run for the whole candidate when ANY of its correspondences is not certified (points near
+//     infinity or near a camera plane, inconsistent systems of minimal samples): the converged homogeneous solution --
+//     inverse iteration on S, one-sided Jacobi on the 4 x 4 matrix itself when its two smallest singular values nearly coincide.
+// The scores therefore equal the reference's for every candidate; on well-posed triplets only the fast tier runs (+8 % on it
+// for the certificate).  `Rt`: candidate pose, row-major 3x4.  tri_vote_fast returns 2 * score + (1 if any correspondence
+// was not certified, in which case the score is not valid).
+__device__ __attribute__((noinline)) int tri_vote_fast(PoseLds* w, const double* pts, int N, int view, const double* camB, const double* Rt) {
     const int lane = lane_id();
-    double PA[9], PB[12], R3[4];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) PA[3 * r + c] = wave_uniform(w->Pfin[0][4 * r + c]);
+    double PA[12], PB[12], R3[4];
+    load_uniform12(w->Pfin[0], PA);                                          // PA[3] = PA[7] = PA[11] = 0
     load_uniform12(camB, PB);
 #pragma unroll
     for (int c = 0; c < 4; ++c) R3[c] = wave_uniform(Rt[8 + c]);
     int score = 0;
+    bool all_certain = true;
     Pt6 pnext = load_pt(pts, (lane < N) ? lane : 0);
 #pragma unroll 1
     for (int i = lane; i < N; i += WAVE) {
@@ -292,10 +402,10 @@ __device__ __attribute__((noinline)) int tri_vote(PoseLds* w, const double* pts,
         const double x1 = p.v[0], y1 = p.v[1], x2 = (view == 1) ? p.v[2] : p.v[4], y2 = (view == 1) ? p.v[3] : p.v[5];
         double a0[3], a1[3], b0[4], b1[4];                                  // rows [0 -1 y; 1 0 -x] * P   (triangulation3D.m:58-59)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { a0[c] = y1 * PA[6 + c] - PA[3 + c]; a1[c] = PA[c] - x1 * PA[6 + c]; }
+        for (int c = 0; c < 3; ++c) { a0[c] = y1 * PA[8 + c] - PA[4 + c]; a1[c] = PA[c] - x1 * PA[8 + c]; }
 #pragma unroll
         for (int c = 0; c < 4; ++c) { b0[c] = y2 * PB[8 + c] - PB[4 + c]; b1[c] = PB[c] - x2 * PB[8 + c]; }
-        double S[4][3];                                                      // lower triangle of A'A, columns 0..2 (S[3][3] is not needed)
+        double S[4][3];                                                      // lower triangle of A'A, columns 0..2
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -306,8 +416,9 @@ __device__ __attribute__((noinline)) int tri_vote(PoseLds* w, const double* pts,
                 S[r][c] = v;
             }
         // Cholesky of S + delta I as in spd_min_eigvec (the shift only conditions the factorisation)
-        const double tr = S[0][0] + S[1][1] + S[2][2] + (b0[3] * b0[3] + b1[3] * b1[3]);
-        const double delta = 1e-14 * tr, pfloor = 1e-3 * delta + 1e-300;
+        const double S33 = b0[3] * b0[3] + b1[3] * b1[3];
+        const double tr3 = S[0][0] + S[1][1] + S[2][2];
+        const double delta = 1e-14 * (tr3 + S33), pfloor = 1e-3 * delta + 1e-300;
         double L[4][3], inv[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -332,16 +443,59 @@ __device__ __attribute__((noinline)) int tri_vote(PoseLds* w, const double* pts,
             for (int k = r + 1; k < 3; ++k) sum -= L[k][r] * z[k];
             z[r] = sum * inv[r];
         }
-        const double z2 = R3[0] * z[0] + R3[1] * z[1] + R3[2] * z[2] + R3[3];
-        score += (int)sgn(z[2]) + (int)sgn(z2);                             // X(4) = 1 > 0
+        const double d1 = z[2], d2 = R3[0] * z[0] + R3[1] * z[1] + R3[2] * z[2] + R3[3];   // depths with X(4) = 1 > 0
+        // certificate (division-free form of  min|d| > (2 rho + 1e-13 cond(S11)) |z|, everything scaled by tr^2 / det(S11))
+        const double d4 = S33 + delta - (L[3][0] * L[3][0] + L[3][1] * L[3][1] + L[3][2] * L[3][2]);   // Schur complement (>= 0)
+        const double zz = z[0] * z[0] + z[1] * z[1] + z[2] * z[2];
+        const double idet = (inv[0] * inv[1]) * (inv[0] * inv[1]) * (inv[2] * inv[2]);                 // 1 / det(S11 + delta I)
+        const double trs = tr3 + 3.0 * delta;
+        const double e = trs * trs * idet;                                   // 4 / nu_low
+        const double Gp = 4.0 * (1.0 + zz) - d4 * e;                         // (nu_low - m), scaled; > 0 required
+        const double rhs = 2.0 * d4 * e + 2.5e-14 * trs * e * Gp;
+        const double dmin2 = fmin(d1 * d1, d2 * d2);
+        const bool certain = Gp > 0.0 && dmin2 * Gp * Gp > rhs * rhs * zz;  // false for NaN / inf
+        all_certain = all_certain && certain;
+        score += (int)sgn(d1) + (int)sgn(d2);
+    }
+    return 2 * wave_sum_i(score) + (wave_any(!all_certain) ? 1 : 0);
+}
+// exact tier: every correspondence from its converged homogeneous point  (R_t_from_TFT.m:98-99)
+__device__ __attribute__((noinline)) int tri_vote_exact(PoseLds* w, const double* pts, int N, int view, const double* camB, const double* Rt) {
+    const int lane = lane_id();
+    double PA[12], PB[12], R3[4];
+    load_uniform12(w->Pfin[0], PA);
+    load_uniform12(camB, PB);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) R3[c] = wave_uniform(Rt[8 + c]);
+    int score = 0;
+#pragma unroll 1
+    for (int i = lane; i < N; i += WAVE) {
+        const Pt6 p = load_pt(pts, i);
+        double X[4];
+        dlt_point<true>(PA, PB, PB, w->Pfin[0], camB, camB, false, p.v[0], p.v[1], (view == 1) ? p.v[2] : p.v[4],
+                        (view == 1) ? p.v[3] : p.v[5], 0.0, 0.0, X);
+        const double s4 = sgn(X[3]);                                         // X1 = X ./ X(4)
+        const double d1 = X[2] * s4, d2 = (R3[0] * X[0] + R3[1] * X[1] + R3[2] * X[2] + R3[3] * X[3]) * s4;
+        score += (int)sgn(d1) + (int)sgn(d2);
     }
     return wave_sum_i(score);
+}
+// EXACT = true: the score (the exact tier runs when needed).  EXACT = false: fast tier only; *ok = false when the score is not
+// certified (the caller hands the triplet to the exact kernel).
+template <bool EXACT = true>
+__device__ __forceinline__ int tri_vote(PoseLds* w, const double* pts, int N, int view, const double* camB, const double* Rt, bool* ok) {
+    const int r = tri_vote_fast(w, pts, N, view, camB, Rt);                   // wave-uniform
+    if (r & 1) {
+        if (EXACT) return tri_vote_exact(w, pts, N, view, camB, Rt);
+        *ok = false;
+    }
+    return r >> 1;
 }
 
 // One pass over the correspondences of the triplet, one lane per correspondence:
 // DLT triangulation (triangulation3D.m:51-63) from camera Pfin[0] = K1 [I|0], camera
 // `camB` and (mode TRI_RECONST) camera `aux`, then a mode-specific epilogue.
-// A single non-inlined copy serves the cheirality vote, the t3 scale and Reconst
+// A single non-inlined copy serves the t3 scale, Reconst and the initial observations
 // (code size: see the instruction-cache note in wave_eig.h).
 //   TRI_SCALE   : aux = [K3*R3 | u3 = K3*t3]; num/den of R_t_from_TFT.m:72-73 -> w->pa[0..1]
 //   TRI_RECONST : aux = third camera; dehomogenised points -> `out` (3 x N column-major)
@@ -351,28 +505,28 @@ __device__ __attribute__((noinline)) int tri_vote(PoseLds* w, const double* pts,
 //   TRI_REPROJECT2 : two views only (Pfin[0], camB; `view` picks the second view's coordinates); the two
 //                 reprojections -> `out` (4 x N), the initial observations of optimF (optimF.m:56-60)
 // `pre` (9 doubles or null): affine map applied to the raw correspondences first (normalised points).
+// Two copies (see dlt_point): tri_pass_fast returns 1 when some correspondence's inverse iteration hit its cap, and
+// tri_pass then repeats the pass with the exact tier enabled (rare: inconsistent systems of minimal samples).
 constexpr int TRI_VOTE = 0, TRI_SCALE = 1, TRI_RECONST = 2, TRI_REPROJECT = 3, TRI_REPROJECT2 = 4;
-__device__ __attribute__((noinline)) int tri_pass(PoseLds* w, const double* pts, int N, int mode, int view, const double* camB,
-                                                   const double* aux, double* out, const double* pre = nullptr) {
+template <bool EXACT>
+__device__ __forceinline__ int tri_pass_impl(PoseLds* w, const double* pts, int N, int mode, int view, const double* camB,
+                                             const double* aux, double* out, const double* pre) {
     const int lane = lane_id();
     double PA[12], PB[12], AX[12];
     load_uniform12(w->Pfin[0], PA);
     load_uniform12(camB, PB);
     load_uniform12(aux, AX);
-    int score = 0;
+    bool all_conv = true;
     double num = 0.0, den = 0.0;
     Pt6 pnext = load_pt(pts, (lane < N) ? lane : 0);                             // software-pipelined: next point in flight
 #pragma unroll 1
     for (int i = lane; i < N; i += WAVE) {
         const Pt6 p = premap(pnext, pre);
         if (i + WAVE < N) pnext = load_pt(pts, i + WAVE);
-        double S[4][4];
-        tri_zero(S);
-        tri_accum(S, PA, p.v[0], p.v[1]);
-        tri_accum(S, PB, (view == 1) ? p.v[2] : p.v[4], (view == 1) ? p.v[3] : p.v[5]);
-        if (mode == TRI_RECONST || mode == TRI_REPROJECT) tri_accum(S, AX, p.v[4], p.v[5]);
         double X[4];
-        spd_min_eigvec<4>(S, X, 40);
+        const bool conv = dlt_point<EXACT>(PA, PB, AX, w->Pfin[0], camB, aux, mode == TRI_RECONST || mode == TRI_REPROJECT, p.v[0], p.v[1],
+                                           (view == 1) ? p.v[2] : p.v[4], (view == 1) ? p.v[3] : p.v[5], p.v[4], p.v[5], X);
+        all_conv = all_conv && conv;
         if (mode == TRI_REPROJECT2) {
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
@@ -423,7 +577,25 @@ __device__ __attribute__((noinline)) int tri_pass(PoseLds* w, const double* pts,
         if (lane == 0) { w->pa[0] = num; w->pa[1] = den; }
         wave_sync();
     }
-    return 0;
+    return wave_any(!all_conv) ? 1 : 0;
+}
+__device__ __attribute__((noinline)) int tri_pass_fast(PoseLds* w, const double* pts, int N, int mode, int view, const double* camB,
+                                                        const double* aux, double* out, const double* pre) {
+    return tri_pass_impl<false>(w, pts, N, mode, view, camB, aux, out, pre);
+}
+__device__ __attribute__((noinline)) int tri_pass_exact(PoseLds* w, const double* pts, int N, int mode, int view, const double* camB,
+                                                         const double* aux, double* out, const double* pre) {
+    return tri_pass_impl<true>(w, pts, N, mode, view, camB, aux, out, pre);
+}
+// Returns true when every correspondence's point is converged (always, with EXACT = true).
+template <bool EXACT = true>
+__device__ __forceinline__ bool tri_pass(PoseLds* w, const double* pts, int N, int mode, int view, const double* camB,
+                                         const double* aux, double* out, const double* pre = nullptr) {
+    if (tri_pass_fast(w, pts, N, mode, view, camB, aux, out, pre)) {
+        if (!EXACT) return false;
+        tri_pass_exact(w, pts, N, mode, view, camB, aux, out, pre);
+    }
+    return true;
 }
 
 // recover_R_t (R_t_from_TFT.m:82-106 == LinearFPoseEstimation.m:84-109):
@@ -480,14 +652,17 @@ __device__ inline void recover_prepare(PoseLds* w, const double* Ein) {
     wave_sync();
 }
 
-__device__ inline int recover_vote(PoseLds* w, const double* pts, int N, double* dbg) {
+// ok (optional, EXACT = false): set to false when a score could not be certified by the fast tier.
+template <bool EXACT = true>
+__device__ inline int recover_vote(PoseLds* w, const double* pts, int N, double* dbg, bool* ok = nullptr) {
     const int lane = lane_id();
     phase_stamp(dbg, 10);
     int status = ST_OK;
+    bool certified = true;
 #pragma unroll 1
     for (int call = 0; call < 2; ++call) {
-        const int sR = tri_vote(w, pts, N, call + 1, w->P[2 * call], w->candRt[2 * call]);
-        const int sRp = tri_vote(w, pts, N, call + 1, w->P[2 * call + 1], w->candRt[2 * call + 1]);
+        const int sR = tri_vote<EXACT>(w, pts, N, call + 1, w->P[2 * call], w->candRt[2 * call], &certified);
+        const int sRp = tri_vote<EXACT>(w, pts, N, call + 1, w->P[2 * call + 1], w->candRt[2 * call + 1], &certified);
         // reference order: k=1 (R,t), k=2 (R,-t), k=3 (Rp,-t), k=4 (Rp,t)   (:92-104)
         const int score[4] = {sR, -sR, -sRp, sRp};
         int seen = 0, pick = -1;
@@ -503,35 +678,40 @@ __device__ inline int recover_vote(PoseLds* w, const double* pts, int N, double*
         }
         wave_sync();
     }
+    if (ok && !certified) *ok = false;
     return status;
 }
 
-__device__ inline int recover_poses(PoseLds* w, const double* Ein, const double* pts, int N, double* dbg) {
+template <bool EXACT = true>
+__device__ inline int recover_poses(PoseLds* w, const double* Ein, const double* pts, int N, double* dbg, bool* ok = nullptr) {
     recover_prepare<64>(w, Ein);
-    return recover_vote(w, pts, N, dbg);
+    return recover_vote<EXACT>(w, pts, N, dbg, ok);
 }
 
 // t3 scale, R_t_from_TFT.m:68-74 == LinearFPoseEstimation.m:64-70.  Scales w->Rt[1](:,4) in place.
-__device__ inline void scale_t3(PoseLds* w, const double* pts, int N, double* dbg) {
+template <bool EXACT = true>
+__device__ inline bool scale_t3(PoseLds* w, const double* pts, int N, double* dbg) {
     const int lane = lane_id();
     if (lane < 2)                                                            // Pfin[1] = K2 [R2|t2];  Pfin[2] = [K3*R3 | u3 = K3*t3]   (:68,:71)
         compose_camera_from_pose(load_K(w->calm, lane + 1), w->Rt[lane], w->Pfin[lane + 1]);
     wave_sync();
-    tri_pass(w, pts, N, TRI_SCALE, 1, w->Pfin[1], w->Pfin[2], nullptr);      // X from views 1,2 (:69-70)
+    const bool conv = tri_pass<EXACT>(w, pts, N, TRI_SCALE, 1, w->Pfin[1], w->Pfin[2], nullptr);      // X from views 1,2 (:69-70)
     const double lam = -w->pa[0] / w->pa[1];                                 // :72-73
     if (dbg && lane == 0) dbg[68] = lam;
     wave_sync();
     if (lane < 3) w->Rt[1][4 * lane + 3] *= lam;                             // :74
     wave_sync();
+    return conv;
 }
 
 // Final reconstruction (LinearTFTPoseEstimation.m:59-60): 3-view DLT with the
 // recovered poses, dehomogenised, written as 3 x N column-major.
-__device__ inline void final_reconst(PoseLds* w, const double* pts, int N, double* __restrict__ out) {
+template <bool EXACT = true>
+__device__ inline bool final_reconst(PoseLds* w, const double* pts, int N, double* __restrict__ out) {
     const int lane = lane_id();
     if (lane == 0) compose_camera_from_pose(load_K(w->calm, 2), w->Rt[1], w->Pfin[2]);
     wave_sync();
-    tri_pass(w, pts, N, TRI_RECONST, 1, w->Pfin[1], w->Pfin[2], out);
+    return tri_pass<EXACT>(w, pts, N, TRI_RECONST, 1, w->Pfin[1], w->Pfin[2], out);
 }
 
 // write the chosen poses (row-major in LDS) as MATLAB column-major 3x4 arrays

@@ -67,8 +67,11 @@ __device__ __forceinline__ void cross3(const double* a, const double* b, double*
 // (triangulation3D.m:61-62, linearTFT.m:71-79, R_t_from_TFT.m:47-55).
 // Returns the number of iterations used; x has unit norm, sign free.
 // --------------------------------------------------------------------------
+// *converged (optional): false when the iteration cap was reached before the iterate stopped moving (nearly coincident
+// smallest eigenvalues) -- the callers with an exact fall-back (hestenes_min_rsv on the matrix itself) test it.
 template <int n>
-__device__ __forceinline__ int spd_min_eigvec(const double (&S)[n][n], double (&x)[n], int maxit = 40) {
+__device__ __forceinline__ int spd_min_eigvec(const double (&S)[n][n], double (&x)[n], int maxit = 40, bool* converged = nullptr) {
+    bool conv = false;
     double tr = 0.0;
 #pragma unroll
     for (int i = 0; i < n; ++i) tr += S[i][i];
@@ -119,7 +122,7 @@ __device__ __forceinline__ int spd_min_eigvec(const double (&S)[n][n], double (&
     }
     double rprev2 = 1.0;
     int it = 0;
-#pragma unroll 1
+#pragma clang loop unroll(disable)
     for (; it < maxit;) {
         double y[n];
         // forward L y = x
@@ -148,11 +151,71 @@ __device__ __forceinline__ int spd_min_eigvec(const double (&S)[n][n], double (&
         for (int i = 0; i < n; ++i) { const double yi = y[i] * sg; const double d = yi - x[i]; r2 += d * d; x[i] = yi; }
         ++it;
         // r2 = |step|^2.  Error of the new iterate ~ rho*|step|/(1-rho), rho ~ |step|/|previous step|.
-        if (!(r2 > 1e-28)) break;                                        // also leaves on NaN
-        if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) break;
+        if (!(r2 > 1e-28)) { conv = (r2 == r2); break; }                 // also leaves on NaN
+        if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) { conv = true; break; }
         rprev2 = r2;
     }
+    if (converged) *converged = conv;
     return it;
+}
+
+// --------------------------------------------------------------------------
+// Right singular vector of the smallest singular value of an R_ x C_ matrix M (per lane, registers) by one-sided
+// Jacobi (Hestenes) rotations of its columns: the reference's [~,~,V] = svd(M); V(:,end) at SVD accuracy
+// (eps sigma_1 / (sigma_(C-1) - sigma_C), no squared conditioning and no dependence of the run time on the gap).
+// The gap-independent fall-back of the Cholesky / inverse-iteration path above for nearly coincident smallest
+// singular values (inconsistent DLT systems of minimal samples: triangulation3D.m:61-62, linearTFT.m:71-79).
+// M is destroyed (its columns end up orthogonal, their norms are the singular values).  x: unit norm, sign free.
+// --------------------------------------------------------------------------
+template <int R_, int C_>
+__device__ inline void hestenes_min_rsv(double (&M)[R_][C_], double (&x)[C_]) {
+    double V[C_][C_];
+#pragma unroll
+    for (int i = 0; i < C_; ++i)
+#pragma unroll
+        for (int j = 0; j < C_; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+#pragma unroll 1
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < C_ - 1; ++p)
+#pragma unroll
+            for (int q = p + 1; q < C_; ++q) {
+                double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll
+                for (int r = 0; r < R_; ++r) { al += M[r][p] * M[r][p]; be += M[r][q] * M[r][q]; ga += M[r][p] * M[r][q]; }
+                if (fabs(ga) > 1e-15 * sqrt(al * be)) {                   // false for NaN and for a zero column
+                    rotated = true;
+                    const double zeta = (be - al) / (2.0 * ga);
+                    const double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double c = rsqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+                    for (int r = 0; r < R_; ++r) {
+                        const double mp = M[r][p], mq = M[r][q];
+                        M[r][p] = c * mp - s * mq;
+                        M[r][q] = s * mp + c * mq;
+                    }
+#pragma unroll
+                    for (int r = 0; r < C_; ++r) {
+                        const double vp = V[r][p], vq = V[r][q];
+                        V[r][p] = c * vp - s * vq;
+                        V[r][q] = s * vp + c * vq;
+                    }
+                }
+            }
+        if (!rotated) break;
+    }
+    double best = 0.0;
+#pragma unroll
+    for (int c = 0; c < C_; ++c) {
+        double nn = 0.0;
+#pragma unroll
+        for (int r = 0; r < R_; ++r) nn += M[r][c] * M[r][c];
+        const bool take = (c == 0) || nn < best;
+        best = take ? nn : best;
+#pragma unroll
+        for (int r = 0; r < C_; ++r) x[r] = take ? V[r][c] : x[r];
+    }
 }
 
 // Lower bound on the largest eigenvalue of a symmetric positive semi-definite E x E matrix: Rayleigh quotients of W e_k and
@@ -303,14 +366,28 @@ __device__ __forceinline__ void svd3(const Mat3& E, Mat3& U, Mat3& V, double (&s
     for (int k = 0; k < 3; ++k) { U.m[k][0] = u1[k]; U.m[k][1] = u2[k]; U.m[k][2] = u3[k]; }
 }
 
-// right null vector of a 3x3 matrix M: smallest eigenvector of M'M
-__device__ __forceinline__ void null3(const Mat3& M, double (&x)[3]) {
+// right null vector of a 3x3 matrix M: smallest eigenvector of M'M.  When its inverse iteration hits the cap (nearly
+// coincident smallest singular values, rare), EXACT = true finishes with the one-sided Jacobi on M itself, EXACT = false
+// only reports it (returns false) so that the caller can hand the triplet to the exact kernel.
+template <bool EXACT = true>
+__device__ __forceinline__ bool null3(const Mat3& M, double (&x)[3]) {
     double S[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) S[i][j] = M.m[0][i] * M.m[0][j] + M.m[1][i] * M.m[1][j] + M.m[2][i] * M.m[2][j];
-    spd_min_eigvec<3>(S, x);
+    bool conv;
+    spd_min_eigvec<3>(S, x, 40, &conv);
+    if (EXACT && !conv) {
+        double A[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) A[i][j] = M.m[i][j];
+        hestenes_min_rsv<3, 3>(A, x);
+        conv = true;
+    }
+    return conv;
 }
 
 }  // namespace tff

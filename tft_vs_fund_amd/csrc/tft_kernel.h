@@ -30,10 +30,15 @@
 // again 4x4 bilinear forms of the moments -- no second pass over the data.
 // rank(E) = 15 always (e21, e31 are unit vectors).
 //
-// Two instantiations: k_linear_tft_pose<false> (Cholesky inverse iteration; a
-// triplet whose iteration does not converge is marked ST_RETRY) and
-// k_linear_tft_pose<true> (Jacobi sweeps in LDS; run as a fix-up pass over the
-// ST_RETRY triplets, or for the whole batch with TFF_OPT_SOLVER = 1).
+// Two instantiations:
+//   k_linear_tft_pose<false>  the fast tiers only: Gram matrix + Cholesky inverse iteration, certified sign-only votes, DLT
+//       points by inverse iteration.  Whatever a fast tier cannot finish or certify (iteration cap, a Gram matrix whose
+//       eigenvector would lose more than ~1e-9 to the squared conditioning, an uncertified cheirality sign) marks the
+//       triplet ST_RETRY;
+//   k_linear_tft_pose<true>   the exact kernel: streaming Householder QR of the explicit 4N x 27 system (wave_qr.h), the
+//       4N x 15 re-solve from R * Up, one-sided Jacobi fall-backs everywhere -- the accuracy of the reference's svd() calls
+//       whatever the gaps.  Runs over the ST_RETRY triplets, for whole batches of minimal samples (N < EXACT_BELOW_N), and
+//       for everything with TFF_OPT_SOLVER = 1.
 #pragma once
 #include "pose_common.h"
 
@@ -170,44 +175,113 @@ __device__ __forceinline__ void up_factors(const double* Q, int m, double (&a2)[
     for (int q = 0; q < 3; ++q) { a2[q] = Q[3 * q + jj]; a3[q] = Q[9 + 3 * q + kk]; }
 }
 
-// linearTFT.m:64-91 from the 96 moment sums in w->mom: everything of linearTFT after the data pass,
-// for the lane group G (the whole wavefront, or one half of it working on its own triplet).
+// Row e (0..3) of correspondence (x1,y1,x2,y2,x3,y3) in the 4N x 27 system of linearTFT.m:51-62:
+//   A(e, j + 3k + 9i) = h1[i] c3[k] c2[j],  h1 = (x1,y1,1),  c2 = (1,0,-x2) | (0,1,-y2),  c3 = (1,0,-x3) | (0,1,-y3).
+__device__ __forceinline__ void tft_system_row(const Pt6& p, const int e, double (&g)[27]) {
+    const double h1[3] = {p.v[0], p.v[1], 1.0};
+    const double c2[3] = {(e & 1) ? 0.0 : 1.0, (e & 1) ? 1.0 : 0.0, (e & 1) ? -p.v[3] : -p.v[2]};
+    const double c3[3] = {(e & 2) ? 0.0 : 1.0, (e & 2) ? 1.0 : 0.0, (e & 2) ? -p.v[5] : -p.v[4]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) g[j + 3 * k + 9 * i] = h1[i] * c3[k] * c2[j];
+}
+// R of the QR factorisation of the 4N x 27 system (normalised correspondences): lane r < 27 ends with row r.
+// Nine correspondences (36 rows, lanes 27..62) per chunk.
+__device__ inline void tft_system_qr(const double* pts, const int N, const double* nrm, double (&g)[27]) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int c = 0; c < 27; ++c) g[c] = 0.0;
+#pragma unroll 1
+    for (int base = 0; base < N; base += 9) {
+        const int slot = lane - 27, i = base + (slot >> 2);
+        if (lane >= 27) {
+            if (slot < 36 && i < N) tft_system_row(premap(load_pt(pts, i), nrm), slot & 3, g);
+            else {
+#pragma unroll
+                for (int c = 0; c < 27; ++c) g[c] = 0.0;
+            }
+        }
+        wave_qr_append<27>(g);
+    }
+}
+
+// linearTFT.m:64-91: everything of linearTFT after the data pass, for the lane group G (the whole wavefront, or one half of it
+// working on its own triplet).  EXACT = false works from the 96 moment sums in w->mom; EXACT = true from the explicit system.
 // Leaves the constrained tensor in w->t, the epipoles in w->epi and (if want_P) linearTFT's `a`
 // (P2 = [reshape(a(1:9),3,3) e21], P3 = [reshape(a(10:18),3,3) e31]) in w->pa.
-// Returns false when an eigen-solve did not converge (JAC = false only).
+// Returns false when a fast tier could not finish (EXACT = false only): eigen-solve not converged or at risk, null vector capped.
+constexpr double GRAM_RISK_MAX = 1e7;      // |G| / (lambda_(n-1) - lambda_n) beyond which the Gram eigenvector is not trusted (error ~ 1e-16 x this)
 template <bool JAC, int G>
-__device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, bool want_P, double* dbg) {
-    static_assert(!JAC || G == 64, "the Jacobi solver works on whole wavefronts");
+__device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double* pts, int N, bool want_P, double* dbg) {
+    static_assert(!JAC || G == 64, "the exact solver works on whole wavefronts");
     using Grp = Group<G>;
     const int lane = Grp::lane();
     const int wl = Grp::index() * G;                                         // first lane of this group (stamp writer)
     int it1 = 0, it2 = 0;
     bool ok = true;
+    double gR[27];                                                           // exact tier: R of the 4N x 27 system, row `lane` (unused otherwise)
     {                                                                        // :64-67
-        double g[27], diag, x;
-        gram_row27(w->mom, (lane < 27) ? lane : 0, g, diag);
-        phase_stamp(dbg, 3, wl);
+        double x;
         if (JAC) {
-            if (lane < 27) for (int c = 0; c < 27; ++c) jw->A[lane * 27 + c] = g[c];
-            wave_sync();
-            x = wave_jacobi_min_eigvec(jw->A, jw->V, 27, 27, &it1);
-            it1 += 1000;
+            double (&g)[27] = gR;
+            tft_system_qr(pts, N, w->nrm, g);
+            phase_stamp(dbg, 3, wl);
+            x = wave_qr_min_rsv<27>(g, jw->A, jw->V, w->Lp, EIG_MAXIT, &it1);
+            it1 += 10000;
         } else {
-            double r2;
-            x = wave_min_eigvec_reg<27, G>(g, diag, w->Lp, EIG_MAXIT, &it1, &r2);
-            ok = ok && eig_converged(r2);
+            double g[27], diag;
+            gram_row27(w->mom, (lane < 27) ? lane : 0, g, diag);
+            phase_stamp(dbg, 3, wl);
+            double r2, risk;
+            x = wave_min_eigvec_reg<27, G>(g, diag, w->Lp, EIG_MAXIT, &it1, &r2, false, 0.0, &risk);
+            ok = ok && eig_converged(r2) && risk < GRAM_RISK_MAX;
         }
         if (lane < 27) w->t[lane] = x;
         wave_sync();
     }
     if (dbg && lane < 27) dbg[lane] = w->t[lane];
     phase_stamp(dbg, 4, wl);
-    epipoles_from_tensor<G>(w->t, w->nullv, w->epi, false);                  // :71-79
+    ok = epipoles_from_tensor<G, JAC>(w->t, w->nullv, w->epi, false) && ok;  // :71-79
     phase_stamp(dbg, 5, wl);
     if (dbg && lane < 6) dbg[27 + lane] = w->epi[lane];
     if (lane == 0) frame_of(w->epi, w->Q);                                   // Q2 from e21
     if (lane == 1) frame_of(w->epi + 3, w->Q + 9);                           // Q3 from e31
     wave_sync();
+    if (JAC) {                                                               // :84 from R: svd(A Up) == svd(R Up), A = Q R
+        const double (&g)[27] = gR;
+        double* Bm = w->Lp;                                                  // 27 x 15 rows of R Up
+        if (lane < 27) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    const int jj = (m < 3) ? 0 : m - 2, kk = (m < 3) ? m : 0;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const int c = j + 3 * k + 9 * i;
+                            acc += ((c >= lane) ? g[c] : 0.0) * w->Q[3 * j + jj] * w->Q[9 + 3 * k + kk];
+                        }
+                    Bm[lane * 15 + 5 * i + m] = acc;
+                }
+        }
+        wave_sync();
+        double h[15];                                                        // lanes 0..14: R2 (zero), lanes 15..41: the rows of R Up
+#pragma unroll
+        for (int c = 0; c < 15; ++c) h[c] = (lane >= 15 && lane < 42) ? Bm[(lane - 15) * 15 + c] : 0.0;
+        wave_sync();
+        wave_qr_append<15>(h);
+        phase_stamp(dbg, 6, wl);
+        const double x = wave_qr_min_rsv<15>(h, jw->A, jw->V, w->Lp, EIG_MAXIT, &it2);
+        it2 += 10000;
+        if (lane < 15) w->tp[lane] = x;
+        wave_sync();
+    } else {
     // Gp = Up' G Up (15x15), lower triangle, packed into Lp; entry (a,b), a = 5 i + m
     double* Gp = w->Lp;
     for (int e = lane; e < 120; e += G) {
@@ -230,28 +304,22 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, bool want_P,
 #pragma unroll
         for (int c = 0; c < 15; ++c) { g[c] = (c <= r) ? Gp[tri_index(r, c)] : 0.0; diag = (c == r) ? g[c] : diag; }
         wave_sync();
-        if (JAC) {
-            if (lane < 15) for (int c = 0; c < 15; ++c) { if (c <= lane) { jw->A[lane * 15 + c] = g[c]; jw->A[c * 15 + lane] = g[c]; } }
-            wave_sync();
-            x = wave_jacobi_min_eigvec(jw->A, jw->V, 15, 15, &it2);
-            it2 += 1000;
-        } else {
-            // start from the unconstrained solution projected onto range(E): tp0 = Up' t (9 non-zeros per basis vector).  The
-            // constrained tensor differs from it at noise level, which saves one of the four inverse iterations.
-            double tp0 = 0.0;
-            if (lane < 15) {
-                const int i = lane / 5, m = lane % 5, jj = (m < 3) ? 0 : m - 2, kk = (m < 3) ? m : 0;
+        // start from the unconstrained solution projected onto range(E): tp0 = Up' t (9 non-zeros per basis vector).  The
+        // constrained tensor differs from it at noise level, which saves one of the four inverse iterations.
+        double tp0 = 0.0;
+        if (lane < 15) {
+            const int i = lane / 5, m = lane % 5, jj = (m < 3) ? 0 : m - 2, kk = (m < 3) ? m : 0;
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
+            for (int k = 0; k < 3; ++k)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) tp0 += w->Q[3 * j + jj] * w->Q[9 + 3 * k + kk] * w->t[j + 3 * k + 9 * i];
-            }
-            double r2;
-            x = wave_min_eigvec_reg<15, G>(g, diag, w->Lp, EIG_MAXIT, &it2, &r2, true, tp0);
-            ok = ok && eig_converged(r2);
+                for (int j = 0; j < 3; ++j) tp0 += w->Q[3 * j + jj] * w->Q[9 + 3 * k + kk] * w->t[j + 3 * k + 9 * i];
         }
+        double r2, risk;
+        x = wave_min_eigvec_reg<15, G>(g, diag, w->Lp, EIG_MAXIT, &it2, &r2, true, tp0, &risk);
+        ok = ok && eig_converged(r2) && risk < GRAM_RISK_MAX;
         if (lane < 15) w->tp[lane] = x;
         wave_sync();
+    }
     }
     phase_stamp(dbg, 7, wl);
     if (lane < 27) {                                                         // t = Up * tp   (:85)
@@ -285,24 +353,24 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, bool want_P,
         for (int j = 0; j < 3; ++j) { w->pa[3 * i + j] = ai[j] + c * e21[j]; w->pa[9 + 3 * i + j] = bi[j] + c * e31[j]; }
     }
     wave_sync();
-    return ok;
+    return !wave_any(!ok);                                                   // wave-uniform
 }
 
 // linearTFT.m:33-91 on the normalised correspondences (data pass + the rest), whole wavefront.
 template <bool JAC>
 __device__ inline bool linear_tft_wave(PoseLds* w, JacobiLds* jw, const double* pts, int N, bool want_P, double* dbg) {
-    accumulate_moments(w, pts, N);
+    if (!JAC) accumulate_moments(w, pts, N);
     phase_stamp(dbg, 2);
-    return linear_tft_middle<JAC, 64>(w, jw, want_P, dbg);
+    return linear_tft_middle<JAC, 64>(w, jw, pts, N, want_P, dbg);
 }
 
 // R_t_from_TFT.m:44-58 and the decomposition of E21, E31 (:85-88): the lane-sparse part of
 // R_t_from_TFT on the de-normalised tensor w->T1, up to the candidate cameras.
-template <int G>
-__device__ inline void rt_prepare(PoseLds* w, double* dbg) {
+template <int G, bool EXACT = true>
+__device__ inline bool rt_prepare(PoseLds* w, double* dbg) {
     const int lane = Group<G>::lane();
     transform_tft_inverse<G>(w->T1, w->T2, w->Lp, [w](int v) { return load_K(w->calm, v); });   // :44
-    epipoles_from_tensor<G>(w->T2, w->nullv, w->epi, true);                  // :47-55
+    const bool ok = epipoles_from_tensor<G, EXACT>(w->T2, w->nullv, w->epi, true);   // :47-55
     double* Ein = w->Minv;                                                   // 18 doubles of scratch
     if (lane < 2) {
         const double* e21 = w->epi; const double* e31 = w->epi + 3;
@@ -331,15 +399,19 @@ __device__ inline void rt_prepare(PoseLds* w, double* dbg) {
     wave_sync();
     phase_stamp(dbg, 9, Group<G>::index() * G);
     recover_prepare<G>(w, Ein);                                              // svd(E), candidate poses and cameras
+    return ok;
 }
 
 // R_t_from_TFT.m:40-76 on the de-normalised tensor w->T1 (whole wavefront).
-__device__ inline int rt_from_tft_wave(PoseLds* w, const double* pts, int N, double* dbg) {
-    rt_prepare<64>(w, dbg);
-    const int st = recover_vote(w, pts, N, dbg);                             // :61,:64
+// *ok (EXACT = false): cleared when a fast tier could not finish or certify its part.
+template <bool EXACT = true>
+__device__ inline int rt_from_tft_wave(PoseLds* w, const double* pts, int N, double* dbg, bool* ok = nullptr) {
+    bool fine = wave_any(!rt_prepare<64, EXACT>(w, dbg)) == false;
+    const int st = recover_vote<EXACT>(w, pts, N, dbg, &fine);               // :61,:64
     phase_stamp(dbg, 11);
-    scale_t3(w, pts, N, dbg);                                                // :68-74
+    fine = scale_t3<EXACT>(w, pts, N, dbg) && fine;                          // :68-74
     phase_stamp(dbg, 12);
+    if (ok && !fine) *ok = false;
     return st;
 }
 
@@ -378,16 +450,18 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose(const LinearTftArgs a
             normalise3(pts, N, w->nrm);                                      // LinearTFTPoseEstimation.m:45-47
             if (dbg && lane < 9) dbg[71 + lane] = w->nrm[lane];
             phase_stamp(dbg, 1);
-            const bool ok = linear_tft_wave<JAC>(w, jw, pts, N, false, dbg);  // :50
+            bool ok = linear_tft_wave<JAC>(w, jw, pts, N, false, dbg);       // :50
             phase_stamp(dbg, 8);
+            if (ok) {
+                transform_tft_inverse(w->t, w->T1, w->Lp, [w](int v) { return normal_matrix(w->nrm, v); });   // :53
+                status = rt_from_tft_wave<JAC>(w, pts, N, dbg, &ok);         // :56
+            }
+            if (ok && a.reconst) ok = final_reconst<JAC>(w, pts, N, a.reconst + b * 3 * (long)N);   // :59-60
             if (!ok) {
                 status = ST_RETRY;                                           // redone by k_linear_tft_pose<true>
             } else {
-                transform_tft_inverse(w->t, w->T1, w->Lp, [w](int v) { return normal_matrix(w->nrm, v); });   // :53
-                status = rt_from_tft_wave(w, pts, N, dbg);                   // :56
                 write_poses(w, a.Rt2 + b * 12, a.Rt3 + b * 12);
                 if (lane < 27) a.T[b * 27 + lane] = w->T1[lane];
-                if (a.reconst) final_reconst(w, pts, N, a.reconst + b * 3 * (long)N);   // :59-60
                 phase_stamp(dbg, 13);
                 // non-finite outputs -> status 2
                 double chk = (lane < 12) ? w->Rt[0][lane] : ((lane < 24) ? w->Rt[1][lane - 12] : ((lane < 51) ? w->T1[lane - 24] : 0.0));
@@ -399,97 +473,6 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose(const LinearTftArgs a
             if (a.iter) a.iter[b] = 0;                                       // :62
             a.status[b] = status;
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// The paired kernel (TFF_OPT_KERNEL = 1; NOT the default): two triplets per 128-thread workgroup.
-//   wave w: stage + Normalize2Ddata + moment sums of triplet 2b + w        (one correspondence per lane)
-//   barrier
-//   wave 0: the lane-sparse middle section of BOTH triplets, one per half-wavefront
-//           (27x27 / 15x15 eigen-solves, epipoles, transform_TFT x2, E21/E31, 3x3 SVDs, candidate cameras);
-//           wave 1 sleeps at the barrier and costs no issue slots
-//   barrier
-//   wave w: cheirality vote, t3 scale, outputs, optional Reconst of triplet 2b + w
-// Those middle stages keep at most 27 of 64 lanes busy, so sharing one instruction stream between
-// two triplets halves their VALU instruction count per triplet.  Measured on MI355X it is nevertheless
-// 1.2-1.3x SLOWER than k_linear_tft_pose<false> (0.57-0.63 ms vs 0.47 ms per 10k x 200 batch at every
-// occupancy tried): a per-half broadcast cannot use v_readlane (the source differs between the halves)
-// and goes through ds_bpermute, whose ~100-cycle latency sits on the sequential dependency chain of the
-// triangular solves while the partner wave idles at the barrier.  Kept, with its tests, as the
-// Group<32> reference implementation and for A/B measurements.
-// Triplets whose inverse iteration does not converge are marked ST_RETRY for k_linear_tft_pose<true>.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(128, 2) k_linear_tft_pose_pair(const LinearTftArgs a) {
-    TFF_DYNAMIC_LDS(double, smem);
-    const int N = a.N;
-    constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
-    const int per_wave = base + (((a.flags & FLAG_STAGE_LDS) || a.sample_idx) ? ((6 * N + 1) & ~1) : 0);
-    const int lane = lane_id(), wave = wave_in_block();
-    PoseLds* w = reinterpret_cast<PoseLds*>(smem + wave * per_wave);
-    double* lds_pts = smem + wave * per_wave + base;
-    __shared__ int ok_flag[2];
-    for (long pb = 2L * blockIdx.x; pb < a.B; pb += 2L * gridDim.x) {
-        const long b = (pb + wave < a.B) ? pb + wave : a.B - 1;               // an odd batch: the last triplet is done twice
-        double* dbg = a.dbg ? a.dbg + b * DBG_STRIDE : nullptr;
-        const double* src = a.corresp + b * 6 * (long)N;
-        const double* pts = src;
-        if (a.sample_idx) {
-            gather_points(a.corresp, a.sample_idx + b * (long)N, lds_pts, N);
-            pts = lds_pts;
-        } else if (a.flags & FLAG_STAGE_LDS) {
-            stage_points(src, lds_pts, N);
-            pts = lds_pts;
-        }
-        if (lane < 27) w->calm[lane] = a.calm[b * a.calm_stride + lane];
-        phase_stamp(dbg, 0);
-        if (N >= 7) {
-            normalise3(pts, N, w->nrm);                                      // LinearTFTPoseEstimation.m:45-47
-            if (dbg && lane < 9) dbg[71 + lane] = w->nrm[lane];
-            phase_stamp(dbg, 1);
-            accumulate_moments(w, pts, N);                                   // data pass of linearTFT   (:50)
-            phase_stamp(dbg, 2);
-        }
-        __syncthreads();
-        if (wave == 0 && N >= 7) {
-            const int half = lane >> 5;
-            PoseLds* wh = reinterpret_cast<PoseLds*>(smem + half * per_wave);
-            const long bh = (pb + half < a.B) ? pb + half : a.B - 1;
-            double* dbgh = a.dbg ? a.dbg + bh * DBG_STRIDE : nullptr;
-            const bool ok = linear_tft_middle<false, 32>(wh, nullptr, false, dbgh);
-            phase_stamp(dbgh, 8, half * 32);
-            transform_tft_inverse<32>(wh->t, wh->T1, wh->Lp, [wh](int v) { return normal_matrix(wh->nrm, v); });   // :53
-            rt_prepare<32>(wh, dbgh);                                        // R_t_from_TFT up to the candidate cameras   (:56)
-            if ((lane & 31) == 0) ok_flag[half] = ok ? 1 : 0;
-        }
-        __syncthreads();
-        int status = ST_OK;
-        if (N < 7) {                                                         // experiments.m:99
-            status = ST_TOO_FEW;
-            const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-            if (lane < 12) { a.Rt2[b * 12 + lane] = qnan; a.Rt3[b * 12 + lane] = qnan; }
-            if (lane < 27) a.T[b * 27 + lane] = qnan;
-            if (a.reconst) for (int i = lane; i < 3 * N; i += WAVE) a.reconst[b * 3 * (long)N + i] = qnan;
-        } else if (!ok_flag[wave]) {
-            status = ST_RETRY;                                               // redone by k_linear_tft_pose<true>
-        } else {
-            status = recover_vote(w, pts, N, dbg);                           // R_t_from_TFT.m:61,:64
-            phase_stamp(dbg, 11);
-            scale_t3(w, pts, N, dbg);                                        // :68-74
-            phase_stamp(dbg, 12);
-            write_poses(w, a.Rt2 + b * 12, a.Rt3 + b * 12);
-            if (lane < 27) a.T[b * 27 + lane] = w->T1[lane];
-            if (a.reconst) final_reconst(w, pts, N, a.reconst + b * 3 * (long)N);   // :59-60
-            phase_stamp(dbg, 13);
-            double chk = (lane < 12) ? w->Rt[0][lane] : ((lane < 24) ? w->Rt[1][lane - 12] : ((lane < 51) ? w->T1[lane - 24] : 0.0));
-            const bool bad = !(fabs(chk) <= 1.79e308);
-            if (wave_any(bad) && status == ST_OK) status = ST_NONFINITE;
-        }
-        if (lane == 0) {
-            if (a.iter) a.iter[b] = 0;                                       // :62
-            a.status[b] = status;
-        }
-        __syncthreads();
     }
 }
 

@@ -26,46 +26,25 @@ namespace tff {
 
 __device__ __forceinline__ int tri_index(int r, int c) { return (r * (r + 1)) / 2 + c; }   // packed lower, c <= r
 
-// g[c] = G[lane][c] for c <= lane (entries c > lane are ignored), diag = G[lane][lane].
-// Lp: n*n doubles of LDS.  On return lane r (< n) holds component r of the
-// unit eigenvector of the smallest eigenvalue; *iters = iterations used,
+// Inverse iteration with a triangular factor held in LDS in ROW-SCALED form: Lp (n x n, row-major, ld = n) holds
+// L' = D^-1 L (unit diagonal, D = diag(L)) with zeros on and above the diagonal, myinv = 1 / L[lane][lane]; the iterated
+// matrix is L L' (= G + delta I after a Cholesky factorisation, = A'A with L = R' after a QR factorisation of A).
+// The substitutions then need no division, no masked load and no per-step select --
+//   L y = x   <=>  L' y = D^-1 x,          L^T z = y  <=>  L'^T (D z) = y,
+// one multiplication by 1 / L_jj before the forward and one after the backward sweep instead of one per step, and a dependent
+// chain of readlane + fma per step.
+// On return lane r (< n) holds component r of the unit eigenvector of the smallest eigenvalue; *iters = iterations used,
 // *resid2 = 0 when the iteration converged, else the last squared step.
 // has_start / start: optional initial guess (component `lane` on lane `lane`), default the uniform vector.
+// *gap_risk (optional): an estimate of 1 / (lambda_(n-1) - lambda_n) from the observed convergence rate and the final
+// Rayleigh quotient -- multiplied by eps |G| it bounds the rounding error of an eigenvector taken from a FORMED Gram matrix
+// (the squared conditioning the reference's svd(A) does not have); callers that factor G route a triplet to the QR-based
+// exact path when it is large.  0 when the rate could not be observed (converged in one step).
 template <int n, int G = 64>
-__device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, double* Lp, const int maxit,
-                                             int* iters, double* resid2, const bool has_start = false, const double start = 0.0) {
-    using Grp = Group<G>;                                   // one lane group per matrix (the whole wave, or one half of it)
+__device__ inline double wave_invit_unit(const double* Lp, const double myinv, const int maxit, int* iters, double* resid2,
+                                         const bool has_start = false, const double start = 0.0, double* gap_risk = nullptr) {
+    using Grp = Group<G>;
     const int lane = Grp::lane();
-    const double tr = Grp::sum(lane < n ? diag : 0.0);
-    const double delta = 1e-14 * tr;
-    const double pfloor = 1e-3 * delta + 1e-300;
-#pragma unroll
-    for (int c = 0; c < n; ++c) g[c] += (c == lane) ? delta : 0.0;
-    double myinv = 0.0;                                     // 1 / L[lane][lane]
-#pragma unroll
-    for (int k = 0; k < n; ++k) {
-        double d = Grp::bcast(g[k], k);                     // pivot (lane k's diagonal, fully updated)
-        d = (d > pfloor) ? d : pfloor;
-        const double rs = rsqrt(d);
-        g[k] = (lane == k) ? d * rs : g[k] * rs;            // column k of L (rows >= k meaningful)
-        myinv = (lane == k) ? rs : myinv;
-#pragma unroll
-        for (int c = k + 1; c < n; ++c) {
-            const double lck = Grp::bcast(g[k], c);         // L[c][k]
-            g[c] -= g[k] * lck;                             // L[r][c] -= L[r][k] L[c][k]   (meaningful for r >= c)
-        }
-    }
-    // Store the ROW-SCALED factor L' = D^-1 L (unit diagonal, D = diag(L)) as a full n x n square (row-major, ld = n) with zeros on
-    // and above the diagonal: the substitutions below then need no division, no masked load and no per-step select --
-    //   L y = x   <=>  L' y = D^-1 x,          L' z' = ... : L^T z = y  <=>  L'^T (D z) = y,
-    // one multiplication by 1 / L_jj before the forward and one after the backward sweep instead of one per step, and a dependent
-    // chain of readlane + fma per step.
-    wave_sync();
-    if (lane < n) {
-#pragma unroll
-        for (int c = 0; c < n; ++c) Lp[lane * n + c] = (c < lane) ? g[c] * myinv : 0.0;
-    }
-    wave_sync();
     const int rl = (lane < n) ? lane : 0;
     double x = (lane < n) ? rsqrt((double)n) : 0.0;
     if (has_start) {                                        // caller's guess (lane r: component r); a zero / non-finite guess falls back
@@ -73,7 +52,7 @@ __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, 
         const double nn0 = Grp::sum(s0 * s0);
         if (nn0 > 1e-300 && nn0 < 1e300) x = s0 * rsqrt(nn0);
     }
-    double rprev2 = 1.0, res = 1.0;
+    double rprev2 = 1.0, res = 1.0, rk_r2 = 0.0, rk_rp = 1.0, rk_nn = 0.0;
     int it = 0;
     bool done = false;                                      // per group; the loop itself is wave-uniform
 #pragma unroll 1
@@ -114,12 +93,61 @@ __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, 
             if (r2 <= 1e-26) { res = 0.0; done = true; }                                     // converged: stopped moving
             else if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) { res = 0.0; done = true; }   // predicted error < 1e-13
             else if (!(r2 == r2) || it >= maxit) { res = (r2 == r2) ? r2 : 1.0; done = true; }             // NaN / iteration cap: not converged
+            if (it >= 2 && r2 > 1e-30) { rk_r2 = r2; rk_rp = rprev2; rk_nn = nn; }            // last observable pair of steps
             rprev2 = r2;
         }
         if (!wave_any(!done)) break;
     }
     *iters = it;
     *resid2 = res;                                                              // 0 when converged, last |step|^2 otherwise
+    if (gap_risk) {
+        // rate rho = (lambda_n + delta) / (lambda_(n-1) + delta) ~ sqrt(r2 / rprev2), lambda_n + delta ~ 1 / |y|:
+        // 1 / gap ~ |y| rho / (1 - rho)
+        const double rho = sqrt(rk_r2 / rk_rp);
+        *gap_risk = (rho < 1.0) ? sqrt(rk_nn) * rho / (1.0 - rho) : ((rk_r2 > 0.0) ? 1e300 : 0.0);
+    }
+    return x;
+}
+
+// g[c] = G[lane][c] for c <= lane (entries c > lane are ignored), diag = G[lane][lane].
+// Lp: n*n doubles of LDS.  Cholesky of G + delta I in registers, then wave_invit_unit (see there for the outputs).
+// *gram_risk (optional): eps-free relative error amplification |G| / (lambda_(n-1) - lambda_n) of the eigenvector of the formed
+// Gram matrix (trace(G) * gap_risk of the iteration).
+template <int n, int G = 64>
+__device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, double* Lp, const int maxit,
+                                             int* iters, double* resid2, const bool has_start = false, const double start = 0.0,
+                                             double* gram_risk = nullptr) {
+    using Grp = Group<G>;                                   // one lane group per matrix (the whole wave, or one half of it)
+    const int lane = Grp::lane();
+    const double tr = Grp::sum(lane < n ? diag : 0.0);
+    const double delta = 1e-14 * tr;
+    const double pfloor = 1e-3 * delta + 1e-300;
+#pragma unroll
+    for (int c = 0; c < n; ++c) g[c] += (c == lane) ? delta : 0.0;
+    double myinv = 0.0;                                     // 1 / L[lane][lane]
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+        double d = Grp::bcast(g[k], k);                     // pivot (lane k's diagonal, fully updated)
+        d = (d > pfloor) ? d : pfloor;
+        const double rs = rsqrt(d);
+        g[k] = (lane == k) ? d * rs : g[k] * rs;            // column k of L (rows >= k meaningful)
+        myinv = (lane == k) ? rs : myinv;
+#pragma unroll
+        for (int c = k + 1; c < n; ++c) {
+            const double lck = Grp::bcast(g[k], c);         // L[c][k]
+            g[c] -= g[k] * lck;                             // L[r][c] -= L[r][k] L[c][k]   (meaningful for r >= c)
+        }
+    }
+    // store the row-scaled factor (see wave_invit_unit) once; the iteration reads the lane's own row / column back into registers
+    wave_sync();
+    if (lane < n) {
+#pragma unroll
+        for (int c = 0; c < n; ++c) Lp[lane * n + c] = (c < lane) ? g[c] * myinv : 0.0;
+    }
+    wave_sync();
+    double risk = 0.0;
+    const double x = wave_invit_unit<n, G>(Lp, myinv, maxit, iters, resid2, has_start, start, &risk);
+    if (gram_risk) *gram_risk = risk * tr;
     return x;
 }
 __device__ __forceinline__ bool eig_converged(double resid2) { return resid2 == 0.0; }
