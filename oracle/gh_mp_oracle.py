@@ -1,0 +1,250 @@
+"""TEST INFRASTRUCTURE ONLY -- never imported by the product (tft_vs_fund_amd/).
+
+Extended-precision (mpmath, 50 digits) evaluation of the reference's Gauss-Helmert iteration
+(Optimization/Gauss_Helmert.m:38-83) with Ressl's callback (TFT_methods/ResslTFTPoseEstimation.m:110-177).
+
+Purpose: `pinv(W + 1e-12 I)` gives every correspondence one direction of weight ~1e12, so A'WA
+cancels ten digits in ANY fp64 evaluation -- the reference's own dense MATLAB product included.  To judge the HIP kernel
+one therefore needs the iteration the reference's FORMULAS define, free of fp64 rounding: this file.  Both the LAPACK-backed
+numpy oracle (oracle/tft_oracle.py, a stand-in for MATLAB's arithmetic) and the kernel are then measured against it; the
+kernel is required to be no noisier than the LAPACK evaluation (tests/test_gpu_gh_noise.py, profiles/r2_gh_noise_mp.txt).
+
+What is exact here and what is not:
+  * every sum, product, eigen-decomposition and the stop tests run in 50-digit arithmetic;
+  * B (4N x 6N) and W = B B' (4N x 4N) are block diagonal (one 4 x 6 / 4 x 4 block per correspondence) -- an identity of
+    the reference's formulas, not an approximation -- so pinv(W + 1e-12 I) is taken block by block;
+  * MATLAB's pinv tolerance max(size(A)) * eps(norm(A)) (documented semantics) is a fixed fp64 number once norm(A) is
+    known: eps() is the double-precision spacing of the (exactly computed, then rounded) 2-norm;
+  * `1e-12` is the double nearest to 1e-12, as MATLAB parses it;
+  * the START of the iteration (parameters p0 and observations x_est from linearTFT and the projective triangulation,
+    ResslTFTPoseEstimation.m:47-81) and the tail after it (transform_TFT, R_t_from_TFT) are the fp64 numpy oracle's:
+    they agree with the kernel's to ~1e-11 and are not what is being measured.
+"""
+import numpy as np
+import mpmath as mp
+
+from oracle import tft_oracle as O
+
+mp.mp.dps = 50
+_EPS12 = mp.mpf(float(1e-12))
+_mpf = np.frompyfunc(mp.mpf, 1, 1)
+_flt = np.frompyfunc(float, 1, 1)
+
+
+def to_mp(a):
+    return _mpf(np.asarray(a, dtype=np.float64))
+
+
+def to_float(a):
+    return _flt(a).astype(np.float64)
+
+
+def _zeros(*shape):
+    z = np.empty(shape, dtype=object)
+    z.fill(mp.mpf(0))
+    return z
+
+
+def _eigsy(Mx):
+    """eigenvalues (ascending) and eigenvectors (columns) of a symmetric object matrix"""
+    n = Mx.shape[0]
+    E, Q = mp.eigsy(mp.matrix(Mx.tolist()))
+    lam = np.array([E[i] for i in range(n)], dtype=object)
+    V = np.array([[Q[i, j] for j in range(n)] for i in range(n)], dtype=object)
+    return lam, V
+
+
+def _matlab_tol(size_max, norm2):
+    """max(size(A)) * eps(norm(A)) with eps() the double-precision spacing"""
+    return mp.mpf(size_max * float(np.spacing(float(norm2))))
+
+
+def _pinv_sym(Mx, size_max=None, norm2=None):
+    """pinv of a symmetric matrix through its eigen-decomposition (singular values = |eigenvalues|), MATLAB tolerance"""
+    lam, V = _eigsy(Mx)
+    nrm = max(abs(l) for l in lam) if norm2 is None else norm2
+    tol = _matlab_tol(Mx.shape[0] if size_max is None else size_max, nrm)
+    out = _zeros(*Mx.shape)
+    kept = 0
+    for k in range(len(lam)):
+        if abs(lam[k]) > tol:
+            kept += 1
+            out = out + np.outer(V[:, k], V[:, k]) / lam[k]
+    return out, kept
+
+
+def _ressl_unpack(p, Ind):
+    Ind2 = [k for k in range(3) if k != Ind]
+    S = p[0:9].reshape(3, 3, order='F')
+    e21 = np.array([mp.mpf(1)] * 3, dtype=object)
+    e21[Ind2] = p[9:11]
+    e31 = p[17:20]
+    mn = _zeros(3, 3)
+    mn[:, Ind2] = p[11:17].reshape(3, 2, order='F')
+    T = _zeros(3, 3, 3)
+    for i in range(3):
+        T[:, :, i] = (np.outer(S[:, i], e21) + np.outer(e31, mn[i, :])).T          # ResslTFT...m:118-120
+    return S, e21, e31, mn, T, Ind2
+
+
+def _ressl_D(S, e21, e31, mn, Ind2):
+    """ResslTFTPoseEstimation.m:164-170: dT/dp, 27 x 20"""
+    D = _zeros(27, 20)
+    one = mp.mpf(1)
+    aux = _zeros(3, 2)
+    aux[Ind2[0], 0] = one
+    aux[Ind2[1], 1] = one
+    for i in range(3):
+        for k in range(3):
+            for j in range(3):
+                r = j + 3 * k + 9 * i                                              # T(j,k,i) = e21(j) S(k,i) + e31(k) mn(i,j)  (transposed slices)
+                D[r, k + 3 * i] = e21[j]                                           # d/dS(k,i)
+                for a in range(2):
+                    D[r, 9 + a] = D[r, 9 + a] + S[k, i] * aux[j, a]                # d/de21(Ind2[a])
+                    D[r, 11 + i + 3 * a] = e31[k] * aux[j, a]                      # d/dmn(i,Ind2[a])   (mn(:) column-major: 3a + i)
+                D[r, 17 + k] = mn[i, j]                                            # d/de31(k)
+    return D
+
+
+def _blocks(xi_i, T):
+    """per-correspondence f (4), Ap (4 x 27), B (4 x 6): ResslTFTPoseEstimation.m:141-161"""
+    x1, y1, x2, y2, x3, y3 = xi_i
+    zero, one = mp.mpf(0), mp.mpf(1)
+    S2 = np.array([[zero, -one], [-one, zero], [y2, x2]], dtype=object)
+    S3 = np.array([[zero, -one], [-one, zero], [y3, x3]], dtype=object)
+    h1 = np.array([x1, y1, one], dtype=object)
+    T1, T2, T3 = T[:, :, 0], T[:, :, 1], T[:, :, 2]
+    f = S2.T.dot(x1 * T1 + y1 * T2 + T3).dot(S3).reshape(4, order='F')
+    Ap = _zeros(4, 27)
+    for b in range(2):
+        for a in range(2):
+            for i in range(3):
+                for k in range(3):
+                    for j in range(3):
+                        Ap[2 * b + a, j + 3 * k + 9 * i] = h1[i] * S3[k, b] * S2[j, a]
+    J3 = T[2, :, :].T                                                                # rows T_i(3,:)
+    K3 = T[:, 2, :]                                                                  # cols T_i(:,3)
+    B = _zeros(4, 6)
+    B[:, 0] = S2.T.dot(T1).dot(S3).reshape(4, order='F')
+    B[:, 1] = S2.T.dot(T2).dot(S3).reshape(4, order='F')
+    u = S3.T.dot(J3.T).dot(h1)                                                       # 2
+    v = S2.T.dot(K3).dot(h1)                                                         # 2
+    sw = [[zero, one], [one, zero]]
+    for r in range(2):
+        for c in range(2):
+            for q in range(2):
+                B[2 * r + q, 2 + c] = u[r] * sw[q][c]                                # kron(u, sw)
+                B[2 * q + r, 4 + c] = sw[q][c] * v[r]                                # kron(sw, v)
+    return f, Ap, B
+
+
+def gauss_helmert_ressl_mp(x, x_est, p0, Ind, it_max=400, return_history=False):
+    """Gauss_Helmert.m:38-83 with Ressl's callback, in extended precision, from the fp64 start (x, x_est, p0).
+    Returns p_opt (float64), xi (float64), it, reason [, history of (|dt|, obj)]."""
+    N = x.shape[0] // 6
+    xm, xi, ti = to_mp(x), to_mp(x_est), to_mp(p0)
+    tol = mp.mpf(float(1e-6))
+    v0 = xi - xm
+    objFunc = sum(v * v for v in v0)
+    reason, it, hist = 'itmax', 0, []
+    u, c = 20, 2
+    for it in range(1, it_max + 1):
+        S, e21, e31, mn, T, Ind2 = _ressl_unpack(ti, Ind)
+        g = np.array([sum(e * e for e in e31) - 1, sum(s * s for s in S.reshape(9)) - 1], dtype=object)
+        C = _zeros(2, 20)
+        C[0, 17:20] = 2 * e31
+        C[1, 0:9] = 2 * S.reshape(9, order='F')
+        D = _ressl_D(S, e21, e31, mn, Ind2)
+        blocks = []
+        lam_max = mp.mpf(0)
+        for i in range(N):
+            f, Ap, B = _blocks(xi[6 * i:6 * i + 6], T)
+            Wb = B.dot(B.T)                                                          # :52 (P = I)
+            lam, V = _eigsy(Wb + _EPS12 * np.eye(4, dtype=object))
+            lam_max = max(lam_max, max(lam))
+            blocks.append((f, Ap.dot(D), B, lam, V))
+        tolW = _matlab_tol(4 * N, lam_max)                                           # pinv's tolerance for the 4N x 4N matrix
+        Nm = _zeros(u, u)
+        rhs = _zeros(u)
+        Ws, ws = [], []
+        for i in range(N):
+            f, A, B, lam, V = blocks[i]
+            Wp = _zeros(4, 4)
+            for k in range(4):
+                if lam[k] > tolW:
+                    Wp = Wp + np.outer(V[:, k], V[:, k]) / lam[k]
+            Wp = Wp + _EPS12 * np.eye(4, dtype=object)                               # :57
+            w = -f - B.dot(xm[6 * i:6 * i + 6] - xi[6 * i:6 * i + 6])                 # :58
+            WA = Wp.dot(A)
+            Nm = Nm + A.T.dot(WA)
+            rhs = rhs + WA.T.dot(w)
+            Ws.append(Wp); ws.append(w)
+        Mk = _zeros(u + c, u + c)
+        Mk[:u, :u] = Nm
+        Mk[:u, u:] = C.T
+        Mk[u:, :u] = C
+        b = np.concatenate([rhs, -g])
+        Pm, kept = _pinv_sym(Mk + _EPS12 * np.eye(u + c, dtype=object))              # :67
+        aux = Pm.dot(b)
+        dt = aux[:u]
+        v = _zeros(6 * N)
+        for i in range(N):
+            f, A, B, lam, V = blocks[i]
+            v[6 * i:6 * i + 6] = -(B.T.dot(Ws[i].dot(A.dot(dt) - ws[i])))            # :69
+        ndt = mp.sqrt(sum(d * d for d in dt))
+        nres = mp.sqrt(sum(r * r for r in (xi - xm - v)))
+        obj = sum(q * q for q in v)
+        hist.append((float(ndt), float(obj), int(kept)))
+        if ndt < tol and nres < tol:                                                 # :71-73 (dy is empty: norm 0)
+            reason = 'converged'
+            break
+        if obj > objFunc:                                                            # :75, factor = 1
+            reason = 'rose'
+            break
+        objFunc = obj
+        xi = xm + v
+        ti = ti + dt                                                                 # :80
+    out = (to_float(ti), to_float(xi), it, reason)
+    return out + (hist,) if return_history else out
+
+
+def ressl_start(Corresp, CalM):
+    """fp64 start of ResslTFTPoseEstimation.m:47-81 (from the numpy oracle): x, x_est, p0, Ind and the normalisations."""
+    x1, N1 = O.Normalize2Ddata(Corresp[0:2, :])
+    x2, N2 = O.Normalize2Ddata(Corresp[2:4, :])
+    x3, N3 = O.Normalize2Ddata(Corresp[4:6, :])
+    T, P1, P2, P3 = O.linearTFT(x1, x2, x3)
+    e21 = P2[:, 3].copy()
+    Ind = int(np.argmax(np.abs(e21)))
+    e21 = e21 / e21[Ind]
+    e31 = P3[:, 3].copy()
+    e31 = e31 / np.linalg.norm(e31)
+    S = np.stack([T[Ind, :, 0], T[Ind, :, 1], T[Ind, :, 2]], axis=1)
+    aux = np.linalg.norm(S.reshape(9))
+    S = S / aux
+    T = T / aux
+    Ind2 = [k for k in range(3) if k != Ind]
+    mn = np.stack([e31 @ (T[:, :, i].T - np.outer(S[:, i], e21)) for i in range(3)], axis=0)[:, Ind2]
+    x, x_est = O._gh_initial_obs(P1, P2, P3, x1, x2, x3)
+    p = np.concatenate([S.reshape(9, order='F'), e21[Ind2], mn.reshape(6, order='F'), e31])
+    return x, x_est, p, Ind, (N1, N2, N3)
+
+
+def ressl_tail(p_opt, Ind, normals, CalM, Corresp):
+    """ResslTFTPoseEstimation.m:87-103 in fp64: T from p_opt, de-normalisation, R_t_from_TFT."""
+    Ind2 = [k for k in range(3) if k != Ind]
+    S = p_opt[0:9].reshape(3, 3, order='F')
+    e21 = np.ones(3); e21[Ind2] = p_opt[9:11]
+    mn = np.zeros((3, 3)); mn[:, Ind2] = p_opt[11:17].reshape(3, 2, order='F')
+    T = O._ressl_T(S, e21, p_opt[17:20], mn)
+    T = O.transform_TFT(T, normals[0], normals[1], normals[2], 1)
+    R_t_2, R_t_3 = O.R_t_from_TFT(T, CalM, Corresp)
+    return R_t_2, R_t_3, T
+
+
+def ResslTFTPoseEstimation_mp(Corresp, CalM):
+    """R_t_2, R_t_3, T, iter, reason with the Gauss-Helmert loop in extended precision."""
+    x, x_est, p0, Ind, normals = ressl_start(Corresp, CalM)
+    p_opt, _, it, reason = gauss_helmert_ressl_mp(x, x_est, p0, Ind)
+    R2, R3, T = ressl_tail(p_opt, Ind, normals, CalM, Corresp)
+    return R2, R3, T, it, reason

@@ -289,6 +289,105 @@ static int linear_tft_pose_one(const double* corresp, const double* calm, int N,
     return status;
 }
 
+/* linearF.m:32-62 on already (outer-)normalised points xa, xb (2 x N each, column-major): normalises again (:45-46), N x 9
+ * DLT (:48-55), inner de-normalisation (:58), rank-2 projection by zeroing the third singular value (:61-62).  F column-major. */
+static void normalize2d_pts(const double* x, int N, double* xn, double* Nm) {   /* Normalize2Ddata.m:33-39 on a 2 x N array */
+    double cx = 0, cy = 0, d = 0;
+    for (int i = 0; i < N; ++i) { cx += x[2 * i]; cy += x[2 * i + 1]; }
+    cx /= N; cy /= N;
+    for (int i = 0; i < N; ++i) { double dx = x[2 * i] - cx, dy = x[2 * i + 1] - cy; d += sqrt(dx * dx + dy * dy); }
+    d /= N;
+    const double s = sqrt(2.0) / d;
+    memset(Nm, 0, 9 * sizeof(double));
+    Nm[IDX(0, 0, 3)] = s; Nm[IDX(1, 1, 3)] = s; Nm[IDX(0, 2, 3)] = -sqrt(2.0) * cx / d; Nm[IDX(1, 2, 3)] = -sqrt(2.0) * cy / d; Nm[IDX(2, 2, 3)] = 1.0;
+    for (int i = 0; i < N; ++i) { xn[2 * i] = Nm[IDX(0, 0, 3)] * x[2 * i] + Nm[IDX(0, 2, 3)]; xn[2 * i + 1] = Nm[IDX(1, 1, 3)] * x[2 * i + 1] + Nm[IDX(1, 2, 3)]; }
+}
+static void linear_f(const double* xa, const double* xb, int N, double* F, double* work) {
+    double* p1 = (double*)malloc(sizeof(double) * 4 * (size_t)N); double* p2 = p1 + 2 * (size_t)N;
+    double N1[9], N2[9];
+    normalize2d_pts(xa, N, p1, N1);
+    normalize2d_pts(xb, N, p2, N2);
+    const int m = N, n = 9;
+    double* A = (double*)malloc(sizeof(double) * (size_t)((m < n ? n : m)) * n);
+    /* with fewer rows than columns (N = 8) MATLAB's full svd still returns a 9 x 9 V whose last column spans the null space:
+     * pad with zero rows so that the one-sided Jacobi sees a 9 x 9 matrix */
+    const int mm = m < n ? n : m;
+    memset(A, 0, sizeof(double) * (size_t)mm * n);
+    for (int i = 0; i < N; ++i) {
+        const double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
+        const double r[9] = {x1 * x2, x1 * y2, x1, y1 * x2, y1 * y2, y1, x2, y2, 1.0};      /* :51-52 */
+        for (int c = 0; c < 9; ++c) A[IDX(i, c, mm)] = r[c];
+    }
+    double v[9], Fn[9], tmp[9], N2t[9];
+    svd_last_v(A, mm, n, v, work);                                              /* :54-55: F = reshape(V(:,9),3,3) */
+    memcpy(Fn, v, sizeof Fn);
+    mat3_T(N2, N2t); mat3_mul(N2t, Fn, tmp); mat3_mul(tmp, N1, Fn);               /* :58 */
+    double US[9], V[9], sv[3], Vt[9];
+    memcpy(US, Fn, sizeof US);
+    svd_jacobi(US, 3, 3, V, sv);                                                /* :61-62: U diag(s1,s2,0) V' */
+    for (int r = 0; r < 3; ++r) US[IDX(r, 2, 3)] = 0.0;
+    mat3_T(V, Vt); mat3_mul(US, Vt, F);
+    free(p1); free(A);
+}
+
+/* TFT_from_P.m:25-33: T(j,k,i) = (-1)^(i+1) det[P1 without row i; P2(j,:); P3(k,:)], unit Frobenius norm.  P column-major 3x4. */
+static double det4(const double m[4][4]) {
+    double d = 0;
+    for (int c = 0; c < 4; ++c) {
+        double s[3][3];
+        for (int r = 1; r < 4; ++r) { int cc = 0; for (int k = 0; k < 4; ++k) if (k != c) s[r - 1][cc++] = m[r][k]; }
+        const double d3 = s[0][0] * (s[1][1] * s[2][2] - s[1][2] * s[2][1]) - s[0][1] * (s[1][0] * s[2][2] - s[1][2] * s[2][0]) + s[0][2] * (s[1][0] * s[2][1] - s[1][1] * s[2][0]);
+        d += ((c & 1) ? -1.0 : 1.0) * m[0][c] * d3;
+    }
+    return d;
+}
+static void tft_from_P(const double* P1, const double* P2, const double* P3, double* T) {
+    double nn = 0;
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) for (int j = 0; j < 3; ++j) {
+        double m[4][4]; int rr = 0;
+        for (int r = 0; r < 3; ++r) if (r != i) { for (int c = 0; c < 4; ++c) m[rr][c] = P1[IDX(r, c, 3)]; ++rr; }
+        for (int c = 0; c < 4; ++c) { m[2][c] = P2[IDX(j, c, 3)]; m[3][c] = P3[IDX(k, c, 3)]; }
+        const double v = ((i & 1) ? -1.0 : 1.0) * det4(m);
+        T[j + 3 * k + 9 * i] = v; nn += v * v;
+    }
+    nn = sqrt(nn);
+    for (int e = 0; e < 27; ++e) T[e] /= nn;
+}
+
+/* LinearFPoseEstimation.m:42-78 for one triplet.  Returns status (0 ok, 1 too few, 3 no pose). */
+static int linear_f_pose_one(const double* corresp, const double* calm, int N, double* Rt2, double* Rt3, double* Tout, double* reconst) {
+    if (N < 8) return 1;
+    double* work = (double*)malloc(sizeof(double) * ((size_t)(N < 9 ? 9 : N) * 9 + 81 + 9 + 64));
+    double* xn = (double*)malloc(sizeof(double) * 6 * (size_t)N);
+    double Nm[3][9];
+    for (int v = 0; v < 3; ++v) normalize2d(corresp, v, N, xn + 2 * (size_t)N * v, Nm[v]);   /* :46-48 */
+    double F21[9], F31[9], tmp[9], Nt[9];
+    linear_f(xn, xn + 2 * (size_t)N, N, F21, work);                              /* :51-52 */
+    linear_f(xn, xn + 4 * (size_t)N, N, F31, work);
+    mat3_T(Nm[1], Nt); mat3_mul(Nt, F21, tmp); mat3_mul(tmp, Nm[0], F21);       /* :55-56 */
+    mat3_T(Nm[2], Nt); mat3_mul(Nt, F31, tmp); mat3_mul(tmp, Nm[0], F31);
+    double Kc[3][9];
+    for (int v = 0; v < 3; ++v) for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Kc[v][IDX(r, c, 3)] = calm[(3 * v + r) + 9 * c];
+    const double *K1 = Kc[0], *K2 = Kc[1], *K3 = Kc[2];
+    double E21[9], E31[9], Kt[9];
+    mat3_T(K2, Kt); mat3_mul(Kt, F21, tmp); mat3_mul(tmp, K1, E21);              /* recover_R_t: E = K2' F K1   (:86) */
+    mat3_T(K3, Kt); mat3_mul(Kt, F31, tmp); mat3_mul(tmp, K1, E31);
+    double R2[9], t2[3], R3[9], t3[3];
+    const int ok = recover_R_t(E21, K1, K2, corresp, 1, N, R2, t2, work) && recover_R_t(E31, K1, K3, corresp, 2, N, R3, t3, work);
+    int status = 0;
+    if (!ok) status = 3;
+    else {
+        t3_scale_and_reconst(K1, K2, K3, R2, t2, R3, t3, corresp, N, reconst, work);   /* :64-76 */
+        write_pose(R2, t2, Rt2); write_pose(R3, t3, Rt3);
+        double P1[12] = {0}, P2[12], P3[12];
+        memcpy(P1, K1, 9 * sizeof(double));
+        compose_cam(K2, R2, t2, P2); compose_cam(K3, R3, t3, P3);
+        tft_from_P(P1, P2, P3, Tout);                                           /* :78 */
+    }
+    free(work); free(xn);
+    return status;
+}
+
 /* Batched entry point with the layout of include/tftfund.h.  threads <= 0: all cores. Returns threads used. */
 int oracle_c_linear_tft_pose_batch(const double* corresp, const double* calm, long calm_stride, long B, int N,
                                    double* Rt2, double* Rt3, double* T, double* reconst, int* status, int threads) {
@@ -301,6 +400,22 @@ int oracle_c_linear_tft_pose_batch(const double* corresp, const double* calm, lo
     for (long b = 0; b < B; ++b) {
         int st = linear_tft_pose_one(corresp + b * 6 * (long)N, calm + b * calm_stride, N, Rt2 + b * 12, Rt3 + b * 12, T + b * 27,
                                      reconst ? reconst + b * 3 * (long)N : 0);
+        if (status) status[b] = st;
+    }
+    return used;
+}
+
+int oracle_c_linear_f_pose_batch(const double* corresp, const double* calm, long calm_stride, long B, int N,
+                                 double* Rt2, double* Rt3, double* T, double* reconst, int* status, int threads) {
+    int used = 1;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    used = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (long b = 0; b < B; ++b) {
+        int st = linear_f_pose_one(corresp + b * 6 * (long)N, calm + b * calm_stride, N, Rt2 + b * 12, Rt3 + b * 12, T + b * 27,
+                                   reconst ? reconst + b * 3 * (long)N : 0);
         if (status) status[b] = st;
     }
     return used;

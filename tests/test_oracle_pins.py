@@ -196,3 +196,47 @@ def test_golden_epfl_linear_quality(golden_dir):
             # AngError does not clamp acos: a NaN means the argument drifted above 1, i.e. ~0 degrees
             assert np.nan_to_num(max(r2, r3)) < 1.0 and np.nan_to_num(max(t2, t3)) < 2.0
             assert float(g[pre + m + "_repr_all"]) < 6.5
+
+
+def test_epfl_ground_truth_pins_seven_methods(golden_dir):
+    """Known answers the reference's own data implies (experiments_real.m:86-91): every method the reference runs on real data
+    (methods_to_test = [1:5,7:8], experiments_real.m:63 -- PiCol is for collinear centres and is excluded there) recovers the
+    `.camera` ground-truth poses of every fixture triplet from its 100-inlier sample: rotations within 2 degrees, translation
+    directions within 2.5 degrees (observed: <= 1.51 / 1.77).  An independent pin of the restatement -- still not a reference run:
+    the MATLAB code itself cannot be executed here."""
+    g = np.load(os.path.join(golden_dir, "epfl.npz"))
+    meths = ["LinearTFTPoseEstimation", "ResslTFTPoseEstimation", "NordbergTFTPoseEstimation", "FaugPapaTFTPoseEstimation",
+             "PiPoseEstimation", "LinearFPoseEstimation", "OptimFPoseEstimation"]
+    for n in range(int(g["count"])):
+        pre = "t%d_" % n
+        Cs, CalM, Rt0 = g[pre + "sample"], g[pre + "CalM"], g[pre + "Rt0"]
+        for m in meths:
+            out = getattr(O, m)(Cs.copy(), CalM)
+            r2, t2 = O.AngError(Rt0[0], out[0])
+            r3, t3 = O.AngError(Rt0[1], out[1])
+            # AngError does not clamp acos: a NaN means the argument drifted above 1, i.e. ~0 degrees
+            assert np.nan_to_num(max(r2, r3)) < 2.0 and np.nan_to_num(max(t2, t3)) < 2.5, (str(g[pre + "name"]), m, r2, r3, t2, t3)
+
+
+def test_mp_callback_is_an_independent_restatement_of_ressl():
+    """oracle/gh_mp_oracle.py restates Ressl's Gauss-Helmert callback index by index (no Kronecker products); converted to
+    fp64 it must equal the numpy oracle's f, A, B, and one Gauss-Helmert run in 50-digit arithmetic must land within the
+    reference's own fp64 noise (~1e-5 at N = 12) of the LAPACK evaluation."""
+    from oracle import gh_mp_oracle as G
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    C, CalM, _, _ = generate_scene_batch(1, 9, noise=1.0, seed=3)
+    Cb = C[0].T.copy()
+    x, x_est, p0, Ind, normals = G.ressl_start(Cb, CalM)
+    f, g_, A, B, Cc, _ = O._ressl_constraintsGH(x_est, p0, Ind)
+    S, e21, e31, mn, T, Ind2 = G._ressl_unpack(G.to_mp(p0), Ind)
+    D = G._ressl_D(S, e21, e31, mn, Ind2)
+    xi = G.to_mp(x_est)
+    for i in range(9):
+        fi, Ap, Bi = G._blocks(xi[6 * i:6 * i + 6], T)
+        assert np.abs(G.to_float(fi) - f[4 * i:4 * i + 4]).max() < 1e-14
+        assert np.abs(G.to_float(Ap.dot(D)) - A[4 * i:4 * i + 4]).max() < 1e-13 * np.abs(A).max()
+        assert np.abs(G.to_float(Bi) - B[4 * i:4 * i + 4, 6 * i:6 * i + 6]).max() < 1e-13 * np.abs(B).max()
+    p_mp, _, it, reason = G.gauss_helmert_ressl_mp(x, x_est, p0, Ind)
+    func = lambda a, b, c: O._ressl_constraintsGH(a, b, Ind)
+    _, p_np, _, it_np, _ = O.Gauss_Helmert(func, x_est, p0, np.zeros(0), x, None, True)
+    assert abs(it - it_np) <= 3 and np.abs(p_mp - p_np).max() < 1e-3
