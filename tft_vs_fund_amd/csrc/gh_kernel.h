@@ -46,6 +46,8 @@ struct GhWork {                       // per-wave LDS carve-up for one Gauss-Hel
     double* V;      // (u+c)^2 eigenvectors of the KKT matrix (pinv path)
     double* xi;     // 6N       current estimates of the observations
     double* pp;     // 14N      per correspondence: W+ (10, packed lower) and W+ w (4); then v (6)
+    double* S;      // workgroup kernel, factored weights: u(u+1)/2 + u sums of the strong-direction terms (LDS), else null
+    double* sb;     // workgroup kernel, factored weights: N x (u+1) global side buffer of this block (sqrt(c) a_i, sqrt(c) n'w), else null
     int u, c;
 };
 __host__ __device__ inline int gh_lds_doubles(int u, int c, int N) {
@@ -68,6 +70,7 @@ __device__ inline GhWork gh_carve(double* base, int u, int c, int N) {
     g.V = q; q += n * n;
     g.xi = q; q += 6 * N;
     g.pp = q; q += 14 * N;
+    g.S = nullptr; g.sb = nullptr;
     g.u = u; g.c = c;
     return g;
 }
@@ -758,6 +761,81 @@ __device__ __forceinline__ bool pinv_one_null_packed(const double (&W)[E][E], co
     return fro2 * tolW * tolW < 1.0;                                         // second-smallest eigenvalue >= 1 / |pinv|_F > tolW
 }
 
+// pinv(B B' + 1e-12 I) (Gauss_Helmert.m:52,57) of one 4 x 4 trilinearity block, evaluated at the accuracy of the FORMULA instead of
+// the accuracy of an fp64 B B'.  A point triplet carries three independent constraints, so B B' has one eigenvalue mu that is zero
+// for consistent observations and ~1e-12 .. 1e-9 (the squared inconsistency) during the iteration -- the size of the 1e-12 shift.
+// pinv gives that direction the weight 1 / (mu + 1e-12) ~ 1e9 .. 1e12, and an fp64 B B' knows mu only to ~1e-16 absolute: the
+// weights of a plain Cholesky / eigen / LAPACK evaluation carry 1e-4 relative noise (the reference's own dense pinv included), which is
+// what made the Gauss-Helmert results agree to 1e-6 .. 1e-4 only.  Here, with n the eigenvector of the smallest eigenvalue of W = B B' + 1e-12 I:
+//   mu = |B' n|^2                      the small eigenvalue WITHOUT the cancellation (relative error ~1e-9)
+//   K  = (W + n n')^-1                 Cholesky of a well conditioned matrix: eigenvalues lambda_k + 1e-12 and 1 + mu + 1e-12
+//   pinv = K + n n' (1/(mu + 1e-12) - 1/(1 + mu + 1e-12))      if mu + 1e-12 > tolW (kept),     K - n n' / (1 + mu + 1e-12) otherwise (truncated)
+// agrees with a 50-digit evaluation of the reference's formulas to ~1e-9 (profiles/r2_gh_noise_mp.txt).
+// Returns false when the block does not have that structure (second-smallest eigenvalue not far above mu, failed factorisation,
+// non-finite data): the caller takes the eigen-decomposition path.  Wp: packed lower triangle, WITHOUT the trailing + 1e-12 I.
+// FACTORED = false: Wp is the full pseudo-inverse.  FACTORED = true: Wp is its REGULAR part only, K - n n' / (1 + mu + 1e-12) (weights
+// 1 / (lambda_k + 1e-12) of the three ordinary directions), and the strong direction comes back separately as (n, *cs) with
+// cs = 1 / (mu + 1e-12) (kept) or 0 (truncated): pinv = Wp + cs n n'.  The caller then evaluates A' pinv A = A' Wp A + cs (A'n)(A'n)'
+// with a = A'n formed FIRST: for the minimal parameterisations n is (nearly) orthogonal to the columns of A -- |a| is the
+// inconsistency of the correspondence, 1e-15 .. 1e-6 -- so the product with the 1e12-size matrix entries cancels ~10 digits
+// (the noise of every fp64 evaluation that forms pinv(W) explicitly, the reference's included), while cs a a' is accurate to ~1e-9.
+template <bool FACTORED>
+__device__ __forceinline__ bool pinv_block_deflated(const double (&B)[4][6], const double (&W)[4][4], const double tolW, double (&Wp)[10],
+                                                    double (&n)[4], double* cs) {
+    bool conv;
+    spd_min_eigvec<4>(W, n, 40, &conv);
+    double mu = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double bn = B[0][k] * n[0] + B[1][k] * n[1] + B[2][k] * n[2] + B[3][k] * n[3];
+        mu += bn * bn;
+    }
+    double Wn[4][4], tr = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        tr += W[a][a];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Wn[a][c] = W[a][c] + n[a] * n[c];
+    }
+    if (!conv || !spd_inverse_packed<4>(Wn, Wp)) return false;
+    const double lam = mu + 1e-12, kn = 1.0 / (1.0 + lam);
+    double fro2 = 0.0;                                                       // |K - n n' / (1 + lam)|_F^2 = sum_k 1 / (lambda_k + 1e-12)^2
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c <= a; ++c) {
+            const double v = Wp[a * (a + 1) / 2 + c] - n[a] * n[c] * kn;
+            Wp[a * (a + 1) / 2 + c] = v;
+            fro2 += (a == c) ? v * v : 2.0 * v * v;
+        }
+    // second-smallest eigenvalue lambda_3 >= 1 / |.|_F: require lambda_3 > 1e-5 trace (n is then determined to ~1e-11) and > 1e3 mu
+    const double l3min = 1e-5 * tr + 1e3 * mu;
+    if (!(fro2 * l3min * l3min < 1.0)) return false;
+    const double c1 = (lam > tolW) ? 1.0 / lam : 0.0;
+    *cs = c1;
+    if (!FACTORED) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c <= a; ++c) Wp[a * (a + 1) / 2 + c] += c1 * n[a] * n[c];
+    }
+    return true;
+}
+
+// gradient of n' f with respect to the 27 tensor entries, q = Ap' n (Ap: ResslTFTPoseEstimation.m:156), for the observation estimate o:
+// f = tril_quad(m), m = x1 T1 + y1 T2 + T3, so q[j + 3k + 9i] = h1[i] gm[j][k], h1 = (x1, y1, 1).
+__device__ __forceinline__ void tril_grad_n(const double (&o)[6], const double (&n)[4], double (&gm)[3][3]) {
+    const double x2 = o[2], y2 = o[3], x3 = o[4], y3 = o[5];
+    const double a0[3] = {-n[1], -n[0], n[0] * y2 + n[1] * x2};              // d(n'f)/d v0[j]
+    const double a1[3] = {-n[3], -n[2], n[2] * y2 + n[3] * x2};              // d(n'f)/d v1[j]
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        gm[j][0] = -a1[j];
+        gm[j][1] = -a0[j];
+        gm[j][2] = y3 * a0[j] + x3 * a1[j];
+    }
+}
+
 // w = -f - B (x - xi) (Gauss_Helmert.m:58); stores W+ (10) and W+ w (4) of correspondence i
 __device__ __forceinline__ void gh_store_point(const GhWork& g, const PoseLds* w, const double* pts, int i, const double (&o)[6],
                                                const double (&f)[4], const double (&B)[4][6], const double (&Wp)[10]) {
@@ -818,27 +896,14 @@ __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, co
         f2max = wave_max(f2max);
         if (wave_any(!finite) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
         // pinv(W + 1e-12 I) (:57) truncates singular values <= 4N eps(lambda_max).  Every eigenvalue of W + 1e-12 I is
-        // >= 1e-12, so while that tolerance is safely below 1e-12 (N up to a few hundred) nothing is truncated and
-        // pinv is the plain inverse of each 4x4 block: Cholesky per lane.  Otherwise: exact path through the per-block
-        // eigen-decompositions (Jacobi), which reproduces the truncation.
-        bool fast = !exact_pinv && 4.0 * (double)N * eps_of(sqrt(f2max)) < 0.9e-12;
+        // >= 1e-12, so while that tolerance is safely below 1e-12 (N up to a few hundred) nothing can be truncated and the
+        // tolerance itself is not needed; otherwise the per-block eigenvalue pass finds lambda_max.  The blocks themselves are
+        // inverted in the deflated form (pinv_block_deflated); the Jacobi eigen-decompositions remain as the fall-back for
+        // blocks without the one-small-eigenvalue structure and as TFF_OPT_GH_EXACT.
+        const bool may_truncate = !(4.0 * (double)N * eps_of(sqrt(f2max)) < 0.9e-12);
         if (it == 1) phase_stamp(dbg, 42);
-        if (fast) {
-            bool bad = false;
-            for (int i = lane; i < N; i += WAVE) {
-                double o[6], f[4], B[4][6], W[4][4], Wp[10];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
-                tril_block(T, o, f, B);
-                block_W(B, W);
-                bad = !spd_inverse_packed<4>(W, Wp) || bad;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
-                gh_store_point(g, w, pts, i, o, f, B, Wp);
-            }
-            if (wave_any(bad)) fast = false;                                 // numerically indefinite block: take the exact path
-        }
-        if (!fast) {
+        double tolW = 0.0;
+        if (may_truncate || exact_pinv) {
             double smax = 0.0;
             for (int i = lane; i < N; i += WAVE) {
                 double o[6], f[4], B[4][6], W[4][4], V[4][4];
@@ -851,7 +916,41 @@ __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, co
                 for (int a = 0; a < 4; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
             }
             smax = wave_max(smax);
-            const double tolW = 4.0 * (double)N * eps_of(smax);
+            tolW = 4.0 * (double)N * eps_of(smax);
+        }
+        bool jacobi = exact_pinv;
+        if (!jacobi) {
+            bool bad = false;
+            for (int i = lane; i < N; i += WAVE) {
+                double o[6], f[4], B[4][6], W[4][4], Wp[10];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                tril_block(T, o, f, B);
+                block_W(B, W);
+                double nn[4], cs;
+                bad = !pinv_block_deflated<false>(B, W, tolW, Wp, nn, &cs) || bad;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
+                gh_store_point(g, w, pts, i, o, f, B, Wp);
+            }
+            if (wave_any(bad)) jacobi = true;                                // a block without the structure: eigen-decompositions for all
+        }
+        if (jacobi) {
+            if (!(may_truncate || exact_pinv)) {                             // the tolerance was not needed so far
+                double smax = 0.0;
+                for (int i = lane; i < N; i += WAVE) {
+                    double o[6], f[4], B[4][6], W[4][4], V[4][4];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                    tril_block(T, o, f, B);
+                    block_W(B, W);
+                    jacobi4<false>(W, V);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+                }
+                smax = wave_max(smax);
+                tolW = 4.0 * (double)N * eps_of(smax);
+            }
             // per block: W+ = pinv(W + 1e-12 I) + 1e-12 I   (:57)
             for (int i = lane; i < N; i += WAVE) {
                 double o[6], f[4], B[4][6], W[4][4], V[4][4];

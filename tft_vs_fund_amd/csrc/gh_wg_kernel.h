@@ -34,7 +34,8 @@ constexpr int GH_REC_DOUBLES = 64;        // t 27 | pa 18 | epi 6 | nrm 9 | pad
 // Ressl at N = 200: 50.4 KB with the header -> three workgroups per CU.
 __host__ __device__ inline int gh_wg_lds_doubles(int u, int c, int N, bool pinv) {
     const int n = u + c;
-    return 2 * ((u + 1) & ~1) + 2 * c + 28 + 28 + 27 * u + 298 + ((27 * u > 298) ? 27 * u : 298) + n * (n + 1) + 112 + 6 * N + 10 * N + 16 + 8;
+    const int strong = pinv ? 0 : ((u * (u + 1) / 2 + u + 1) & ~1);          // sums of the factored strong-direction terms (minimal parameterisations)
+    return 2 * ((u + 1) & ~1) + 2 * c + 28 + 28 + 27 * u + 298 + ((27 * u > 298) ? 27 * u : 298) + n * (n + 1) + 112 + strong + 6 * N + 10 * N + 16 + 8;
 }
 __device__ inline GhWork gh_wg_carve(double* base, PoseLds* w, int u, int c, int N, bool pinv, double** red) {
     GhWork g;
@@ -50,6 +51,8 @@ __device__ inline GhWork gh_wg_carve(double* base, PoseLds* w, int u, int c, int
     g.Y = q; q += (27 * u > 298) ? 27 * u : 298;
     g.M = q; q += n * (n + 1);
     g.V = pinv ? g.D : q; q += 112;                                                // 108 doubles of scratch (Nordberg's rotations)
+    g.S = pinv ? nullptr : q; q += pinv ? 0 : ((u * (u + 1) / 2 + u + 1) & ~1);
+    g.sb = nullptr;
     g.xi = q; q += 6 * N;
     g.pp = q; q += 10 * N;
     *red = q;
@@ -75,6 +78,7 @@ struct GhWgArgs {
     double* topt;            // B x 27 (k_gh_block out, k_gh_finish in): optimised tensor in the normalised frame
     double* Rt2; double* Rt3; double* T; double* reconst; int* iter; int* status; double* dbg;
     double* spill; long spill_stride;   // see LinearTftArgs
+    double* strong; long strong_stride; // k_gh_block, minimal parameterisations: global side buffer, gridDim.x slices of N (u + 1) doubles (or null: unfactored weights)
 };
 
 template <bool JAC>
@@ -243,57 +247,70 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         }
         f2max = block_max(f2max, red);
         if (block_any(!finite, red) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
-        bool fast = !exact_pinv && 4.0 * (double)N * eps_of(sqrt(f2max)) < 0.9e-12;
+        // blocks in the deflated form (gh_kernel.h, pinv_block_deflated); pinv's tolerance is needed only when it can truncate
+        const bool may_truncate = !(4.0 * (double)N * eps_of(sqrt(f2max)) < 0.9e-12);
         if (it == 1) phase_stamp(sdbg, 42);
-        if (fast) {
-            bool bad = false;
-            for (int i = tid; i < N; i += GH_WG_THREADS) {
-                double o[6], f[4], B[4][6], W[4][4], Wp[10];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
-                tril_block(T, o, f, B);
-                block_W(B, W);
-                bad = !spd_inverse_packed<4>(W, Wp) || bad;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
-#pragma unroll
-                for (int k = 0; k < 10; ++k) g.pp[10 * i + k] = Wp[k];
-            }
-            if (block_any(bad, red)) fast = false;
-        }
-        if (!fast) {
-            // pinv's tolerance 4N eps(max_i lambda_max(W_i)) needs only the binade of that maximum: when the bounds above agree on it,
-            // the eigenvalue pass that would find the maximum is skipped
-            double umax = 0.0, lmax = 0.0;                                   // upper / lower bound on max_i lambda_max(W_i)
-            for (int i = tid; i < N; i += GH_WG_THREADS) {
-                double o[6], f[4], B[4][6], W[4][4];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
-                tril_block(T, o, f, B);
-                block_W(B, W);
-                double up, lo;
-                psd_lambda_max_bounds(W, up, lo);
-                umax = (up > umax) ? up : umax;
-                lmax = (lo > lmax) ? lo : lmax;
-            }
-            umax = block_max(umax, red);
-            lmax = block_max(lmax, red);
-            double smax = umax;
-            if (eps_of(lmax) != eps_of(umax)) {
-                smax = 0.0;
+        double tolW = 0.0;
+        bool have_tol = false, jacobi = exact_pinv;
+        // minimal parameterisations with a side buffer: regular part of pinv(W) in pp, strong direction factored (pinv_block_deflated)
+        const bool want_factored = !Model::IDENTITY_D && g.sb != nullptr && g.S != nullptr;
+        bool factored = false;
+#pragma unroll 1
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if ((may_truncate || jacobi) && !have_tol) {
+                // pinv's tolerance 4N eps(max_i lambda_max(W_i)) needs only the binade of that maximum: when cheap bounds agree on it,
+                // the eigenvalue pass that would find the maximum is skipped
+                double umax = 0.0, lmax = 0.0;                               // upper / lower bound on max_i lambda_max(W_i)
                 for (int i = tid; i < N; i += GH_WG_THREADS) {
-                    double o[6], f[4], B[4][6], W[4][4], V[4][4];
+                    double o[6], f[4], B[4][6], W[4][4];
 #pragma unroll
                     for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
                     tril_block(T, o, f, B);
                     block_W(B, W);
-                    jacobi4<false>(W, V);
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+                    double up, lo;
+                    psd_lambda_max_bounds(W, up, lo);
+                    umax = (up > umax) ? up : umax;
+                    lmax = (lo > lmax) ? lo : lmax;
                 }
-                smax = block_max(smax, red);
+                umax = block_max(umax, red);
+                lmax = block_max(lmax, red);
+                double smax = umax;
+                if (eps_of(lmax) != eps_of(umax)) {
+                    smax = 0.0;
+                    for (int i = tid; i < N; i += GH_WG_THREADS) {
+                        double o[6], f[4], B[4][6], W[4][4], V[4][4];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                        tril_block(T, o, f, B);
+                        block_W(B, W);
+                        jacobi4<false>(W, V);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+                    }
+                    smax = block_max(smax, red);
+                }
+                tolW = 4.0 * (double)N * eps_of(smax);
+                have_tol = true;
             }
-            const double tolW = 4.0 * (double)N * eps_of(smax);
+            if (!jacobi) {
+                bool bad = false;
+                for (int i = tid; i < N; i += GH_WG_THREADS) {
+                    double o[6], f[4], B[4][6], W[4][4], Wp[10];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                    tril_block(T, o, f, B);
+                    block_W(B, W);
+                    double nn[4], cs;
+                    bad = !(want_factored ? pinv_block_deflated<true>(B, W, tolW, Wp, nn, &cs) : pinv_block_deflated<false>(B, W, tolW, Wp, nn, &cs)) || bad;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) g.pp[10 * i + k] = Wp[k];
+                }
+                if (!block_any(bad, red)) { factored = want_factored; break; }
+                jacobi = true;                                               // a block without the structure: eigen-decompositions for all
+                continue;
+            }
             for (int i = tid; i < N; i += GH_WG_THREADS) {
                 double o[6], f[4], B[4][6], W[4][4], V[4][4];
 #pragma unroll
@@ -314,8 +331,84 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
 #pragma unroll
                 for (int k = 0; k < 10; ++k) g.pp[10 * i + k] = Wp[k];
             }
+            break;
         }
         if (it == 1) phase_stamp(sdbg, 43);
+        // ---- strong-direction terms, factored: N_s = sum_i cs_i a_i a_i', r_s = sum_i cs_i a_i (n_i' w_i), a_i = D' (Ap_i' n_i) ----
+        if (factored) {
+            const int rec = u + 1;
+            for (int i = tid; i < N; i += GH_WG_THREADS) {                   // per correspondence: sqrt(cs) a (u), sqrt(cs) n'w
+                double o[6], f[4], B[4][6], W[4][4], Wp[10], nn[4], cs = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                tril_block(T, o, f, B);
+                block_W(B, W);
+                pinv_block_deflated<true>(B, W, tolW, Wp, nn, &cs);          // succeeded in the weights pass (same inputs, same result)
+                double gm[3][3];
+                tril_grad_n(o, nn, gm);
+                const double sc = sqrt(cs);
+                const double h1[3] = {o[0], o[1], 1.0};
+                double* out = g.sb + (long)i * rec;
+#pragma unroll 1
+                for (int pcol = 0; pcol < u; ++pcol) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i1 = 0; i1 < 3; ++i1) {
+                        double part = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) part += g.D[(j + 3 * k + 9 * i1) * u + pcol] * gm[j][k];
+                        acc += h1[i1] * part;
+                    }
+                    out[pcol] = sc * acc;
+                }
+                // n'w = -n'f - (B'n) . (x - xi)
+                const Pt6 x = premap(load_pt(pts, i), w->nrm);
+                double nw = -(nn[0] * f[0] + nn[1] * f[1] + nn[2] * f[2] + nn[3] * f[3]);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) nw -= (B[0][k] * nn[0] + B[1][k] * nn[1] + B[2][k] * nn[2] + B[3][k] * nn[3]) * (x.v[k] - o[k]);
+                out[u] = sc * nw;
+            }
+            __syncthreads();
+            // sums over the correspondences: thread e owns entry e of [N_s (lower triangle) | r_s]; the records are staged through LDS
+            // (Ghat's slot, not yet in use) in chunks, so that the dependent chain holds LDS reads, not global loads
+            const int ntri = u * (u + 1) / 2;
+            int er[2], ec[2];
+            double sacc[2] = {0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int e = tid + k * GH_WG_THREADS;
+                int r = 0, cc = 0;
+                if (e < ntri) {
+                    r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                    while (tri_index(r + 1, 0) <= e) ++r;
+                    while (tri_index(r, 0) > e) --r;
+                    cc = e - tri_index(r, 0);
+                } else if (e < ntri + u) { r = e - ntri; cc = u; }
+                er[k] = r; ec[k] = cc;
+            }
+            const int chunk = 729 / rec;                                     // correspondences per chunk (34 for u = 20)
+            double* stage = g.G;
+#pragma unroll 1
+            for (int base = 0; base < N; base += chunk) {
+                const int cnt = (N - base < chunk) ? N - base : chunk;
+                for (int e = tid; e < cnt * rec; e += GH_WG_THREADS) stage[e] = g.sb[(long)base * rec + e];
+                __syncthreads();
+                if (tid < ntri + u) {
+#pragma unroll 4
+                    for (int i = 0; i < cnt; ++i) sacc[0] += stage[i * rec + er[0]] * stage[i * rec + ec[0]];
+                }
+                if (tid + GH_WG_THREADS < ntri + u) {
+#pragma unroll 4
+                    for (int i = 0; i < cnt; ++i) sacc[1] += stage[i * rec + er[1]] * stage[i * rec + ec[1]];
+                }
+                __syncthreads();
+            }
+            if (tid < ntri + u) g.S[tid] = sacc[0];
+            if (tid + GH_WG_THREADS < ntri + u) g.S[tid + GH_WG_THREADS] = sacc[1];
+            __syncthreads();
+        }
         // ---- Ghat, ghat: the ten sweeps are dealt to the four wavefronts, each sweep runs over ALL correspondences on one wavefront
         //      (4 per lane at N = 200) and ends in one reduce-scatter: a quarter of the reductions of the per-wavefront-partial layout
         //      and no combine step ----
@@ -351,9 +444,11 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
                 double acc = 0.0;
                 if (e < u * u) {
                     for (int k = 0; k < 27; ++k) acc += g.D[k * u + pr] * g.Y[k * u + pc];
+                    if (factored) acc += g.S[(pr >= pc) ? tri_index(pr, pc) : tri_index(pc, pr)];
                     g.M[pr * ld + pc] = acc + ((pr == pc) ? 1e-12 : 0.0);
                 } else {
                     for (int k = 0; k < 27; ++k) acc += g.D[k * u + pc] * g.H[270 + k];
+                    if (factored) acc += g.S[u * (u + 1) / 2 + pc];
                     g.M[pc * ld + n] = acc;
                 }
             }
@@ -420,9 +515,18 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
 #pragma unroll
             for (int a = 0; a < 4; ++a)
                 r[a] = wp_at(Wp, a, 0) * wv[0] + wp_at(Wp, a, 1) * wv[1] + wp_at(Wp, a, 2) * wv[2] + wp_at(Wp, a, 3) * wv[3];
+            double bn[6] = {0, 0, 0, 0, 0, 0}, sterm = 0.0;                  // strong direction: -cs (B'n) n'(A dt - w)
+            if (factored) {
+                double W[4][4], Wq[10], nn[4], cs = 0.0;
+                block_W(B, W);
+                pinv_block_deflated<true>(B, W, tolW, Wq, nn, &cs);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) bn[k] = B[0][k] * nn[0] + B[1][k] * nn[1] + B[2][k] * nn[2] + B[3][k] * nn[3];
+                sterm = cs * (nn[0] * wv[0] + nn[1] * wv[1] + nn[2] * wv[2] + nn[3] * wv[3]);
+            }
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                const double v = -(B[0][k] * r[0] + B[1][k] * r[1] + B[2][k] * r[2] + B[3][k] * r[3]);
+                const double v = -(B[0][k] * r[0] + B[1][k] * r[1] + B[2][k] * r[2] + B[3][k] * r[3]) - bn[k] * sterm;
                 g.pp[10 * i + k] = v;
                 obj += v * v;
                 const double d = o[k] - x.v[k] - v;
@@ -466,6 +570,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::REDUNDANT_CONSTRAINTS ? 
         double* red;
         GhWork g = gh_wg_carve(ghbase, w, Model::U, Model::C, a.spill ? 0 : N, Model::REDUNDANT_CONSTRAINTS, &red);
         if (a.spill) { g.xi = a.spill + blockIdx.x * a.spill_stride; g.pp = g.xi + 6 * (long)N; }
+        g.sb = a.strong ? a.strong + blockIdx.x * a.strong_stride : nullptr;
         const int own = (int)(b & (GH_WG_WAVES - 1));
         const double* r = a.rec + b * GH_REC_DOUBLES;
         if (tid < 27) w->t[tid] = r[tid];

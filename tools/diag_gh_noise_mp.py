@@ -1,0 +1,69 @@
+"""Ressl's Gauss-Helmert refinement: deviation of (i) the LAPACK-backed numpy oracle and (ii) the HIP kernel from the 50-digit
+evaluation of the reference's formulas (tests/golden/gh_mp.npz, oracle/gh_mp_oracle.py), and the iteration-count differences.
+GPU box (kernel column) or build container (--no-gpu: oracle column only)."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from helpers import rel_err_T, rel_err, golden_cases
+
+
+def dev(T, R2, R3, g, pre, b):
+    return max(rel_err_T(T, g[pre + "mp_T"][b]), rel_err(R2, g[pre + "mp_Rt2"][b]), rel_err(R3, g[pre + "mp_Rt3"][b]))
+
+
+def table(ctx=None, exact=False):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "gh_mp.npz"))
+    rows = []
+    for ci, pre in golden_cases(g):
+        N, B, noise = g[pre + "meta"]
+        N, B = int(N), int(B)
+        C, CalM = g[pre + "Corresp"], g[pre + "CalM"]
+        d_np = np.array([dev(g[pre + "np_T"][b], g[pre + "np_Rt2"][b], g[pre + "np_Rt3"][b], g, pre, b) for b in range(B)])
+        di_np = g[pre + "np_iter"] - g[pre + "mp_iter"]
+        row = dict(N=N, B=B, np=d_np, np_it=di_np)
+        if ctx is not None:
+            if exact:
+                ctx.set_gh_exact(True)
+            out = ctx.pose_batch("ResslTFTPoseEstimation", C, CalM, reconst=False)
+            if exact:
+                ctx.set_gh_exact(False)
+            assert np.all(out["status"] == 0)
+            row["k"] = np.array([dev(out["T"][b], out["R_t_2"][b], out["R_t_3"][b], g, pre, b) for b in range(B)])
+            row["k_it"] = out["iter"] - g[pre + "mp_iter"]
+        rows.append(row)
+    return rows
+
+
+def fmt(d):
+    return "p50 %.1e  p90 %.1e  max %.1e" % (np.quantile(d, 0.5), np.quantile(d, 0.9), d.max())
+
+
+if __name__ == "__main__":
+    ctx = None
+    if "--no-gpu" not in sys.argv:
+        from tft_vs_fund_amd import api
+        ctx = api.Context(0)
+    for exact in ((False, True) if ctx else (False,)):
+        print("# deviation from the 50-digit Gauss-Helmert evaluation (max rel. over T up to sign, R_t_2, R_t_3); kernel pinv(W): %s" % ("eigen-decomposition (TFF_OPT_GH_EXACT)" if exact else "default"))
+        for r in table(ctx, exact):
+            print("N=%-4d scenes %-3d LAPACK oracle: %s  iter diff %s" % (r["N"], r["B"], fmt(r["np"]), np.bincount(np.abs(r["np_it"])).tolist()))
+            if "k" in r:
+                print("                   HIP kernel   : %s  iter diff %s" % (fmt(r["k"]), np.bincount(np.abs(r["k_it"])).tolist()))
+    if ctx is not None:
+        # same-algebra restatement (oracle/gh_block_oracle.py): kernel vs block oracle, both vs the 50-digit evaluation
+        from oracle import gh_block_oracle as GB
+        g = np.load(os.path.join(ROOT, "tests", "golden", "gh_mp.npz"))
+        print("# kernel vs the same-algebra numpy restatement (oracle/gh_block_oracle.py), and that restatement vs the 50-digit evaluation")
+        for ci, pre in golden_cases(g):
+            C, CalM = g[pre + "Corresp"], g[pre + "CalM"]
+            B, N = C.shape[0], C.shape[1]
+            out = ctx.pose_batch("ResslTFTPoseEstimation", C, CalM, reconst=False)
+            dk, db, same = [], [], 0
+            for b in range(B):
+                R2, R3, _, T, it = GB.ResslTFTPoseEstimation_blocks(C[b].T.copy(), CalM)
+                dk.append(max(rel_err_T(out["T"][b], T), rel_err(out["R_t_2"][b], R2), rel_err(out["R_t_3"][b], R3)))
+                db.append(dev(T, R2, R3, g, pre, b))
+                same += int(it == int(out["iter"][b]))
+            dk, db = np.array(dk), np.array(db)
+            print("N=%-4d kernel vs block oracle: %s  same iteration count %d/%d;  block oracle vs 50-digit: %s" % (N, fmt(dk), same, B, fmt(db)))
