@@ -106,11 +106,6 @@ static int emu_gh_wg_impl(const double* corresp, const double* calm, long calm_s
     m.flags |= tff::FLAG_ONLY_RETRY;
     emu::launch(tff::k_gh_linear<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
     const size_t lds = (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, N, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double);
-    std::vector<double> strong;                                              // side buffer of the factored strong-direction terms (as the C ABI)
-    if (!Model::IDENTITY_D) {
-        strong.resize((size_t)emu_grid(B) * N * (Model::U + 1));
-        a.strong = strong.data(); a.strong_stride = (long)N * (Model::U + 1);
-    }
     emu::launch(tff::k_gh_block<Model>, emu_grid(B), tff::GH_WG_THREADS, lds, a);
     emu::launch(tff::k_gh_finish, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
     return 0;

@@ -1,0 +1,69 @@
+"""
+Gauss-Helmert parity against the FORMULAS of the reference, not against one fp64 evaluation of them.
+
+`pinv(W + 1e-12 I)` (Gauss_Helmert.m:57) gives every correspondence one direction of weight ~1e12; any evaluation that forms
+that matrix in fp64 -- MATLAB's dense one included -- carries ~1e-4 relative noise in those weights and cancels ten digits in
+A'WA.  tests/golden/gh_mp.npz holds ResslTFTPoseEstimation with the Gauss-Helmert loop evaluated in 50-digit arithmetic
+(oracle/gh_mp_oracle.py, generator tests/golden/make_gh_mp.py).  Measured against it (profiles/r2_gh_noise_mp.txt):
+  LAPACK-backed numpy oracle (stand-in for MATLAB's arithmetic): median 7e-7 .. 4e-6, max 3e-5 .. 1e-3, a different
+      stopping iteration in ~40 % of the scenes;
+  HIP kernel (deflated block pseudo-inverse + factored strong-direction terms, gh_kernel.h / gh_wg_kernel.h):
+      <= 6e-11, identical iteration counts in every scene.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from helpers import rel_err_T, rel_err, golden_cases   # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu_ctx():
+    from tft_vs_fund_amd import api
+    return api.Context(0)
+
+
+def _dev(T, R2, R3, g, pre, b):
+    return max(rel_err_T(T, g[pre + "mp_T"][b]), rel_err(R2, g[pre + "mp_Rt2"][b]), rel_err(R3, g[pre + "mp_Rt3"][b]))
+
+
+def test_ressl_kernel_reproduces_the_extended_precision_iteration(gpu_ctx, golden_dir):
+    """N in {12, 60, 200}: T (up to sign), R_t_2, R_t_3 within 1e-9 of the 50-digit evaluation and the SAME number of
+    Gauss-Helmert iterations, scene by scene (north_star's bar is 1e-6)."""
+    g = np.load(os.path.join(golden_dir, "gh_mp.npz"))
+    for ci, pre in golden_cases(g):
+        C, CalM = g[pre + "Corresp"], g[pre + "CalM"]
+        out = gpu_ctx.pose_batch("ResslTFTPoseEstimation", C, CalM, reconst=False)
+        assert np.all(out["status"] == 0)
+        for b in range(C.shape[0]):
+            assert int(out["iter"][b]) == int(g[pre + "mp_iter"][b]), (ci, b)
+            assert _dev(out["T"][b], out["R_t_2"][b], out["R_t_3"][b], g, pre, b) < 1e-9, (ci, b)
+
+
+def test_ressl_kernel_is_no_noisier_than_the_lapack_evaluation(gpu_ctx, golden_dir):
+    """The kernel's deviation from the 50-digit evaluation, percentile by percentile, against the LAPACK-backed numpy oracle's
+    (recomputed here, on this host's LAPACK): kernel <= oracle at p50, p90 and max, and the oracle's own noise is what the
+    tolerances of the oracle-based Gauss-Helmert tests (test_gpu_parity.py::_ressl_tol) have to allow for."""
+    from oracle import tft_oracle as O
+    g = np.load(os.path.join(golden_dir, "gh_mp.npz"))
+    for ci, pre in golden_cases(g):
+        C, CalM = g[pre + "Corresp"], g[pre + "CalM"]
+        B = C.shape[0]
+        out = gpu_ctx.pose_batch("ResslTFTPoseEstimation", C, CalM, reconst=False)
+        dk = np.array([_dev(out["T"][b], out["R_t_2"][b], out["R_t_3"][b], g, pre, b) for b in range(B)])
+        do = []
+        for b in range(B):
+            o2, o3, _, oT, _ = O.ResslTFTPoseEstimation(C[b].T.copy(), CalM)
+            do.append(_dev(oT, o2, o3, g, pre, b))
+        do = np.array(do)
+        for q in (0.5, 0.9, 1.0):
+            assert np.quantile(dk, q) <= np.quantile(do, q), (ci, q, np.quantile(dk, q), np.quantile(do, q))
+        # the reference-noise envelope the oracle-based tests rely on (see _ressl_tol): same-algebra noise of a LAPACK evaluation
+        N = C.shape[1]
+        assert np.quantile(do, 0.5) < (2e-5 if N < 50 else 1e-5) and do.max() < (1e-2 if N < 50 else 2e-3), (ci, np.quantile(do, 0.5), do.max())

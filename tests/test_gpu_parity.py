@@ -310,16 +310,18 @@ def test_linear_f_full_size_properties(gpu_ctx):
 # ---------------------------------------------------------------------------
 # ResslTFTPoseEstimation + Gauss_Helmert (TFT_methods/ResslTFTPoseEstimation.m, Optimization/Gauss_Helmert.m)
 #
-# Parity here is statistical by construction: pinv(W + 1e-12 I) gives every
-# correspondence one direction of weight ~1e12, so A'WA cancels ten digits in ANY evaluation order
-# (the reference's own dense product included), and the exit test "objective rose" compares
-# objectives that agree to ~1e-9 once the iteration stagnates.  Two evaluations of the same
-# formulas therefore agree to ~1e-6 at N >= 50 and ~1e-4..1e-3 at N = 12 (cond-amplified), and may
-# stop one or two iterations apart.
+# The parity gate for Ressl is tests/test_gpu_gh_noise.py: the kernel reproduces a 50-digit evaluation of the reference's
+# iteration to 1e-9 with identical iteration counts.  THIS file compares with the LAPACK-backed numpy oracle
+# (oracle/tft_oracle.py), whose own fp64 evaluation of pinv(W + 1e-12 I) -- every correspondence gets one direction of weight
+# ~1e12, A'WA cancels ten digits -- deviates from that exact iteration by the amounts measured in profiles/r2_gh_noise_mp.txt:
+#   same stopping iteration as the exact evaluation: median 7e-7 (N = 200) .. 4e-6 (N = 12);
+#   a different stopping iteration (~40 % of the scenes: the exit test "objective rose" compares objectives that agree to
+#   ~1e-9 once the iteration stagnates): up to 3e-5 (N = 200), 1e-4 (N = 60), 1e-3 (N = 12).
+# The tolerances below are that reference-noise envelope with a factor ~3 of head room (asserted against the fixture in
+# test_gpu_gh_noise.py::test_ressl_kernel_is_no_noisier_than_the_lapack_evaluation); Nordberg, FaugPapa and the Pi methods share
+# the weight blocks and are held to the same envelope (no extended-precision restatement of their callbacks exists).
 # ---------------------------------------------------------------------------
 def _ressl_tol(N, same_iterations=True):
-    # same stopping iteration: rounding noise of the 1e12-weighted normal equations (cond-amplified at N = 12);
-    # different stopping iteration: one late step (~1e-4 relative) is or is not applied (Gauss_Helmert.m:75-80)
     if same_iterations:
         return 2e-3 if N < 50 else 1e-4
     return 1e-2 if N < 50 else 2e-3

@@ -51,7 +51,7 @@ struct tff_ctx {
     int solver = 0;
     int exact_below = tff::EXACT_BELOW_N;   // TFF_OPT_EXACT_BELOW
     int stage = -1;
-    DevBuf in, calm, out, idx, scratch_status, gh_rec, gh_topt, spill, gh_strong;
+    DevBuf in, calm, out, idx, scratch_status, gh_rec, gh_topt, spill;
     const int32_t* sample_idx = nullptr;   // set around a *_sampled_dev call
     double* init_p = nullptr; double* init_x = nullptr;   // set around tff_pi_pose_batch_debug_dev
     int kernel_variant = 0;                // TFF_OPT_KERNEL
@@ -175,10 +175,8 @@ int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_
 // Iterative TFT methods: three launches, a workgroup of four wavefronts per triplet for the iteration (gh_wg_kernel.h,
 // pi_wg_kernel.h): k_gh_linear (+ Jacobi fix-up), the block kernel, k_gh_finish.  wg_lds(n): LDS bytes of the block kernel for n
 // correspondences held in LDS.
-// strong_rec: doubles per correspondence of the side buffer for the factored strong-direction terms (u + 1 for the minimal
-// parameterisations, 0: none), see gh_wg_kernel.h.
 template <class KBlock, class LdsFn>
-int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, int strong_rec, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
+int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     if (B == 0) return 0;
@@ -214,14 +212,6 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, int st
         unsigned grid = tff::pose_grid(B);
         size_t lds;
         if (int r = plan_spill(c, wg_lds(N), wg_lds(0), &grid, &m.spill, &m.spill_stride, &lds, occupancy_cap)) return r;
-        if (strong_rec > 0 && N > 0) {                                         // one slice per block of the (possibly capped) grid
-            const size_t per_block = (size_t)N * strong_rec * sizeof(double);
-            size_t blocks = ((size_t)512 << 20) / per_block;
-            if (blocks < 256) blocks = 256;
-            if (grid > blocks) grid = (unsigned)blocks;
-            if (int r = c->gh_strong.reserve((size_t)grid * per_block)) return r;
-            m.strong = (double*)c->gh_strong.p; m.strong_stride = (long)(per_block / sizeof(double));
-        }
         if (int r = ensure_lds(kblock, lds)) return r;
         hipLaunchKernelGGL(kblock, dim3(grid), dim3(tff::GH_WG_THREADS), lds, c->stream, m);
         TFF_HIP(hipGetLastError());
@@ -244,7 +234,7 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
     if (c->kernel_variant == 1 || c->solver != 0 || small)
         return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, 0, std::is_same<Model, tff::ResslModel>::value ? 8 : 4, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
-    return launch_wg(c, tff::k_gh_block<Model>, wg_lds, Model::REDUNDANT_CONSTRAINTS ? 4 : 3, Model::IDENTITY_D ? 0 : Model::U + 1, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    return launch_wg(c, tff::k_gh_block<Model>, wg_lds, Model::WG_PER_CU, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 template <class Model>
 int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
@@ -254,7 +244,7 @@ int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64
         return launch_pose(c, tff::k_pi_tft_pose<Model, false>, tff::k_pi_tft_pose<Model, true>, tff::pi_lds_bytes<Model>, 0, 4,
                            corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::pi_wg_lds_doubles(Model::E, Model::C, n)) * sizeof(double); };
-    return launch_wg(c, tff::k_pi_block<Model>, wg_lds, Model::PINV_KKT ? 4 : 2, 0, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    return launch_wg(c, tff::k_pi_block<Model>, wg_lds, Model::PINV_KKT ? 4 : 2, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 int launch_ressl_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
@@ -346,7 +336,7 @@ void tff_ctx_destroy(tff_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own) { (void)hipStreamSynchronize(c->own); (void)hipStreamDestroy(c->own); }
-    c->in.release(); c->calm.release(); c->out.release(); c->idx.release(); c->scratch_status.release(); c->gh_rec.release(); c->gh_topt.release(); c->spill.release(); c->gh_strong.release();
+    c->in.release(); c->calm.release(); c->out.release(); c->idx.release(); c->scratch_status.release(); c->gh_rec.release(); c->gh_topt.release(); c->spill.release();
     delete c;
 }
 

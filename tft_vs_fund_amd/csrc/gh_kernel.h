@@ -47,7 +47,6 @@ struct GhWork {                       // per-wave LDS carve-up for one Gauss-Hel
     double* xi;     // 6N       current estimates of the observations
     double* pp;     // 14N      per correspondence: W+ (10, packed lower) and W+ w (4); then v (6)
     double* S;      // workgroup kernel, factored weights: u(u+1)/2 + u sums of the strong-direction terms (LDS), else null
-    double* sb;     // workgroup kernel, factored weights: N x (u+1) global side buffer of this block (sqrt(c) a_i, sqrt(c) n'w), else null
     int u, c;
 };
 __host__ __device__ inline int gh_lds_doubles(int u, int c, int N) {
@@ -70,7 +69,7 @@ __device__ inline GhWork gh_carve(double* base, int u, int c, int N) {
     g.V = q; q += n * n;
     g.xi = q; q += 6 * N;
     g.pp = q; q += 14 * N;
-    g.S = nullptr; g.sb = nullptr;
+    g.S = nullptr;
     g.u = u; g.c = c;
     return g;
 }
@@ -348,6 +347,10 @@ __device__ __forceinline__ double cof3(const double (&A)[3][3]) {
 struct FaugPapaModel {
     static constexpr int U = 27, C = 12;
     static constexpr bool IDENTITY_D = true;
+    static constexpr int WG_PER_CU = 4;                                      // workgroups per CU the block kernel is compiled for (measured best)
+    static constexpr bool SPARSE_DT = false;
+    __device__ __forceinline__ void share(double*) const {}
+    __device__ __forceinline__ void adopt(const double*) {}
     static constexpr bool REDUNDANT_CONSTRAINTS = true;     // trifocal tensors have codimension 9 < 12: singular KKT, pinv truncates
     __device__ inline void init(PoseLds* w, GhWork& g) {                    // param0 = T(:)   (:65)
         const int lane = lane_id();
@@ -441,7 +444,11 @@ __device__ inline void wave_pinv_solve_sym(double* M, double* ZT, int n, double*
 //      (NordbergTFTPoseEstimation.m:47-222) ----
 struct NordbergModel {
     static constexpr int U = 19, C = 1;
+    static constexpr int WG_PER_CU = 3;
     static constexpr bool IDENTITY_D = false;
+    static constexpr bool SPARSE_DT = false;
+    __device__ __forceinline__ void share(double*) const {}
+    __device__ __forceinline__ void adopt(const double*) {}
     static constexpr bool REDUNDANT_CONSTRAINTS = false;
     int bad;                                                                 // P2 or P3 of rank < 2: H(4,1:3) = null(.)' is an error in the reference (:56-62)
 
@@ -622,7 +629,59 @@ struct NordbergModel {
 struct ResslModel {
     int Ind;                                                                 // argmax |e21|, 0-based
     static constexpr int U = 20, C = 2;
+    static constexpr int WG_PER_CU = 2;                                      // 256 registers: at three the factored weight pass spills (3.5 vs 3.0 ms per 10k x 200)
     static constexpr bool IDENTITY_D = false;
+    static constexpr bool SPARSE_DT = true;
+    // workgroup kernel: the wavefront that ran init() publishes the per-triplet model state the other wavefronts need (apply_Dt)
+    __device__ __forceinline__ void share(double* slot) const { slot[0] = (double)Ind; }
+    __device__ __forceinline__ void adopt(const double* slot) { Ind = (int)slot[0]; }
+    // a = D' q for q[j + 3k + 9i] = h1[i] gm[j][k], from the structure of D (eval below): T(j,k,i) = e21(j) S(k,i) + mn(i,j) e31(k)
+    __device__ __forceinline__ void apply_Dt(const GhWork& g, const double (&h1)[3], const double (&gm)[3][3], double (&a)[U]) const {
+        const int i2a = (Ind == 0) ? 1 : 0, i2b = (Ind == 2) ? 1 : 2;
+        double e21[3], S[3][3], e31[3], mn[3][3];                           // wave-uniform parameters (scalar registers)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) e21[j] = (j == Ind) ? 1.0 : wave_uniform(g.p[(j == i2a) ? 9 : 10]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            e31[k] = wave_uniform(g.p[17 + k]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) S[k][i] = wave_uniform(g.p[k + 3 * i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) mn[i][j] = (j == Ind) ? 0.0 : wave_uniform(g.p[11 + i + 3 * ((j == i2a) ? 0 : 1)]);
+        double bj[3] = {0.0, 0.0, 0.0}, cij[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a[17 + k] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                double sk = 0.0;                                             // d/dS(k,i): sum_j e21(j) q(j,k,i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) sk += e21[j] * gm[j][k];
+                a[k + 3 * i] = h1[i] * sk;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double sS = 0.0, sE = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { sS += S[k][i] * gm[j][k]; sE += e31[k] * gm[j][k]; }
+                bj[j] += h1[i] * sS;                                         // d/de21(j): sum_{k,i} S(k,i) q(j,k,i)
+                cij[i][j] = h1[i] * sE;                                      // d/dmn(i,j): sum_k e31(k) q(j,k,i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) a[17 + k] += mn[i][j] * h1[i] * gm[j][k];   // d/de31(k): sum_{i,j} mn(i,j) q(j,k,i)
+            }
+        }
+        a[9] = (i2a == 0) ? bj[0] : bj[1];
+        a[10] = (i2b == 1) ? bj[1] : bj[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            a[11 + i] = (i2a == 0) ? cij[i][0] : cij[i][1];
+            a[14 + i] = (i2b == 1) ? cij[i][1] : cij[i][2];
+        }
+    }
     static constexpr bool REDUNDANT_CONSTRAINTS = false;
     // initial parameters from linearTFT's output (w->t constrained tensor, w->epi)
     __device__ inline void init(PoseLds* w, GhWork& g) {

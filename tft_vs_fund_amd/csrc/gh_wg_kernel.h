@@ -52,7 +52,6 @@ __device__ inline GhWork gh_wg_carve(double* base, PoseLds* w, int u, int c, int
     g.M = q; q += n * (n + 1);
     g.V = pinv ? g.D : q; q += 112;                                                // 108 doubles of scratch (Nordberg's rotations)
     g.S = pinv ? nullptr : q; q += pinv ? 0 : ((u * (u + 1) / 2 + u + 1) & ~1);
-    g.sb = nullptr;
     g.xi = q; q += 6 * N;
     g.pp = q; q += 10 * N;
     *red = q;
@@ -78,7 +77,6 @@ struct GhWgArgs {
     double* topt;            // B x 27 (k_gh_block out, k_gh_finish in): optimised tensor in the normalised frame
     double* Rt2; double* Rt3; double* T; double* reconst; int* iter; int* status; double* dbg;
     double* spill; long spill_stride;   // see LinearTftArgs
-    double* strong; long strong_stride; // k_gh_block, minimal parameterisations: global side buffer, gridDim.x slices of N (u + 1) doubles (or null: unfactored weights)
 };
 
 template <bool JAC>
@@ -180,6 +178,69 @@ __device__ inline void gh_sweep_part(const GhWork& g, double* Hp, int N, const d
     }
 }
 
+// ---- factored strong-direction terms (see pinv_block_deflated<true>) -------------------------------------------------------------
+// Per correspondence the thread holds b = sqrt(cs) a (U doubles, a = D' Ap' n) and t = sqrt(cs) n'w in registers; the sums
+//   N_s[r][c] = sum_i b_i[r] b_i[c]  (lower triangle, U (U + 1) / 2 entries)   and   r_s[r] = sum_i b_i[r] t_i  (U entries)
+// are taken 32 at a time with the halving butterfly (compile-time entry indices, so b stays in registers) and added to the calling
+// wavefront's own partial-sum slot.
+template <int U, int E>
+__device__ __forceinline__ double strong_entry(const double (&b)[U], const double t) {
+    constexpr int ntri = U * (U + 1) / 2;
+    if constexpr (E < ntri) return b[tri_row_of(E)] * b[tri_col_of(E)];
+    else if constexpr (E < ntri + U) return b[E - ntri] * t;
+    else return 0.0;
+}
+template <int U, int SW>
+__device__ __forceinline__ void strong_sweep(const double (&b)[U], const double t, double* slot) {
+    constexpr int total = U * (U + 1) / 2 + U;
+    if constexpr (32 * SW < total) {
+        double acc[32];
+        acc[0] = strong_entry<U, 32 * SW + 0>(b, t);   acc[1] = strong_entry<U, 32 * SW + 1>(b, t);   acc[2] = strong_entry<U, 32 * SW + 2>(b, t);   acc[3] = strong_entry<U, 32 * SW + 3>(b, t);
+        acc[4] = strong_entry<U, 32 * SW + 4>(b, t);   acc[5] = strong_entry<U, 32 * SW + 5>(b, t);   acc[6] = strong_entry<U, 32 * SW + 6>(b, t);   acc[7] = strong_entry<U, 32 * SW + 7>(b, t);
+        acc[8] = strong_entry<U, 32 * SW + 8>(b, t);   acc[9] = strong_entry<U, 32 * SW + 9>(b, t);   acc[10] = strong_entry<U, 32 * SW + 10>(b, t); acc[11] = strong_entry<U, 32 * SW + 11>(b, t);
+        acc[12] = strong_entry<U, 32 * SW + 12>(b, t); acc[13] = strong_entry<U, 32 * SW + 13>(b, t); acc[14] = strong_entry<U, 32 * SW + 14>(b, t); acc[15] = strong_entry<U, 32 * SW + 15>(b, t);
+        acc[16] = strong_entry<U, 32 * SW + 16>(b, t); acc[17] = strong_entry<U, 32 * SW + 17>(b, t); acc[18] = strong_entry<U, 32 * SW + 18>(b, t); acc[19] = strong_entry<U, 32 * SW + 19>(b, t);
+        acc[20] = strong_entry<U, 32 * SW + 20>(b, t); acc[21] = strong_entry<U, 32 * SW + 21>(b, t); acc[22] = strong_entry<U, 32 * SW + 22>(b, t); acc[23] = strong_entry<U, 32 * SW + 23>(b, t);
+        acc[24] = strong_entry<U, 32 * SW + 24>(b, t); acc[25] = strong_entry<U, 32 * SW + 25>(b, t); acc[26] = strong_entry<U, 32 * SW + 26>(b, t); acc[27] = strong_entry<U, 32 * SW + 27>(b, t);
+        acc[28] = strong_entry<U, 32 * SW + 28>(b, t); acc[29] = strong_entry<U, 32 * SW + 29>(b, t); acc[30] = strong_entry<U, 32 * SW + 30>(b, t); acc[31] = strong_entry<U, 32 * SW + 31>(b, t);
+        const double tot = wave_reduce_scatter<32>(acc);
+        const int lane = lane_id(), e = 32 * SW + reduce32_index(lane);
+        if ((lane & 1) == 0 && e < total) slot[e] += tot;
+        sched_fence();                                                       // keep the sweeps apart: interleaved, their 32 accumulators each would spill
+    }
+}
+template <int U>
+__device__ inline void strong_accumulate(const double (&b)[U], const double t, double* slot) {
+    static_assert(U * (U + 1) / 2 + U <= 12 * 32, "twelve sweeps");
+    strong_sweep<U, 0>(b, t, slot); strong_sweep<U, 1>(b, t, slot); strong_sweep<U, 2>(b, t, slot); strong_sweep<U, 3>(b, t, slot);
+    strong_sweep<U, 4>(b, t, slot); strong_sweep<U, 5>(b, t, slot); strong_sweep<U, 6>(b, t, slot); strong_sweep<U, 7>(b, t, slot);
+    strong_sweep<U, 8>(b, t, slot); strong_sweep<U, 9>(b, t, slot); strong_sweep<U, 10>(b, t, slot); strong_sweep<U, 11>(b, t, slot);
+}
+// a = D' q for q = h1 (x) vec(gm) (27): through the model's sparse form when it has one, else the dense 27 x U matrix in LDS
+template <class Model>
+__device__ __forceinline__ void strong_apply_Dt(const Model& model, const GhWork& g, const double (&h1)[3], const double (&gm)[3][3], double (&a)[Model::U]) {
+    if constexpr (Model::SPARSE_DT) {
+        model.apply_Dt(g, h1, gm, a);
+    } else {
+        constexpr int u = Model::U;
+#pragma unroll 1
+        for (int pcol = 0; pcol < u; ++pcol) {
+            double acc = 0.0;
+#pragma unroll
+            for (int i1 = 0; i1 < 3; ++i1) {
+                double part = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) part += g.D[(j + 3 * k + 9 * i1) * u + pcol] * gm[j][k];
+                acc += h1[i1] * part;
+            }
+#pragma unroll
+            for (int c = 0; c < u; ++c) a[c] = (c == pcol) ? acc : a[c];
+        }
+    }
+}
+
 // x_est: reprojection of the projective triangulation with P1 (Pfin[0]), P2 (P[0]), P3 (P[1])   (ResslTFT...m:72-75)
 __device__ inline void gh_block_reproject(PoseLds* w, const double* pts, int N, double* xi) {
     double PA[12], PB[12], PC[12];
@@ -252,8 +313,8 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         if (it == 1) phase_stamp(sdbg, 42);
         double tolW = 0.0;
         bool have_tol = false, jacobi = exact_pinv;
-        // minimal parameterisations with a side buffer: regular part of pinv(W) in pp, strong direction factored (pinv_block_deflated)
-        const bool want_factored = !Model::IDENTITY_D && g.sb != nullptr && g.S != nullptr;
+        // minimal parameterisations: regular part of pinv(W) in pp, strong direction factored (pinv_block_deflated)
+        const bool want_factored = !Model::IDENTITY_D && g.S != nullptr;
         bool factored = false;
 #pragma unroll 1
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -294,18 +355,54 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
             }
             if (!jacobi) {
                 bool bad = false;
-                for (int i = tid; i < N; i += GH_WG_THREADS) {
-                    double o[6], f[4], B[4][6], W[4][4], Wp[10];
+                constexpr int SLOT = (Model::U * (Model::U + 1) / 2 + Model::U + 1) & ~1;
+                double* slot = nullptr;
+                if (want_factored) {                                         // per-wavefront partial sums of the strong-direction terms
+                    slot = (wave < 3) ? g.G + wave * SLOT : g.S;             // Ghat's slot is not yet in use; 3 SLOT <= 729
+                    for (int e = lane; e < SLOT; e += WAVE) slot[e] = 0.0;
+                }
+#pragma unroll 1
+                for (int base = 0; base < N; base += GH_WG_THREADS) {        // block-uniform trip count (the butterflies need whole wavefronts)
+                    const int i = base + tid;
+                    double bv[Model::U], tv = 0.0;
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
-                    tril_block(T, o, f, B);
-                    block_W(B, W);
-                    double nn[4], cs;
-                    bad = !(want_factored ? pinv_block_deflated<true>(B, W, tolW, Wp, nn, &cs) : pinv_block_deflated<false>(B, W, tolW, Wp, nn, &cs)) || bad;
+                    for (int k = 0; k < Model::U; ++k) bv[k] = 0.0;
+                    if (i < N) {
+                        double o[6], f[4], B[4][6], W[4][4], Wp[10];
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
+                        for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                        tril_block(T, o, f, B);
+                        block_W(B, W);
+                        double nn[4], cs = 0.0;
+                        const bool ok = want_factored ? pinv_block_deflated<true>(B, W, tolW, Wp, nn, &cs) : pinv_block_deflated<false>(B, W, tolW, Wp, nn, &cs);
+                        bad = !ok || bad;
 #pragma unroll
-                    for (int k = 0; k < 10; ++k) g.pp[10 * i + k] = Wp[k];
+                        for (int a = 0; a < 4; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
+#pragma unroll
+                        for (int k = 0; k < 10; ++k) g.pp[10 * i + k] = Wp[k];
+                        if constexpr (!Model::IDENTITY_D) if (want_factored && ok) {
+                            // b = sqrt(cs) D' (Ap' n),  t = sqrt(cs) n'w,  n'w = -n'f - (B'n) . (x - xi)
+                            double gm[3][3];
+                            tril_grad_n(o, nn, gm);
+                            const double h1[3] = {o[0], o[1], 1.0};
+                            strong_apply_Dt<Model>(model, g, h1, gm, bv);
+                            const double sc = sqrt(cs);
+#pragma unroll
+                            for (int k = 0; k < Model::U; ++k) bv[k] *= sc;
+                            const Pt6 x = premap(load_pt(pts, i), w->nrm);
+                            double nw = -(nn[0] * f[0] + nn[1] * f[1] + nn[2] * f[2] + nn[3] * f[3]);
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) nw -= (B[0][k] * nn[0] + B[1][k] * nn[1] + B[2][k] * nn[2] + B[3][k] * nn[3]) * (x.v[k] - o[k]);
+                            tv = sc * nw;
+                        }
+                    }
+                    if constexpr (!Model::IDENTITY_D) { if (want_factored) strong_accumulate<Model::U>(bv, tv, slot); }
+                }
+                if (want_factored) {
+                    __syncthreads();
+                    constexpr int total = Model::U * (Model::U + 1) / 2 + Model::U;
+                    if (tid < total) g.S[tid] = (g.G[tid] + g.G[SLOT + tid]) + (g.G[2 * SLOT + tid] + g.S[tid]);
+                    if (tid + GH_WG_THREADS < total) g.S[tid + GH_WG_THREADS] = (g.G[tid + GH_WG_THREADS] + g.G[SLOT + tid + GH_WG_THREADS]) + (g.G[2 * SLOT + tid + GH_WG_THREADS] + g.S[tid + GH_WG_THREADS]);
                 }
                 if (!block_any(bad, red)) { factored = want_factored; break; }
                 jacobi = true;                                               // a block without the structure: eigen-decompositions for all
@@ -334,81 +431,6 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
             break;
         }
         if (it == 1) phase_stamp(sdbg, 43);
-        // ---- strong-direction terms, factored: N_s = sum_i cs_i a_i a_i', r_s = sum_i cs_i a_i (n_i' w_i), a_i = D' (Ap_i' n_i) ----
-        if (factored) {
-            const int rec = u + 1;
-            for (int i = tid; i < N; i += GH_WG_THREADS) {                   // per correspondence: sqrt(cs) a (u), sqrt(cs) n'w
-                double o[6], f[4], B[4][6], W[4][4], Wp[10], nn[4], cs = 0.0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
-                tril_block(T, o, f, B);
-                block_W(B, W);
-                pinv_block_deflated<true>(B, W, tolW, Wp, nn, &cs);          // succeeded in the weights pass (same inputs, same result)
-                double gm[3][3];
-                tril_grad_n(o, nn, gm);
-                const double sc = sqrt(cs);
-                const double h1[3] = {o[0], o[1], 1.0};
-                double* out = g.sb + (long)i * rec;
-#pragma unroll 1
-                for (int pcol = 0; pcol < u; ++pcol) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int i1 = 0; i1 < 3; ++i1) {
-                        double part = 0.0;
-#pragma unroll
-                        for (int k = 0; k < 3; ++k)
-#pragma unroll
-                            for (int j = 0; j < 3; ++j) part += g.D[(j + 3 * k + 9 * i1) * u + pcol] * gm[j][k];
-                        acc += h1[i1] * part;
-                    }
-                    out[pcol] = sc * acc;
-                }
-                // n'w = -n'f - (B'n) . (x - xi)
-                const Pt6 x = premap(load_pt(pts, i), w->nrm);
-                double nw = -(nn[0] * f[0] + nn[1] * f[1] + nn[2] * f[2] + nn[3] * f[3]);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) nw -= (B[0][k] * nn[0] + B[1][k] * nn[1] + B[2][k] * nn[2] + B[3][k] * nn[3]) * (x.v[k] - o[k]);
-                out[u] = sc * nw;
-            }
-            __syncthreads();
-            // sums over the correspondences: thread e owns entry e of [N_s (lower triangle) | r_s]; the records are staged through LDS
-            // (Ghat's slot, not yet in use) in chunks, so that the dependent chain holds LDS reads, not global loads
-            const int ntri = u * (u + 1) / 2;
-            int er[2], ec[2];
-            double sacc[2] = {0.0, 0.0};
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int e = tid + k * GH_WG_THREADS;
-                int r = 0, cc = 0;
-                if (e < ntri) {
-                    r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-                    while (tri_index(r + 1, 0) <= e) ++r;
-                    while (tri_index(r, 0) > e) --r;
-                    cc = e - tri_index(r, 0);
-                } else if (e < ntri + u) { r = e - ntri; cc = u; }
-                er[k] = r; ec[k] = cc;
-            }
-            const int chunk = 729 / rec;                                     // correspondences per chunk (34 for u = 20)
-            double* stage = g.G;
-#pragma unroll 1
-            for (int base = 0; base < N; base += chunk) {
-                const int cnt = (N - base < chunk) ? N - base : chunk;
-                for (int e = tid; e < cnt * rec; e += GH_WG_THREADS) stage[e] = g.sb[(long)base * rec + e];
-                __syncthreads();
-                if (tid < ntri + u) {
-#pragma unroll 4
-                    for (int i = 0; i < cnt; ++i) sacc[0] += stage[i * rec + er[0]] * stage[i * rec + ec[0]];
-                }
-                if (tid + GH_WG_THREADS < ntri + u) {
-#pragma unroll 4
-                    for (int i = 0; i < cnt; ++i) sacc[1] += stage[i * rec + er[1]] * stage[i * rec + ec[1]];
-                }
-                __syncthreads();
-            }
-            if (tid < ntri + u) g.S[tid] = sacc[0];
-            if (tid + GH_WG_THREADS < ntri + u) g.S[tid + GH_WG_THREADS] = sacc[1];
-            __syncthreads();
-        }
         // ---- Ghat, ghat: the ten sweeps are dealt to the four wavefronts, each sweep runs over ALL correspondences on one wavefront
         //      (4 per lane at N = 200) and ends in one reduce-scatter: a quarter of the reductions of the per-wavefront-partial layout
         //      and no combine step ----
@@ -554,7 +576,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
 }
 
 template <class Model>
-__global__ void __launch_bounds__(GH_WG_THREADS, Model::REDUNDANT_CONSTRAINTS ? 4 : 3) k_gh_block(const GhWgArgs a) {
+__global__ void __launch_bounds__(GH_WG_THREADS, Model::WG_PER_CU) k_gh_block(const GhWgArgs a) {
     static_assert(!Model::REDUNDANT_CONSTRAINTS || (Model::IDENTITY_D && 2 * 27 * Model::U + 298 >= (Model::U + Model::C) * (Model::U + Model::C + 2)),
                   "pseudo-inverse workspace must fit D | H | Y");
     TFF_DYNAMIC_LDS(double, smem);
@@ -570,7 +592,6 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::REDUNDANT_CONSTRAINTS ? 
         double* red;
         GhWork g = gh_wg_carve(ghbase, w, Model::U, Model::C, a.spill ? 0 : N, Model::REDUNDANT_CONSTRAINTS, &red);
         if (a.spill) { g.xi = a.spill + blockIdx.x * a.spill_stride; g.pp = g.xi + 6 * (long)N; }
-        g.sb = a.strong ? a.strong + blockIdx.x * a.strong_stride : nullptr;
         const int own = (int)(b & (GH_WG_WAVES - 1));
         const double* r = a.rec + b * GH_REC_DOUBLES;
         if (tid < 27) w->t[tid] = r[tid];
@@ -581,8 +602,12 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::REDUNDANT_CONSTRAINTS ? 
         Model model;
         double* sdbg = (a.dbg && wave == own) ? a.dbg + b * DBG_STRIDE : nullptr;
         phase_stamp(sdbg, 36);
-        if (wave == own) model.init(w, g);                                   // initial parameters; cameras P1, P2, P3 of the linear solution
+        if (wave == own) {                                                   // initial parameters; cameras P1, P2, P3 of the linear solution
+            model.init(w, g);
+            if (lane == 0) model.share(red + 10);
+        }
         __syncthreads();
+        if (wave != own) model.adopt(red + 10);
         phase_stamp(sdbg, 37);
         gh_block_reproject(w, pts, N, g.xi);
         __syncthreads();

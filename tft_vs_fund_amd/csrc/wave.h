@@ -41,6 +41,7 @@ __device__ inline double wave_uniform(double v) { return v; }
 __device__ inline int wave_uniform_i(int v) { return v; }
 typedef double* lds_ptr;
 __device__ inline lds_ptr to_lds(double* p) { return p; }
+__device__ inline void sched_fence() {}
 #else
 #define TFF_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 // Lanes of one wavefront exchange data through LDS without a workgroup
@@ -74,6 +75,8 @@ __device__ __forceinline__ int wave_uniform_i(int v) { return __builtin_amdgcn_r
 // local address space restores ds_read / ds_write.
 typedef __attribute__((address_space(3))) double* lds_ptr;
 __device__ __forceinline__ lds_ptr to_lds(double* p) { return (lds_ptr)p; }
+// the instruction scheduler does not move anything across this point
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 #endif
 
 // Coarse phase stamps for the *_debug_dev entry points (shader clock, lane 0):

@@ -27,3 +27,7 @@ if variant == 0:
     print("  k_gh_block: model.init %.0f, reprojection %.0f, whole iteration loop %.0f cycles" % ((s4[:, 1] - s4[:, 0]).mean(), (s4[:, 2] - s4[:, 1]).mean(), (s4[:, 3] - s4[:, 2]).mean()))
 for k, nme in enumerate(names):
     print("  %-28s %9.0f  %5.1f%%" % (nme, dt[:, k].mean(), 100 * dt[:, k].mean() / tot.mean()))
+if variant == 0:
+    s3 = dbg[:, 110:113]
+    if s3[:, 2].max() > 0:
+        print("  inside '10 sweeps': strong-direction terms per correspondence %.0f, their sums %.0f cycles" % ((s3[:, 1] - s3[:, 0]).mean(), (s3[:, 2] - s3[:, 1]).mean()))
