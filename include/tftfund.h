@@ -25,12 +25,18 @@
  * Every function returns 0 on success or a negative code (-hipError_t for HIP
  * failures, TFF_E_* otherwise); tff_last_error() gives a thread-local message.
  * `_dev` variants take device pointers valid on the context's device and only
- * enqueue work on the context's stream (no synchronisation; no allocation when a
- * status array is supplied -- then they are safe inside a hipGraph capture; with
- * status == NULL the context grows a scratch status array on first use).  `_host` variants take host pointers and perform
- * H2D, compute, D2H and a stream synchronisation.
- * A context is bound to one device; calls on one context are serialised by its
- * stream; different contexts are independent.  No global state.
+ * enqueue work on the context's stream (no synchronisation).  The context owns device
+ * workspaces (status scratch when status == NULL, the records and spill slices of the
+ * iterative methods) that grow on demand: a call with a larger B or N than any earlier
+ * call of that method may hipMalloc / hipFree.  Inside a hipGraph capture use a `_dev`
+ * entry point only after a warm-up call with the same method and B, N at least as large.
+ * `_host` variants take host pointers and perform H2D, compute, D2H and a stream
+ * synchronisation.
+ * A context is bound to one device.  Its entry points are serialised by an internal lock
+ * (the workspaces are shared state) and its work by its stream; when the stream is changed
+ * (tff_ctx_set_stream) work on the new stream waits, on the device, for the work already
+ * enqueued on the old one.  For concurrent streams or threads use one context each:
+ * different contexts are independent.  No global state.
  */
 #ifndef TFTFUND_H
 #define TFTFUND_H
@@ -240,6 +246,35 @@ int tff_linear_tft_pose_sampled_dev(tff_ctx* ctx, const double* scene, int32_t N
 int tff_linear_f_pose_sampled_dev(tff_ctx* ctx, const double* scene, int32_t Ns, const double* calm,
                                   const int32_t* sample_idx, int64_t B, int32_t n, double* Rt2, double* Rt3,
                                   double* T, int32_t* status);
+
+/* ---- multi-GPU (one process, one host thread + stream per device) ----------------------------------
+ * The reference runs its triplets one after the other in one MATLAB thread (experiments.m:91-108); they are independent,
+ * so a batch is cut into contiguous shards of ceil(B / G) triplets, shard g on device g, with no collective on the data
+ * path.  tff_pose_batch_host_multi lands every shard directly in the caller's host arrays (same argument meaning as the
+ * single-device `_host` entry points).  tff_pose_batch_dev_multi works on device-resident shards and gathers the
+ * fixed-size result records (51 doubles per triplet: Rt2 | Rt3 | T) of all shards onto every device with one
+ * ncclAllGather (RCCL over xGMI; librccl.so is opened on first use). */
+typedef struct tff_multi tff_multi;
+#define TFF_METHOD_LINEAR_TFT 0   /* method ids: the order of experiments.m:51-59 */
+#define TFF_METHOD_RESSL_TFT 1
+#define TFF_METHOD_NORDBERG_TFT 2
+#define TFF_METHOD_FAUGPAPA_TFT 3
+#define TFF_METHOD_PI 4
+#define TFF_METHOD_PICOL 5
+#define TFF_METHOD_LINEAR_F 6
+#define TFF_METHOD_OPTIM_F 7
+int tff_multi_create(tff_multi** out, const int32_t* devices, int32_t n_devices);   /* devices NULL: 0..n-1; n_devices <= 0: all visible */
+void tff_multi_destroy(tff_multi* m);
+int32_t tff_multi_size(const tff_multi* m);
+tff_ctx* tff_multi_ctx(tff_multi* m, int32_t rank);                                  /* per-device context (options, synchronisation) */
+void tff_multi_shard(const tff_multi* m, int64_t B, int32_t rank, int64_t* begin, int64_t* end);   /* [rank*chunk, min(B,(rank+1)*chunk)), chunk = ceil(B/G) */
+int tff_pose_batch_host_multi(tff_multi* m, int32_t method, const double* corresp, const double* calm, int64_t calm_stride,
+                              int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                              int32_t* status);
+/* corresp[g], calm[g]: shard g on device g.  records[g]: G * chunk * 51 doubles on device g; afterwards block r of EVERY
+ * device = [Rt2 (chunk x 12) | Rt3 (chunk x 12) | T (chunk x 27)] of shard r.  status[g] (or status == NULL): G * chunk int32. */
+int tff_pose_batch_dev_multi(tff_multi* m, int32_t method, const double* const* corresp, const double* const* calm,
+                             int64_t calm_stride, int64_t B, int32_t N, double* const* records, int32_t* const* status);
 
 #ifdef __cplusplus
 }

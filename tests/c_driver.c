@@ -70,6 +70,27 @@ int main(void) {
     /* invalid arguments -> error code + message */
     if (tff_linear_tft_pose_batch_host(ctx, NULL, calm, 0, 1, 8, Rt2, Rt3, T, NULL, NULL, status) == 0 || strlen(tff_last_error()) == 0) ++fails;
     tff_ctx_destroy(ctx);
+    /* multi-GPU entry point over all visible devices (one host thread + stream per device; one device: a clique of one) */
+    {
+        tff_multi* mg = NULL;
+        if (tff_multi_create(&mg, NULL, 0) != 0) { fprintf(stderr, "tff_multi_create: %s\n", tff_last_error()); return 4; }
+        double mRt2[B * 12], mRt3[B * 12], mT[B * 27];
+        int32_t mst[B];
+        if (tff_pose_batch_host_multi(mg, TFF_METHOD_LINEAR_TFT, corresp, calm, 0, B, N, mRt2, mRt3, mT, NULL, NULL, mst) != 0) {
+            fprintf(stderr, "tff_pose_batch_host_multi: %s\n", tff_last_error()); return 5;
+        }
+        double worst = 0;
+        for (int b = 0; b < B; ++b) {
+            if (mst[b] != TFF_ST_OK) ++fails;
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) worst = fmax(worst, fabs(mRt2[b * 12 + r + 3 * c] - R2[3 * r + c]));
+        }
+        int64_t b0, b1;
+        tff_multi_shard(mg, B, tff_multi_size(mg) - 1, &b0, &b1);
+        printf("multi (%d device%s)            max |R2 - ground truth| = %.2e, last shard [%lld, %lld)\n", (int)tff_multi_size(mg),
+               tff_multi_size(mg) == 1 ? "" : "s", worst, (long long)b0, (long long)b1);
+        if (!(worst < 1e-7) || b1 != B) ++fails;
+        tff_multi_destroy(mg);
+    }
     free(corresp);
     printf(fails ? "FAILED (%d)\n" : "c_driver ok\n", fails);
     return fails ? 1 : 0;

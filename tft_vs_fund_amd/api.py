@@ -98,11 +98,18 @@ def load_library(path=None):
             "tff_pi_pose_batch_debug_dev": [V, I32, V, V, I64, I64, I32, V, V, V, V, V, V, V, V],
             "tff_linear_tft_pose_sampled_dev": [V, V, I32, V, V, I64, I32, V, V, V, V],
             "tff_linear_f_pose_sampled_dev": [V, V, I32, V, V, I64, I32, V, V, V, V],
+            "tff_multi_create": [ctypes.POINTER(ctypes.c_void_p), V, I32],
+            "tff_pose_batch_host_multi": [V, I32, V, V, I64, I64, I32, V, V, V, V, V, V],
+            "tff_pose_batch_dev_multi": [V, I32, V, V, I64, I64, I32, V, V],
         }
         for name, sig in protos.items():
             fn = getattr(lib, name)
             fn.argtypes = sig
             fn.restype = ctypes.c_int
+        lib.tff_multi_destroy.argtypes = [V]; lib.tff_multi_destroy.restype = None
+        lib.tff_multi_size.argtypes = [V]; lib.tff_multi_size.restype = I32
+        lib.tff_multi_ctx.argtypes = [V, I32]; lib.tff_multi_ctx.restype = V
+        lib.tff_multi_shard.argtypes = [V, I64, I32, ctypes.POINTER(I64), ctypes.POINTER(I64)]; lib.tff_multi_shard.restype = None
         if path is None:
             _lib = lib
         return lib
@@ -134,7 +141,12 @@ EXPORTED_SYMBOLS = [
     "tff_pi_pose_batch_debug_dev",
     "tff_triangulate_batch_dev", "tff_repr_error_batch_dev", "tff_inlier_count_batch_dev", "tff_transform_tft_batch_dev",
     "tff_rt_from_tft_batch_dev", "tff_linear_tft_batch_dev", "tff_linear_f_batch_dev", "tff_bundle_adjust_batch_dev", "tff_bundle_adjust_batch_host", "tff_linear_tft_pose_sampled_dev", "tff_linear_f_pose_sampled_dev",
+    "tff_multi_create", "tff_multi_destroy", "tff_multi_size", "tff_multi_ctx", "tff_multi_shard", "tff_pose_batch_host_multi", "tff_pose_batch_dev_multi",
 ]
+
+# method ids of the multi-GPU entry points (include/tftfund.h TFF_METHOD_*: the order of experiments.m:51-59)
+METHOD_IDS = {"LinearTFTPoseEstimation": 0, "ResslTFTPoseEstimation": 1, "NordbergTFTPoseEstimation": 2, "FaugPapaTFTPoseEstimation": 3,
+              "PiPoseEstimation": 4, "PiColPoseEstimation": 5, "LinearFPoseEstimation": 6, "OptimFPoseEstimation": 7}
 
 
 def _check(lib, rc, what):
@@ -424,13 +436,84 @@ class Context:
                     T=T.reshape(B, 3, 3, 3).permute(0, 3, 2, 1), status=st, _raw=(Rt2, Rt3, T))
 
 
-_default_ctx = {}
+class MultiContext:
+    """A tff_multi: one process, one context + host thread + stream per device (include/tftfund.h, multi-GPU section).
+    `devices`: list of HIP ordinals, or None for all visible devices."""
+
+    def __init__(self, devices=None, lib_path=None):
+        self.lib = load_library(lib_path)
+        h = ctypes.c_void_p()
+        if devices is None:
+            arr, n = None, 0
+        else:
+            arr = (ctypes.c_int32 * len(devices))(*devices); n = len(devices)
+        _check(self.lib, self.lib.tff_multi_create(ctypes.byref(h), arr, n), "tff_multi_create")
+        self.handle = h
+        self.size = int(self.lib.tff_multi_size(h))
+
+    def shard(self, B, rank):
+        b0, b1 = ctypes.c_int64(), ctypes.c_int64()
+        self.lib.tff_multi_shard(self.handle, B, rank, ctypes.byref(b0), ctypes.byref(b1))
+        return b0.value, b1.value
+
+    def pose_batch(self, method, corresp, calm, reconst=True):
+        """Host arrays in, host arrays out: corresp (B, N, 6), calm (9, 3) or (B, 9, 3); the shards run concurrently on the devices."""
+        C = np.ascontiguousarray(corresp, dtype=np.float64)
+        B, N, _ = C.shape
+        calm = np.asarray(calm, dtype=np.float64)
+        if calm.ndim == 2:
+            cm, stride = np.ascontiguousarray(calm.T).reshape(27), 0
+        else:
+            cm, stride = np.ascontiguousarray(calm.transpose(0, 2, 1)).reshape(B, 27), 27
+        Rt2 = np.empty((B, 12)); Rt3 = np.empty((B, 12)); T = np.empty((B, 27))
+        Rec = np.empty((B, N, 3)) if reconst else None
+        it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32)
+        p = lambda a: ctypes.c_void_p(a.ctypes.data) if a is not None else None
+        _check(self.lib, self.lib.tff_pose_batch_host_multi(self.handle, METHOD_IDS[method], p(C), p(cm), stride, B, N, p(Rt2), p(Rt3), p(T),
+                                                            p(Rec), p(it), p(st)), "tff_pose_batch_host_multi")
+        return dict(R_t_2=Rt2.reshape(B, 4, 3).transpose(0, 2, 1), R_t_3=Rt3.reshape(B, 4, 3).transpose(0, 2, 1),
+                    T=T.reshape(B, 3, 3, 3).transpose(0, 3, 2, 1), Reconst=None if Rec is None else Rec.transpose(0, 2, 1), iter=it, status=st)
+
+    def pose_batch_dev(self, method, corresp_shards, calm_shards, B):
+        """Device-resident shards (torch CUDA tensors, shard g on device g, each (b1-b0, N, 6)); returns per device the gathered
+        record tensor (G * chunk, 51) laid out as G blocks [Rt2 (chunk x 12) | Rt3 (chunk x 12) | T (chunk x 27)] and the status."""
+        import torch
+        G = self.size
+        N = int(corresp_shards[0].shape[1])
+        chunk = (B + G - 1) // G
+        recs = [torch.zeros(G * chunk * 51, dtype=torch.float64, device=corresp_shards[g].device) for g in range(G)]
+        sts = [torch.zeros(G * chunk, dtype=torch.int32, device=corresp_shards[g].device) for g in range(G)]
+        cms = [c.t().contiguous().reshape(27) for c in calm_shards]
+        ptr = lambda ts: (ctypes.c_void_p * G)(*[t.data_ptr() for t in ts])
+        _check(self.lib, self.lib.tff_pose_batch_dev_multi(self.handle, METHOD_IDS[method], ptr(corresp_shards), ptr(cms), 0, B, N, ptr(recs), ptr(sts)),
+               "tff_pose_batch_dev_multi")
+        for g in range(G):
+            _check(self.lib, self.lib.tff_ctx_synchronize(self.lib.tff_multi_ctx(self.handle, g)), "synchronize")
+        return recs, sts, chunk
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.tff_multi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = threading.local()
 
 
 def default_context(device=0):
-    c = _default_ctx.get(device)
+    """One context per (thread, device): a context's workspaces are shared state, so threads do not share one."""
+    d = getattr(_default_ctx, "by_device", None)
+    if d is None:
+        d = _default_ctx.by_device = {}
+    c = d.get(device)
     if c is None:
-        c = _default_ctx[device] = Context(device)
+        c = d[device] = Context(device)
     return c
 
 

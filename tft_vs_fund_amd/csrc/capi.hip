@@ -1,6 +1,7 @@
 // C ABI of libtftfund.so (see include/tftfund.h).  gfx950 only; there is no
 // CPU path behind these entry points: without a HIP device they fail loudly.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -21,6 +22,7 @@ int hip_fail(hipError_t e, const char* where) {
     g_err = std::string(where) + ": " + hipGetErrorString(e);
     return -(int)e;
 }
+#define TFF_LOCK(c) std::lock_guard<std::recursive_mutex> lk__((c)->mu)
 #define TFF_HIP(call)                                    \
     do {                                                 \
         hipError_t e__ = (call);                         \
@@ -45,14 +47,17 @@ struct DevBuf {
 }  // namespace
 
 struct tff_ctx {
+    std::recursive_mutex mu;               // serialises the entry points of one context (its workspaces are shared state; _host calls nest)
     int device = 0;
     hipStream_t own = nullptr;
     hipStream_t stream = nullptr;
+    hipEvent_t handover = nullptr;         // orders work across a change of stream (tff_ctx_set_stream)
     int solver = 0;
     int exact_below = tff::EXACT_BELOW_N;   // TFF_OPT_EXACT_BELOW
     int stage = -1;
     DevBuf in, calm, out, idx, scratch_status, gh_rec, gh_topt, spill;
     const int32_t* sample_idx = nullptr;   // set around a *_sampled_dev call
+    int32_t sample_ns = 0;                 //   size of the scene the indices refer to
     double* init_p = nullptr; double* init_x = nullptr;   // set around tff_pi_pose_batch_debug_dev
     int kernel_variant = 0;                // TFF_OPT_KERNEL
     int gh_exact = 0;                      // TFF_OPT_GH_EXACT
@@ -119,6 +124,7 @@ template <class KMain, class KJac>
 int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_n, int occupancy_cap, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
                 int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
+    TFF_LOCK(c);
     if (B == 0) return 0;
     if (!Rt2 || !Rt3 || !T) return fail(TFF_E_INVALID, "null output pointer");
     TFF_HIP(hipSetDevice(c->device));
@@ -127,7 +133,7 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_
         status = (int32_t*)c->scratch_status.p;
     }
     tff::LinearTftArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr),
-                         Rt2, Rt3, T, reconst, iter, status, dbg, c->sample_idx, c->init_p, c->init_x};
+                         Rt2, Rt3, T, reconst, iter, status, dbg, c->sample_idx, c->init_p, c->init_x, nullptr, 0, c->sample_ns};
     if (c->sample_idx) {                   // gathered samples always live in LDS
         if (!stage_max_n) return fail(TFF_E_INVALID, "sampled hypotheses are not supported by this method");
         a.flags |= tff::FLAG_STAGE_LDS;
@@ -139,6 +145,10 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_
         m.flags = stage_max_n ? staged_flags(c, N, a.flags, false, stage_max_n) : a.flags;
         unsigned grid = tff::pose_grid(B);
         size_t lds;
+        if ((m.flags & tff::FLAG_STAGE_LDS) && ldsfn(N, m.flags, false) > LDS_LIMIT) {   // staged correspondences would not fit the LDS
+            if (c->sample_idx) return fail(TFF_E_INVALID, "sample too large for the LDS (sampled hypotheses are gathered into LDS)");
+            m.flags &= ~tff::FLAG_STAGE_LDS;                                              // re-read them through L2 instead
+        }
         if (int r = plan_spill(c, ldsfn(N, m.flags, false), ldsfn(0, m.flags, false), &grid, &m.spill, &m.spill_stride, &lds, occupancy_cap)) return r;
         if (int r = ensure_lds(kmain, lds)) return r;
         hipLaunchKernelGGL(kmain, dim3(grid), dim3(64), lds, c->stream, m);
@@ -148,6 +158,10 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_
     if (stage_max_n) a.flags = staged_flags(c, N, a.flags, true, stage_max_n);
     unsigned grid = !all_exact ? (unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID) : tff::pose_grid(B);
     size_t lds;
+    if ((a.flags & tff::FLAG_STAGE_LDS) && ldsfn(N, a.flags, true) > LDS_LIMIT) {
+        if (c->sample_idx) return fail(TFF_E_INVALID, "sample too large for the LDS (sampled hypotheses are gathered into LDS)");
+        a.flags &= ~tff::FLAG_STAGE_LDS;
+    }
     if (int r = plan_spill(c, ldsfn(N, a.flags, true), ldsfn(0, a.flags, true), &grid, &a.spill, &a.spill_stride, &lds)) return r;
     if (int r = ensure_lds(kjac, lds)) return r;
     hipLaunchKernelGGL(kjac, dim3(grid), dim3(64), lds, c->stream, a);
@@ -179,6 +193,7 @@ template <class KBlock, class LdsFn>
 int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
+    TFF_LOCK(c);
     if (B == 0) return 0;
     if (!Rt2 || !Rt3 || !T) return fail(TFF_E_INVALID, "null output pointer");
     TFF_HIP(hipSetDevice(c->device));
@@ -277,6 +292,7 @@ typedef int (*pose_launcher)(tff_ctx*, const double*, const double*, int64_t, in
 int pose_batch_host(pose_launcher launch, tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
                     int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
+    TFF_LOCK(c);
     if (B == 0) return 0;
     if (!Rt2 || !Rt3 || !T) return fail(TFF_E_INVALID, "null output pointer");
     TFF_HIP(hipSetDevice(c->device));
@@ -336,24 +352,38 @@ void tff_ctx_destroy(tff_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own) { (void)hipStreamSynchronize(c->own); (void)hipStreamDestroy(c->own); }
+    if (c->handover) (void)hipEventDestroy(c->handover);
     c->in.release(); c->calm.release(); c->out.release(); c->idx.release(); c->scratch_status.release(); c->gh_rec.release(); c->gh_topt.release(); c->spill.release();
     delete c;
 }
 
+// The workspaces of a context (status scratch, Gauss-Helmert records, spill slices, host-path staging) are reused by every
+// call, so work enqueued on the previous stream must finish before work on the new one touches them: an event recorded on the
+// old stream, waited for by the new one (no host synchronisation).
+static int switch_stream(tff_ctx* c, hipStream_t s) {
+    if (s == c->stream) return 0;
+    TFF_HIP(hipSetDevice(c->device));
+    if (!c->handover) TFF_HIP(hipEventCreateWithFlags(&c->handover, hipEventDisableTiming));
+    TFF_HIP(hipEventRecord(c->handover, c->stream));
+    TFF_HIP(hipStreamWaitEvent(s, c->handover, 0));
+    c->stream = s;
+    return 0;
+}
 int tff_ctx_set_stream(tff_ctx* c, void* s) {
     if (!c) return fail(TFF_E_INVALID, "null context");
-    c->stream = (hipStream_t)s;
-    return 0;
+    TFF_LOCK(c);
+    return switch_stream(c, (hipStream_t)s);
 }
 int tff_ctx_use_own_stream(tff_ctx* c) {
     if (!c) return fail(TFF_E_INVALID, "null context");
-    c->stream = c->own;
-    return 0;
+    TFF_LOCK(c);
+    return switch_stream(c, c->own);
 }
 void* tff_ctx_get_stream(tff_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int tff_ctx_set_option(tff_ctx* c, int option, long value) {
     if (!c) return fail(TFF_E_INVALID, "null context");
+    TFF_LOCK(c);
     switch (option) {
         case TFF_OPT_SOLVER: if (value != 0 && value != 1) return fail(TFF_E_INVALID, "solver must be 0 or 1"); c->solver = (int)value; return 0;
         case TFF_OPT_EXACT_BELOW: if (value < 0 || value > (1L << 30)) return fail(TFF_E_INVALID, "exact_below must be >= 0"); c->exact_below = (int)value; return 0;
@@ -366,6 +396,7 @@ int tff_ctx_set_option(tff_ctx* c, int option, long value) {
 
 int tff_ctx_synchronize(tff_ctx* c) {
     if (!c) return fail(TFF_E_INVALID, "null context");
+    TFF_LOCK(c);
     TFF_HIP(hipSetDevice(c->device));
     TFF_HIP(hipStreamSynchronize(c->stream));
     return 0;
@@ -457,6 +488,7 @@ int tff_pi_pose_batch_debug_dev(tff_ctx* c, int32_t collinear, const double* cor
                                  int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status,
                                  double* init_p, double* init_x) {
     if (!c) return fail(TFF_E_INVALID, "null context");
+    TFF_LOCK(c);
     if ((init_p == nullptr) != (init_x == nullptr)) return fail(TFF_E_INVALID, "init_p and init_x come together");
     c->init_p = init_p; c->init_x = init_x;
     const int r = (collinear ? launch_picol : launch_pi)(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, nullptr);
@@ -492,6 +524,7 @@ int tff_linear_f_pose_batch_host(tff_ctx* c, const double* corresp, const double
 int tff_triangulate_batch_dev(tff_ctx* c, const double* cams, int64_t cam_stride, const double* pts, int64_t B, int32_t M,
                               int32_t N, double* X) {
     if (!c) return fail(TFF_E_INVALID, "null context");
+    TFF_LOCK(c);
     if (B < 0 || N < 0 || (M != 2 && M != 3)) return fail(TFF_E_INVALID, "triangulate: M must be 2 or 3");    // triangulation3D.m:33,46
     if (cam_stride != 0 && cam_stride != 12 * M) return fail(TFF_E_INVALID, "cam_stride must be 0 or 12*M");
     if (B == 0 || N == 0) return 0;
@@ -506,6 +539,7 @@ int tff_triangulate_batch_dev(tff_ctx* c, const double* cams, int64_t cam_stride
 int tff_repr_error_batch_dev(tff_ctx* c, const double* cams, int64_t cam_stride, const double* corresp, int64_t corresp_stride,
                              const double* pts3d, int64_t B, int32_t N, double* err) {
     if (!c) return fail(TFF_E_INVALID, "null context");
+    TFF_LOCK(c);
     if (B < 0 || N < 0) return fail(TFF_E_INVALID, "negative size");
     if (cam_stride != 0 && cam_stride != 36) return fail(TFF_E_INVALID, "cam_stride must be 0 or 36");
     if (corresp_stride != 0 && corresp_stride != 6 * (int64_t)N) return fail(TFF_E_INVALID, "corresp_stride must be 0 or 6*N");
@@ -521,6 +555,7 @@ int tff_repr_error_batch_dev(tff_ctx* c, const double* cams, int64_t cam_stride,
 int tff_inlier_count_batch_dev(tff_ctx* c, const double* scene, int32_t Ns, const double* calm, const double* Rt2, const double* Rt3,
                                int64_t B, double threshold, int32_t* counts, double* err) {
     if (!c) return fail(TFF_E_INVALID, "null context");
+    TFF_LOCK(c);
     if (B < 0 || Ns < 0) return fail(TFF_E_INVALID, "negative size");
     if (B == 0) return 0;
     if (!scene || !calm || !Rt2 || !Rt3 || !counts) return fail(TFF_E_INVALID, "null pointer");
@@ -534,6 +569,7 @@ int tff_inlier_count_batch_dev(tff_ctx* c, const double* scene, int32_t Ns, cons
 int tff_transform_tft_batch_dev(tff_ctx* c, const double* T, const double* M1, const double* M2, const double* M3, int64_t m_stride,
                                 int64_t B, int32_t inverse, double* Tout) {
     if (!c) return fail(TFF_E_INVALID, "null context");
+    TFF_LOCK(c);
     if (B < 0 || (m_stride != 0 && m_stride != 9) || (inverse != 0 && inverse != 1)) return fail(TFF_E_INVALID, "bad argument");
     if (B == 0) return 0;
     if (!T || !M1 || !M2 || !M3 || !Tout) return fail(TFF_E_INVALID, "null pointer");
@@ -547,6 +583,7 @@ int tff_transform_tft_batch_dev(tff_ctx* c, const double* T, const double* M1, c
 int tff_rt_from_tft_batch_dev(tff_ctx* c, const double* T, const double* calm, int64_t calm_stride, const double* corresp, int64_t B,
                               int32_t N, double* Rt2, double* Rt3, int32_t* status) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
+    TFF_LOCK(c);
     if (B == 0) return 0;
     if (!T || !Rt2 || !Rt3) return fail(TFF_E_INVALID, "null pointer");
     TFF_HIP(hipSetDevice(c->device));
@@ -560,6 +597,7 @@ int tff_rt_from_tft_batch_dev(tff_ctx* c, const double* T, const double* calm, i
 int tff_linear_tft_batch_dev(tff_ctx* c, const double* corresp, int64_t B, int32_t N, double* T, double* P2, double* P3,
                              int32_t* status) {
     if (!c) return fail(TFF_E_INVALID, "null context");
+    TFF_LOCK(c);
     if (B < 0 || N < 0) return fail(TFF_E_INVALID, "negative size");
     if (B == 0) return 0;
     if (!corresp || !T || ((P2 == nullptr) != (P3 == nullptr))) return fail(TFF_E_INVALID, "null pointer (P2 and P3 come together)");
@@ -586,6 +624,7 @@ int tff_bundle_adjust_batch_dev(tff_ctx* c, const double* calm, int64_t calm_str
                                 const double* corresp, int64_t B, int32_t N, const double* reconst0, double* Rt2, double* Rt3,
                                 double* reconst, int32_t* iter, double* repr_err, int32_t* status) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
+    TFF_LOCK(c);
     if (B == 0) return 0;
     if (!Rt2_in || !Rt3_in || !Rt2 || !Rt3) return fail(TFF_E_INVALID, "null pose pointer");
     if (N < 1) return fail(TFF_E_INVALID, "bundle adjustment needs at least one correspondence");
@@ -603,6 +642,7 @@ int tff_bundle_adjust_batch_host(tff_ctx* c, const double* calm, int64_t calm_st
                                  const double* corresp, int64_t B, int32_t N, const double* reconst0, double* Rt2, double* Rt3,
                                  double* reconst, int32_t* iter, double* repr_err, int32_t* status) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
+    TFF_LOCK(c);
     if (B == 0) return 0;
     if (!Rt2_in || !Rt3_in || !Rt2 || !Rt3) return fail(TFF_E_INVALID, "null pose pointer");
     TFF_HIP(hipSetDevice(c->device));
@@ -637,6 +677,7 @@ int tff_bundle_adjust_batch_host(tff_ctx* c, const double* calm, int64_t calm_st
 int tff_linear_f_batch_dev(tff_ctx* c, const double* corresp, int64_t B, int32_t N, int32_t refine, double* F21, double* F31,
                            int32_t* iter, int32_t* status) {
     if (!c) return fail(TFF_E_INVALID, "null context");
+    TFF_LOCK(c);
     if (B < 0 || N < 0) return fail(TFF_E_INVALID, "negative size");
     if (B == 0) return 0;
     if (!corresp || !F21 || !F31) return fail(TFF_E_INVALID, "null pointer");
@@ -674,19 +715,214 @@ int tff_linear_f_batch_dev(tff_ctx* c, const double* corresp, int64_t B, int32_t
 // Minimal-sample hypotheses (config 4): hypothesis b uses correspondences sample_idx[b*n .. b*n+n) of ONE shared scene.
 int tff_linear_tft_pose_sampled_dev(tff_ctx* c, const double* scene, int32_t Ns, const double* calm, const int32_t* sample_idx, int64_t B,
                                     int32_t n, double* Rt2, double* Rt3, double* T, int32_t* status) {
+    if (!c) return fail(TFF_E_INVALID, "null context");
     if (!sample_idx || Ns <= 0) return fail(TFF_E_INVALID, "null sample indices / empty scene");
-    c->sample_idx = sample_idx;
+    TFF_LOCK(c);
+    c->sample_idx = sample_idx; c->sample_ns = Ns;
     const int r = launch_linear_tft(c, scene, calm, 0, B, n, Rt2, Rt3, T, nullptr, nullptr, status, nullptr);
-    c->sample_idx = nullptr;
+    c->sample_idx = nullptr; c->sample_ns = 0;
     return r;
 }
 int tff_linear_f_pose_sampled_dev(tff_ctx* c, const double* scene, int32_t Ns, const double* calm, const int32_t* sample_idx, int64_t B,
                                   int32_t n, double* Rt2, double* Rt3, double* T, int32_t* status) {
+    if (!c) return fail(TFF_E_INVALID, "null context");
     if (!sample_idx || Ns <= 0) return fail(TFF_E_INVALID, "null sample indices / empty scene");
-    c->sample_idx = sample_idx;
+    TFF_LOCK(c);
+    c->sample_idx = sample_idx; c->sample_ns = Ns;
     const int r = launch_linear_f(c, scene, calm, 0, B, n, Rt2, Rt3, T, nullptr, nullptr, status, nullptr);
-    c->sample_idx = nullptr;
+    c->sample_idx = nullptr; c->sample_ns = 0;
     return r;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU behind the C ABI: ONE process, one context + one host thread + one stream per
+// device; the batch is cut into contiguous shards of ceil(B / G) triplets; independent triplets need no
+// collective on the data path.  The _host variant lands every shard directly in the caller's host
+// arrays.  The _dev variant leaves shard g on device g and then gathers the fixed-size result records
+// of all shards onto every device with ONE ncclAllGather over xGMI (RCCL, single-process communicators
+// from ncclCommInitAll; librccl.so is opened on first use, libtftfund.so itself does not depend on it).
+// ---------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <thread>
+
+struct tff_multi {
+    std::vector<tff_ctx*> ctx;
+    std::vector<int> devices;
+    // RCCL (lazily): communicators of the single-process clique, one per device
+    void* rccl = nullptr;
+    std::vector<void*> comms;
+    int (*p_init_all)(void**, int, const int*) = nullptr;
+    int (*p_allgather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*p_group_start)() = nullptr;
+    int (*p_group_end)() = nullptr;
+    int (*p_comm_destroy)(void*) = nullptr;
+    const char* (*p_err)(int) = nullptr;
+};
+
+namespace {
+
+pose_launcher method_launcher(int32_t method) {
+    switch (method) {
+        case TFF_METHOD_LINEAR_TFT: return launch_linear_tft;
+        case TFF_METHOD_RESSL_TFT: return launch_ressl_tft;
+        case TFF_METHOD_NORDBERG_TFT: return launch_nordberg_tft;
+        case TFF_METHOD_FAUGPAPA_TFT: return launch_faugpapa_tft;
+        case TFF_METHOD_PI: return launch_pi;
+        case TFF_METHOD_PICOL: return launch_picol;
+        case TFF_METHOD_LINEAR_F: return launch_linear_f;
+        case TFF_METHOD_OPTIM_F: return launch_optim_f;
+        default: return nullptr;
+    }
+}
+
+int multi_load_rccl(tff_multi* m) {
+    if (m->rccl) return 0;
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(TFF_E_INVALID, "librccl.so not found (needed only by tff_pose_batch_dev_multi)");
+    m->p_init_all = (int (*)(void**, int, const int*))dlsym(h, "ncclCommInitAll");
+    m->p_allgather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+    m->p_group_start = (int (*)())dlsym(h, "ncclGroupStart");
+    m->p_group_end = (int (*)())dlsym(h, "ncclGroupEnd");
+    m->p_comm_destroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    m->p_err = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!m->p_init_all || !m->p_allgather || !m->p_group_start || !m->p_group_end || !m->p_comm_destroy) {
+        dlclose(h);
+        return fail(TFF_E_INVALID, "librccl.so lacks the expected symbols");
+    }
+    m->comms.assign(m->ctx.size(), nullptr);
+    const int rc = m->p_init_all(m->comms.data(), (int)m->devices.size(), m->devices.data());
+    if (rc != 0) {
+        g_err = std::string("ncclCommInitAll: ") + (m->p_err ? m->p_err(rc) : "error");
+        dlclose(h);
+        m->comms.clear();
+        return TFF_E_INVALID;
+    }
+    m->rccl = h;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tff_multi_create(tff_multi** out, const int32_t* devices, int32_t n_devices) {
+    if (!out) return fail(TFF_E_INVALID, "null out pointer");
+    *out = nullptr;
+    int have = 0;
+    TFF_HIP(hipGetDeviceCount(&have));
+    if (n_devices <= 0) n_devices = have;                                    // all visible devices
+    if (n_devices <= 0 || n_devices > have) return fail(TFF_E_INVALID, "no such set of HIP devices");
+    tff_multi* m = new (std::nothrow) tff_multi();
+    if (!m) return fail(TFF_E_NOMEM, "out of host memory");
+    for (int g = 0; g < n_devices; ++g) {
+        const int dev = devices ? devices[g] : g;
+        for (int d : m->devices) if (d == dev) { tff_multi_destroy(m); return fail(TFF_E_INVALID, "duplicate device"); }
+        tff_ctx* c = nullptr;
+        const int rc = tff_ctx_create(&c, dev);
+        if (rc != 0) { tff_multi_destroy(m); return rc; }
+        m->ctx.push_back(c);
+        m->devices.push_back(dev);
+    }
+    *out = m;
+    return 0;
+}
+
+void tff_multi_destroy(tff_multi* m) {
+    if (!m) return;
+    if (m->rccl) {
+        for (void* cm : m->comms) if (cm) (void)m->p_comm_destroy(cm);
+        dlclose(m->rccl);
+    }
+    for (tff_ctx* c : m->ctx) tff_ctx_destroy(c);
+    delete m;
+}
+
+int32_t tff_multi_size(const tff_multi* m) { return m ? (int32_t)m->ctx.size() : 0; }
+tff_ctx* tff_multi_ctx(tff_multi* m, int32_t rank) { return (m && rank >= 0 && rank < (int32_t)m->ctx.size()) ? m->ctx[rank] : nullptr; }
+
+void tff_multi_shard(const tff_multi* m, int64_t B, int32_t rank, int64_t* begin, int64_t* end) {
+    const int64_t G = m ? (int64_t)m->ctx.size() : 1;
+    const int64_t chunk = (B + G - 1) / G;
+    int64_t b0 = chunk * rank, b1 = b0 + chunk;
+    if (b0 > B) b0 = B;
+    if (b1 > B) b1 = B;
+    if (begin) *begin = b0;
+    if (end) *end = b1;
+}
+
+int tff_pose_batch_host_multi(tff_multi* m, int32_t method, const double* corresp, const double* calm, int64_t calm_stride,
+                              int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                              int32_t* status) {
+    if (!m) return fail(TFF_E_INVALID, "null multi-GPU handle");
+    pose_launcher launch = method_launcher(method);
+    if (!launch) return fail(TFF_E_INVALID, "unknown method id");
+    if (B < 0 || N < 0) return fail(TFF_E_INVALID, "negative batch or correspondence count");
+    if (calm_stride != 0 && calm_stride != 27) return fail(TFF_E_INVALID, "calm_stride must be 0 (shared CalM) or 27");
+    const int G = (int)m->ctx.size();
+    std::vector<int> rc(G, 0);
+    std::vector<std::string> msg(G);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g) {
+        th.emplace_back([&, g]() {
+            int64_t b0, b1;
+            tff_multi_shard(m, B, g, &b0, &b1);
+            if (b1 <= b0) return;
+            rc[g] = pose_batch_host(launch, m->ctx[g], corresp + b0 * 6 * (int64_t)N, calm + b0 * calm_stride, calm_stride, b1 - b0, N,
+                                    Rt2 + b0 * 12, Rt3 + b0 * 12, T + b0 * 27, reconst ? reconst + b0 * 3 * (int64_t)N : nullptr,
+                                    iter ? iter + b0 : nullptr, status ? status + b0 : nullptr);
+            if (rc[g] != 0) msg[g] = g_err;                                  // tff_last_error() is thread-local: carry it over
+        });
+    }
+    for (auto& t : th) t.join();
+    for (int g = 0; g < G; ++g) if (rc[g] != 0) { g_err = "device " + std::to_string(m->devices[g]) + ": " + msg[g]; return rc[g]; }
+    return 0;
+}
+
+// Device-resident variant.  corresp[g], calm[g]: device pointers ON DEVICE g holding shard g of the batch (shard bounds:
+// tff_multi_shard).  records[g]: device buffer on device g of G * chunk * 51 doubles, chunk = ceil(B / G); after the call
+// EVERY device holds all shards: block r (chunk * 51 doubles) = [Rt2 (chunk x 12) | Rt3 (chunk x 12) | T (chunk x 27)] of
+// shard r.  status[g] (optional): G * chunk int32 per device, gathered the same way.  Work is enqueued on each context's
+// stream; tff_ctx_synchronize(tff_multi_ctx(m, g)) to wait.
+int tff_pose_batch_dev_multi(tff_multi* m, int32_t method, const double* const* corresp, const double* const* calm,
+                             int64_t calm_stride, int64_t B, int32_t N, double* const* records, int32_t* const* status) {
+    if (!m) return fail(TFF_E_INVALID, "null multi-GPU handle");
+    pose_launcher launch = method_launcher(method);
+    if (!launch) return fail(TFF_E_INVALID, "unknown method id");
+    if (!corresp || !calm || !records) return fail(TFF_E_INVALID, "null pointer array");
+    if (int r = multi_load_rccl(m)) return r;
+    const int G = (int)m->ctx.size();
+    const int64_t chunk = (B + G - 1) / G;
+    std::vector<int> rc(G, 0);
+    std::vector<std::string> msg(G);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g) {
+        th.emplace_back([&, g]() {
+            int64_t b0, b1;
+            tff_multi_shard(m, B, g, &b0, &b1);
+            if (b1 <= b0) return;
+            double* blk = records[g] + (int64_t)g * chunk * 51;
+            rc[g] = launch(m->ctx[g], corresp[g], calm[g], calm_stride, b1 - b0, N, blk, blk + chunk * 12, blk + chunk * 24, nullptr, nullptr,
+                           status ? status[g] + (int64_t)g * chunk : nullptr, nullptr);
+            if (rc[g] != 0) msg[g] = g_err;
+        });
+    }
+    for (auto& t : th) t.join();
+    for (int g = 0; g < G; ++g) if (rc[g] != 0) { g_err = "device " + std::to_string(m->devices[g]) + ": " + msg[g]; return rc[g]; }
+    // one collective per result kind, all devices in one group (single-process clique)
+    int nrc = m->p_group_start();
+    for (int g = 0; g < G && nrc == 0; ++g) {
+        TFF_HIP(hipSetDevice(m->devices[g]));
+        nrc = m->p_allgather(records[g] + (int64_t)g * chunk * 51, records[g], (size_t)(chunk * 51), 8 /* ncclFloat64 */, m->comms[g], m->ctx[g]->stream);
+        if (nrc == 0 && status) nrc = m->p_allgather(status[g] + (int64_t)g * chunk, status[g], (size_t)chunk, 2 /* ncclInt32 */, m->comms[g], m->ctx[g]->stream);
+    }
+    const int erc = m->p_group_end();
+    if (nrc == 0) nrc = erc;
+    if (nrc != 0) { g_err = std::string("ncclAllGather: ") + (m->p_err ? m->p_err(nrc) : "error"); return TFF_E_INVALID; }
+    return 0;
 }
 
 }  // extern "C"

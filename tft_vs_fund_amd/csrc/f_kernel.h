@@ -396,8 +396,9 @@ __global__ void __launch_bounds__(64, METHOD == 1 ? 3 : 2) k_f_pose(const Linear
         const double* src = a.corresp + b * 6 * (long)N;
         const double* pts = src;
         wave_sync();
+        bool bad_index = false;
         if (a.sample_idx) {
-            gather_points(a.corresp, a.sample_idx + b * (long)N, lds_pts, N);
+            bad_index = gather_points(a.corresp, a.sample_idx + b * (long)N, lds_pts, N, a.sample_ns);
             pts = lds_pts;
         } else if (a.flags & FLAG_STAGE_LDS) {
             stage_points(src, lds_pts, N);
@@ -405,7 +406,7 @@ __global__ void __launch_bounds__(64, METHOD == 1 ? 3 : 2) k_f_pose(const Linear
         }
         if (lane < 27) w->calm[lane] = a.calm[b * a.calm_stride + lane];
         int status = ST_OK, iters = 0;
-        if (N < 8) {                                                         // linearF.m:35-37, optimF.m:36-38
+        if (N < 8 || bad_index) {                                            // linearF.m:35-37, optimF.m:36-38 (or a sample index outside the scene)
             status = ST_TOO_FEW;
             const double qnan = __longlong_as_double(0x7ff8000000000000LL);
             if (lane < 12) { a.Rt2[b * 12 + lane] = qnan; a.Rt3[b * 12 + lane] = qnan; }

@@ -783,10 +783,11 @@ __device__ __forceinline__ bool spd_inverse_packed(const double (&W)[E][E], doub
     return ok;
 }
 
-// pinv(W + 1e-12 I) under MATLAB's tolerance tolW for a positive semi-definite block whose ONLY eigenvalue below the tolerance is its
-// (shifted) null direction n -- the generic case of the rank-(E-1) weight blocks once 4N eps(|W|) exceeds 1e-12.  With
-// Wn = W + 1e-12 I + n n' (well conditioned, so its Cholesky inverse is accurate)
-//     pinv = Wn^-1 - n n' / (1 + 1e-12)
+// pinv(W) under MATLAB's tolerance tolW for a positive definite block W (= B B' + 1e-12 I ALREADY: the callers pass the shifted
+// matrix) whose ONLY eigenvalue at or below the tolerance is its shifted null direction n -- the generic case of the rank-(E-1)
+// weight blocks once E N eps(|W|) exceeds 1e-12.  With lam = n'Wn that eigenvalue and Wn = W + n n' (well conditioned, so its
+// Cholesky inverse is accurate)
+//     pinv = Wn^-1 - n n' / (1 + lam)
 // exactly, at a fifth of the cost of the Jacobi eigen-decomposition.  Returns false when the structure does not hold (no eigenvalue
 // under the tolerance, a second one, or a failed factorisation): the caller then takes the eigen-decomposition.
 template <int E>
@@ -801,19 +802,20 @@ __device__ __forceinline__ bool pinv_one_null_packed(const double (&W)[E][E], co
         for (int c = 0; c < E; ++c) wn += W[a][c] * n[c];
         lam += n[a] * wn;
     }
-    if (!(lam + 1e-12 <= tolW)) return false;                                // nothing is truncated here (or NaN)
+    if (!(lam <= tolW)) return false;                                        // nothing is truncated here (or NaN)
     double Wn[E][E];
 #pragma unroll
     for (int a = 0; a < E; ++a)
 #pragma unroll
-        for (int c = 0; c < E; ++c) Wn[a][c] = W[a][c] + n[a] * n[c] + ((a == c) ? 1e-12 : 0.0);
+        for (int c = 0; c < E; ++c) Wn[a][c] = W[a][c] + n[a] * n[c];
     if (!spd_inverse_packed<E>(Wn, Wp)) return false;
+    const double kn = 1.0 / (1.0 + lam);
     double fro2 = 0.0;
 #pragma unroll
     for (int a = 0; a < E; ++a)
 #pragma unroll
         for (int c = 0; c <= a; ++c) {
-            const double v = Wp[a * (a + 1) / 2 + c] - n[a] * n[c] / (1.0 + 1e-12);
+            const double v = Wp[a * (a + 1) / 2 + c] - n[a] * n[c] * kn;
             Wp[a * (a + 1) / 2 + c] = v;
             fro2 += (a == c) ? v * v : 2.0 * v * v;
         }

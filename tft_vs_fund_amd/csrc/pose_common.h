@@ -87,15 +87,22 @@ __device__ inline void stage_points(const double* __restrict__ src, double* dst,
     wave_sync();
 }
 
-// Minimal-sample hypotheses (config 4): gather N correspondences of one shared scene by index.
-__device__ inline void gather_points(const double* __restrict__ scene, const int* __restrict__ idx, double* dst, int N) {
+// Minimal-sample hypotheses (config 4): gather N correspondences of one shared scene by index.  Returns true (wave-uniform)
+// when an index falls outside [0, Ns): that correspondence is not read (zeros) and the caller reports ST_TOO_FEW.
+__device__ inline bool gather_points(const double* __restrict__ scene, const int* __restrict__ idx, double* dst, int N, int Ns) {
     const int lane = lane_id();
+    bool bad = false;
     for (int e = lane; e < 3 * N; e += WAVE) {
         const int i = e / 3, part = e % 3;
-        const double2* s2 = reinterpret_cast<const double2*>(scene + 6 * (long)idx[i]);
-        reinterpret_cast<double2*>(dst)[e] = s2[part];
+        const int k = idx[i];
+        const bool ok = k >= 0 && k < Ns;
+        bad = bad || !ok;
+        double2 v; v.x = 0.0; v.y = 0.0;
+        if (ok) v = reinterpret_cast<const double2*>(scene + 6 * (long)k)[part];
+        reinterpret_cast<double2*>(dst)[e] = v;
     }
     wave_sync();
+    return wave_any(bad);
 }
 
 // Normalize2Ddata.m:33-39 for the three views at once.  nrm[3v..3v+2] = s, ox, oy.

@@ -63,6 +63,7 @@ struct LinearTftArgs {
     double* init_x;          // with init_p: B x 6N initial observation estimates
     double* spill;           // null, or global workspace for the per-correspondence state of the iterative methods when it does not
     long spill_stride;       //   fit the 160 KB of LDS (large N): gridDim.x blocks of spill_stride doubles
+    int sample_ns;           // with sample_idx: number of correspondences in the shared scene (indices outside [0, sample_ns) -> ST_TOO_FEW)
 };
 
 // Inverse-iteration cap before a triplet is handed to the Jacobi fix-up pass: 300 iterations (~0.13 M
@@ -430,8 +431,9 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose(const LinearTftArgs a
         const double* src = a.corresp + b * 6 * (long)N;
         const double* pts = src;
         wave_sync();
+        bool bad_index = false;
         if (a.sample_idx) {
-            gather_points(a.corresp, a.sample_idx + b * (long)N, lds_pts, N);
+            bad_index = gather_points(a.corresp, a.sample_idx + b * (long)N, lds_pts, N, a.sample_ns);
             pts = lds_pts;
         } else if (a.flags & FLAG_STAGE_LDS) {
             stage_points(src, lds_pts, N);
@@ -440,7 +442,7 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose(const LinearTftArgs a
         if (lane < 27) w->calm[lane] = a.calm[b * a.calm_stride + lane];
         phase_stamp(dbg, 0);
         int status = ST_OK;
-        if (N < 7) {                                                         // experiments.m:99
+        if (N < 7 || bad_index) {                                            // experiments.m:99 (or a sample index outside the scene)
             status = ST_TOO_FEW;
             const double qnan = __longlong_as_double(0x7ff8000000000000LL);
             if (lane < 12) { a.Rt2[b * 12 + lane] = qnan; a.Rt3[b * 12 + lane] = qnan; }

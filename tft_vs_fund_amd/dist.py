@@ -100,3 +100,33 @@ def all_gather_counts(local_counts, B):
         lo, hi = shard_bounds(B, world, r)
         parts.append(out[r * bmax: r * bmax + (hi - lo)])
     return torch.cat(parts)
+
+
+class OverlappedGather:
+    """The double-buffered step / gather pipeline of bench.py: step k computes into record buffer k % nbuf and then
+    all-gathers it with async_op=True, so that the gather of step k overlaps the compute of step k + 1; a buffer is reused only
+    after its previous gather has completed.  `compute(record_buffer, k)` enqueues the work of one step (the HIP launch in
+    bench.py; a stub in the gloo test).  world == 1: no collective, no extra buffers."""
+
+    def __init__(self, world, numel, device, compute, nbuf=2, dtype=torch.float64):
+        self.world, self.nbuf, self.compute = world, nbuf, compute
+        self.recs = [torch.empty(numel, dtype=dtype, device=device) for _ in range(nbuf)]
+        self.gathered = [torch.empty((world, numel), dtype=dtype, device=device) for _ in range(nbuf)] if world > 1 else None
+        self.pending = [None] * nbuf
+
+    def step(self, k):
+        buf = k % self.nbuf
+        if self.pending[buf] is not None:              # the gather that last used this buffer
+            self.pending[buf].wait()
+            self.pending[buf] = None
+        r = self.recs[buf]
+        self.compute(r, k)
+        if self.world > 1:
+            self.pending[buf] = dist.all_gather_into_tensor(self.gathered[buf].reshape(-1), r, async_op=True)
+        return buf
+
+    def drain(self):
+        for i in range(self.nbuf):
+            if self.pending[i] is not None:
+                self.pending[i].wait()
+                self.pending[i] = None
