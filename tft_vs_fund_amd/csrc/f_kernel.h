@@ -304,7 +304,7 @@ __device__ inline bool linear_f_wave(PoseLds* w, JacobiLds* jw, const double* pt
             }
             double r2, risk;
             x = wave_min_eigvec_reg<9>(g, diag, w->Lp, EIG_MAXIT, &its, &r2, false, 0.0, &risk);
-            ok = ok && eig_converged(r2) && risk < GRAM_RISK_MAX;
+            ok = ok && eig_converged(r2) && risk == 0.0;
         }
         if (dbg && lane == 0) dbg[69 + pair] = (double)its;
         // F = reshape(V(:,9),3,3): F(rr,cc) = v[rr + 3 cc]   (linearF.m:55); stored row-major

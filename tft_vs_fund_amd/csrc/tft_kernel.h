@@ -214,7 +214,8 @@ __device__ inline void tft_system_qr(const double* pts, const int N, const doubl
 // Leaves the constrained tensor in w->t, the epipoles in w->epi and (if want_P) linearTFT's `a`
 // (P2 = [reshape(a(1:9),3,3) e21], P3 = [reshape(a(10:18),3,3) e31]) in w->pa.
 // Returns false when a fast tier could not finish (EXACT = false only): eigen-solve not converged or at risk, null vector capped.
-constexpr double GRAM_RISK_MAX = 1e7;      // |G| / (lambda_(n-1) - lambda_n) beyond which the Gram eigenvector is not trusted (error ~ 1e-16 x this)
+// |G| / (lambda_(n-1) - lambda_n) beyond which the Gram eigenvector is not trusted: 1e7 (error ~ 1e-16 x this), the default limit of
+// wave_min_eigvec_reg's gram_risk flag
 template <bool JAC, int G>
 __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double* pts, int N, bool want_P, double* dbg) {
     static_assert(!JAC || G == 64, "the exact solver works on whole wavefronts");
@@ -238,7 +239,7 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double
             phase_stamp(dbg, 3, wl);
             double r2, risk;
             x = wave_min_eigvec_reg<27, G>(g, diag, w->Lp, EIG_MAXIT, &it1, &r2, false, 0.0, &risk);
-            ok = ok && eig_converged(r2) && risk < GRAM_RISK_MAX;
+            ok = ok && eig_converged(r2) && risk == 0.0;
         }
         if (lane < 27) w->t[lane] = x;
         wave_sync();
@@ -317,7 +318,7 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double
         }
         double r2, risk;
         x = wave_min_eigvec_reg<15, G>(g, diag, w->Lp, EIG_MAXIT, &it2, &r2, true, tp0, &risk);
-        ok = ok && eig_converged(r2) && risk < GRAM_RISK_MAX;
+        ok = ok && eig_converged(r2) && risk == 0.0;
         if (lane < 15) w->tp[lane] = x;
         wave_sync();
     }

@@ -36,10 +36,10 @@ __device__ __forceinline__ int tri_index(int r, int c) { return (r * (r + 1)) / 
 // On return lane r (< n) holds component r of the unit eigenvector of the smallest eigenvalue; *iters = iterations used,
 // *resid2 = 0 when the iteration converged, else the last squared step.
 // has_start / start: optional initial guess (component `lane` on lane `lane`), default the uniform vector.
-// *gap_risk (optional): an estimate of 1 / (lambda_(n-1) - lambda_n) from the observed convergence rate and the final
-// Rayleigh quotient -- multiplied by eps |G| it bounds the rounding error of an eigenvector taken from a FORMED Gram matrix
-// (the squared conditioning the reference's svd(A) does not have); callers that factor G route a triplet to the QR-based
-// exact path when it is large.  0 when the rate could not be observed (converged in one step).
+// gap_risk (optional, two doubles): numerator and denominator of an upper estimate of 1 / (lambda_(n-1) - lambda_n)^2 from the
+// observed convergence rate and the final Rayleigh quotient -- sqrt(num / den) eps |G| bounds the rounding error of an
+// eigenvector taken from a FORMED Gram matrix (the squared conditioning the reference's svd(A) does not have); callers that factor
+// G route a triplet to the QR-based exact path when it is large.  num = 0 when the rate could not be observed (converged in one step).
 template <int n, int G = 64>
 __device__ inline double wave_invit_unit(const double* Lp, const double myinv, const int maxit, int* iters, double* resid2,
                                          const bool has_start = false, const double start = 0.0, double* gap_risk = nullptr) {
@@ -55,28 +55,22 @@ __device__ inline double wave_invit_unit(const double* Lp, const double myinv, c
     double rprev2 = 1.0, res = 1.0, rk_r2 = 0.0, rk_rp = 1.0, rk_nn = 0.0;
     int it = 0;
     bool done = false;                                      // per group; the loop itself is wave-uniform
+    // the lane's own row and column of L' stay in registers for all iterations (2 n doubles; the factor is read from LDS once)
+    double row[n], col[n];                                  // L'[lane][j] (0 for j >= lane);  L'[j][lane] (0 for j <= lane)
+#pragma unroll
+    for (int j = 0; j < n; ++j) { row[j] = Lp[rl * n + j]; col[j] = Lp[j * n + rl]; }
 #pragma unroll 1
     while (true) {
         double y = x * myinv;
-        {
-            double row[n];                                  // L'[lane][j] (0 for j >= lane)
 #pragma unroll
-            for (int j = 0; j < n; ++j) row[j] = Lp[rl * n + j];
-#pragma unroll
-            for (int j = 0; j < n; ++j) {                   // forward  L' y = D^-1 x
-                const double yj = Grp::bcast(y, j);
-                y -= row[j] * yj;
-            }
+        for (int j = 0; j < n; ++j) {                       // forward  L' y = D^-1 x
+            const double yj = Grp::bcast(y, j);
+            y -= row[j] * yj;
         }
-        {
-            double col[n];                                  // L'[j][lane] (0 for j <= lane)
 #pragma unroll
-            for (int j = 0; j < n; ++j) col[j] = Lp[j * n + rl];
-#pragma unroll
-            for (int j = n - 1; j >= 0; --j) {              // backward L'^T u = y,  u = D z
-                const double uj = Grp::bcast(y, j);
-                y -= col[j] * uj;
-            }
+        for (int j = n - 1; j >= 0; --j) {                  // backward L'^T u = y,  u = D z
+            const double uj = Grp::bcast(y, j);
+            y -= col[j] * uj;
         }
         y *= myinv;
         if (lane >= n) y = 0.0;
@@ -102,21 +96,23 @@ __device__ inline double wave_invit_unit(const double* Lp, const double myinv, c
     *resid2 = res;                                                              // 0 when converged, last |step|^2 otherwise
     if (gap_risk) {
         // rate rho = (lambda_n + delta) / (lambda_(n-1) + delta) ~ sqrt(r2 / rprev2), lambda_n + delta ~ 1 / |y|:
-        // 1 / gap ~ |y| rho / (1 - rho)
-        const double rho = sqrt(rk_r2 / rk_rp);
-        *gap_risk = (rho < 1.0) ? sqrt(rk_nn) * rho / (1.0 - rho) : ((rk_r2 > 0.0) ? 1e300 : 0.0);
+        // 1 / gap ~ |y| rho / (1 - rho).  Returned SQUARED and without sqrt / division on the hot path: with q = rho^2,
+        // 1 - rho >= (1 - q) / 2, so  (1 / gap)^2 <= 4 |y|^2 q / (1 - q)^2 =: risk2_num / risk2_den (an upper bound: flags slightly early).
+        gap_risk[0] = 4.0 * rk_nn * rk_r2 * rk_rp;                          // numerator   x rk_rp^2
+        const double d = rk_rp - rk_r2;                                      // (1 - q) rk_rp
+        gap_risk[1] = (rk_r2 < rk_rp) ? d * d : 0.0;                         // denominator x rk_rp^2 (0: no gap observed)
     }
     return x;
 }
 
 // g[c] = G[lane][c] for c <= lane (entries c > lane are ignored), diag = G[lane][lane].
 // Lp: n*n doubles of LDS.  Cholesky of G + delta I in registers, then wave_invit_unit (see there for the outputs).
-// *gram_risk (optional): eps-free relative error amplification |G| / (lambda_(n-1) - lambda_n) of the eigenvector of the formed
-// Gram matrix (trace(G) * gap_risk of the iteration).
+// *gram_risk (optional): 1.0 when the eps-free error amplification |G| / (lambda_(n-1) - lambda_n) of the eigenvector of the formed
+// Gram matrix may exceed sqrt(gram_risk_limit2), else 0.0.
 template <int n, int G = 64>
 __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, double* Lp, const int maxit,
                                              int* iters, double* resid2, const bool has_start = false, const double start = 0.0,
-                                             double* gram_risk = nullptr) {
+                                             double* gram_risk = nullptr, const double gram_risk_limit2 = 1e14) {
     using Grp = Group<G>;                                   // one lane group per matrix (the whole wave, or one half of it)
     const int lane = Grp::lane();
     const double tr = Grp::sum(lane < n ? diag : 0.0);
@@ -145,9 +141,10 @@ __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, 
         for (int c = 0; c < n; ++c) Lp[lane * n + c] = (c < lane) ? g[c] * myinv : 0.0;
     }
     wave_sync();
-    double risk = 0.0;
-    const double x = wave_invit_unit<n, G>(Lp, myinv, maxit, iters, resid2, has_start, start, &risk);
-    if (gram_risk) *gram_risk = risk * tr;
+    double risk[2] = {0.0, 1.0};
+    const double x = wave_invit_unit<n, G>(Lp, myinv, maxit, iters, resid2, has_start, start, gram_risk ? risk : nullptr);
+    // |G| / gap < limit  <=>  tr^2 num < limit^2 den
+    if (gram_risk) *gram_risk = (tr * tr * risk[0] < gram_risk_limit2 * risk[1]) ? 0.0 : 1.0;
     return x;
 }
 __device__ __forceinline__ bool eig_converged(double resid2) { return resid2 == 0.0; }

@@ -1,7 +1,7 @@
 """Condense rocprofv3 CSV output (kernel stats + PMC passes) into a small text/JSON summary for profiles/."""
 import csv, glob, json, os, sys
 root = sys.argv[1]
-KERN = "k_linear_tft_pose"
+KERN = os.environ.get("PROFILE_KERNEL", "k_linear_tft_pose")
 out = {}
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
