@@ -275,6 +275,111 @@ def real_sweep(ctx, triplets, initial_sample_size=100, repr_err_th=1.0, methods=
     return out
 
 
+def load_epfl_all(npz_path, dataset, n_triplets=None):
+    """The all-triplets EPFL fixture (tests/golden/epfl_all.npz, made by tests/golden/make_epfl_all.py from the reference's Data/
+    directory): `dataset` in {"fountain", "herzjesu"}, the first `n_triplets` of indexes_sorted (experiments_real.m:31-35,78:
+    70 for fountain-P11, 50 for Herz-Jesu-P8; None = all)."""
+    g = np.load(npz_path)
+    trips = np.asarray(g[dataset + "_triplets"]); off = np.asarray(g[dataset + "_offsets"]); C = np.asarray(g[dataset + "_corresp"])
+    K, R, t = np.asarray(g[dataset + "_K"]), np.asarray(g[dataset + "_R"]), np.asarray(g[dataset + "_t"])
+    out = []
+    for n, (i1, i2, i3, cnt) in enumerate(trips[:n_triplets]):
+        a, b, c = i1 - 1, i2 - 1, i3 - 1
+        Rt0 = [np.hstack([R[b] @ R[a].T, (t[b] - R[b] @ R[a].T @ t[a]).reshape(3, 1)]),
+               np.hstack([R[c] @ R[a].T, (t[c] - R[c] @ R[a].T @ t[a]).reshape(3, 1)])]                # experiments_real.m:90-91
+        out.append(dict(name="%s (%d,%d,%d)" % (dataset, i1, i2, i3), Corresp=np.ascontiguousarray(C[off[n]:off[n + 1]].T),
+                        CalM=np.vstack([K[a], K[b], K[c]]), R_t0=Rt0))
+    return out
+
+
+def epfl_inliers(ctx, tr, repr_err_th=1.0):
+    """experiments_real.m:93-99: triangulate with the ground-truth cameras, keep the correspondences whose six reprojection
+    residuals are all <= 1 px.  Returns the inlier correspondences (6 x Ni)."""
+    Corresp, CalM, R_t0 = tr["Corresp"], tr["CalM"], tr["R_t0"]
+    P0 = _cameras(CalM, R_t0[0][None], R_t0[1][None])[0]
+    X = _np(ctx.triangulate(P0, np.ascontiguousarray(Corresp.T)[None]))[0]
+    X = X[0:3] / X[3:4]
+    Xh = np.vstack([X, np.ones(X.shape[1])])
+    proj = np.concatenate([(P @ Xh)[0:2] / (P @ Xh)[2:3] for P in P0])
+    return Corresp[:, np.sum(np.abs(proj - Corresp) > repr_err_th, axis=0) == 0]
+
+
+def real_trials(ctx, triplets, n_trials=100, sigma=0.5, initial_sample_size=100, methods=None, seed=1):
+    """BASELINE.json configs[4]: experiments_real.m's evaluation repeated over `n_trials` noise trials per triplet, all
+    (triplet, trial) problems of equal sample size batched into ONE C-ABI call per method.
+    Trial k of triplet t: a fresh min(100, Ni)-correspondence sample of the inliers (Philox keyed by (seed, t, k); the reference
+    takes one sample per triplet, experiments_real.m:104-105) with N(0, sigma^2) noise added to the sampled coordinates (the
+    reference adds none to real data: sigma = 0 reproduces it).  Per trial and method: ReprError over ALL inliers of the triplet
+    after re-triangulation with the estimated cameras (:130-131), AngError of both poses against the `.camera` ground truth
+    (:133-136), iterations.  Returns per-method means over all (triplet, trial) pairs and over triplets, and the throughput."""
+    import torch
+    mt = [0, 1, 2, 3, 4, 6, 7] if methods is None else list(methods)                               # :62
+    info, groups = [], {}
+    for ti, tr in enumerate(triplets):
+        Ci = epfl_inliers(ctx, tr)
+        Ni = Ci.shape[1]
+        info.append(dict(name=tr.get("name", str(ti)), matches=int(tr["Corresp"].shape[1]), inliers=int(Ni)))
+        n = min(initial_sample_size, Ni)
+        if n < 7:
+            continue
+        S = np.empty((n_trials, n, 6))
+        for k in range(n_trials):
+            rng = np.random.Generator(np.random.Philox(key=[seed, 1000003 * ti + k]))
+            sel = np.sort(rng.choice(Ni, size=n, replace=False))
+            S[k] = Ci[:, sel].T + sigma * rng.standard_normal((n, 6))
+        groups.setdefault(n, []).append((ti, S, Ci))
+    T = len(triplets)
+    keys = ("repr_err", "rot_err", "t_err", "iter")
+    res = {k: np.full((len(METHODS), T, n_trials), np.inf) for k in keys}
+    gpu_seconds = np.zeros(len(METHODS))
+    problems = np.zeros(len(METHODS))
+    for n, members in groups.items():
+        C = torch.from_numpy(np.concatenate([m[1] for m in members])).cuda()                     # (len(members) * n_trials, n, 6)
+        CalB = torch.from_numpy(np.concatenate([np.broadcast_to(triplets[m[0]]["CalM"], (n_trials, 9, 3)) for m in members]).copy()).cuda()
+        for mi in mt:
+            if mi > 5 and n < 8:
+                continue
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ctx.pose_batch(METHODS[mi], C, CalB, reconst=False)                                  # warm-up (workspace growth)
+            torch.cuda.synchronize()
+            a.record()
+            out = ctx.pose_batch(METHODS[mi], C, CalB, reconst=False)
+            b.record()
+            torch.cuda.synchronize()
+            gpu_seconds[mi] += a.elapsed_time(b) * 1e-3
+            problems[mi] += C.shape[0]
+            st = _np(out["status"]); R2 = _np(out["R_t_2"]); R3 = _np(out["R_t_3"]); its = _np(out["iter"])
+            for j, (ti, _, Ci) in enumerate(members):
+                sl = slice(j * n_trials, (j + 1) * n_trials)
+                ok = st[sl] == 0
+                if not ok.any():
+                    continue
+                tr = triplets[ti]
+                P = _cameras(tr["CalM"], R2[sl][ok], R3[sl][ok])
+                res["repr_err"][mi, ti, ok] = _np(ctx.repr_error(P, np.ascontiguousarray(Ci.T)))   # all inliers, shared by the trials
+                r2, t2 = AngError_batch(tr["R_t0"][0], R2[sl][ok]); r3, t3 = AngError_batch(tr["R_t0"][1], R3[sl][ok])
+                res["rot_err"][mi, ti, ok] = (r2 + r3) / 2
+                res["t_err"][mi, ti, ok] = (t2 + t3) / 2
+                res["iter"][mi, ti, ok] = its[sl][ok]
+    summary = {}
+    for mi in mt:
+        fin = np.isfinite(res["rot_err"][mi])
+        summary[METHODS[mi]] = dict(
+            problems=int(problems[mi]), solved=int(fin.sum()),
+            mean_repr_err=float(np.mean(res["repr_err"][mi][fin])) if fin.any() else None,
+            median_repr_err=float(np.median(res["repr_err"][mi][fin])) if fin.any() else None,
+            mean_rot_err_deg=float(np.nanmean(res["rot_err"][mi][fin])) if fin.any() else None,
+            mean_t_err_deg=float(np.nanmean(res["t_err"][mi][fin])) if fin.any() else None,
+            median_rot_err_deg=float(np.nanmedian(res["rot_err"][mi][fin])) if fin.any() else None,
+            mean_iter=float(np.mean(res["iter"][mi][fin])) if fin.any() else None,
+            gpu_seconds=float(gpu_seconds[mi]), problems_per_s=float(problems[mi] / gpu_seconds[mi]) if gpu_seconds[mi] > 0 else None)
+    return dict(n_trials=n_trials, sigma=sigma, sample=initial_sample_size, triplets=info, methods_tested=[METHODS[m] for m in mt], summary=summary,
+                per_triplet_mean_rot_err={METHODS[mi]: [float(np.nanmean(np.where(np.isfinite(res["rot_err"][mi, t]), res["rot_err"][mi, t], np.nan)))
+                                                        if np.isfinite(res["rot_err"][mi, t]).any() else None for t in range(T)] for mi in mt},
+                note="(triplet, trial) problems of one sample size go through ONE batched call per method; AngError's acos is not clamped "
+                     "(AngError.m:21-28): a NaN means ~0 degrees and is skipped in the means")
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--option", choices=sorted(INTERVALS), default="noise")
@@ -284,14 +389,21 @@ def main():
     ap.add_argument("--focal", type=float, default=50.0)
     ap.add_argument("--angle", type=float, default=0.0)
     ap.add_argument("--real", default=None, help="tests/golden/epfl.npz, or a Data/<dataset> directory of the reference")
-    ap.add_argument("--n-triplets", type=int, default=70)
+    ap.add_argument("--n-triplets", type=int, default=None, help="first n of indexes_sorted (default 70 fountain / 50 herzjesu, experiments_real.m:31-35)")
+    ap.add_argument("--dataset", choices=["fountain", "herzjesu"], default=None, help="with --real tests/golden/epfl_all.npz")
+    ap.add_argument("--noise-trials", type=int, default=0, help="configs[4]: K noise trials per triplet, batched (real_trials)")
+    ap.add_argument("--sigma", type=float, default=0.5, help="pixel noise of the trials")
+    ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     from . import api
     ctx = api.Context(0)
     if args.real:
-        trips = load_epfl_fixture(args.real) if args.real.endswith(".npz") else load_epfl_dataset(args.real, args.n_triplets)
-        res = real_sweep(ctx, trips)
+        if args.dataset:
+            trips = load_epfl_all(args.real, args.dataset, args.n_triplets or (70 if args.dataset == "fountain" else 50))
+        else:
+            trips = load_epfl_fixture(args.real) if args.real.endswith(".npz") else load_epfl_dataset(args.real, args.n_triplets or 70)
+        res = real_trials(ctx, trips, args.noise_trials, args.sigma, seed=args.seed) if args.noise_trials else real_sweep(ctx, trips)
     else:
         res = synthetic_sweep(ctx, args.option, n_sim=args.n_sim, N=args.points, noise=args.noise, f=args.focal, angle=args.angle)
     txt = json.dumps(res)
