@@ -17,7 +17,8 @@
  *
  * Build (where MATLAB's mex and ROCm are installed; cannot be built in the GPU-less CI image):
  *   mex -I../include tftfund_mex.c -L../tft_vs_fund_amd -ltftfund -lamdhip64
- * The three wrappers LinearTFTPoseEstimation.m / LinearFPoseEstimation.m in this directory keep the
+ * The nine one-call wrappers in this directory (the eight *PoseEstimation.m methods of experiments.m:51-59 and
+ * BundleAdjustment.m) keep the
  * reference's names and signatures; put this directory ahead of the reference on the MATLAB path.
  */
 #include <string.h>
@@ -106,6 +107,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         const mwSize* dk = mxGetDimensions(prhs[2]);
         mwSize ndk = mxGetNumberOfDimensions(prhs[2]);
         if (dk[0] != 9 || dk[1] != 3) mexErrMsgIdAndTxt("tftfund:shape", "CalM must be 9 x 3 (x B)");
+        if (ndk == 3 && dk[2] != 1 && dk[2] != B) mexErrMsgIdAndTxt("tftfund:shape", "CalM is 9 x 3 x K: K must be 1 or the batch size");
         calm_stride = (ndk == 3 && dk[2] == B && B > 1) ? 27 : 0;
     }
     if (!g_ctx) {

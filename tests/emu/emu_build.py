@@ -18,7 +18,7 @@ def build(sanitize=False):
     deps += [os.path.join(csrc, f) for f in os.listdir(csrc)]
     if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
-    cmd = ["g++", "-std=c++20", "-O1", "-g", "-pthread", "-shared", "-fPIC", "-I" + HERE, "-o", out, src]
+    cmd = ["g++", "-std=c++20", "-O1", "-g", "-pthread", "-shared", "-fPIC", "-I" + HERE, "-I" + csrc, "-o", out, src]   # tests/emu first: <wave_target.h>
     if sanitize:
         cmd[3:3] = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
     subprocess.run(cmd, check=True)

@@ -2,7 +2,6 @@
 // CPU through tests/emu/hip_emu.h (one std::thread per lane) so that their
 // logic is covered by `pytest -m "not gpu"` and can be run under sanitizers.
 // Never linked into libtftfund.so.
-#define TFF_CPU_EMU 1
 #include <vector>
 #include "../../tft_vs_fund_amd/csrc/launch.h"
 

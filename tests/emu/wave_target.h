@@ -1,0 +1,66 @@
+// TEST INFRASTRUCTURE ONLY: the hardware primitives underneath tft_vs_fund_amd/csrc/wave.h, emulated on the thread-per-lane
+// emulator (hip_emu.h).  Same names and the same semantics as csrc/wave_target.h -- DPP row / quad controls with their
+// out-of-row rule, the permlane swaps, readlane broadcasts -- so that the reductions of wave.h (common code) run in the
+// GPU's order and emulated results are bit-comparable with it.  Selected by the include path of tests/emu/emu_build.py.
+#pragma once
+#include "hip_emu.h"
+
+namespace tff {
+
+#define TFF_DYNAMIC_LDS(type, name) type* name = reinterpret_cast<type*>(emu::dyn_smem())
+
+inline int emu_lane() { return (int)(threadIdx.x & 63u); }
+inline uint64_t emu_bits(double v) { uint64_t u; std::memcpy(&u, &v, 8); return u; }
+inline double emu_dbl(uint64_t u) { double v; std::memcpy(&v, &u, 8); return v; }
+
+inline void wave_sync() { emu::wave_barrier(); }
+inline double wave_shfl_xor(double v, int mask) { return emu_dbl(emu::exchange(emu_bits(v), emu_lane() ^ mask)); }
+inline int wave_shfl_xor_i(int v, int mask) { return (int)emu::exchange((uint64_t)(uint32_t)v, emu_lane() ^ mask); }
+inline double wave_bcast(double v, int src) { return emu_dbl(emu::exchange(emu_bits(v), src)); }
+inline int wave_bcast_i(int v, int src) { return (int)emu::exchange((uint64_t)(uint32_t)v, src); }
+inline double half_bcast(double v, int src) { return emu_dbl(emu::exchange(emu_bits(v), (emu_lane() & 32) | src)); }
+inline double wave_uniform(double v) { return v; }
+inline int wave_uniform_i(int v) { return v; }
+typedef double* lds_ptr;
+inline lds_ptr to_lds(double* p) { return p; }
+inline void sched_fence() {}
+inline long long shader_clock() { return 0; }
+inline int wave_first_lane(bool p) {
+    int c = p ? emu_lane() : 64;
+    for (int m = 32; m >= 1; m >>= 1) { const int o = wave_shfl_xor_i(c, m); c = (o < c) ? o : c; }
+    return c;
+}
+
+// source lane of a DPP control for lane l (or -1 when it falls outside the row of 16)
+template <int CTRL>
+inline int emu_dpp_source(int l) {
+    const int row = l & ~15, rl = l & 15;
+    if constexpr (CTRL >= 0x111 && CTRL <= 0x11F) { const int s = rl - (CTRL - 0x110); return s >= 0 ? row + s : -1; }          // row_shr:n
+    else if constexpr (CTRL >= 0x101 && CTRL <= 0x10F) { const int s = rl + (CTRL - 0x100); return s < 16 ? row + s : -1; }     // row_shl:n
+    else if constexpr (CTRL >= 0x121 && CTRL <= 0x12F) { return row + ((rl - (CTRL - 0x120)) & 15); }                           // row_ror:n
+    else { static_assert(CTRL >= 0 && CTRL <= 0xFF, "unsupported DPP control"); return (l & ~3) + ((CTRL >> (2 * (l & 3))) & 3); }   // quad_perm
+}
+template <int CTRL>
+inline double dpp_mov(double v) {
+    const int s = emu_dpp_source<CTRL>(emu_lane());
+    const double got = emu_dbl(emu::exchange(emu_bits(v), s < 0 ? emu_lane() : s));
+    return s < 0 ? 0.0 : got;
+}
+template <int CTRL>
+inline double dpp_mov_keep(double v) {
+    const int s = emu_dpp_source<CTRL>(emu_lane());
+    const double got = emu_dbl(emu::exchange(emu_bits(v), s < 0 ? emu_lane() : s));
+    return s < 0 ? v : got;
+}
+// v_permlane32_swap / v_permlane16_swap followed by the sum of the two results (see csrc/wave_target.h)
+template <int MASK>
+inline double swap_sum(double a, double b) {
+    static_assert(MASK == 32 || MASK == 16, "permlane swaps exist for the two widest steps");
+    const bool up = (emu_lane() & MASK) != 0;
+    const double keep = up ? b : a, send = up ? a : b;
+    const double got = emu_dbl(emu::exchange(emu_bits(send), emu_lane() ^ MASK));
+    // r0 + r1: lower half-block a[l] + a[l ^ MASK], upper half-block b[l ^ MASK] + b[l]
+    return up ? got + keep : keep + got;
+}
+
+}  // namespace tff

@@ -22,7 +22,7 @@ def build_library(force=False, verbose=False):
     if not force and not _stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", OUT] + SOURCES
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-I" + CSRC, "-shared", "-fPIC", "-o", OUT] + SOURCES
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

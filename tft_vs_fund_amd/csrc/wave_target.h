@@ -1,0 +1,87 @@
+// gfx950 (CDNA4) implementation of the hardware primitives underneath csrc/wave.h.  Nothing here has an alternative: the
+// GPU-less unit tests put tests/emu/ in front of this directory on the include path and get tests/emu/wave_target.h instead.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tff {
+
+#define TFF_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+
+// Lanes of one wavefront exchange data through LDS without a workgroup barrier: DS operations of a wave execute in program
+// order, so only the compiler has to be told not to move accesses across this point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double wave_shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ int wave_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
+// src must be wave-uniform: lowers to v_readlane_b32 pairs (no LDS crossbar).
+__device__ __forceinline__ double wave_bcast(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int wave_bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+// lane (l & 32) | src of the caller's own half-wavefront: the source differs between the halves -> ds_bpermute
+__device__ __forceinline__ double half_bcast(double v, int src) { return __shfl(v, ((int)(threadIdx.x & 32u)) | src, 64); }
+// v holds the same value in every lane: move it to scalar registers (v_readfirstlane) so that it costs SGPRs, not VGPRs,
+// while it stays live across a per-lane loop.
+__device__ __forceinline__ double wave_uniform(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int wave_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// A pointer into LDS that went through a non-inlined call is a generic pointer (flat_load / flat_store); casting it back to
+// the local address space restores ds_read / ds_write.
+typedef __attribute__((address_space(3))) double* lds_ptr;
+__device__ __forceinline__ lds_ptr to_lds(double* p) { return (lds_ptr)p; }
+// the instruction scheduler does not move anything across this point
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+__device__ __forceinline__ long long shader_clock() { return clock64(); }
+// lowest lane whose predicate holds (64 if none); wave-uniform
+__device__ __forceinline__ int wave_first_lane(bool p) {
+    const unsigned long long m = __ballot(p);
+    return m ? (__ffsll((long long)m) - 1) : 64;
+}
+
+// DPP move (v_mov_b32 with a dpp control, both halves of the double): row_shr:n = 0x110 + n, row_shl:n = 0x100 + n,
+// row_ror:n = 0x120 + n, quad_perm = 0x00..0xFF.  dpp_mov: lanes whose source falls outside the row of 16 read 0;
+// dpp_mov_keep: they keep their own value.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_keep(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// v_permlane32_swap / v_permlane16_swap (gfx950) do the keep/send exchange of one halving step in place:
+// swap(a, b) -> r0 = {a on the lower half-blocks, b's lower half-blocks moved up}, r1 = {a's upper half-blocks moved down,
+// b on the upper half-blocks}; r0 + r1 is a[l] + a[l ^ MASK] where bit MASK of l is clear and b[l] + b[l ^ MASK] where it is set.
+template <int MASK>
+__device__ __forceinline__ double swap_sum(double a, double b) {
+    static_assert(MASK == 32 || MASK == 16, "permlane swaps exist for the two widest steps");
+    const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    if constexpr (MASK == 32) {
+        const auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    } else {
+        const auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    }
+}
+
+}  // namespace tff

@@ -3,7 +3,7 @@ import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(ROOT, "tft_vs_fund_amd", "csrc")
 out = os.path.join(ROOT, "tft_vs_fund_amd", "libtftfund.so")
-r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", out, "capi.hip",
+r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-I" + csrc, "-shared", "-fPIC", "-o", out, "capi.hip",
                     "-Rpass-analysis=kernel-resource-usage"], cwd=csrc, capture_output=True, text=True)
 txt = r.stderr
 if r.returncode:
