@@ -683,17 +683,16 @@ def _axis_angle(U):
     return vec, o
 
 
-def NordbergTFTPoseEstimation(Corresp, CalM, return_debug=False):
-    """TFT_methods/NordbergTFTPoseEstimation.m:47-124"""
-    x1, Normal1 = Normalize2Ddata(Corresp[0:2, :])
-    x2, Normal2 = Normalize2Ddata(Corresp[2:4, :])
-    x3, Normal3 = Normalize2Ddata(Corresp[4:6, :])
-    T, P1, P2, P3 = linearTFT(x1, x2, x3)
+def nordberg_param0(T, P1, P2, P3, null_sign=1.0):
+    """NordbergTFTPoseEstimation.m:55-94: projective fix-up for a rank-deficient P3(:,1:3) / P2(:,1:3), then the initial 19
+    parameters (three axis-angle vectors and the 10 sparse tensor entries).  Returns the (possibly transformed) cameras and param0.
+    null_sign: the sign of null(.) is whatever svd returns (MATLAB leaves it open); -1 replays the other choice, which gives
+    projectively equivalent cameras and a different but equivalent parameter vector."""
     H = np.eye(4)
     if rank(P3[:, 0:3]) < 3:
-        H[3, 0:3] = null(P3[:, 0:3])[:, 0]
+        H[3, 0:3] = null_sign * null(P3[:, 0:3])[:, 0]
     elif rank(P2[:, 0:3]) < 3:
-        H[3, 0:3] = null(P2[:, 0:3])[:, 0]
+        H[3, 0:3] = null_sign * null(P2[:, 0:3])[:, 0]
     P1, P2, P3 = P1 @ H, P2 @ H, P3 @ H
     A = P2[:, 0:3]
     a = P2[:, 3]
@@ -715,8 +714,17 @@ def NordbergTFTPoseEstimation(Corresp, CalM, return_debug=False):
     Ts = _transf_t(T, U, V, W)
     paramT = _vecT(Ts)[_NORD_IND]
     paramT = paramT / np.linalg.norm(paramT)
+    return P1, P2, P3, np.concatenate([vec_u * o_u, vec_v * o_v, vec_w * o_w, paramT])
+
+
+def NordbergTFTPoseEstimation(Corresp, CalM, return_debug=False):
+    """TFT_methods/NordbergTFTPoseEstimation.m:47-124"""
+    x1, Normal1 = Normalize2Ddata(Corresp[0:2, :])
+    x2, Normal2 = Normalize2Ddata(Corresp[2:4, :])
+    x3, Normal3 = Normalize2Ddata(Corresp[4:6, :])
+    T, P1, P2, P3 = linearTFT(x1, x2, x3)
+    P1, P2, P3, param0 = nordberg_param0(T, P1, P2, P3)
     obs, obs_est = _gh_initial_obs(P1, P2, P3, x1, x2, x3)
-    param0 = np.concatenate([vec_u * o_u, vec_v * o_v, vec_w * o_w, paramT])
     func = lambda a_, b_, c_: _nordberg_constrGH(a_, b_)
     _, param, _, it, reason = Gauss_Helmert(func, obs_est, param0, np.zeros(0), obs, None, True)
     Rm = []

@@ -178,3 +178,30 @@ extern "C" int emu_eigh(const double* Maug, long B, int n, double* lam, double* 
     emu::launch(k_emu_eigh, emu_grid(B), 64, sizeof(double) * (size_t)(2 * n * (n + 1) + n * n + 3 * n), a);
     return 0;
 }
+
+// NordbergModel::init on caller-supplied linearTFT output (t 27, a 18, epipoles 6): the initial 19 parameters and the
+// rank flag -- exercises the projective fix-up for a rank-deficient P2(:,1:3) / P3(:,1:3) (NordbergTFTPoseEstimation.m:56-62),
+// which no correspondence set reaches through the whole pipeline (it needs sigma_3 <= 3 eps(sigma_1) in the linear solution).
+namespace {
+struct NordInitArgs { const double* t; const double* pa; const double* epi; double* p; int* bad; };
+__global__ void k_emu_nordberg_init(NordInitArgs a) {
+    TFF_DYNAMIC_LDS(double, smem);
+    tff::PoseLds* w = reinterpret_cast<tff::PoseLds*>(smem);
+    const int lane = tff::lane_id();
+    if (lane < 27) w->t[lane] = a.t[lane];
+    if (lane < 18) w->pa[lane] = a.pa[lane];
+    if (lane < 6) w->epi[lane] = a.epi[lane];
+    tff::wave_sync();
+    tff::GhWork g = tff::gh_carve(smem + ((tff::POSE_LDS_DOUBLES + 1) & ~1), tff::NordbergModel::U, tff::NordbergModel::C, 0);
+    tff::NordbergModel model;
+    model.init(w, g);
+    if (lane < 19) a.p[lane] = g.p[lane];
+    if (lane == 0) *a.bad = model.bad;
+}
+}  // namespace
+extern "C" int emu_nordberg_init(const double* t, const double* pa, const double* epi, double* p, int* bad) {
+    NordInitArgs a{t, pa, epi, p, bad};
+    const size_t lds = (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_lds_doubles(tff::NordbergModel::U, tff::NordbergModel::C, 0)) * sizeof(double);
+    emu::launch(k_emu_nordberg_init, 1, 64, lds, a);
+    return 0;
+}

@@ -290,3 +290,42 @@ def test_ressl_kernel_matches_block_checker(emu, golden_dir):
     assert abs(int(out["iter"][0]) - it) <= 1 and abs(int(out["iter"][0]) - int(g["c1_ressl_iter"][1])) <= 2
     assert rel_err_T(out["T"][0], T) < 2e-3 and rel_err(out["R_t_3"][0], R3) < 2e-3
     assert rel_err_T(out["T"][0], g["c1_ressl_T"][1]) < 1e-2 and rel_err(out["R_t_3"][0], g["c1_ressl_Rt3"][1]) < 1e-2
+
+
+@pytest.mark.parametrize("deficient", ["P2", "P3", "none"])
+def test_nordberg_projective_fixup_executes(emu, deficient):
+    """NordbergTFTPoseEstimation.m:56-62: when P3(:,1:3) (else P2(:,1:3)) of the linear solution has rank 2, the cameras are
+    transformed by H = [I 0; null(.)' 1] before the parameterisation.  No correspondence set reaches that branch through the
+    whole pipeline (it needs sigma_3 <= 3 eps(sigma_1) in linearTFT's output), so the kernel's NordbergModel::init is fed
+    cameras with an EXACTLY rank-deficient block and compared with the oracle's nordberg_param0 on the same cameras."""
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((3, 3)); B = rng.standard_normal((3, 3))
+    a = rng.standard_normal(3); a /= np.linalg.norm(a)
+    b = rng.standard_normal(3); b /= np.linalg.norm(b)
+    if deficient == "P2":
+        A[:, 2] = 2.0 * A[:, 0] - 0.5 * A[:, 1]                               # exact rank 2 (up to one rounding per entry)
+    if deficient == "P3":
+        B[:, 1] = 0.25 * B[:, 0] + 3.0 * B[:, 2]
+    if deficient != "none":
+        M = A if deficient == "P2" else B
+        s = np.linalg.svd(M, compute_uv=False)
+        if not s[2] <= 3 * np.spacing(s[0]):                                  # one more projection makes it rank 2 to the last bit rank() looks at
+            U, sv, Vt = np.linalg.svd(M); sv[2] = 0.0; M[:] = (U * sv) @ Vt
+        assert O.rank(M) == 2
+    P1 = np.eye(3, 4); P2 = np.hstack([A, a.reshape(3, 1)]); P3 = np.hstack([B, b.reshape(3, 1)])
+    T = np.stack([np.outer(A[:, i], b) - np.outer(a, B[:, i]) for i in range(3)], axis=2)       # T_i = a_i e31' - e21 b_i'   (linearTFT.m:87-91)
+    T = T / np.linalg.norm(T)
+    refs = [O.nordberg_param0(T, P1, P2, P3, sg) for sg in ((1.0, -1.0) if deficient != "none" else (1.0,))]
+    _, oP2, oP3, _ = refs[0]
+    if deficient != "none":
+        assert O.rank(oP2[:, 0:3]) == 3 and O.rank(oP3[:, 0:3]) == 3 and (np.abs(oP2 - P2).max() > 1e-3 or np.abs(oP3 - P3).max() > 1e-3)
+    t = np.ascontiguousarray(T.transpose(2, 1, 0)).reshape(27)               # vec order j + 3k + 9i
+    pa = np.concatenate([A.reshape(9, order="F"), B.reshape(9, order="F")])
+    epi = np.concatenate([a, b])
+    p = np.zeros(19); bad = ctypes.c_int(-1)
+    emu.emu_nordberg_init(_p(t), _p(pa), _p(epi), _p(p), ctypes.byref(bad))
+    assert bad.value == 0
+    # null(.)'s sign is svd's choice: the kernel must reproduce the oracle's parameters under one of the two signs
+    # (rotation vectors directly; the normalised sparse tensor part up to its global sign)
+    dev = [max(np.abs(p[0:9] - r[3][0:9]).max(), min(np.abs(p[9:19] - r[3][9:19]).max(), np.abs(p[9:19] + r[3][9:19]).max())) for r in refs]
+    assert min(dev) < 1e-8, dev
