@@ -1,12 +1,15 @@
 /*
  * tftfund_mex.c -- MEX gateway from MATLAB to libtftfund.so (C ABI in include/tftfund.h).
  *
- *   [R_t_2, R_t_3, Reconst, T, iter] = tftfund_mex(method, Corresp, CalM)
+ *   [R_t_2, R_t_3, Reconst, T, iter] = tftfund_mex(method, Corresp, CalM [, devices])
  *
  * method : 'linear_tft' | 'linear_f' | 'ressl_tft' | 'nordberg_tft' | 'faugpapa_tft' | 'optim_f' | 'pi' | 'picol'
  *          (one entry per tff_<method>_pose_batch_host symbol)
  * Corresp: 6 x N double, or 6 x N x B for a batch of B triplets
  * CalM   : 9 x 3 double (shared) or 9 x 3 x B
+ * devices: optional row vector of HIP device ordinals (0-based).  Given, the batch is cut into contiguous shards, one per
+ *          device, each on its own host thread and stream (tff_pose_batch_host_multi: independent triplets, no collective);
+ *          omitted: device 0.
  * Outputs follow the reference's calling convention (experiments.m:108):
  *   R_t_2, R_t_3  3 x 4 (x B),  Reconst 3 x N (x B),  T 3 x 3 x 3 (x B),  iter 1 x B double.
  * Fewer outputs may be requested (example.m:42 takes three; experiments_real.m:126 skips
@@ -26,9 +29,13 @@
 #include "tftfund.h"
 
 static tff_ctx* g_ctx = NULL;
+static tff_multi* g_multi = NULL;      /* multi-GPU handle for the device list last used */
+static int32_t g_multi_dev[64];
+static int32_t g_multi_n = 0;
 
 static void cleanup(void) {
     if (g_ctx) { tff_ctx_destroy(g_ctx); g_ctx = NULL; }
+    if (g_multi) { tff_multi_destroy(g_multi); g_multi = NULL; g_multi_n = 0; }
 }
 
 typedef int (*pose_host_fn)(tff_ctx*, const double*, const double*, int64_t, int64_t, int32_t, double*, double*, double*,
@@ -72,6 +79,7 @@ static void bundle_adjustment(int nlhs, mxArray* plhs[], int nrhs, const mxArray
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     char method[32];
     pose_host_fn fn = NULL;
+    int32_t method_id = -1;
     const mwSize* dc;
     mwSize ndc, N, B, b;
     int64_t calm_stride;
@@ -84,17 +92,17 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         bundle_adjustment(nlhs, plhs, nrhs, prhs);
         return;
     }
-    if (nrhs != 3) mexErrMsgIdAndTxt("tftfund:nargin", "usage: tftfund_mex(method, Corresp, CalM)");
+    if (nrhs != 3 && nrhs != 4) mexErrMsgIdAndTxt("tftfund:nargin", "usage: tftfund_mex(method, Corresp, CalM [, devices])");
     if (nlhs > 5) mexErrMsgIdAndTxt("tftfund:nargout", "at most five outputs");
     if (mxGetString(prhs[0], method, sizeof method)) mexErrMsgIdAndTxt("tftfund:method", "method must be a string");
-    if (!strcmp(method, "linear_tft")) fn = tff_linear_tft_pose_batch_host;
-    else if (!strcmp(method, "linear_f")) fn = tff_linear_f_pose_batch_host;
-    else if (!strcmp(method, "ressl_tft")) fn = tff_ressl_tft_pose_batch_host;
-    else if (!strcmp(method, "nordberg_tft")) fn = tff_nordberg_tft_pose_batch_host;
-    else if (!strcmp(method, "faugpapa_tft")) fn = tff_faugpapa_tft_pose_batch_host;
-    else if (!strcmp(method, "optim_f")) fn = tff_optim_f_pose_batch_host;
-    else if (!strcmp(method, "pi")) fn = tff_pi_pose_batch_host;
-    else if (!strcmp(method, "picol")) fn = tff_picol_pose_batch_host;
+    if (!strcmp(method, "linear_tft")) { fn = tff_linear_tft_pose_batch_host; method_id = TFF_METHOD_LINEAR_TFT; }
+    else if (!strcmp(method, "linear_f")) { fn = tff_linear_f_pose_batch_host; method_id = TFF_METHOD_LINEAR_F; }
+    else if (!strcmp(method, "ressl_tft")) { fn = tff_ressl_tft_pose_batch_host; method_id = TFF_METHOD_RESSL_TFT; }
+    else if (!strcmp(method, "nordberg_tft")) { fn = tff_nordberg_tft_pose_batch_host; method_id = TFF_METHOD_NORDBERG_TFT; }
+    else if (!strcmp(method, "faugpapa_tft")) { fn = tff_faugpapa_tft_pose_batch_host; method_id = TFF_METHOD_FAUGPAPA_TFT; }
+    else if (!strcmp(method, "optim_f")) { fn = tff_optim_f_pose_batch_host; method_id = TFF_METHOD_OPTIM_F; }
+    else if (!strcmp(method, "pi")) { fn = tff_pi_pose_batch_host; method_id = TFF_METHOD_PI; }
+    else if (!strcmp(method, "picol")) { fn = tff_picol_pose_batch_host; method_id = TFF_METHOD_PICOL; }
     else mexErrMsgIdAndTxt("tftfund:method", "unknown method '%s'", method);
     if (!mxIsDouble(prhs[1]) || mxIsComplex(prhs[1]) || !mxIsDouble(prhs[2]) || mxIsComplex(prhs[2]))
         mexErrMsgIdAndTxt("tftfund:type", "Corresp and CalM must be real double");
@@ -127,7 +135,27 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     iter = (int32_t*)mxCalloc(B ? B : 1, sizeof(int32_t));
     status = (int32_t*)mxCalloc(B ? B : 1, sizeof(int32_t));
     /* MATLAB's column-major 6 x N x B and 9 x 3 (x B) arrays are exactly the C ABI's layout */
-    rc = fn(g_ctx, mxGetPr(prhs[1]), mxGetPr(prhs[2]), calm_stride, (int64_t)B, (int32_t)N, Rt2, Rt3, T, Rec, iter, status);
+    if (nrhs == 4) {                                                   /* device list: shard the batch over several GPUs */
+        const mwSize nd = mxGetNumberOfElements(prhs[3]);
+        int32_t dev[64];
+        mwSize k;
+        int same;
+        if (!mxIsDouble(prhs[3]) || nd < 1 || nd > 64) mexErrMsgIdAndTxt("tftfund:devices", "devices must be a vector of 1..64 device ordinals");
+        for (k = 0; k < nd; ++k) dev[k] = (int32_t)mxGetPr(prhs[3])[k];
+        same = g_multi && g_multi_n == (int32_t)nd;
+        for (k = 0; same && k < nd; ++k) same = dev[k] == g_multi_dev[k];
+        if (!same) {
+            if (g_multi) { tff_multi_destroy(g_multi); g_multi = NULL; }
+            if (tff_multi_create(&g_multi, dev, (int32_t)nd) != 0) mexErrMsgIdAndTxt("tftfund:hip", "tff_multi_create: %s", tff_last_error());
+            for (k = 0; k < nd; ++k) g_multi_dev[k] = dev[k];
+            g_multi_n = (int32_t)nd;
+            mexAtExit(cleanup);
+        }
+        rc = tff_pose_batch_host_multi(g_multi, method_id, mxGetPr(prhs[1]), mxGetPr(prhs[2]), calm_stride, (int64_t)B, (int32_t)N,
+                                       Rt2, Rt3, T, Rec, iter, status);
+    } else {
+        rc = fn(g_ctx, mxGetPr(prhs[1]), mxGetPr(prhs[2]), calm_stride, (int64_t)B, (int32_t)N, Rt2, Rt3, T, Rec, iter, status);
+    }
     if (rc != 0) mexErrMsgIdAndTxt("tftfund:hip", "%s: %s", method, tff_last_error());
     if (B == 1 && status[0] == TFF_ST_TOO_FEW)
         mexErrMsgIdAndTxt("tftfund:tooFew", "not enough correspondences for %s (N = %d)", method, (int)N);
