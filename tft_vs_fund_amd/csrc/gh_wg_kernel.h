@@ -25,6 +25,10 @@ namespace tff {
 constexpr int GH_WG_WAVES = 4;
 constexpr int GH_WG_THREADS = 64 * GH_WG_WAVES;
 constexpr int GH_REC_DOUBLES = 64;        // t 27 | pa 18 | epi 6 | nrm 9 | pad
+// record strides of the per-correspondence state xi / W+.  Even (16-byte aligned records): the loads are ds_read_b128.  Padding them to
+// odd strides (7 / 11 doubles: 32 distinct bank pairs for consecutive lanes instead of 16) was measured SLOWER -- Ressl 3.0 -> 3.5 ms,
+// the sweeps 17 k -> 26 k cycles -- because the records lose their alignment and every access becomes two ds_read_b64.
+constexpr int GH_XI = 6, GH_PP = 10;
 
 // LDS of k_gh_block after the PoseLds header: p, dt, Tc, dT, D, H, Y, M, V (112 doubles of scratch), xi (6N), W+ (10N), reduction slots.
 // `pinv` (FaugPapa: D is the identity and never stored): the eigenvectors + scratch of the pseudo-inverse (n^2 + 2n) overlay D | H | Y,
@@ -35,7 +39,7 @@ constexpr int GH_REC_DOUBLES = 64;        // t 27 | pa 18 | epi 6 | nrm 9 | pad
 __host__ __device__ inline int gh_wg_lds_doubles(int u, int c, int N, bool pinv) {
     const int n = u + c;
     const int strong = pinv ? 0 : ((u * (u + 1) / 2 + u + 1) & ~1);          // sums of the factored strong-direction terms (minimal parameterisations)
-    return 2 * ((u + 1) & ~1) + 2 * c + 28 + 28 + 27 * u + 298 + ((27 * u > 298) ? 27 * u : 298) + n * (n + 1) + 112 + strong + 6 * N + 10 * N + 16 + 8;
+    return 2 * ((u + 1) & ~1) + 2 * c + 28 + 28 + 27 * u + 298 + ((27 * u > 298) ? 27 * u : 298) + n * (n + 1) + 112 + strong + GH_XI * N + GH_PP * N + 16 + 8;
 }
 __device__ inline GhWork gh_wg_carve(double* base, PoseLds* w, int u, int c, int N, bool pinv, double** red) {
     GhWork g;
@@ -52,8 +56,8 @@ __device__ inline GhWork gh_wg_carve(double* base, PoseLds* w, int u, int c, int
     g.M = q; q += n * (n + 1);
     g.V = pinv ? g.D : q; q += 112;                                                // 108 doubles of scratch (Nordberg's rotations)
     g.S = pinv ? nullptr : q; q += pinv ? 0 : ((u * (u + 1) / 2 + u + 1) & ~1);
-    g.xi = q; q += 6 * N;
-    g.pp = q; q += 10 * N;
+    g.xi = q; q += GH_XI * N;
+    g.pp = q; q += GH_PP * N;
     *red = q;
     g.u = u; g.c = c;
     return g;
@@ -152,9 +156,9 @@ __device__ inline void gh_sweep_part(const GhWork& g, double* Hp, int N, const d
     for (int i = lane; i < N; i += WAVE) {
         GhPoint pt;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) pt.o[k] = g.xi[6 * i + k];
+        for (int k = 0; k < 6; ++k) pt.o[k] = g.xi[GH_XI * i + k];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) pt.Wp[k] = g.pp[10 * i + k];
+        for (int k = 0; k < 10; ++k) pt.Wp[k] = g.pp[GH_PP * i + k];
         if constexpr (CH == 9) {                                             // W+ w is not stored: recompute w from the observations
             double f[4], B[4][6], wv[4];
             tril_block(T, pt.o, f, B);
@@ -258,8 +262,8 @@ __device__ inline void gh_block_reproject(PoseLds* w, const double* pts, int N, 
             const double aa = P[0] * X[0] + P[1] * X[1] + P[2] * X[2] + P[3] * X[3];
             const double bb = P[4] * X[0] + P[5] * X[1] + P[6] * X[2] + P[7] * X[3];
             const double cc = P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11] * X[3];
-            xi[6 * (long)i + 2 * v] = aa / cc;
-            xi[6 * (long)i + 2 * v + 1] = bb / cc;
+            xi[GH_XI * (long)i + 2 * v] = aa / cc;
+            xi[GH_XI * (long)i + 2 * v + 1] = bb / cc;
         }
     }
 }
@@ -276,7 +280,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
     for (int i = tid; i < N; i += GH_WG_THREADS) {
         const Pt6 x = premap(load_pt(pts, i), w->nrm);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { const double d = g.xi[6 * i + k] - x.v[k]; objFunc += d * d; }
+        for (int k = 0; k < 6; ++k) { const double d = g.xi[GH_XI * i + k] - x.v[k]; objFunc += d * d; }
     }
     objFunc = block_sum(objFunc, red);
     int it = 0;
@@ -294,7 +298,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         for (int i = tid; i < N; i += GH_WG_THREADS) {
             double o[6], f[4], B[4][6], W[4][4];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+            for (int k = 0; k < 6; ++k) o[k] = g.xi[GH_XI * i + k];
             tril_block(T, o, f, B);
             block_W(B, W);
             double chk = 0.0, fro2 = 0.0;
@@ -325,7 +329,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
                 for (int i = tid; i < N; i += GH_WG_THREADS) {
                     double o[6], f[4], B[4][6], W[4][4];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                    for (int k = 0; k < 6; ++k) o[k] = g.xi[GH_XI * i + k];
                     tril_block(T, o, f, B);
                     block_W(B, W);
                     double up, lo;
@@ -341,7 +345,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
                     for (int i = tid; i < N; i += GH_WG_THREADS) {
                         double o[6], f[4], B[4][6], W[4][4], V[4][4];
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                        for (int k = 0; k < 6; ++k) o[k] = g.xi[GH_XI * i + k];
                         tril_block(T, o, f, B);
                         block_W(B, W);
                         jacobi4<false>(W, V);
@@ -370,7 +374,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
                     if (i < N) {
                         double o[6], f[4], B[4][6], W[4][4], Wp[10];
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                        for (int k = 0; k < 6; ++k) o[k] = g.xi[GH_XI * i + k];
                         tril_block(T, o, f, B);
                         block_W(B, W);
                         double nn[4], cs = 0.0;
@@ -379,7 +383,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
 #pragma unroll
                         for (int a = 0; a < 4; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
 #pragma unroll
-                        for (int k = 0; k < 10; ++k) g.pp[10 * i + k] = Wp[k];
+                        for (int k = 0; k < 10; ++k) g.pp[GH_PP * i + k] = Wp[k];
                         if constexpr (!Model::IDENTITY_D) if (want_factored && ok) {
                             // b = sqrt(cs) D' (Ap' n),  t = sqrt(cs) n'w,  n'w = -n'f - (B'n) . (x - xi)
                             double gm[3][3];
@@ -411,7 +415,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
             for (int i = tid; i < N; i += GH_WG_THREADS) {
                 double o[6], f[4], B[4][6], W[4][4], V[4][4];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[GH_XI * i + k];
                 tril_block(T, o, f, B);
                 block_W(B, W);
                 jacobi4<true>(W, V);
@@ -426,7 +430,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
                         Wp[a * (a + 1) / 2 + b] = V[a][0] * inv[0] * V[b][0] + V[a][1] * inv[1] * V[b][1] + V[a][2] * inv[2] * V[b][2]
                                                   + V[a][3] * inv[3] * V[b][3] + ((a == b) ? 1e-12 : 0.0);
 #pragma unroll
-                for (int k = 0; k < 10; ++k) g.pp[10 * i + k] = Wp[k];
+                for (int k = 0; k < 10; ++k) g.pp[GH_PP * i + k] = Wp[k];
             }
             break;
         }
@@ -516,7 +520,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         for (int i = tid; i < N; i += GH_WG_THREADS) {
             double o[6], f[4], B[4][6], Ad[4];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+            for (int k = 0; k < 6; ++k) o[k] = g.xi[GH_XI * i + k];
             tril_block(T, o, f, B);
             {
                 double m[3][3], t1[3][3], t2[3][3];
@@ -525,7 +529,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
             }
             double Wp[10], r[4], wv[4];
 #pragma unroll
-            for (int k = 0; k < 10; ++k) Wp[k] = g.pp[10 * i + k];
+            for (int k = 0; k < 10; ++k) Wp[k] = g.pp[GH_PP * i + k];
             const Pt6 x = premap(load_pt(pts, i), w->nrm);
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -549,7 +553,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 const double v = -(B[0][k] * r[0] + B[1][k] * r[1] + B[2][k] * r[2] + B[3][k] * r[3]) - bn[k] * sterm;
-                g.pp[10 * i + k] = v;
+                g.pp[GH_PP * i + k] = v;
                 obj += v * v;
                 const double d = o[k] - x.v[k] - v;
                 diff += d * d;
@@ -566,7 +570,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         for (int i = tid; i < N; i += GH_WG_THREADS) {                       // xi = x + v; ti = ti + dt   (:80)
             const Pt6 x = premap(load_pt(pts, i), w->nrm);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) g.xi[6 * i + k] = x.v[k] + g.pp[10 * i + k];
+            for (int k = 0; k < 6; ++k) g.xi[GH_XI * i + k] = x.v[k] + g.pp[GH_PP * i + k];
         }
         if (tid < u) g.p[tid] += g.dt[tid];
         __syncthreads();
@@ -591,7 +595,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::WG_PER_CU) k_gh_block(co
         const double* pts = a.corresp + b * 6 * (long)N;
         double* red;
         GhWork g = gh_wg_carve(ghbase, w, Model::U, Model::C, a.spill ? 0 : N, Model::REDUNDANT_CONSTRAINTS, &red);
-        if (a.spill) { g.xi = a.spill + blockIdx.x * a.spill_stride; g.pp = g.xi + 6 * (long)N; }
+        if (a.spill) { g.xi = a.spill + blockIdx.x * a.spill_stride; g.pp = g.xi + GH_XI * (long)N; }
         const int own = (int)(b & (GH_WG_WAVES - 1));
         const double* r = a.rec + b * GH_REC_DOUBLES;
         if (tid < 27) w->t[tid] = r[tid];

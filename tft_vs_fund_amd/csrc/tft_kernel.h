@@ -224,11 +224,10 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double
     const int wl = Grp::index() * G;                                         // first lane of this group (stamp writer)
     int it1 = 0, it2 = 0;
     bool ok = true;
-    double gR[27];                                                           // exact tier: R of the 4N x 27 system, row `lane` (unused otherwise)
     {                                                                        // :64-67
         double x;
         if (JAC) {
-            double (&g)[27] = gR;
+            double g[27];                                                    // R of the 4N x 27 system, row `lane`; survives in jw->A
             tft_system_qr(pts, N, w->nrm, g);
             phase_stamp(dbg, 3, wl);
             x = wave_qr_min_rsv<27>(g, jw->A, jw->V, w->Lp, EIG_MAXIT, &it1);
@@ -253,7 +252,10 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double
     if (lane == 1) frame_of(w->epi + 3, w->Q + 9);                           // Q3 from e31
     wave_sync();
     if (JAC) {                                                               // :84 from R: svd(A Up) == svd(R Up), A = Q R
-        const double (&g)[27] = gR;
+        double g[27];                                                        // row `lane` of R (zeros below the diagonal), from the stage above
+#pragma unroll
+        for (int c = 0; c < 27; ++c) g[c] = (lane < 27) ? jw->A[lane * 27 + c] : 0.0;
+        wave_sync();
         double* Bm = w->Lp;                                                  // 27 x 15 rows of R Up
         if (lane < 27) {
 #pragma unroll
@@ -267,7 +269,7 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double
 #pragma unroll
                         for (int j = 0; j < 3; ++j) {
                             const int c = j + 3 * k + 9 * i;
-                            acc += ((c >= lane) ? g[c] : 0.0) * w->Q[3 * j + jj] * w->Q[9 + 3 * k + kk];
+                            acc += g[c] * w->Q[3 * j + jj] * w->Q[9 + 3 * k + kk];
                         }
                     Bm[lane * 15 + 5 * i + m] = acc;
                 }

@@ -129,7 +129,8 @@ __device__ inline double wave_hestenes_min_rsv(double* Rm, double* V, const int 
     return (lane < n) ? V[lane * n + best] : 0.0;
 }
 
-// Steps 2 and 3 for an R held in registers (lane r < n: row r).  Rm, Vm: n x n LDS each; Lp: n x n LDS.
+// Steps 2 and 3 for an R held in registers (lane r < n: row r).  Rm, Vm: n x n LDS each; Lp: n x n LDS.  On return Rm holds R
+// (row-major, exact zeros below the diagonal) whichever path ran.
 // *iters: inverse iterations, or 1000 + sweeps when the one-sided Jacobi ran.
 template <int n>
 __device__ inline double wave_qr_min_rsv(const double (&g)[n], double* Rm, double* Vm, double* Lp, const int maxit, int* iters) {
@@ -137,9 +138,12 @@ __device__ inline double wave_qr_min_rsv(const double (&g)[n], double* Rm, doubl
     int it = 0;
     double r2 = 0.0;
     double x = wave_invit_unit<n, 64>(Lp, myinv, maxit, &it, &r2);
-    if (!eig_converged(r2)) {
+    if (!eig_converged(r2)) {                               // on a COPY of R (the factor in Lp is dead by now): Rm stays intact for the caller
+        const int lane = lane_id();
+        for (int e = lane; e < n * n; e += WAVE) Lp[e] = Rm[e];
+        wave_sync();
         int sw = 0;
-        x = wave_hestenes_min_rsv(Rm, Vm, n, &sw);
+        x = wave_hestenes_min_rsv(Lp, Vm, n, &sw);
         it = 1000 + sw;
     }
     *iters = it;
