@@ -42,7 +42,7 @@ extern "C" int emu_linear_tft_pose(const double* corresp, const double* calm, lo
 }
 extern "C" int emu_linear_f_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
                                  double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
-    return emu_pose(tff::k_f_pose<false, 0>, tff::k_f_pose<true, 0>, tff::pose_lds_bytes, true, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T,
+    return emu_pose(tff::k_f_pose<false, 0>, tff::k_f_pose<true, 0>, tff::f_pose_lds_bytes, true, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T,
                     reconst, iter, status, dbg);
 }
 extern "C" int emu_optim_f_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
@@ -129,9 +129,9 @@ extern "C" int emu_linear_f(const double* corresp, long B, int N, int refine, do
         a.flags |= tff::FLAG_ONLY_RETRY;
         emu::launch(tff::k_linear_f<true, 1>, emu_grid(B), 64, tff::optimf_lds_bytes(N, 0, true), a);
     } else {
-        emu::launch(tff::k_linear_f<false, 0>, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
+        emu::launch(tff::k_linear_f<false, 0>, emu_grid(B), 64, tff::f_pose_lds_bytes(N, 0, false), a);
         a.flags |= tff::FLAG_ONLY_RETRY;
-        emu::launch(tff::k_linear_f<true, 0>, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, true), a);
+        emu::launch(tff::k_linear_f<true, 0>, emu_grid(B), 64, tff::f_pose_lds_bytes(N, 0, true), a);
     }
     return 0;
 }

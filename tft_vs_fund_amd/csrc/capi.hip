@@ -177,7 +177,7 @@ int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int
 }
 int launch_linear_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    return launch_pose(c, tff::k_f_pose<false, 0>, tff::k_f_pose<true, 0>, tff::pose_lds_bytes, tff::STAGE_MAX_N_F, 0, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
+    return launch_pose(c, tff::k_f_pose<false, 0>, tff::k_f_pose<true, 0>, tff::f_pose_lds_bytes, tff::STAGE_MAX_N_F, 0, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
                        reconst, iter, status, dbg);
 }
 int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
@@ -702,11 +702,11 @@ int tff_linear_f_batch_dev(tff_ctx* c, const double* corresp, int64_t B, int32_t
         hipLaunchKernelGGL((tff::k_linear_f<true, 1>), dim3(fix_grid), dim3(64), lds, c->stream, a);
     } else {
         if (!all_exact) {
-            hipLaunchKernelGGL((tff::k_linear_f<false, 0>), dim3(tff::pose_grid(B)), dim3(64), tff::pose_lds_bytes(N, 0, false), c->stream, a);
+            hipLaunchKernelGGL((tff::k_linear_f<false, 0>), dim3(tff::pose_grid(B)), dim3(64), tff::f_pose_lds_bytes(N, 0, false), c->stream, a);
             TFF_HIP(hipGetLastError());
             a.flags |= tff::FLAG_ONLY_RETRY;
         }
-        hipLaunchKernelGGL((tff::k_linear_f<true, 0>), dim3(fix_grid), dim3(64), tff::pose_lds_bytes(N, 0, true), c->stream, a);
+        hipLaunchKernelGGL((tff::k_linear_f<true, 0>), dim3(fix_grid), dim3(64), tff::f_pose_lds_bytes(N, 0, true), c->stream, a);
     }
     TFF_HIP(hipGetLastError());
     return 0;

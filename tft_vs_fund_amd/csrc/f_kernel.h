@@ -260,11 +260,30 @@ __device__ inline int gauss_helmert_f_wave(PoseLds* w, OptimFLds* g, double* xi,
     return (it > 400) ? 400 : it;
 }
 
+// R of the N x 9 system of linearF.m:48-53 for N <= M correspondences, column layout (wave_qr_cols_append), left in Rl (9 x 9 LDS)
+template <int M>
+__device__ inline void linear_f_system_cols(PoseLds* w, const double* pts, int N, int pair, double* Rl) {
+    const int lane = lane_id();
+    for (int e = lane; e < 81; e += WAVE) Rl[e] = 0.0;
+    wave_sync();
+    const int col = (lane < 9) ? lane : 0, ca = col / 3, cb = col % 3;
+    double a[M];
+#pragma unroll
+    for (int q = 0; q < M; ++q) {
+        const Pt6 p = premap(premap(load_pt(pts, (q < N) ? q : 0), w->nrm), w->nrm2);   // wave-uniform address
+        const double h1 = (ca == 0) ? p.v[0] : (ca == 1) ? p.v[1] : 1.0;
+        const double x2 = pair ? p.v[4] : p.v[2], y2 = pair ? p.v[5] : p.v[3];
+        const double h2 = (cb == 0) ? x2 : (cb == 1) ? y2 : 1.0;
+        a[q] = (q < N && lane < 9) ? h1 * h2 : 0.0;
+    }
+    wave_qr_cols_append<9, M>(a, Rl);
+}
+
 // linearF(x1,x2) and linearF(x1,x3) (F_methods/linearF.m:45-62) on the points premapped by w->nrm, with linearF's own
 // normalisation in w->nrm2: 8-point DLT through the 72 moment sums, inner de-normalisation, rank-2 projection.
 // Result: w->Fm[9 pair + 3 r + c] (row-major), optionally scaled to unit Frobenius norm.  false: eigen-solver wants the Jacobi pass.
 template <bool JAC>
-__device__ inline bool linear_f_wave(PoseLds* w, JacobiLds* jw, const double* pts, int N, double* dbg, bool unit_norm) {
+__device__ inline bool linear_f_wave(PoseLds* w, JacobiLdsF* jw, const double* pts, int N, double* dbg, bool unit_norm) {
     const int lane = lane_id();
     if (!JAC) accumulate_moments_f(w, pts, N);
     bool ok = true;
@@ -274,9 +293,17 @@ __device__ inline bool linear_f_wave(PoseLds* w, JacobiLds* jw, const double* pt
         int its = 0;
         if (JAC) {
             // exact tier: streaming QR of the N x 9 system itself (linearF.m:48-53; row = h1 (x) h2, position 3a + b), 55 rows per chunk
+            // (minimal samples, N <= 16: one chunk in the column layout -- lane c < 9 owns column c -- at a third of the instructions)
             double g[9];
 #pragma unroll
             for (int c = 0; c < 9; ++c) g[c] = 0.0;
+            if (N <= 8) {
+                linear_f_system_cols<8>(w, pts, N, pair, jw->A);
+                wave_qr_rows_from_lds<9>(jw->A, g);
+            } else if (N <= 16) {
+                linear_f_system_cols<16>(w, pts, N, pair, jw->A);
+                wave_qr_rows_from_lds<9>(jw->A, g);
+            } else
 #pragma unroll 1
             for (int base = 0; base < N; base += 55) {
                 const int i = base + lane - 9;
@@ -379,12 +406,12 @@ __device__ inline int optim_f_refine(PoseLds* w, OptimFLds* og, double* oxi, con
 
 // METHOD 0: LinearFPoseEstimation; METHOD 1: OptimFPoseEstimation (F_methods/OptimFPoseEstimation.m:44-73)
 template <bool JAC, int METHOD>
-__global__ void __launch_bounds__(64, METHOD == 1 ? 3 : 2) k_f_pose(const LinearTftArgs a) {
+__global__ void __launch_bounds__(64, (METHOD == 1 || JAC) ? 3 : 2) k_f_pose(const LinearTftArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
     PoseLds* w = reinterpret_cast<PoseLds*>(smem);
     constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
-    JacobiLds* jw = JAC ? reinterpret_cast<JacobiLds*>(smem + base) : nullptr;
-    double* extra = smem + base + (JAC ? ((JACOBI_LDS_DOUBLES + 1) & ~1) : 0);
+    JacobiLdsF* jw = JAC ? reinterpret_cast<JacobiLdsF*>(smem + base) : nullptr;
+    double* extra = smem + base + (JAC ? ((JACOBI_F_LDS_DOUBLES + 1) & ~1) : 0);
     OptimFLds* og = (METHOD == 1) ? reinterpret_cast<OptimFLds*>(extra) : nullptr;
     double* oxi = a.spill ? a.spill + blockIdx.x * a.spill_stride : extra + ((OPTIMF_FIXED_DOUBLES + 1) & ~1);   // METHOD 1: xi (4N), then v (4N); large N: global
     double* lds_pts = (METHOD == 1) ? oxi + 8 * a.N + 2 : extra;             // staged correspondences (METHOD 0, or sampled)
@@ -495,8 +522,8 @@ __global__ void __launch_bounds__(64, 2) k_linear_f(const LinearFOnlyArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
     PoseLds* w = reinterpret_cast<PoseLds*>(smem);
     constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
-    JacobiLds* jw = JAC ? reinterpret_cast<JacobiLds*>(smem + base) : nullptr;
-    double* extra = smem + base + (JAC ? ((JACOBI_LDS_DOUBLES + 1) & ~1) : 0);
+    JacobiLdsF* jw = JAC ? reinterpret_cast<JacobiLdsF*>(smem + base) : nullptr;
+    double* extra = smem + base + (JAC ? ((JACOBI_F_LDS_DOUBLES + 1) & ~1) : 0);
     OptimFLds* og = REFINE ? reinterpret_cast<OptimFLds*>(extra) : nullptr;
     double* oxi = extra + ((OPTIMF_FIXED_DOUBLES + 1) & ~1);
     const int lane = lane_id();

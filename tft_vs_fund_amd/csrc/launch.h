@@ -18,6 +18,13 @@ inline size_t pose_lds_bytes(int N, int flags, bool jacobi) {
     if (flags & FLAG_STAGE_LDS) d += 6 * (size_t)N;
     return d * sizeof(double);
 }
+// ... of the fundamental-matrix pose kernels (9 x 9 exact-tier workspace)
+inline size_t f_pose_lds_bytes(int N, int flags, bool jacobi) {
+    size_t d = (size_t)((POSE_LDS_DOUBLES + 1) & ~1);
+    if (jacobi) d += (size_t)((JACOBI_F_LDS_DOUBLES + 1) & ~1);
+    if (flags & FLAG_STAGE_LDS) d += 6 * (size_t)N;
+    return d * sizeof(double);
+}
 // Stage the correspondences in LDS only while that does not cost occupancy: measured on MI355X (tools/bench_n_sweep.py, STAGE=0 / 1)
 // re-reading them through L2 / MALL wins from N ~ 220 for the trifocal kernel (26 vs 19 M/s at N = 300, 10.9 vs 4.4 M/s at
 // N = 1000, where the staged points would leave two wavefronts per CU) and from N ~ 64 for the fundamental-matrix kernel, whose
@@ -47,7 +54,7 @@ inline size_t pi_lds_bytes(int N, int /*flags*/, bool jacobi) {
 // OptimFPoseEstimation: xi and v (4N each) + the 11 x 11 KKT workspace
 inline size_t optimf_lds_bytes(int N, int flags, bool jacobi) {
     size_t d = (size_t)((POSE_LDS_DOUBLES + 1) & ~1);
-    if (jacobi) d += (size_t)((JACOBI_LDS_DOUBLES + 1) & ~1);
+    if (jacobi) d += (size_t)((JACOBI_F_LDS_DOUBLES + 1) & ~1);
     d += (size_t)((OPTIMF_FIXED_DOUBLES + 1) & ~1) + 8 * (size_t)N + 2;
     if (flags & FLAG_STAGE_LDS) d += 6 * (size_t)N;
     return d * sizeof(double);

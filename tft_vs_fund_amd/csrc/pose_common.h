@@ -49,13 +49,19 @@ struct PoseLds {
     double nrm2[9];        // linearF's inner normalisation (of the already normalised points)
     double Fm[18];         // F21, F31 (row-major)
 };
-// extra workspace of the Jacobi kernel variant: full matrix + eigenvector matrix
+// extra workspace of the exact kernel variant: R of the 4N x 27 system (kept for the second solve of linearTFT.m:84; the rotations
+// of a Hestenes fall-back go to PoseLds::Lp).  One 27 x 27 array, not two: 16 KB per wavefront with PoseLds -- eight wavefronts per CU
 struct JacobiLds {
     double A[27 * 27];
-    double V[27 * 27];
+};
+// the same for the fundamental-matrix kernels (9 x 9): 1.3 KB instead of 11.7 KB per wavefront
+struct JacobiLdsF {
+    double A[9 * 9];
+    double V[9 * 9];
 };
 constexpr int POSE_LDS_DOUBLES = (int)(sizeof(PoseLds) / sizeof(double));
 constexpr int JACOBI_LDS_DOUBLES = (int)(sizeof(JacobiLds) / sizeof(double));
+constexpr int JACOBI_F_LDS_DOUBLES = (int)(sizeof(JacobiLdsF) / sizeof(double));
 
 __device__ __forceinline__ Mat3 load_K(const double* calm, int v) {
     Mat3 K;

@@ -176,36 +176,30 @@ __device__ __forceinline__ void up_factors(const double* Q, int m, double (&a2)[
     for (int q = 0; q < 3; ++q) { a2[q] = Q[3 * q + jj]; a3[q] = Q[9 + 3 * q + kk]; }
 }
 
-// Row e (0..3) of correspondence (x1,y1,x2,y2,x3,y3) in the 4N x 27 system of linearTFT.m:51-62:
+// Row e (0..3) of correspondence (x1,y1,x2,y2,x3,y3) in the 4N x 27 system of linearTFT.m:51-62 is
 //   A(e, j + 3k + 9i) = h1[i] c3[k] c2[j],  h1 = (x1,y1,1),  c2 = (1,0,-x2) | (0,1,-y2),  c3 = (1,0,-x3) | (0,1,-y3).
-__device__ __forceinline__ void tft_system_row(const Pt6& p, const int e, double (&g)[27]) {
-    const double h1[3] = {p.v[0], p.v[1], 1.0};
-    const double c2[3] = {(e & 1) ? 0.0 : 1.0, (e & 1) ? 1.0 : 0.0, (e & 1) ? -p.v[3] : -p.v[2]};
-    const double c3[3] = {(e & 2) ? 0.0 : 1.0, (e & 2) ? 1.0 : 0.0, (e & 2) ? -p.v[5] : -p.v[4]};
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) g[j + 3 * k + 9 * i] = h1[i] * c3[k] * c2[j];
-}
-// R of the QR factorisation of the 4N x 27 system (normalised correspondences): lane r < 27 ends with row r.
-// Nine correspondences (36 rows, lanes 27..62) per chunk.
-__device__ inline void tft_system_qr(const double* pts, const int N, const double* nrm, double (&g)[27]) {
+// R of the QR factorisation of the 4N x 27 system (normalised correspondences), left in Rl (27 x 27 LDS, row-major).
+// Column layout (wave_qr_cols_append): lane c < 27 owns column c = j + 3k + 9i and builds its entry of the four rows of each
+// correspondence from the formula above; seven correspondences (28 rows) per chunk -- a minimal sample is one chunk.
+__device__ inline void tft_system_qr(const double* pts, const int N, const double* nrm, double* Rl) {
     const int lane = lane_id();
-#pragma unroll
-    for (int c = 0; c < 27; ++c) g[c] = 0.0;
+    for (int e = lane; e < 27 * 27; e += WAVE) Rl[e] = 0.0;
+    wave_sync();
+    const int col = (lane < 27) ? lane : 0, ci = col / 9, ck = (col % 9) / 3, cj = col % 3;
 #pragma unroll 1
-    for (int base = 0; base < N; base += 9) {
-        const int slot = lane - 27, i = base + (slot >> 2);
-        if (lane >= 27) {
-            if (slot < 36 && i < N) tft_system_row(premap(load_pt(pts, i), nrm), slot & 3, g);
-            else {
+    for (int base = 0; base < N; base += 7) {
+        double a[28];
 #pragma unroll
-                for (int c = 0; c < 27; ++c) g[c] = 0.0;
-            }
+        for (int q = 0; q < 7; ++q) {
+            const int i = base + q;                                          // wave-uniform: every lane reads the same point
+            const Pt6 p = premap(load_pt(pts, (i < N) ? i : 0), nrm);
+            const double h = (i < N && lane < 27) ? ((ci == 0) ? p.v[0] : (ci == 1) ? p.v[1] : 1.0) : 0.0;
+            const double c2x = (cj == 0) ? 1.0 : (cj == 1) ? 0.0 : -p.v[2], c2y = (cj == 0) ? 0.0 : (cj == 1) ? 1.0 : -p.v[3];
+            const double c3x = (ck == 0) ? 1.0 : (ck == 1) ? 0.0 : -p.v[4], c3y = (ck == 0) ? 0.0 : (ck == 1) ? 1.0 : -p.v[5];
+            const double hx = h * c3x, hy = h * c3y;
+            a[4 * q + 0] = hx * c2x; a[4 * q + 1] = hx * c2y; a[4 * q + 2] = hy * c2x; a[4 * q + 3] = hy * c2y;
         }
-        wave_qr_append<27>(g);
+        wave_qr_cols_append<27, 28>(a, Rl);
     }
 }
 
@@ -227,10 +221,17 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double
     {                                                                        // :64-67
         double x;
         if (JAC) {
-            double g[27];                                                    // R of the 4N x 27 system, row `lane`; survives in jw->A
-            tft_system_qr(pts, N, w->nrm, g);
+            tft_system_qr(pts, N, w->nrm, jw->A);                            // R of the 4N x 27 system; survives in jw->A
             phase_stamp(dbg, 3, wl);
-            x = wave_qr_min_rsv<27>(g, jw->A, jw->V, w->Lp, EIG_MAXIT, &it1);
+            double g[27];
+            wave_qr_rows_from_lds<27>(jw->A, g);
+            x = wave_qr_min_rsv<27>(g, jw->A, w->Lp, w->Lp, EIG_MAXIT, &it1);
+            if (it1 >= 1000) {                                               // the fall-back rotated R away: factor again (rare)
+                if (lane < 27) w->t[lane] = x;
+                wave_sync();
+                tft_system_qr(pts, N, w->nrm, jw->A);
+                x = (lane < 27) ? w->t[lane] : 0.0;
+            }
             it1 += 10000;
         } else {
             double g[27], diag;
@@ -252,12 +253,11 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double
     if (lane == 1) frame_of(w->epi + 3, w->Q + 9);                           // Q3 from e31
     wave_sync();
     if (JAC) {                                                               // :84 from R: svd(A Up) == svd(R Up), A = Q R
-        double g[27];                                                        // row `lane` of R (zeros below the diagonal), from the stage above
-#pragma unroll
-        for (int c = 0; c < 27; ++c) g[c] = (lane < 27) ? jw->A[lane * 27 + c] : 0.0;
-        wave_sync();
-        double* Bm = w->Lp;                                                  // 27 x 15 rows of R Up
+        double* Bm = w->Lp;                                                  // R Up, 27 x 15: row r built by lane r ...
         if (lane < 27) {
+            double g[27];                                                    // row `lane` of R (zeros below the diagonal)
+#pragma unroll
+            for (int c = 0; c < 27; ++c) g[c] = jw->A[lane * 27 + c];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -267,21 +267,23 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            const int c = j + 3 * k + 9 * i;
-                            acc += g[c] * w->Q[3 * j + jj] * w->Q[9 + 3 * k + kk];
-                        }
+                        for (int j = 0; j < 3; ++j) acc += g[j + 3 * k + 9 * i] * w->Q[3 * j + jj] * w->Q[9 + 3 * k + kk];
                     Bm[lane * 15 + 5 * i + m] = acc;
                 }
         }
         wave_sync();
-        double h[15];                                                        // lanes 0..14: R2 (zero), lanes 15..41: the rows of R Up
+        double a[27];                                                        // ... column c read back by lane c < 15
 #pragma unroll
-        for (int c = 0; c < 15; ++c) h[c] = (lane >= 15 && lane < 42) ? Bm[(lane - 15) * 15 + c] : 0.0;
+        for (int r = 0; r < 27; ++r) a[r] = (lane < 15) ? Bm[r * 15 + lane] : 0.0;
         wave_sync();
-        wave_qr_append<15>(h);
+        double* R2 = jw->A;                                                  // 15 x 15; R itself is no longer needed
+        for (int e = lane; e < 225; e += WAVE) R2[e] = 0.0;
+        wave_sync();
+        wave_qr_cols_append<15, 27>(a, R2);
         phase_stamp(dbg, 6, wl);
-        const double x = wave_qr_min_rsv<15>(h, jw->A, jw->V, w->Lp, EIG_MAXIT, &it2);
+        double h[15];
+        wave_qr_rows_from_lds<15>(R2, h);
+        const double x = wave_qr_min_rsv<15>(h, jw->A, jw->A + 256, w->Lp, EIG_MAXIT, &it2);
         it2 += 10000;
         if (lane < 15) w->tp[lane] = x;
         wave_sync();

@@ -55,6 +55,48 @@ __device__ inline void wave_qr_append(double (&g)[n]) {
     }
 }
 
+// The same factorisation with the roles of lanes and registers exchanged: lane j < n owns COLUMN j, a[0..M) are that column's
+// entries in M new rows of A, and R (n x n, row-major, zeros below the diagonal) lives in LDS (Rl).  A reflector then needs no
+// cross-lane reduction at all -- its vector comes from lane k by v_readlane into scalar registers, v'A(:,j) is a serial dot
+// product inside lane j -- 2 M readlanes + 3 M fused multiply-adds per step against ~420 instructions of wave_qr_append
+// (select chain, 32 products, 31-add butterfly, n broadcasts).  Only n of 64 lanes work, but the instruction count is what a
+// wavefront pays for: 28 x 27 in 5 k instead of 11 k instructions.  On return a[] holds rounding-level leftovers.
+template <int n, int M>
+__device__ inline void wave_qr_cols_append(double (&a)[M], double* Rl) {
+    const int lane = lane_id();
+    const int col = (lane < n) ? lane : 0;
+#pragma unroll 1
+    for (int k = 0; k < n; ++k) {
+        const double rk = (lane < n) ? Rl[k * n + col] : 0.0;             // row k of R: zero left of the diagonal
+        const double rkk = wave_bcast(rk, k);
+        double s[M], sigma = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) { s[i] = wave_bcast(a[i], k); sigma = fma(s[i], s[i], sigma); }
+        if (!(sigma > 0.0)) continue;                                       // nothing below the diagonal (wave-uniform; also NaN)
+        const double nrm = sqrt(fma(rkk, rkk, sigma));
+        const double alpha = (rkk > 0.0) ? -nrm : nrm;
+        const double v0 = rkk - alpha;                                      // Householder vector (v0, s)
+        const double beta = 1.0 / (fma(rkk, rkk, sigma) - rkk * alpha);     // 2 / v'v
+        double wj = v0 * rk;
+#pragma unroll
+        for (int i = 0; i < M; ++i) wj = fma(s[i], a[i], wj);
+        const double bw = beta * wj;
+#pragma unroll
+        for (int i = 0; i < M; ++i) a[i] = fma(-bw, s[i], a[i]);
+        if (lane < n && lane >= k) Rl[k * n + col] = (lane == k) ? alpha : fma(-bw, v0, rk);
+    }
+    wave_sync();
+}
+
+// Row r of an R kept in LDS by wave_qr_cols_append -> registers of lane r (the layout wave_qr_to_factor / wave_qr_min_rsv take)
+template <int n>
+__device__ inline void wave_qr_rows_from_lds(const double* Rl, double (&g)[n]) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int c = 0; c < n; ++c) g[c] = (lane < n) ? Rl[lane * n + c] : 0.0;
+    wave_sync();
+}
+
 // R (lane r < n: row r in g) -> the row-scaled factor of wave_invit_unit in Lp (n x n) and myinv = 1 / R[lane][lane];
 // Rm (n x n LDS, row-major) receives R itself with exact zeros below the diagonal (for the Hestenes fall-back and R * Up).
 // A zero pivot (rank-deficient A, e.g. noise-free data) is floored at 1e-20 |R|_F: inverse iteration then converges in one step.
@@ -129,21 +171,19 @@ __device__ inline double wave_hestenes_min_rsv(double* Rm, double* V, const int 
     return (lane < n) ? V[lane * n + best] : 0.0;
 }
 
-// Steps 2 and 3 for an R held in registers (lane r < n: row r).  Rm, Vm: n x n LDS each; Lp: n x n LDS.  On return Rm holds R
-// (row-major, exact zeros below the diagonal) whichever path ran.
-// *iters: inverse iterations, or 1000 + sweeps when the one-sided Jacobi ran.
+// Steps 2 and 3 for an R held in registers (lane r < n: row r).  Rm: n x n LDS, receives R; Lp: n x n LDS, the factor; Vm: n x n LDS
+// for the rotations of the fall-back -- it MAY BE Lp itself (the factor is dead when the fall-back starts).  The fall-back works
+// in place: *iters >= 1000 (1000 + sweeps) tells the caller that Rm no longer holds R.
 template <int n>
 __device__ inline double wave_qr_min_rsv(const double (&g)[n], double* Rm, double* Vm, double* Lp, const int maxit, int* iters) {
     const double myinv = wave_qr_to_factor<n>(g, Rm, Lp);
     int it = 0;
     double r2 = 0.0;
     double x = wave_invit_unit<n, 64>(Lp, myinv, maxit, &it, &r2);
-    if (!eig_converged(r2)) {                               // on a COPY of R (the factor in Lp is dead by now): Rm stays intact for the caller
-        const int lane = lane_id();
-        for (int e = lane; e < n * n; e += WAVE) Lp[e] = Rm[e];
+    if (!eig_converged(r2)) {
         wave_sync();
         int sw = 0;
-        x = wave_hestenes_min_rsv(Lp, Vm, n, &sw);
+        x = wave_hestenes_min_rsv(Rm, Vm, n, &sw);
         it = 1000 + sw;
     }
     *iters = it;

@@ -19,5 +19,6 @@ for rec in (False, True):
     dt = np.diff(st, axis=1)
     tot = st[:, 13] - st[:, 0]
     print("reconst", rec, "mean cycles/wave %.0f  (its27 mean %.2f, its15 mean %.2f)" % (tot.mean(), dbg[:, 69].mean(), dbg[:, 70].mean()))
+    print("   fall-backs to one-sided Jacobi: 27-column solve %d, 15-column solve %d of %d" % (((dbg[:, 69] % 10000) >= 1000).sum(), ((dbg[:, 70] % 10000) >= 1000).sum(), B))
     for k, nme in enumerate(names):
         print("  %-24s %9.0f  %5.1f%%" % (nme, dt[:, k].mean(), 100 * dt[:, k].mean() / tot.mean()))
