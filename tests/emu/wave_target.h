@@ -23,6 +23,8 @@ inline double wave_uniform(double v) { return v; }
 inline int wave_uniform_i(int v) { return v; }
 typedef double* lds_ptr;
 inline lds_ptr to_lds(double* p) { return p; }
+inline double fast_rcp(double v) { return 1.0 / v; }
+inline int opaque_int(int v) { return v; }
 inline void sched_fence() {}
 inline long long shader_clock() { return 0; }
 inline int wave_first_lane(bool p) {

@@ -134,7 +134,10 @@ def test_config4_minimal_hypotheses_and_inlier_counts(gpu_ctx):
         idx = np.stack([rng.choice(Ns, n, replace=False) for _ in range(B)]).astype(np.int32)
         hyp = gpu_ctx.pose_sampled(method, scene, CalM, idx)
         cnt, err = gpu_ctx.inlier_count(scene, CalM, hyp["R_t_2"], hyp["R_t_3"], 1.0, with_error=True)
+        cnt_only = gpu_ctx.inlier_count(scene, CalM, hyp["R_t_2"], hyp["R_t_3"], 1.0)
         torch.cuda.synchronize()
+        # count-only calls skip the triangulation of certain outliers (pivot test on S - thr^2 Z): same counts
+        assert torch.equal(cnt, cnt_only), (method, (cnt != cnt_only).sum())
         st = hyp["status"].cpu().numpy(); cnt = cnt.cpu().numpy()
         R2 = hyp["R_t_2"].cpu().numpy(); R3 = hyp["R_t_3"].cpu().numpy()
         assert np.all(st == 0)

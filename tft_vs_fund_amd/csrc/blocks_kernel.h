@@ -66,6 +66,33 @@ struct ReprErrorArgs {
     double* err;             // B or null: RMS reprojection error (ReprError.m:65)
     int* inliers;            // B or null: #{n : all six |residuals| <= thr}   (experiments_real.m:98)
 };
+// true only if S - Z (lower triangles) is positive definite with a margin that covers the approximate reciprocals (v_rcp_f64,
+// ~1e-7 relative) of this division-free pivot test: every pivot of the LDL' factorisation above 1e-4 of its diagonal entry
+__device__ __forceinline__ bool certainly_positive_definite(const double (&S)[4][4], const double (&Z)[4][4]) {
+    double A[4][4], L[4][4], d[4], rd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) A[i][j] = S[i][j] - Z[i][j];
+    bool pd = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double dj = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) dj -= L[j][k] * L[j][k] * d[k];
+        pd = pd && (dj > 1e-4 * S[j][j]);
+        d[j] = dj;
+        rd[j] = fast_rcp(dj);
+#pragma unroll
+        for (int i = j + 1; i < 4; ++i) {
+            double v = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * d[k];
+            L[i][j] = v * rd[j];
+        }
+    }
+    return pd;
+}
 __global__ void __launch_bounds__(64, 4) k_repr_error(const ReprErrorArgs a) {
     __shared__ double cam[3][12];
     const int lane = lane_id();
@@ -89,6 +116,20 @@ __global__ void __launch_bounds__(64, 4) k_repr_error(const ReprErrorArgs a) {
         load_uniform12(cam[1], P[1]);
         load_uniform12(cam[2], P[2]);
         const double* c = a.corresp + b * a.corresp_stride;
+        // Inlier count only: a correspondence whose DLT point X passes the rule has |M X|^2 = sum_v z_v^2 (dx_v^2 + dy_v^2) <=
+        // thr^2 X'Z X with z_v = P_v(3,:) X and Z = 2 sum_v P_v(3,:)' P_v(3,:) (each DLT row is the depth times one residual).
+        // So S - thr^2 Z positive definite  =>  NO X passes, whatever the eigen-solve would return: a certain outlier for the
+        // price of one 4 x 4 pivot test.  Against a wrong hypothesis that is nearly every correspondence of the scene, and the
+        // (divergent, gap-dependent) eigen-solves are left to the correspondences that could be inliers.
+        const bool count_only = a.inliers && !a.err && !a.pts3d;
+        double Zt[4][4];
+        if (count_only) {
+            const double k2 = 2.0 * a.thr * a.thr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) Zt[i][j] = k2 * (P[0][8 + i] * P[0][8 + j] + P[1][8 + i] * P[1][8 + j] + P[2][8 + i] * P[2][8 + j]);
+        }
         double ss = 0.0;
         int cnt = 0;
 #pragma unroll 1
@@ -99,7 +140,13 @@ __global__ void __launch_bounds__(64, 4) k_repr_error(const ReprErrorArgs a) {
                 const double* q = a.pts3d + (b * a.N + i) * 3;
                 X[0] = q[0]; X[1] = q[1]; X[2] = q[2]; X[3] = 1.0;
             } else {
-                dlt_point<true>(P[0], P[1], P[2], cam[0], cam[1], cam[2], true, p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], p.v[5], X);
+                double S[4][4];
+                tri_zero(S);
+                tri_accum(S, P[0], p.v[0], p.v[1]);
+                tri_accum(S, P[1], p.v[2], p.v[3]);
+                tri_accum(S, P[2], p.v[4], p.v[5]);
+                if (count_only && certainly_positive_definite(S, Zt)) continue;
+                dlt_point_solve<true>(S, cam[0], cam[1], cam[2], true, p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], p.v[5], X);
             }
             bool in = true;
 #pragma unroll

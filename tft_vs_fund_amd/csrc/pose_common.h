@@ -334,6 +334,55 @@ __device__ __attribute__((noinline)) Vec4 dlt_point_exact(const double* camA, co
     return X;
 }
 
+// Steps B - D of spd_min_eigvec_cert for the DLT system (see small_la.h), from the iterate `start` of its step A.  Out of line
+// like dlt_point_exact (a caller's register budget is the maximum over its callees); the rows of the system are re-derived from
+// the cameras in LDS wherever they are needed instead of being kept.  *ok = 0: not certified, the caller goes on to dlt_point_exact.
+__device__ __attribute__((noinline)) Vec4 dlt_point_cert(const double* camA, const double* camB, const double* camC, const int three,
+                                                         const double xa, const double ya, const double xb, const double yb,
+                                                         const double xc, const double yc, const Vec4 start, int* ok) {
+    const int views = three ? 3 : 2;
+    auto rows = [&](const int v, double (&r0)[4], double (&r1)[4]) {
+        const double* P = (v == 0) ? camA : ((v == 1) ? camB : camC);
+        const double x = (v == 0) ? xa : ((v == 1) ? xb : xc), y = (v == 0) ? ya : ((v == 1) ? yb : yc);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { r0[c] = y * P[8 + c] - P[4 + c]; r1[c] = P[c] - x * P[8 + c]; }
+    };
+    double S[4][4];
+    tri_zero(S);
+#pragma unroll 1
+    for (int v = 0; v < views; ++v) {
+        double r0[4], r1[4];
+        rows(v, r0, r1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) S[i][j] += r0[i] * r0[j] + r1[i] * r1[j];
+    }
+    double x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = start.v[k];
+    const bool fine = spd_min_eigvec_cert_tail<4>(S, x, [&](const double (&u)[4], double (&out)[4], double& rho) {
+        rho = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[c] = 0.0;
+#pragma unroll 1
+        for (int v = 0; v < views; ++v) {
+            double r0[4], r1[4];
+            rows(v, r0, r1);
+            const double m0 = r0[0] * u[0] + r0[1] * u[1] + r0[2] * u[2] + r0[3] * u[3];
+            const double m1 = r1[0] * u[0] + r1[1] * u[1] + r1[2] * u[2] + r1[3] * u[3];
+            rho += m0 * m0 + m1 * m1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[c] += r0[c] * m0 + r1[c] * m1;
+        }
+    });
+    *ok = fine ? 1 : 0;
+    Vec4 X;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) X.v[k] = x[k];
+    return X;
+}
+
 // The DLT point of one correspondence (triangulation3D.m:51-63): V(:,4) of the 2M x 4 system of cameras PA, PB and (three) PC,
 // unit norm, sign free.  Fast tier: Cholesky + inverse iteration on the 4 x 4 normal matrix, run until the iterate stops
 // moving.  When the two smallest singular values nearly coincide (inconsistent systems: minimal samples, wrong candidates) the
@@ -344,6 +393,10 @@ __device__ __attribute__((noinline)) Vec4 dlt_point_exact(const double* camA, co
 //                  restore ~35 registers on every entry.
 // PA.. hold the cameras as (wave-uniform) values, camA.. point to the same cameras in LDS (for the exact tier).
 template <bool EXACT>
+__device__ __forceinline__ bool dlt_point_solve(const double (&S)[4][4], const double* camA, const double* camB, const double* camC, const bool three,
+                                                const double xa, const double ya, const double xb, const double yb, const double xc, const double yc,
+                                                double (&X)[4]);
+template <bool EXACT>
 __device__ __forceinline__ bool dlt_point(const double (&PA)[12], const double (&PB)[12], const double (&PC)[12],
                                           const double* camA, const double* camB, const double* camC, const bool three,
                                           const double xa, const double ya, const double xb, const double yb, const double xc, const double yc,
@@ -353,8 +406,27 @@ __device__ __forceinline__ bool dlt_point(const double (&PA)[12], const double (
     tri_accum(S, PA, xa, ya);
     tri_accum(S, PB, xb, yb);
     if (three) tri_accum(S, PC, xc, yc);
+    return dlt_point_solve<EXACT>(S, camA, camB, camC, three, xa, ya, xb, yb, xc, yc, X);
+}
+// ... from the normal matrix S = M'M of the system (lower triangle), for callers that need S themselves
+template <bool EXACT>
+__device__ __forceinline__ bool dlt_point_solve(const double (&S)[4][4], const double* camA, const double* camB, const double* camC, const bool three,
+                                                const double xa, const double ya, const double xb, const double yb, const double xc, const double yc,
+                                                double (&X)[4]) {
     bool conv;
-    spd_min_eigvec<4>(S, X, 40, &conv);
+    spd_min_eigvec<4>(S, X, EXACT ? opaque_int(3) : 40, &conv);
+    if constexpr (EXACT) {
+        if (!conv) {                                                         // gap-independent tier (small_la.h), out of line
+            Vec4 E;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) E.v[k] = X[k];
+            int ok = 0;
+            E = dlt_point_cert(camA, camB, camC, three ? 1 : 0, xa, ya, xb, yb, xc, yc, E, &ok);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) X[k] = E.v[k];
+            conv = ok != 0;
+        }
+    }
     if (EXACT && !conv) {
         Vec4 E; E = dlt_point_exact(camA, camB, camC, three ? 1 : 0, xa, ya, xb, yb, xc, yc);
 #pragma unroll
@@ -475,9 +547,10 @@ __device__ __attribute__((noinline)) int tri_vote_fast(PoseLds* w, const double*
 // exact tier: every correspondence from its converged homogeneous point  (R_t_from_TFT.m:98-99)
 __device__ __attribute__((noinline)) int tri_vote_exact(PoseLds* w, const double* pts, int N, int view, const double* camB, const double* Rt) {
     const int lane = lane_id();
-    double PA[12], PB[12], R3[4];
-    load_uniform12(w->Pfin[0], PA);
-    load_uniform12(camB, PB);
+    typedef const double (&cam_ref)[12];                                     // cameras read from LDS where used: see tri_pass_impl
+    cam_ref PA = *reinterpret_cast<const double(*)[12]>(w->Pfin[0]);
+    cam_ref PB = *reinterpret_cast<const double(*)[12]>(camB);
+    double R3[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) R3[c] = wave_uniform(Rt[8 + c]);
     int score = 0;
@@ -525,10 +598,18 @@ template <bool EXACT>
 __device__ __forceinline__ int tri_pass_impl(PoseLds* w, const double* pts, int N, int mode, int view, const double* camB,
                                              const double* aux, double* out, const double* pre) {
     const int lane = lane_id();
-    double PA[12], PB[12], AX[12];
-    load_uniform12(w->Pfin[0], PA);
-    load_uniform12(camB, PB);
-    load_uniform12(aux, AX);
+    // EXACT: the cameras are read from LDS where they are used instead of being held in registers, so that none of their 36
+    // values stays live across the out-of-line tiers of dlt_point (a function's register budget is what its callers must keep free)
+    double PAr[12], PBr[12], AXr[12];
+    if (!EXACT) {
+        load_uniform12(w->Pfin[0], PAr);
+        load_uniform12(camB, PBr);
+        load_uniform12(aux, AXr);
+    }
+    typedef const double (&cam_ref)[12];
+    cam_ref PA = EXACT ? *reinterpret_cast<const double(*)[12]>(w->Pfin[0]) : PAr;
+    cam_ref PB = EXACT ? *reinterpret_cast<const double(*)[12]>(camB) : PBr;
+    cam_ref AX = EXACT ? *reinterpret_cast<const double(*)[12]>(aux) : AXr;
     bool all_conv = true;
     double num = 0.0, den = 0.0;
     Pt6 pnext = load_pt(pts, (lane < N) ? lane : 0);                             // software-pipelined: next point in flight

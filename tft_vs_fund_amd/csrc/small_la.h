@@ -160,6 +160,142 @@ __device__ __forceinline__ int spd_min_eigvec(const double (&S)[n][n], double (&
 }
 
 // --------------------------------------------------------------------------
+// The same eigenvector for the exact tiers, at SVD accuracy and with an iteration count that does not depend on the gap between
+// the two smallest eigenvalues (inconsistent DLT systems -- outliers, wrong pose candidates, minimal samples -- have
+// lambda_n / lambda_(n-1) anywhere in (0, 1) and plain inverse iteration then needs up to hundreds of steps):
+//   A. spd_min_eigvec with a cap of three iterations: well-posed systems finish here, exactly as in the fast tier;
+//   B. shifted inverse iteration, the shift sigma = rho - |S x - rho x| re-chosen every round (rho the Rayleigh quotient): for
+//      an iterate a v_n + b v_(n-1), a > b, sigma lies below lambda_n and the round contracts by ~b, i.e. quadratically; every
+//      factorisation is a CHOLESKY of S - sigma I, so a shift that overshoots lambda_n is detected (non-positive pivot) and
+//      retried four residuals lower -- no indefinite factorisation anywhere;
+//   C. certificate: S - (rho + g) I + tr(S) x x' positive definite  =>  (Courant-Fischer on the complement of x) every other
+//      eigenvalue exceeds rho + g, so x belongs to the smallest one and sin(angle) <= |S x - rho x| / g <= 1e-3;
+//   D. two refinement steps x -= (S - rho I + tr x x')^-1 (M'(M x) - rho x) with the residual evaluated from the matrix M
+//      itself (mtm): the fixed point no longer depends on the rounding of S = M'M (eps tr / gap), only the contraction does,
+//      which the certified gap g >= 1e-11 tr bounds by 1e-5.  Result: eps sigma_1 / (sigma_(n-1) - sigma_n), what svd(M) gives.
+// Returns false (x unspecified) when B does not converge in 12 rounds or C fails -- nearly coincident smallest singular
+// values, 7e-4 of the inconsistent systems of a RANSAC scene with the cap at 8 -- for the caller's one-sided Jacobi on M.
+// mtm(x, out, rho): out = M'(M x), rho = |M x|^2.
+// --------------------------------------------------------------------------
+template <int n>
+__device__ __forceinline__ bool chol_shifted(const double (&S)[n][n], const double sigma, const double kappa, const double (&x)[n],
+                                             const double pfloor, double (&L)[n][n], double (&inv)[n]) {
+    bool pd = true;
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+        double d = S[j][j] - sigma + kappa * x[j] * x[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        pd = pd && ((j == n - 1) ? (d > 0.0) : (d > pfloor));
+        d = (d > pfloor) ? d : pfloor;
+        const double rs = rsqrt(d);
+        L[j][j] = d * rs;
+        inv[j] = rs;
+#pragma unroll
+        for (int i = j + 1; i < n; ++i) {
+            double s = S[i][j] + kappa * x[i] * x[j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            L[i][j] = s * rs;
+        }
+    }
+    return pd;
+}
+template <int n>
+__device__ __forceinline__ void chol_solve(const double (&L)[n][n], const double (&inv)[n], const double (&b)[n], double (&y)[n]) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+        y[i] = s * inv[i];
+    }
+#pragma unroll
+    for (int i = n - 1; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < n; ++k) s -= L[k][i] * y[k];
+        y[i] = s * inv[i];
+    }
+}
+// rho = x'Sx and |S x - rho x| for a unit x (lower triangle of S read)
+template <int n>
+__device__ __forceinline__ void rayleigh(const double (&S)[n][n], const double (&x)[n], double& rho, double& rn) {
+    double Sx[n];
+    rho = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < n; ++j) s += ((j <= i) ? S[i][j] : S[j][i]) * x[j];
+        Sx[i] = s;
+        rho += s * x[i];
+    }
+    double r2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) { const double d = Sx[i] - rho * x[i]; r2 += d * d; }
+    rn = sqrt(r2);
+}
+// steps B - D, from the iterate x that step A left
+template <int n, class MtM>
+__device__ __forceinline__ bool spd_min_eigvec_cert_tail(const double (&S)[n][n], double (&x)[n], MtM&& mtm) {
+    bool conv = false;
+    double tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) tr += S[i][i];
+    const double pfloor = 1e-30 * tr + 1e-300;
+    double L[n][n], inv[n], y[n];
+    double mult = 1.0;
+#pragma unroll 1
+    for (int rnd = 0; rnd < 12; ++rnd) {                                    // B
+        double rho, rn;
+        rayleigh<n>(S, x, rho, rn);
+        if (!(rn > 4e-14 * tr)) { conv = (rn == rn); break; }               // an eigenvector of S to rounding (also leaves on NaN)
+        if (!chol_shifted<n>(S, rho - mult * rn - 1e-15 * tr, 0.0, x, pfloor, L, inv)) { mult *= 4.0; continue; }
+        mult = 1.0;
+        chol_solve<n>(L, inv, x, y);
+        double nn = 0.0, dot = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) { nn += y[i] * y[i]; dot += y[i] * x[i]; }
+        const double rs = rsqrt(nn), sg = (dot < 0.0) ? -rs : rs;
+        double r2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) { const double yi = y[i] * sg; const double d = yi - x[i]; r2 += d * d; x[i] = yi; }
+        if (r2 < 1e-12) { conv = true; break; }
+    }
+    if (!conv) return false;
+    {                                                                       // C
+        double rho, rn;
+        rayleigh<n>(S, x, rho, rn);
+        const double g = fmax(1e3 * rn, 1e-11 * tr);
+        if (!chol_shifted<n>(S, rho + g, tr, x, pfloor, L, inv)) return false;
+    }
+#pragma unroll 1
+    for (int k = 0; k < 2; ++k) {                                           // D
+        double out[n], rho;
+        mtm(x, out, rho);
+#pragma unroll
+        for (int i = 0; i < n; ++i) out[i] -= rho * x[i];
+        if (!chol_shifted<n>(S, rho, tr, x, pfloor, L, inv)) return false;
+        chol_solve<n>(L, inv, out, y);
+        double nn = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) { x[i] -= y[i]; nn += x[i] * x[i]; }
+        const double rs = rsqrt(nn);
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] *= rs;
+    }
+    return true;
+}
+template <int n, class MtM>
+__device__ __forceinline__ bool spd_min_eigvec_cert(const double (&S)[n][n], double (&x)[n], MtM&& mtm) {
+    bool conv;
+    spd_min_eigvec<n>(S, x, opaque_int(3), &conv);                          // A
+    if (conv) return true;
+    return spd_min_eigvec_cert_tail<n>(S, x, mtm);
+}
+
+// --------------------------------------------------------------------------
 // Right singular vector of the smallest singular value of an R_ x C_ matrix M (per lane, registers) by one-sided
 // Jacobi (Hestenes) rotations of its columns: the reference's [~,~,V] = svd(M); V(:,end) at SVD accuracy
 // (eps sigma_1 / (sigma_(C-1) - sigma_C), no squared conditioning and no dependence of the run time on the gap).
@@ -377,7 +513,18 @@ __device__ __forceinline__ bool null3(const Mat3& M, double (&x)[3]) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) S[i][j] = M.m[0][i] * M.m[0][j] + M.m[1][i] * M.m[1][j] + M.m[2][i] * M.m[2][j];
     bool conv;
-    spd_min_eigvec<3>(S, x, 40, &conv);
+    if constexpr (EXACT) {
+        conv = spd_min_eigvec_cert<3>(S, x, [&](const double (&v)[3], double (&out)[3], double& rho) {
+            double mv[3];
+            rho = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { mv[i] = M.m[i][0] * v[0] + M.m[i][1] * v[1] + M.m[i][2] * v[2]; rho += mv[i] * mv[i]; }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) out[j] = M.m[0][j] * mv[0] + M.m[1][j] * mv[1] + M.m[2][j] * mv[2];
+        });
+    } else {
+        spd_min_eigvec<3>(S, x, 40, &conv);
+    }
     if (EXACT && !conv) {
         double A[3][3];
 #pragma unroll

@@ -39,6 +39,10 @@ __device__ __forceinline__ int wave_uniform_i(int v) { return __builtin_amdgcn_r
 // the local address space restores ds_read / ds_write.
 typedef __attribute__((address_space(3))) double* lds_ptr;
 __device__ __forceinline__ lds_ptr to_lds(double* p) { return (lds_ptr)p; }
+// approximate reciprocal (v_rcp_f64: ~1e-7 relative), for sign / margin tests only
+__device__ __forceinline__ double fast_rcp(double v) { return __builtin_amdgcn_rcp(v); }
+// a wave-uniform integer the optimiser cannot see through (keeps a loop with a small constant trip count rolled)
+__device__ __forceinline__ int opaque_int(int v) { asm volatile("" : "+s"(v)); return v; }
 // the instruction scheduler does not move anything across this point
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ long long shader_clock() { return clock64(); }
