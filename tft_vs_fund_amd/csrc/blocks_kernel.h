@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(64, 4) k_triangulate(const TriangulateArgs a) 
         for (int i = lane; i < a.N; i += WAVE) {
             const double* q = p + 2 * (long)a.M * i;
             double X[4];
-            dlt_point<true>(P0, P1, P2, cam[0], cam[1], cam[2], a.M > 2, q[0], q[1], q[2], q[3], (a.M > 2) ? q[4] : 0.0, (a.M > 2) ? q[5] : 0.0, X);
+            dlt_point<true, true>(P0, P1, P2, cam[0], cam[1], cam[2], a.M > 2, q[0], q[1], q[2], q[3], (a.M > 2) ? q[4] : 0.0, (a.M > 2) ? q[5] : 0.0, X);
 #pragma unroll
             for (int k = 0; k < 4; ++k) out[4 * (long)i + k] = X[k];
         }
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(64, 4) k_repr_error(const ReprErrorArgs a) {
                 tri_accum(S, P[1], p.v[2], p.v[3]);
                 tri_accum(S, P[2], p.v[4], p.v[5]);
                 if (count_only && certainly_positive_definite(S, Zt)) continue;
-                dlt_point_solve<true>(S, cam[0], cam[1], cam[2], true, p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], p.v[5], X);
+                dlt_point_solve<true, true>(S, cam[0], cam[1], cam[2], true, p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], p.v[5], X);
             }
             bool in = true;
 #pragma unroll

@@ -406,7 +406,7 @@ __device__ inline int optim_f_refine(PoseLds* w, OptimFLds* og, double* oxi, con
 
 // METHOD 0: LinearFPoseEstimation; METHOD 1: OptimFPoseEstimation (F_methods/OptimFPoseEstimation.m:44-73)
 template <bool JAC, int METHOD>
-__global__ void __launch_bounds__(64, (METHOD == 1 || JAC) ? 3 : 2) k_f_pose(const LinearTftArgs a) {
+__global__ void __launch_bounds__(64, (METHOD == 1 && !JAC) ? 3 : 2) k_f_pose(const LinearTftArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
     PoseLds* w = reinterpret_cast<PoseLds*>(smem);
     constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;

@@ -392,11 +392,11 @@ __device__ __attribute__((noinline)) Vec4 dlt_point_cert(const double* camA, con
 //                  per-correspondence loops then contain no call, which would make their (non-inlined) functions save and
 //                  restore ~35 registers on every entry.
 // PA.. hold the cameras as (wave-uniform) values, camA.. point to the same cameras in LDS (for the exact tier).
-template <bool EXACT>
+template <bool EXACT, bool CERT = false>
 __device__ __forceinline__ bool dlt_point_solve(const double (&S)[4][4], const double* camA, const double* camB, const double* camC, const bool three,
                                                 const double xa, const double ya, const double xb, const double yb, const double xc, const double yc,
                                                 double (&X)[4]);
-template <bool EXACT>
+template <bool EXACT, bool CERT = false>
 __device__ __forceinline__ bool dlt_point(const double (&PA)[12], const double (&PB)[12], const double (&PC)[12],
                                           const double* camA, const double* camB, const double* camC, const bool three,
                                           const double xa, const double ya, const double xb, const double yb, const double xc, const double yc,
@@ -406,16 +406,32 @@ __device__ __forceinline__ bool dlt_point(const double (&PA)[12], const double (
     tri_accum(S, PA, xa, ya);
     tri_accum(S, PB, xb, yb);
     if (three) tri_accum(S, PC, xc, yc);
-    return dlt_point_solve<EXACT>(S, camA, camB, camC, three, xa, ya, xb, yb, xc, yc, X);
+    if constexpr (EXACT && CERT) {
+        return dlt_point_solve<true, true>(S, camA, camB, camC, three, xa, ya, xb, yb, xc, yc, X);
+    } else {
+        bool conv;
+        spd_min_eigvec<4>(S, X, 40, &conv);
+        if (EXACT && !conv) {
+            Vec4 E; E = dlt_point_exact(camA, camB, camC, three ? 1 : 0, xa, ya, xb, yb, xc, yc);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) X[k] = E.v[k];
+            conv = true;
+        }
+        return conv;
+    }
 }
-// ... from the normal matrix S = M'M of the system (lower triangle), for callers that need S themselves
-template <bool EXACT>
+// ... from the normal matrix S = M'M of the system (lower triangle), for callers that need S themselves.
+// CERT (with EXACT): the gap-independent certified tier of small_la.h between the three-iteration fast tier and the one-sided Jacobi
+// -- for the kernels that triangulate many correspondences of unknown consistency (k_repr_error, k_triangulate).  The passes over a
+// triplet's own correspondences keep the plain ladder: the extra level of calls raised the register count of every kernel that
+// reaches tri_pass_exact / tri_vote_exact (168 -> 231, three -> two wavefronts per SIMD for the F kernels) for no measured gain.
+template <bool EXACT, bool CERT>
 __device__ __forceinline__ bool dlt_point_solve(const double (&S)[4][4], const double* camA, const double* camB, const double* camC, const bool three,
                                                 const double xa, const double ya, const double xb, const double yb, const double xc, const double yc,
                                                 double (&X)[4]) {
     bool conv;
-    spd_min_eigvec<4>(S, X, EXACT ? opaque_int(3) : 40, &conv);
-    if constexpr (EXACT) {
+    spd_min_eigvec<4>(S, X, (EXACT && CERT) ? opaque_int(3) : 40, &conv);
+    if constexpr (EXACT && CERT) {
         if (!conv) {                                                         // gap-independent tier (small_la.h), out of line
             Vec4 E;
 #pragma unroll
