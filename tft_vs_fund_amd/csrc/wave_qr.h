@@ -5,9 +5,11 @@
 // eps |A|^2 / (sigma_(n-1)^2 - sigma_n^2), the square of what the reference's svd(A) has.  Triplets for which that matters
 // (minimal samples, nearly coincident smallest singular values -- detected through wave_invit_unit's gap estimate) are
 // redone here:
-//   1. streaming Householder QR of A: lane r < n holds row r of R in registers, the other 64 - n lanes each take one new row
-//      of A per chunk; the reflector products v'A for all columns come from one halving butterfly (wave_reduce_scatter).
-//      Any N, no LDS, backward stable: R'R = (A + dA)'(A + dA), |dA| ~ eps |A|.
+//   1. streaming Householder QR of A, backward stable: R'R = (A + dA)'(A + dA), |dA| ~ eps |A|, any N.  Two layouts:
+//      wave_qr_cols_append -- lane c < n owns COLUMN c, M new rows per chunk in its registers, R in LDS; reflector through
+//      v_readlane, no cross-lane reduction (the 4N x 27 and 27 x 15 systems of linearTFT, minimal samples of linearF);
+//      wave_qr_append -- lane r < n holds ROW r of R in registers, the other 64 - n lanes each take one new row of A per chunk,
+//      the reflector products v'A for all columns come from one halving butterfly (N x 9 systems with many rows per chunk).
 //   2. inverse iteration with L = R' (wave_invit_unit): the triangular solves perturb R componentwise, so the iterate
 //      converges to the singular vector of a matrix within eps |A| of A -- error eps sigma_1 / (sigma_(n-1) - sigma_n), as svd(A).
 //   3. if the iteration hits its cap (sigma_n / sigma_(n-1) > ~0.97): one-sided Jacobi (Hestenes) on R in LDS, gap-independent.
