@@ -205,3 +205,23 @@ extern "C" int emu_nordberg_init(const double* t, const double* pa, const double
     emu::launch(k_emu_nordberg_init, 1, 64, lds, a);
     return 0;
 }
+
+// The two evaluations of pinv(W) for a 4 x 4 weight block with one direction under the tolerance (pi_kernel.h): the Cholesky
+// shortcut pinv_one_null_packed and the Jacobi eigen-decomposition it replaces.  W: 4 x 4 symmetric (row-major, already shifted by
+// 1e-12 I as pi_block_W delivers it); outputs: packed lower triangles (10 doubles each), *ok = the shortcut's own verdict.
+extern "C" int emu_pinv_one_null(const double* W16, double tolW, double* wp_shortcut, double* wp_jacobi, int* ok) {
+    double W[4][4], V[4][4], Wp[10];
+    for (int a = 0; a < 4; ++a) for (int c = 0; c < 4; ++c) W[a][c] = W16[4 * a + c];
+    *ok = tff::pinv_one_null_packed<4>(W, tolW, Wp) ? 1 : 0;
+    for (int e = 0; e < 10; ++e) wp_shortcut[e] = Wp[e];
+    tff::jacobi_small<4, true>(W, V);
+    double inv[4];
+    for (int a = 0; a < 4; ++a) inv[a] = (W[a][a] > tolW) ? 1.0 / W[a][a] : 0.0;
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b <= a; ++b) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) acc += V[a][k] * inv[k] * V[b][k];
+            wp_jacobi[a * (a + 1) / 2 + b] = acc;
+        }
+    return 0;
+}

@@ -329,3 +329,35 @@ def test_nordberg_projective_fixup_executes(emu, deficient):
     # (rotation vectors directly; the normalised sparse tensor part up to its global sign)
     dev = [max(np.abs(p[0:9] - r[3][0:9]).max(), min(np.abs(p[9:19] - r[3][9:19]).max(), np.abs(p[9:19] + r[3][9:19]).max())) for r in refs]
     assert min(dev) < 1e-8, dev
+
+
+def test_pinv_shortcut_equals_jacobi_branch_on_graded_blocks(emu):
+    """pinv_one_null_packed (Cholesky of W + nn', pi_kernel.h) against the Jacobi eigen-decomposition branch it replaces, on weight
+    blocks whose kept eigenvalues reach down to ~1e-6 of the largest while ONE direction sits under MATLAB's pinv tolerance
+    (Gauss_Helmert.m:52,57: W = B B' + 1e-12 I, the shift already applied by the caller)."""
+    emu.emu_pinv_one_null.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    rng = np.random.default_rng(12)
+    worst = 0.0
+    for trial in range(200):
+        Q, _ = np.linalg.qr(rng.standard_normal((4, 4)))
+        lam = np.array([10 ** rng.uniform(2, 4), 10 ** rng.uniform(-1, 2), 10 ** rng.uniform(-3, -1), 10 ** rng.uniform(-14, -11)])
+        W = (Q * (lam + 1e-12)) @ Q.T
+        W = 0.5 * (W + W.T)
+        tolW = 4 * 200 * np.spacing(lam[0])                                      # E N eps(|W|): between lam[3] and lam[2]
+        assert lam[3] + 1e-12 < tolW < lam[2]
+        a = np.zeros(10); b = np.zeros(10); ok = ctypes.c_int(0)
+        emu.emu_pinv_one_null(_p(np.ascontiguousarray(W)), float(tolW), _p(a), _p(b), ctypes.byref(ok))
+        assert ok.value == 1, trial
+        ref = (Q[:, :3] / (lam[:3] + 1e-12)) @ Q[:, :3].T                        # the pseudo-inverse itself, from the construction
+        refp = np.array([ref[i, j] for i in range(4) for j in range(i + 1)])
+        scale = np.abs(refp).max()
+        # both branches within the conditioning of the problem (1e-16 lam_1 / lam_3 ~ 1e-9 at worst) of the construction
+        assert np.abs(a - refp).max() < 1e-8 * scale, (trial, np.abs(a - refp).max() / scale)
+        assert np.abs(b - refp).max() < 1e-8 * scale, (trial, np.abs(b - refp).max() / scale)
+        worst = max(worst, np.abs(a - b).max() / scale)
+    assert worst < 1e-8
+    # no direction under the tolerance: the shortcut declines (the caller then takes the Jacobi branch)
+    W = np.diag([100.0, 10.0, 1.0, 0.5])
+    a = np.zeros(10); b = np.zeros(10); ok = ctypes.c_int(1)
+    emu.emu_pinv_one_null(_p(W), 1e-9, _p(a), _p(b), ctypes.byref(ok))
+    assert ok.value == 0
