@@ -28,6 +28,9 @@ constexpr int GH_REC_DOUBLES = 64;        // t 27 | pa 18 | epi 6 | nrm 9 | pad
 // record strides of the per-correspondence state xi / W+.  Even (16-byte aligned records): the loads are ds_read_b128.  Padding them to
 // odd strides (7 / 11 doubles: 32 distinct bank pairs for consecutive lanes instead of 16) was measured SLOWER -- Ressl 3.0 -> 3.5 ms,
 // the sweeps 17 k -> 26 k cycles -- because the records lose their alignment and every access becomes two ds_read_b64.
+// A component-major layout (xi[k * N + i]: conflict-free ds_read_b64) was measured slower too -- the ten sweeps 17.3 k -> 22.5 k cycles,
+// twice the LDS instructions and 20 more spilled registers: the SQ_LDS_BANK_CONFLICT share of profiles/r2_ressl_* (0.75 of the LDS
+// instruction cycles) is not what bounds these passes, LDS instruction issue is.
 constexpr int GH_XI = 6, GH_PP = 10;
 
 // LDS of k_gh_block after the PoseLds header: p, dt, Tc, dT, D, H, Y, M, V (112 doubles of scratch), xi (6N), W+ (10N), reduction slots.
