@@ -1,7 +1,8 @@
 """TEST INFRASTRUCTURE ONLY -- never imported by the product (tft_vs_fund_amd/).
 
 Extended-precision (mpmath, 50 digits) evaluation of the reference's Gauss-Helmert iteration
-(Optimization/Gauss_Helmert.m:38-83) with Ressl's callback (TFT_methods/ResslTFTPoseEstimation.m:110-177).
+(Optimization/Gauss_Helmert.m:38-83) with Ressl's callback (TFT_methods/ResslTFTPoseEstimation.m:110-177) and Nordberg's
+(TFT_methods/NordbergTFTPoseEstimation.m:128-222).
 
 Purpose: `pinv(W + 1e-12 I)` gives every correspondence one direction of weight ~1e12, so A'WA
 cancels ten digits in ANY fp64 evaluation -- the reference's own dense MATLAB product included.  To judge the HIP kernel
@@ -138,23 +139,18 @@ def _blocks(xi_i, T):
     return f, Ap, B
 
 
-def gauss_helmert_ressl_mp(x, x_est, p0, Ind, it_max=400, return_history=False):
-    """Gauss_Helmert.m:38-83 with Ressl's callback, in extended precision, from the fp64 start (x, x_est, p0).
-    Returns p_opt (float64), xi (float64), it, reason [, history of (|dt|, obj)]."""
+def gauss_helmert_mp(x, x_est, p0, model, u, c, it_max=400, return_history=False):
+    """Gauss_Helmert.m:38-83 in extended precision for a trifocal-tensor callback, from the fp64 start (x, x_est, p0).
+    model(t) -> (T 3x3x3, D = dT(:)/dt 27 x u, g (c), C (c x u)), all object arrays; the per-correspondence blocks f, Ap, B are the
+    ones every TFT callback shares (`_blocks`; A = Ap D).  Returns p_opt (float64), xi (float64), it, reason [, history]."""
     N = x.shape[0] // 6
     xm, xi, ti = to_mp(x), to_mp(x_est), to_mp(p0)
     tol = mp.mpf(float(1e-6))
     v0 = xi - xm
     objFunc = sum(v * v for v in v0)
     reason, it, hist = 'itmax', 0, []
-    u, c = 20, 2
     for it in range(1, it_max + 1):
-        S, e21, e31, mn, T, Ind2 = _ressl_unpack(ti, Ind)
-        g = np.array([sum(e * e for e in e31) - 1, sum(s * s for s in S.reshape(9)) - 1], dtype=object)
-        C = _zeros(2, 20)
-        C[0, 17:20] = 2 * e31
-        C[1, 0:9] = 2 * S.reshape(9, order='F')
-        D = _ressl_D(S, e21, e31, mn, Ind2)
+        T, D, g, C = model(ti)
         blocks = []
         lam_max = mp.mpf(0)
         for i in range(N):
@@ -206,6 +202,112 @@ def gauss_helmert_ressl_mp(x, x_est, p0, Ind, it_max=400, return_history=False):
         ti = ti + dt                                                                 # :80
     out = (to_float(ti), to_float(xi), it, reason)
     return out + (hist,) if return_history else out
+
+
+def ressl_model(Ind):
+    """Ressl's callback (ResslTFTPoseEstimation.m:110-177) as a model for gauss_helmert_mp: 20 parameters, 2 constraints"""
+    def model(ti):
+        S, e21, e31, mn, T, Ind2 = _ressl_unpack(ti, Ind)
+        g = np.array([sum(e * e for e in e31) - 1, sum(s * s for s in S.reshape(9)) - 1], dtype=object)
+        C = _zeros(2, 20)
+        C[0, 17:20] = 2 * e31
+        C[1, 0:9] = 2 * S.reshape(9, order='F')
+        return T, _ressl_D(S, e21, e31, mn, Ind2), g, C
+    return model
+
+
+def gauss_helmert_ressl_mp(x, x_est, p0, Ind, it_max=400, return_history=False):
+    return gauss_helmert_mp(x, x_est, p0, ressl_model(Ind), 20, 2, it_max, return_history)
+
+
+# ---- Nordberg's callback (NordbergTFTPoseEstimation.m:128-222): 19 parameters (three axis-angle rotations, ten entries of the sparse
+# ---- tensor), one constraint
+def _cross_mp(v):
+    z = mp.mpf(0)
+    return np.array([[z, -v[2], v[1]], [v[2], z, -v[0]], [-v[1], v[0], z]], dtype=object)
+
+
+def _transf_t_mp(T0, U, V, W):
+    """NordbergTFTPoseEstimation.m:217-222"""
+    T = _zeros(3, 3, 3)
+    for i in range(3):
+        T[:, :, i] = V.T.dot(U[0, i] * T0[:, :, 0] + U[1, i] * T0[:, :, 1] + U[2, i] * T0[:, :, 2]).dot(W)
+    return T
+
+
+def nordberg_model(ti):
+    one = mp.mpf(1)
+    I3 = np.array([[one if r == c else mp.mpf(0) for c in range(3)] for r in range(3)], dtype=object)
+    o, vec, Rm = [], [], []
+    for k in range(3):
+        xk = ti[3 * k:3 * k + 3]
+        ok = mp.sqrt(sum(e * e for e in xk))
+        vk = xk / ok
+        cm = _cross_mp(vk)
+        o.append(ok); vec.append(vk)
+        Rm.append(I3 + mp.sin(ok) * cm + (1 - mp.cos(ok)) * cm.dot(cm))              # :133-141 (Rodrigues)
+    U, V, W = Rm
+    paramT = ti[9:19]
+    tsv = _zeros(27)
+    tsv[O._NORD_IND] = paramT
+    Ts = tsv.reshape(3, 3, 3, order='F')
+    T = _transf_t_mp(Ts, U.T, V.T, W.T)
+    J = _zeros(27, 19)
+    for i in range(10):
+        e = _zeros(27)
+        e[O._NORD_IND[i]] = one
+        J[:, i + 9] = _transf_t_mp(e.reshape(3, 3, 3, order='F'), U.T, V.T, W.T).reshape(27, order='F')
+    dR = [[None] * 3 for _ in range(3)]
+    for k in range(3):
+        ok, vk = o[k], vec[k]
+        cm = _cross_mp(vk)
+        for i in range(3):
+            ei = I3[:, i]
+            dR[k][i] = (-vk[i] * mp.sin(ok) * I3 + vk[i] * mp.cos(ok) * cm
+                        + mp.sin(ok) * (1 / ok) * (_cross_mp(ei) - vk[i] * cm)
+                        + vk[i] * mp.sin(ok) * np.outer(vk, vk)
+                        + (1 - mp.cos(ok)) * (1 / ok) * (np.outer(vk, ei) + np.outer(ei, vk) - 2 * vk[i] * np.outer(vk, vk)))   # :176-190
+    for i in range(3):
+        J[:, i] = _transf_t_mp(Ts, dR[0][i].T, V.T, W.T).reshape(27, order='F')
+        J[:, i + 3] = _transf_t_mp(Ts, U.T, dR[1][i].T, W.T).reshape(27, order='F')
+        J[:, i + 6] = _transf_t_mp(Ts, U.T, V.T, dR[2][i].T).reshape(27, order='F')
+    g = np.array([sum(q * q for q in paramT) - 1], dtype=object)
+    C = _zeros(1, 19)
+    C[0, 9:19] = 2 * paramT
+    return T, J, g, C
+
+
+def nordberg_start(Corresp, CalM):
+    """fp64 start of NordbergTFTPoseEstimation.m:47-96 (from the numpy oracle)"""
+    x1, N1 = O.Normalize2Ddata(Corresp[0:2, :])
+    x2, N2 = O.Normalize2Ddata(Corresp[2:4, :])
+    x3, N3 = O.Normalize2Ddata(Corresp[4:6, :])
+    T, P1, P2, P3 = O.linearTFT(x1, x2, x3)
+    P1, P2, P3, param0 = O.nordberg_param0(T, P1, P2, P3)
+    x, x_est = O._gh_initial_obs(P1, P2, P3, x1, x2, x3)
+    return x, x_est, param0, (N1, N2, N3)
+
+
+def nordberg_tail(param, normals, CalM, Corresp):
+    """NordbergTFTPoseEstimation.m:104-124 in fp64"""
+    Rm = []
+    for k in range(3):
+        ok = np.linalg.norm(param[3 * k:3 * k + 3])
+        Rm.append(O._rodrigues(ok, param[3 * k:3 * k + 3] / ok))
+    U, V, W = Rm
+    tsv = np.zeros(27)
+    tsv[O._NORD_IND] = param[9:19]
+    T = O._transf_t(O._unvecT(tsv), U.T, V.T, W.T)
+    T = O.transform_TFT(T, normals[0], normals[1], normals[2], 1)
+    R_t_2, R_t_3 = O.R_t_from_TFT(T, CalM, Corresp)
+    return R_t_2, R_t_3, T
+
+
+def NordbergTFTPoseEstimation_mp(Corresp, CalM):
+    x, x_est, p0, normals = nordberg_start(Corresp, CalM)
+    p_opt, _, it, reason = gauss_helmert_mp(x, x_est, p0, nordberg_model, 19, 1)
+    R2, R3, T = nordberg_tail(p_opt, normals, CalM, Corresp)
+    return R2, R3, T, it, reason
 
 
 def ressl_start(Corresp, CalM):

@@ -263,12 +263,21 @@ def linearTFT(p1, p2, p3, return_debug=False):
     V21, V31 = _epipoles_from_T(T)                      # :71-79
     epi31 = V31[:, -1]
     epi21 = V21[:, -1]
+    # [~,~,V] = svd(...); epi = V(:,3): the SIGN of each epipole is whatever the SVD routine returns.  It flips the blocks
+    # a(1:9) / a(10:18) below with it (P2 = [A | e21], P3 = [B | e31] stay a valid camera pair of the same T), which is a LINEAR
+    # change of every later parameterisation but Nordberg's -- its three rotations are built from these cameras through
+    # orth(), so its Gauss-Helmert iterates (not its fixed point) depend on the convention.  EPIPOLE_SIGNS replays the others.
+    if EPIPOLE_SIGNS is not None:
+        epi21 = epi21 * EPIPOLE_SIGNS[0]
+        epi31 = epi31 * EPIPOLE_SIGNS[1]
     E = np.hstack([np.kron(np.eye(3), np.kron(epi31.reshape(3, 1), np.eye(3))),
                    -np.kron(np.eye(9), epi21.reshape(3, 1))])   # :82
     U, S, V = _svd(E)
     rk = rank(E)                                        # :83
     Up, Vp, Sp = U[:, :rk], V[:, :rk], np.diag(S[:rk])
     tp = _svdV(A @ Up)[:, -1]                           # :84
+    if EPIPOLE_SIGNS is not None and len(EPIPOLE_SIGNS) > 2:
+        tp = tp * EPIPOLE_SIGNS[2]                      # ... and so is the sign of this V(:,end): it flips T, a(1:9) and a(10:18) together
     t = Up @ tp                                         # :85
     a = Vp @ np.linalg.inv(Sp) @ tp                     # :86
     P1 = np.eye(3, 4)
@@ -279,6 +288,15 @@ def linearTFT(p1, p2, p3, return_debug=False):
         return T, P1, P2, P3, dict(rankE=rk, epi21=epi21, epi31=epi31,
                                    sv_A=np.linalg.svd(A, compute_uv=False))
     return T, P1, P2, P3
+
+
+EPIPOLE_SIGNS = None    # test hook, see linearTFT
+
+
+def set_epipole_signs(signs):
+    """signs: None (numpy's LAPACK as is) or (sign of e21, sign of e31[, sign of the constrained solution tp]) applied inside linearTFT."""
+    global EPIPOLE_SIGNS
+    EPIPOLE_SIGNS = signs
 
 
 E_SVD_SIGNS = None      # test hook, see _recover_R_t_core

@@ -1,6 +1,7 @@
-"""Generates tests/golden/gh_mp.npz: ResslTFTPoseEstimation with the Gauss-Helmert loop evaluated in 50-digit arithmetic
-(oracle/gh_mp_oracle.py) on seeded synthetic scenes, N in {12, 60, 200}.  Build-container script (needs mpmath; ~20 min on
-8 cores); the fixture holds inputs and expected outputs only.  Usage: python tests/golden/make_gh_mp.py"""
+"""Generates tests/golden/gh_mp.npz (Ressl) / gh_mp_nordberg.npz: the method with its Gauss-Helmert loop evaluated in 50-digit
+arithmetic (oracle/gh_mp_oracle.py) on seeded synthetic scenes, N in {12, 60, 200}.  Build-container script (needs mpmath; ~20 min
+on 8 cores for Ressl's 64 scenes); the fixtures hold inputs and expected outputs only.
+Usage: python tests/golden/make_gh_mp.py [ressl|nordberg]"""
 import os, sys, time
 from multiprocessing import Pool
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,22 +11,36 @@ from oracle import tft_oracle as O
 from oracle import gh_mp_oracle as G
 from tft_vs_fund_amd.scenes import generate_scene_batch
 
-CASES = [(12, 32, 1.0), (60, 20, 1.0), (200, 12, 1.0)]            # N, scenes, pixel noise
+METHOD = sys.argv[1] if len(sys.argv) > 1 else "ressl"
+CASES = {"ressl": [(12, 32, 1.0), (60, 20, 1.0), (200, 12, 1.0)],               # N, scenes, pixel noise
+         "nordberg": [(12, 24, 1.0), (60, 12, 1.0), (200, 6, 1.0)]}[METHOD]
+SEED0 = {"ressl": 4000, "nordberg": 5000}[METHOD]
+MP_FN = {"ressl": G.ResslTFTPoseEstimation_mp, "nordberg": G.NordbergTFTPoseEstimation_mp}[METHOD]
+NP_FN = {"ressl": O.ResslTFTPoseEstimation, "nordberg": O.NordbergTFTPoseEstimation}[METHOD]
+OUT = {"ressl": "gh_mp.npz", "nordberg": "gh_mp_nordberg.npz"}[METHOD]
 
 
 def one(args):
     Cb, CalM = args
     t0 = time.time()
-    R2, R3, T, it, reason = G.ResslTFTPoseEstimation_mp(Cb, CalM)
-    o2, o3, _, oT, oit, dbg = O.ResslTFTPoseEstimation(Cb, CalM, True)
-    return R2, R3, T, it, reason, o2, o3, oT, oit, dbg["reason"], time.time() - t0
+    R2, R3, T, it, reason = MP_FN(Cb, CalM)
+    o2, o3, _, oT, oit, dbg = NP_FN(Cb, CalM, True)
+    alt = []
+    if METHOD == "nordberg":                         # the other seven sign conventions of linearTFT's three V(:,end) (tests/helpers.py)
+        for sg in [(a, b, c) for c in (1, -1) for a in (1, -1) for b in (1, -1)][1:]:
+            O.set_epipole_signs(sg)
+            try:
+                alt.append(MP_FN(Cb, CalM))
+            finally:
+                O.set_epipole_signs(None)
+    return R2, R3, T, it, reason, o2, o3, oT, oit, dbg["reason"], time.time() - t0, alt
 
 
 if __name__ == "__main__":
     out = {}
     with Pool(8) as pool:
         for ci, (N, B, noise) in enumerate(CASES):
-            C, CalM, _, _ = generate_scene_batch(B, N, noise=noise, seed=4000 + N)
+            C, CalM, _, _ = generate_scene_batch(B, N, noise=noise, seed=SEED0 + N)
             res = pool.map(one, [(C[b].T.copy(), CalM) for b in range(B)], chunksize=1)
             pre = "c%d_" % ci
             out[pre + "meta"] = np.array([N, B, noise])
@@ -37,5 +52,10 @@ if __name__ == "__main__":
             out[pre + "np_Rt2"] = np.stack([r[5] for r in res]); out[pre + "np_Rt3"] = np.stack([r[6] for r in res])
             out[pre + "np_T"] = np.stack([r[7] for r in res]); out[pre + "np_iter"] = np.array([r[8] for r in res])
             out[pre + "np_reason"] = np.array([r[9] for r in res])
+            if METHOD == "nordberg":                 # [scene, convention]: convention 0 = numpy's LAPACK as is (the mp_* arrays above)
+                out[pre + "mp4_Rt2"] = np.stack([np.stack([r[0]] + [a[0] for a in r[11]]) for r in res])
+                out[pre + "mp4_Rt3"] = np.stack([np.stack([r[1]] + [a[1] for a in r[11]]) for r in res])
+                out[pre + "mp4_T"] = np.stack([np.stack([r[2]] + [a[2] for a in r[11]]) for r in res])
+                out[pre + "mp4_iter"] = np.array([[r[3]] + [a[3] for a in r[11]] for r in res])
             print("N=%d: %d scenes, %.0f s of mp arithmetic; iterations mp %s / numpy %s" % (N, B, sum(r[10] for r in res), out[pre + "mp_iter"].tolist(), out[pre + "np_iter"].tolist()), flush=True)
-    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "gh_mp.npz"), **out)
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), OUT), **out)

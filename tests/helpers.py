@@ -121,3 +121,24 @@ def pose_err_any_convention(out_b, fn, Cb, CalM):
     e0 = pose_err(out_b, refs[0]) if refs[0] is not None else float("inf")
     eb = min([pose_err(out_b, r) for r in refs if r is not None] or [float("inf")])
     return e0, eb
+
+
+EPIPOLE_CONVENTIONS = [(a, b, c) for c in (1, -1) for a in (1, -1) for b in (1, -1)]      # (1, 1, 1) first: numpy's LAPACK as is
+
+
+def oracle_under_epipole_conventions(fn, Cb, CalM):
+    """Outputs of an oracle pose method under the eight sign conventions of linearTFT's three singular vectors that feed the cameras
+    (`V(:,3)` of the two epipole svd calls, linearTFT.m:71-79, and `V(:,end)` of the constrained solve, :84; MATLAB leaves each
+    sign open).  They flip e21 with a(10:18), e31 with a(1:9), and T with a(1:18): always a valid camera pair of the same tensor.
+    Only Nordberg's parameterisation feels them: its rotations are built from those cameras through orth(), a NONLINEAR function
+    of the convention (U, V, W each change by a half-turn), so Gauss-Helmert iterates differ at second order in the step (1e-5 ..
+    4e-4 when the loop stops after one update) although the fixed point is the same."""
+    from oracle import tft_oracle as O
+    outs = []
+    try:
+        for sg in EPIPOLE_CONVENTIONS:
+            O.set_epipole_signs(None if sg == (1, 1, 1) else sg)
+            outs.append(fn(Cb, CalM))
+    finally:
+        O.set_epipole_signs(None)
+    return outs

@@ -3,7 +3,8 @@ Gauss-Helmert parity against the FORMULAS of the reference, not against one fp64
 
 `pinv(W + 1e-12 I)` (Gauss_Helmert.m:57) gives every correspondence one direction of weight ~1e12; any evaluation that forms
 that matrix in fp64 -- MATLAB's dense one included -- carries ~1e-4 relative noise in those weights and cancels ten digits in
-A'WA.  tests/golden/gh_mp.npz holds ResslTFTPoseEstimation with the Gauss-Helmert loop evaluated in 50-digit arithmetic
+A'WA.  tests/golden/gh_mp.npz / gh_mp_nordberg.npz hold ResslTFTPoseEstimation / NordbergTFTPoseEstimation with the Gauss-Helmert loop
+evaluated in 50-digit arithmetic
 (oracle/gh_mp_oracle.py, generator tests/golden/make_gh_mp.py).  Measured against it (profiles/r2_gh_noise_mp.txt):
   LAPACK-backed numpy oracle (stand-in for MATLAB's arithmetic): median 7e-7 .. 4e-6, max 3e-5 .. 1e-3, a different
       stopping iteration in ~40 % of the scenes;
@@ -33,33 +34,55 @@ def _dev(T, R2, R3, g, pre, b):
     return max(rel_err_T(T, g[pre + "mp_T"][b]), rel_err(R2, g[pre + "mp_Rt2"][b]), rel_err(R3, g[pre + "mp_Rt3"][b]))
 
 
-def test_ressl_kernel_reproduces_the_extended_precision_iteration(gpu_ctx, golden_dir):
+def _dev_conventions(T, R2, R3, it, g, pre, b):
+    """(deviation, iteration difference) against the 50-digit evaluation under the sign convention of linearTFT's singular vectors
+    (tests/helpers.py::oracle_under_epipole_conventions) that fits best.  Ressl's parameters change LINEARLY with those signs
+    (Gauss-Newton steps are invariant): one evaluation.  Nordberg's rotations are a nonlinear function of them, its iterates
+    differ at second order in the step (up to 4e-4 between conventions in this fixture when the loop stops after one update),
+    and MATLAB leaves the signs open: the fixture holds all eight (mp4_*[scene, convention], convention 0 = numpy's LAPACK as
+    is) and the kernel has to reproduce ONE of them."""
+    if pre + "mp4_T" not in g.files:
+        return _dev(T, R2, R3, g, pre, b), int(it) - int(g[pre + "mp_iter"][b])
+    cand = []
+    for c in range(g[pre + "mp4_T"].shape[1]):
+        d = max(rel_err_T(T, g[pre + "mp4_T"][b, c]), rel_err(R2, g[pre + "mp4_Rt2"][b, c]), rel_err(R3, g[pre + "mp4_Rt3"][b, c]))
+        cand.append((d, int(it) - int(g[pre + "mp4_iter"][b, c])))
+    return min(cand)
+
+
+CASES = [("ResslTFTPoseEstimation", "gh_mp.npz"), ("NordbergTFTPoseEstimation", "gh_mp_nordberg.npz")]
+
+
+@pytest.mark.parametrize("method,fixture", CASES)
+def test_kernel_reproduces_the_extended_precision_iteration(gpu_ctx, golden_dir, method, fixture):
     """N in {12, 60, 200}: T (up to sign), R_t_2, R_t_3 within 1e-9 of the 50-digit evaluation and the SAME number of
     Gauss-Helmert iterations, scene by scene (north_star's bar is 1e-6)."""
-    g = np.load(os.path.join(golden_dir, "gh_mp.npz"))
+    g = np.load(os.path.join(golden_dir, fixture))
     for ci, pre in golden_cases(g):
         C, CalM = g[pre + "Corresp"], g[pre + "CalM"]
-        out = gpu_ctx.pose_batch("ResslTFTPoseEstimation", C, CalM, reconst=False)
+        out = gpu_ctx.pose_batch(method, C, CalM, reconst=False)
         assert np.all(out["status"] == 0)
         for b in range(C.shape[0]):
-            assert int(out["iter"][b]) == int(g[pre + "mp_iter"][b]), (ci, b)
-            assert _dev(out["T"][b], out["R_t_2"][b], out["R_t_3"][b], g, pre, b) < 1e-9, (ci, b)
+            d, dit = _dev_conventions(out["T"][b], out["R_t_2"][b], out["R_t_3"][b], out["iter"][b], g, pre, b)
+            assert dit == 0, (ci, b, dit)
+            assert d < 1e-9, (ci, b, d)
 
 
-def test_ressl_kernel_is_no_noisier_than_the_lapack_evaluation(gpu_ctx, golden_dir):
+@pytest.mark.parametrize("method,fixture", CASES)
+def test_kernel_is_no_noisier_than_the_lapack_evaluation(gpu_ctx, golden_dir, method, fixture):
     """The kernel's deviation from the 50-digit evaluation, percentile by percentile, against the LAPACK-backed numpy oracle's
     (recomputed here, on this host's LAPACK): kernel <= oracle at p50, p90 and max, and the oracle's own noise is what the
     tolerances of the oracle-based Gauss-Helmert tests (test_gpu_parity.py::_ressl_tol) have to allow for."""
     from oracle import tft_oracle as O
-    g = np.load(os.path.join(golden_dir, "gh_mp.npz"))
+    g = np.load(os.path.join(golden_dir, fixture))
     for ci, pre in golden_cases(g):
         C, CalM = g[pre + "Corresp"], g[pre + "CalM"]
         B = C.shape[0]
-        out = gpu_ctx.pose_batch("ResslTFTPoseEstimation", C, CalM, reconst=False)
-        dk = np.array([_dev(out["T"][b], out["R_t_2"][b], out["R_t_3"][b], g, pre, b) for b in range(B)])
+        out = gpu_ctx.pose_batch(method, C, CalM, reconst=False)
+        dk = np.array([_dev_conventions(out["T"][b], out["R_t_2"][b], out["R_t_3"][b], out["iter"][b], g, pre, b)[0] for b in range(B)])
         do = []
         for b in range(B):
-            o2, o3, _, oT, _ = O.ResslTFTPoseEstimation(C[b].T.copy(), CalM)
+            o2, o3, _, oT, _ = getattr(O, method)(C[b].T.copy(), CalM)
             do.append(_dev(oT, o2, o3, g, pre, b))
         do = np.array(do)
         for q in (0.5, 0.9, 1.0):

@@ -240,3 +240,27 @@ def test_mp_callback_is_an_independent_restatement_of_ressl():
     func = lambda a, b, c: O._ressl_constraintsGH(a, b, Ind)
     _, p_np, _, it_np, _ = O.Gauss_Helmert(func, x_est, p0, np.zeros(0), x, None, True)
     assert abs(it - it_np) <= 3 and np.abs(p_mp - p_np).max() < 1e-3
+
+
+def test_mp_callback_is_an_independent_restatement_of_nordberg():
+    """The same for Nordberg's callback (NordbergTFTPoseEstimation.m:128-222: three Rodrigues rotations and their derivatives, ten
+    sparse tensor entries): g, C, A = Ap J of the 50-digit restatement equal the numpy oracle's at fp64 inputs, and one 50-digit
+    Gauss-Helmert run lands within the LAPACK evaluation's own noise of it."""
+    from oracle import gh_mp_oracle as G
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    C, CalM, _, _ = generate_scene_batch(1, 9, noise=1.0, seed=4)
+    Cb = C[0].T.copy()
+    x, x_est, p0, normals = G.nordberg_start(Cb, CalM)
+    f, g_, A, B, Cc, _ = O._nordberg_constrGH(x_est, p0)
+    T, J, gm, Cm = G.nordberg_model(G.to_mp(p0))
+    assert abs(float(gm[0]) - g_[0]) < 1e-15 and np.abs(G.to_float(Cm) - Cc).max() < 1e-15
+    xi = G.to_mp(x_est)
+    for i in range(9):
+        fi, Ap, Bi = G._blocks(xi[6 * i:6 * i + 6], T)
+        assert np.abs(G.to_float(fi) - f[4 * i:4 * i + 4]).max() < 1e-14
+        assert np.abs(G.to_float(Ap.dot(J)) - A[4 * i:4 * i + 4]).max() < 1e-13 * np.abs(A).max()
+        assert np.abs(G.to_float(Bi) - B[4 * i:4 * i + 4, 6 * i:6 * i + 6]).max() < 1e-13 * np.abs(B).max()
+    p_mp, _, it, reason = G.gauss_helmert_mp(x, x_est, p0, G.nordberg_model, 19, 1)
+    func = lambda a, b, c: O._nordberg_constrGH(a, b)
+    _, p_np, _, it_np, _ = O.Gauss_Helmert(func, x_est, p0, np.zeros(0), x, None, True)
+    assert abs(it - it_np) <= 3 and np.abs(p_mp - p_np).max() < 1e-3
