@@ -1,8 +1,8 @@
 """TEST INFRASTRUCTURE ONLY -- never imported by the product (tft_vs_fund_amd/).
 
 Extended-precision (mpmath, 50 digits) evaluation of the reference's Gauss-Helmert iteration
-(Optimization/Gauss_Helmert.m:38-83) with Ressl's callback (TFT_methods/ResslTFTPoseEstimation.m:110-177) and Nordberg's
-(TFT_methods/NordbergTFTPoseEstimation.m:128-222).
+(Optimization/Gauss_Helmert.m:38-83) with Ressl's callback (TFT_methods/ResslTFTPoseEstimation.m:110-177), Nordberg's
+(TFT_methods/NordbergTFTPoseEstimation.m:128-222) and Faugeras-Papadopoulo's (TFT_methods/FaugPapaTFTPoseEstimation.m:87-159).
 
 Purpose: `pinv(W + 1e-12 I)` gives every correspondence one direction of weight ~1e12, so A'WA
 cancels ten digits in ANY fp64 evaluation -- the reference's own dense MATLAB product included.  To judge the HIP kernel
@@ -350,3 +350,74 @@ def ResslTFTPoseEstimation_mp(Corresp, CalM):
     p_opt, _, it, reason = gauss_helmert_ressl_mp(x, x_est, p0, Ind)
     R2, R3, T = ressl_tail(p_opt, Ind, normals, CalM, Corresp)
     return R2, R3, T, it, reason
+
+
+# ---- Faugeras-Papadopoulo's callback (FaugPapaTFTPoseEstimation.m:87-159): all 27 tensor entries, 12 algebraic constraints
+def _det3_mp(A):
+    return (A[0, 0] * (A[1, 1] * A[2, 2] - A[1, 2] * A[2, 1]) - A[0, 1] * (A[1, 0] * A[2, 2] - A[1, 2] * A[2, 0])
+            + A[0, 2] * (A[1, 0] * A[2, 1] - A[1, 1] * A[2, 0]))
+
+
+def _minor_mp(A, i, j):
+    """:156-159 (signed cofactor of a 3 x 3 matrix; i, j 0-based)"""
+    r = [k for k in range(3) if k != i]
+    c = [k for k in range(3) if k != j]
+    d = A[r[0], c[0]] * A[r[1], c[1]] - A[r[0], c[1]] * A[r[1], c[0]]
+    return d if (i + j) % 2 == 0 else -d
+
+
+def _fp_stack_mp(T, idx3):
+    out = _zeros(3, 3)
+    for c, (a, b) in enumerate(idx3):
+        out[c, :] = T[a, b, :]
+    return out
+
+
+def faugpapa_model(ti):
+    T = ti.reshape(3, 3, 3, order='F')
+    one = mp.mpf(1)
+    D = _zeros(27, 27)
+    for k in range(27):
+        D[k, k] = one
+    g = _zeros(12)
+    C = _zeros(12, 27)
+    for i in range(3):                                                               # :116-124: det(T_i) = 0
+        g[i] = _det3_mp(T[:, :, i])
+        for j in range(3):
+            for k in range(3):
+                C[i, j + 3 * k + 9 * i] = _minor_mp(T[:, :, i], j, k)
+    i = -1
+    for k2 in range(2):                                                              # :126-152: the nine extended-rank constraints
+        for k3 in range(2):
+            for l2 in range(k2 + 1, 3):
+                for l3 in range(k3 + 1, 3):
+                    i += 1
+                    A1 = _fp_stack_mp(T, [(k2, k3), (k2, l3), (l2, l3)])
+                    A2 = _fp_stack_mp(T, [(k2, k3), (l2, k3), (l2, l3)])
+                    A3 = _fp_stack_mp(T, [(l2, k3), (k2, l3), (l2, l3)])
+                    A4 = _fp_stack_mp(T, [(k2, k3), (l2, k3), (k2, l3)])
+                    d1, d2, d3, d4 = _det3_mp(A1), _det3_mp(A2), _det3_mp(A3), _det3_mp(A4)
+                    g[3 + i] = d1 * d2 - d3 * d4
+                    for i1 in range(3):
+                        C[3 + i, k2 + 3 * k3 + 9 * i1] = _minor_mp(A1, i1, 0) * d2 + d1 * _minor_mp(A2, i1, 0) - d3 * _minor_mp(A4, i1, 0)
+                        C[3 + i, k2 + 3 * l3 + 9 * i1] = _minor_mp(A1, i1, 1) * d2 - _minor_mp(A3, i1, 1) * d4 - d3 * _minor_mp(A4, i1, 2)
+                        C[3 + i, l2 + 3 * l3 + 9 * i1] = _minor_mp(A1, i1, 2) * d2 + d1 * _minor_mp(A2, i1, 2) - _minor_mp(A3, i1, 2) * d4
+                        C[3 + i, l2 + 3 * k3 + 9 * i1] = d1 * _minor_mp(A2, i1, 1) - _minor_mp(A3, i1, 0) * d4 - d3 * _minor_mp(A4, i1, 1)
+    return T, D, g, C
+
+
+def faugpapa_start(Corresp, CalM):
+    x1, N1 = O.Normalize2Ddata(Corresp[0:2, :])
+    x2, N2 = O.Normalize2Ddata(Corresp[2:4, :])
+    x3, N3 = O.Normalize2Ddata(Corresp[4:6, :])
+    T, P1, P2, P3 = O.linearTFT(x1, x2, x3)
+    x, x_est = O._gh_initial_obs(P1, P2, P3, x1, x2, x3)
+    return x, x_est, O._vecT(T), (N1, N2, N3)
+
+
+def FaugPapaTFTPoseEstimation_mp(Corresp, CalM):
+    x, x_est, p0, normals = faugpapa_start(Corresp, CalM)
+    p_opt, _, it, reason = gauss_helmert_mp(x, x_est, p0, faugpapa_model, 27, 12)
+    T = O.transform_TFT(O._unvecT(p_opt), normals[0], normals[1], normals[2], 1)
+    R_t_2, R_t_3 = O.R_t_from_TFT(T, CalM, Corresp)
+    return R_t_2, R_t_3, T, it, reason

@@ -264,3 +264,22 @@ def test_mp_callback_is_an_independent_restatement_of_nordberg():
     func = lambda a, b, c: O._nordberg_constrGH(a, b)
     _, p_np, _, it_np, _ = O.Gauss_Helmert(func, x_est, p0, np.zeros(0), x, None, True)
     assert abs(it - it_np) <= 3 and np.abs(p_mp - p_np).max() < 1e-3
+
+
+def test_mp_callback_is_an_independent_restatement_of_faugpapa():
+    """... and for Faugeras-Papadopoulo's callback (FaugPapaTFTPoseEstimation.m:87-159: determinants and signed cofactors of 3 x 3
+    stacks of tensor entries): g and C of the 50-digit restatement equal the numpy oracle's at fp64 inputs."""
+    from oracle import gh_mp_oracle as G
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    C, CalM, _, _ = generate_scene_batch(1, 9, noise=1.0, seed=6)
+    Cb = C[0].T.copy()
+    x, x_est, p0, normals = G.faugpapa_start(Cb, CalM)
+    f, g_, A, B, Cc, _ = O._faugpapa_constrGH(x_est, p0)
+    T, D, gm, Cm = G.faugpapa_model(G.to_mp(p0))
+    assert np.abs(G.to_float(gm) - g_).max() < 1e-15 * max(1.0, np.abs(g_).max())
+    assert np.abs(G.to_float(Cm) - Cc).max() < 1e-14 * np.abs(Cc).max()
+    assert np.abs(G.to_float(D) - np.eye(27)).max() == 0.0
+    xi = G.to_mp(x_est)
+    for i in range(9):
+        fi, Ap, Bi = G._blocks(xi[6 * i:6 * i + 6], T)
+        assert np.abs(G.to_float(Ap) - A[4 * i:4 * i + 4]).max() < 1e-13 * np.abs(A).max()

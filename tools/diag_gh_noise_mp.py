@@ -1,4 +1,4 @@
-"""Ressl's (default) or Nordberg's (--nordberg) Gauss-Helmert refinement: deviation of (i) the LAPACK-backed numpy oracle and (ii) the HIP kernel from the 50-digit
+"""Ressl's (default), Nordberg's (--nordberg) or Faugeras-Papadopoulo's (--faugpapa) Gauss-Helmert refinement: deviation of (i) the LAPACK-backed numpy oracle and (ii) the HIP kernel from the 50-digit
 evaluation of the reference's formulas (tests/golden/gh_mp.npz, oracle/gh_mp_oracle.py), and the iteration-count differences.
 GPU box (kernel column) or build container (--no-gpu: oracle column only)."""
 import sys, os
@@ -12,9 +12,9 @@ def dev(T, R2, R3, g, pre, b):
     return max(rel_err_T(T, g[pre + "mp_T"][b]), rel_err(R2, g[pre + "mp_Rt2"][b]), rel_err(R3, g[pre + "mp_Rt3"][b]))
 
 
-NORD = "--nordberg" in sys.argv
-METHOD = "NordbergTFTPoseEstimation" if NORD else "ResslTFTPoseEstimation"
-FIXTURE = "gh_mp_nordberg.npz" if NORD else "gh_mp.npz"
+NORD = "--nordberg" in sys.argv or "--faugpapa" in sys.argv      # no same-algebra block below
+METHOD = "NordbergTFTPoseEstimation" if "--nordberg" in sys.argv else ("FaugPapaTFTPoseEstimation" if "--faugpapa" in sys.argv else "ResslTFTPoseEstimation")
+FIXTURE = {"NordbergTFTPoseEstimation": "gh_mp_nordberg.npz", "FaugPapaTFTPoseEstimation": "gh_mp_faugpapa.npz", "ResslTFTPoseEstimation": "gh_mp.npz"}[METHOD]
 
 
 def table(ctx=None, exact=False):
