@@ -238,14 +238,14 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
     }
     return 0;
 }
-// TFF_OPT_KERNEL = 1 or TFF_OPT_SOLVER = 1 select the fused single-wavefront kernels (gh_kernel.h, pi_kernel.h).
+// TFF_OPT_KERNEL = 1 selects the fused single-wavefront kernels (gh_kernel.h; for the Pi methods also TFF_OPT_SOLVER = 1, pi_kernel.h).
 template <class Model, class KFused, class KFusedJac>
 int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     // No small-N route to the fused kernel any more (Nordberg below N ~ 64 was ~1.3x faster there): only the workgroup kernel
     // evaluates the weights in the factored form that reproduces the 50-digit iteration (gh_wg_kernel.h); the fused kernel's
     // results carry the 1e-6 .. 1e-4 noise of an fp64 pinv(W) (measured on tests/golden/gh_mp_nordberg.npz at N = 12 and 60).
-    if (c->kernel_variant == 1 || c->solver != 0)
+    if (c->kernel_variant == 1)                                              // TFF_OPT_SOLVER = 1 is honoured by launch_wg's linear stage
         return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, 0, std::is_same<Model, tff::ResslModel>::value ? 8 : 4, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
     return launch_wg(c, tff::k_gh_block<Model>, wg_lds, Model::WG_PER_CU, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
