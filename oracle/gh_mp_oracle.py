@@ -2,7 +2,7 @@
 
 Extended-precision (mpmath, 50 digits) evaluation of the reference's Gauss-Helmert iteration
 (Optimization/Gauss_Helmert.m:38-83) with Ressl's callback (TFT_methods/ResslTFTPoseEstimation.m:110-177), Nordberg's
-(TFT_methods/NordbergTFTPoseEstimation.m:128-222) and Faugeras-Papadopoulo's (TFT_methods/FaugPapaTFTPoseEstimation.m:87-159).
+(TFT_methods/NordbergTFTPoseEstimation.m:128-222) Faugeras-Papadopoulo's (TFT_methods/FaugPapaTFTPoseEstimation.m:87-159) and the Ponce-Hebert Pi-matrix one (TFT_methods/PiPoseEstimation.m:109-182).
 
 Purpose: `pinv(W + 1e-12 I)` gives every correspondence one direction of weight ~1e12, so A'WA
 cancels ten digits in ANY fp64 evaluation -- the reference's own dense MATLAB product included.  To judge the HIP kernel
@@ -142,7 +142,8 @@ def _blocks(xi_i, T):
 def gauss_helmert_mp(x, x_est, p0, model, u, c, it_max=400, return_history=False):
     """Gauss_Helmert.m:38-83 in extended precision for a trifocal-tensor callback, from the fp64 start (x, x_est, p0).
     model(t) -> (T 3x3x3, D = dT(:)/dt 27 x u, g (c), C (c x u)), all object arrays; the per-correspondence blocks f, Ap, B are the
-    ones every TFT callback shares (`_blocks`; A = Ap D).  Returns p_opt (float64), xi (float64), it, reason [, history]."""
+    ones every TFT callback shares (`_blocks`; A = Ap D).  Or model(t) -> (point_fn, g, C) with point_fn(o) -> (f 4, A 4 x u, B 4 x 6)
+    for callbacks with blocks of their own (the Pi-matrix method).  Returns p_opt (float64), xi (float64), it, reason [, history]."""
     N = x.shape[0] // 6
     xm, xi, ti = to_mp(x), to_mp(x_est), to_mp(p0)
     tol = mp.mpf(float(1e-6))
@@ -150,15 +151,20 @@ def gauss_helmert_mp(x, x_est, p0, model, u, c, it_max=400, return_history=False
     objFunc = sum(v * v for v in v0)
     reason, it, hist = 'itmax', 0, []
     for it in range(1, it_max + 1):
-        T, D, g, C = model(ti)
+        ev = model(ti)
+        if len(ev) == 4:                                                             # trifocal-tensor callbacks: (T, D, g, C)
+            T, D, g, C = ev
+            point_fn = lambda o: (lambda fAB: (fAB[0], fAB[1].dot(D), fAB[2]))(_blocks(o, T))
+        else:                                                                        # callbacks with their own blocks: (point_fn, g, C)
+            point_fn, g, C = ev
         blocks = []
         lam_max = mp.mpf(0)
         for i in range(N):
-            f, Ap, B = _blocks(xi[6 * i:6 * i + 6], T)
+            f, A, B = point_fn(xi[6 * i:6 * i + 6])
             Wb = B.dot(B.T)                                                          # :52 (P = I)
             lam, V = _eigsy(Wb + _EPS12 * np.eye(4, dtype=object))
             lam_max = max(lam_max, max(lam))
-            blocks.append((f, Ap.dot(D), B, lam, V))
+            blocks.append((f, A, B, lam, V))
         tolW = _matlab_tol(4 * N, lam_max)                                           # pinv's tolerance for the 4N x 4N matrix
         Nm = _zeros(u, u)
         rhs = _zeros(u)
@@ -420,4 +426,83 @@ def FaugPapaTFTPoseEstimation_mp(Corresp, CalM):
     p_opt, _, it, reason = gauss_helmert_mp(x, x_est, p0, faugpapa_model, 27, 12)
     T = O.transform_TFT(O._unvecT(p_opt), normals[0], normals[1], normals[2], 1)
     R_t_2, R_t_3 = O.R_t_from_TFT(T, CalM, Corresp)
+    return R_t_2, R_t_3, T, it, reason
+
+
+# ---- Ponce-Hebert Pi-matrix callback (PiPoseEstimation.m:109-182): 27 parameters (nine 3-vectors), 9 constraints; per correspondence
+# ---- three epipolar equations and one trilinearity
+def pi_model(ti):
+    pi = ti
+    pi21, pi31, pi41 = pi[0:3], pi[3:6], pi[6:9]
+    pi12, pi32, pi42 = pi[9:12], pi[12:15], pi[15:18]
+    pi13, pi23, pi43 = pi[18:21], pi[21:24], pi[24:27]
+    F12 = np.outer(pi41, pi32) - np.outer(pi31, pi42)                                # :118-120
+    F13 = np.outer(pi41, pi23) - np.outer(pi21, pi43)
+    F23 = np.outer(pi42, pi13) - np.outer(pi12, pi43)
+    dot = lambda a, b: sum(x * y for x, y in zip(a, b))
+    g = np.array([dot(pi41, pi41) - 1, dot(pi42, pi42) - 1, dot(pi43, pi43) - 1,
+                  dot(pi21, pi21) - 1, dot(pi32, pi32) - 1, dot(pi13, pi13) - 1,
+                  dot(pi21, pi41), dot(pi32, pi42), dot(pi13, pi43)], dtype=object)   # :123-125
+    C = _zeros(9, 27)                                                                # :128-137
+    C[0, 6:9] = 2 * pi41
+    C[1, 15:18] = 2 * pi42
+    C[2, 24:27] = 2 * pi43
+    C[3, 0:3] = 2 * pi21
+    C[4, 12:15] = 2 * pi32
+    C[5, 18:21] = 2 * pi13
+    C[6, 0:3] = pi41; C[6, 6:9] = pi21
+    C[7, 12:15] = pi42; C[7, 15:18] = pi32
+    C[8, 18:21] = pi43; C[8, 24:27] = pi13
+
+    def point_fn(o):
+        one = mp.mpf(1)
+        p1 = np.array([o[0], o[1], one], dtype=object)
+        p2 = np.array([o[2], o[3], one], dtype=object)
+        p3 = np.array([o[4], o[5], one], dtype=object)
+        a21, a31, a41 = dot(pi21, p1), dot(pi31, p1), dot(pi41, p1)
+        a12, a32, a42 = dot(pi12, p2), dot(pi32, p2), dot(pi42, p2)
+        a13, a23, a43 = dot(pi13, p3), dot(pi23, p3), dot(pi43, p3)
+        f = np.array([p1.dot(F12).dot(p2), p1.dot(F13).dot(p3), p2.dot(F23).dot(p3), a21 * a32 * a13 - a31 * a12 * a23], dtype=object)   # :152-153
+        A = _zeros(4, 27)                                                            # :156-164
+        A[0, 3:6] = -a42 * p1; A[0, 6:9] = a32 * p1
+        A[0, 12:15] = a41 * p2; A[0, 15:18] = -a31 * p2
+        A[1, 0:3] = -a43 * p1; A[1, 6:9] = a23 * p1
+        A[1, 21:24] = a41 * p3; A[1, 24:27] = -a21 * p3
+        A[2, 9:12] = -a43 * p2; A[2, 15:18] = a13 * p2
+        A[2, 18:21] = a42 * p3; A[2, 24:27] = -a12 * p3
+        A[3, 0:3] = p1 * (a32 * a13); A[3, 3:6] = -p1 * (a12 * a23)
+        A[3, 9:12] = -(a31 * a23) * p2; A[3, 12:15] = (a21 * a13) * p2
+        A[3, 18:21] = (a21 * a32) * p3; A[3, 21:24] = -(a31 * a12) * p3
+        B = _zeros(4, 6)                                                             # :166-171
+        B[0, 0:2] = F12.dot(p2)[0:2]; B[0, 2:4] = p1.dot(F12)[0:2]
+        B[1, 0:2] = F13.dot(p3)[0:2]; B[1, 4:6] = p1.dot(F13)[0:2]
+        B[2, 2:4] = F23.dot(p3)[0:2]; B[2, 4:6] = p2.dot(F23)[0:2]
+        B[3, 0:2] = (pi21 * (a32 * a13) - pi31 * (a12 * a23))[0:2]
+        B[3, 2:4] = (pi32 * (a21 * a13) - pi12 * (a31 * a23))[0:2]
+        B[3, 4:6] = (pi13 * (a21 * a32) - pi23 * (a31 * a12))[0:2]
+        return f, A, B
+    return point_fn, g, C
+
+
+def pi_start(Corresp, CalM):
+    """fp64 start of PiPoseEstimation.m:50-88 (from the numpy oracle): x, x_est, pi0 and the normalisations"""
+    x1, N1 = O.Normalize2Ddata(Corresp[0:2, :])
+    x2, N2 = O.Normalize2Ddata(Corresp[2:4, :])
+    x3, N3 = O.Normalize2Ddata(Corresp[4:6, :])
+    pi0, x_est = O.PiPoseEstimation(Corresp, CalM, init_only=True)
+    N = x1.shape[1]
+    x = np.vstack([x1[0:2, :], x2[0:2, :], x3[0:2, :]]).reshape(6 * N, order='F')
+    return x, x_est, pi0, (N1, N2, N3)
+
+
+def PiPoseEstimation_mp(Corresp, CalM):
+    x, x_est, p0, normals = pi_start(Corresp, CalM)
+    p_opt, _, it, reason = gauss_helmert_mp(x, x_est, p0, pi_model, 27, 9)
+    inv = np.linalg.inv
+    Pi1 = p_opt[0:9].reshape(3, 3); Pi2 = p_opt[9:18].reshape(3, 3); Pi3 = p_opt[18:27].reshape(3, 3)   # :94-96
+    P1 = np.zeros((3, 4)); P2 = np.zeros((3, 4)); P3 = np.zeros((3, 4))
+    P1[:, 1:4] = inv(Pi1)
+    P2[:, [0, 2, 3]] = inv(Pi2)
+    P3[:, [0, 1, 3]] = inv(Pi3)
+    R_t_2, R_t_3, _, T = O._pi_finish(P1, P2, P3, normals[0], normals[1], normals[2], CalM, Corresp)
     return R_t_2, R_t_3, T, it, reason

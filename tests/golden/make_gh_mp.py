@@ -1,7 +1,7 @@
 """Generates tests/golden/gh_mp.npz (Ressl) / gh_mp_nordberg.npz: the method with its Gauss-Helmert loop evaluated in 50-digit
 arithmetic (oracle/gh_mp_oracle.py) on seeded synthetic scenes, N in {12, 60, 200}.  Build-container script (needs mpmath; ~20 min
 on 8 cores for Ressl's 64 scenes); the fixtures hold inputs and expected outputs only.
-Usage: python tests/golden/make_gh_mp.py [ressl|nordberg|faugpapa]"""
+Usage: python tests/golden/make_gh_mp.py [ressl|nordberg|faugpapa|pi]"""
 import os, sys, time
 from multiprocessing import Pool
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,11 +14,14 @@ from tft_vs_fund_amd.scenes import generate_scene_batch
 METHOD = sys.argv[1] if len(sys.argv) > 1 else "ressl"
 CASES = {"ressl": [(12, 32, 1.0), (60, 20, 1.0), (200, 12, 1.0)],               # N, scenes, pixel noise
          "nordberg": [(12, 24, 1.0), (60, 12, 1.0), (200, 6, 1.0)],
-         "faugpapa": [(12, 24, 1.0), (60, 16, 1.0), (200, 8, 1.0)]}[METHOD]
-SEED0 = {"ressl": 4000, "nordberg": 5000, "faugpapa": 6000}[METHOD]
-MP_FN = {"ressl": G.ResslTFTPoseEstimation_mp, "nordberg": G.NordbergTFTPoseEstimation_mp, "faugpapa": G.FaugPapaTFTPoseEstimation_mp}[METHOD]
-NP_FN = {"ressl": O.ResslTFTPoseEstimation, "nordberg": O.NordbergTFTPoseEstimation, "faugpapa": O.FaugPapaTFTPoseEstimation}[METHOD]
-OUT = {"ressl": "gh_mp.npz", "nordberg": "gh_mp_nordberg.npz", "faugpapa": "gh_mp_faugpapa.npz"}[METHOD]
+         "faugpapa": [(12, 24, 1.0), (60, 16, 1.0), (200, 8, 1.0)],
+         "pi": [(12, 24, 1.0), (60, 16, 1.0), (200, 8, 1.0)]}[METHOD]
+SEED0 = {"ressl": 4000, "nordberg": 5000, "faugpapa": 6000, "pi": 7000}[METHOD]
+MP_FN = {"ressl": G.ResslTFTPoseEstimation_mp, "nordberg": G.NordbergTFTPoseEstimation_mp, "faugpapa": G.FaugPapaTFTPoseEstimation_mp,
+         "pi": G.PiPoseEstimation_mp}[METHOD]
+NP_FN = {"ressl": O.ResslTFTPoseEstimation, "nordberg": O.NordbergTFTPoseEstimation, "faugpapa": O.FaugPapaTFTPoseEstimation,
+         "pi": O.PiPoseEstimation}[METHOD]
+OUT = {"ressl": "gh_mp.npz", "nordberg": "gh_mp_nordberg.npz", "faugpapa": "gh_mp_faugpapa.npz", "pi": "gh_mp_pi.npz"}[METHOD]
 
 
 def one(args):

@@ -283,3 +283,22 @@ def test_mp_callback_is_an_independent_restatement_of_faugpapa():
     for i in range(9):
         fi, Ap, Bi = G._blocks(xi[6 * i:6 * i + 6], T)
         assert np.abs(G.to_float(Ap) - A[4 * i:4 * i + 4]).max() < 1e-13 * np.abs(A).max()
+
+
+def test_mp_callback_is_an_independent_restatement_of_pi():
+    """... and for the Ponce-Hebert Pi-matrix callback (PiPoseEstimation.m:109-182), which has per-correspondence blocks of its own
+    (three epipolar equations and one trilinearity): f, A, B, g, C of the 50-digit restatement equal the numpy oracle's at fp64 inputs."""
+    from oracle import gh_mp_oracle as G
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    C, CalM, _, _ = generate_scene_batch(1, 9, noise=1.0, seed=8)
+    Cb = C[0].T.copy()
+    x, x_est, p0, normals = G.pi_start(Cb, CalM)
+    f, g_, A, B, Cc, _ = O._pi_constraintsGH(x_est, p0)
+    point_fn, gm, Cm = G.pi_model(G.to_mp(p0))
+    assert np.abs(G.to_float(gm) - g_).max() < 1e-15 and np.abs(G.to_float(Cm) - Cc).max() < 1e-15
+    xi = G.to_mp(x_est)
+    for i in range(9):
+        fi, Ai, Bi = point_fn(xi[6 * i:6 * i + 6])
+        assert np.abs(G.to_float(fi) - f[4 * i:4 * i + 4]).max() < 1e-14
+        assert np.abs(G.to_float(Ai) - A[4 * i:4 * i + 4]).max() < 1e-13 * np.abs(A).max()
+        assert np.abs(G.to_float(Bi) - B[4 * i:4 * i + 4, 6 * i:6 * i + 6]).max() < 1e-13 * np.abs(B).max()

@@ -12,9 +12,9 @@ def dev(T, R2, R3, g, pre, b):
     return max(rel_err_T(T, g[pre + "mp_T"][b]), rel_err(R2, g[pre + "mp_Rt2"][b]), rel_err(R3, g[pre + "mp_Rt3"][b]))
 
 
-NORD = "--nordberg" in sys.argv or "--faugpapa" in sys.argv      # no same-algebra block below
-METHOD = "NordbergTFTPoseEstimation" if "--nordberg" in sys.argv else ("FaugPapaTFTPoseEstimation" if "--faugpapa" in sys.argv else "ResslTFTPoseEstimation")
-FIXTURE = {"NordbergTFTPoseEstimation": "gh_mp_nordberg.npz", "FaugPapaTFTPoseEstimation": "gh_mp_faugpapa.npz", "ResslTFTPoseEstimation": "gh_mp.npz"}[METHOD]
+NORD = "--nordberg" in sys.argv or "--faugpapa" in sys.argv or "--pi" in sys.argv      # no same-algebra block below
+METHOD = "NordbergTFTPoseEstimation" if "--nordberg" in sys.argv else ("FaugPapaTFTPoseEstimation" if "--faugpapa" in sys.argv else ("PiPoseEstimation" if "--pi" in sys.argv else "ResslTFTPoseEstimation"))
+FIXTURE = {"NordbergTFTPoseEstimation": "gh_mp_nordberg.npz", "FaugPapaTFTPoseEstimation": "gh_mp_faugpapa.npz", "ResslTFTPoseEstimation": "gh_mp.npz", "PiPoseEstimation": "gh_mp_pi.npz"}[METHOD]
 
 
 def table(ctx=None, exact=False):
