@@ -253,8 +253,9 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
 template <class Model>
 int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    const bool small = !Model::PINV_KKT && N < 176 && c->kernel_variant == 0;   // measured crossover for Pi at N ~ 180
-    if (c->kernel_variant == 1 || c->solver != 0 || c->init_p || small)      // the debug outputs (init_p, init_x) come from the fused kernel
+    // Pi: every N takes the workgroup kernel -- only it evaluates the weights in the factored form that reproduces the 50-digit
+    // iteration (pi_wg_kernel.h); the fused kernel (faster below N ~ 180) carries the noise of an fp64 pinv(W), 1e-5 at N = 12.
+    if (c->kernel_variant == 1 || c->solver != 0 || c->init_p)                // the debug outputs (init_p, init_x) come from the fused kernel
         return launch_pose(c, tff::k_pi_tft_pose<Model, false>, tff::k_pi_tft_pose<Model, true>, tff::pi_lds_bytes<Model>, 0, 4,
                            corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::pi_wg_lds_doubles(Model::E, Model::C, n)) * sizeof(double); };

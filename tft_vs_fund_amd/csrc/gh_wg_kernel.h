@@ -218,10 +218,11 @@ __device__ __forceinline__ void strong_sweep(const double (&b)[U], const double 
 }
 template <int U>
 __device__ inline void strong_accumulate(const double (&b)[U], const double t, double* slot) {
-    static_assert(U * (U + 1) / 2 + U <= 12 * 32, "twelve sweeps");
+    static_assert(U * (U + 1) / 2 + U <= 13 * 32, "thirteen sweeps");
     strong_sweep<U, 0>(b, t, slot); strong_sweep<U, 1>(b, t, slot); strong_sweep<U, 2>(b, t, slot); strong_sweep<U, 3>(b, t, slot);
     strong_sweep<U, 4>(b, t, slot); strong_sweep<U, 5>(b, t, slot); strong_sweep<U, 6>(b, t, slot); strong_sweep<U, 7>(b, t, slot);
     strong_sweep<U, 8>(b, t, slot); strong_sweep<U, 9>(b, t, slot); strong_sweep<U, 10>(b, t, slot); strong_sweep<U, 11>(b, t, slot);
+    strong_sweep<U, 12>(b, t, slot);
 }
 // a = D' q for q = h1 (x) vec(gm) (27): through the model's sparse form when it has one, else the dense 27 x U matrix in LDS
 template <class Model>

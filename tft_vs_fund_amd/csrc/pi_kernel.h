@@ -33,6 +33,7 @@ struct PiWork {
     double* V;      // n x n    eigenvectors of the KKT matrix, then n coefficients (pseudo-inverse path)
     double* xi;     // 6N       current estimates of the observations
     double* pp;     // PP * N   per correspondence: W+ (packed lower), W+ w; later v (6)
+    double* sn;     // workgroup kernel (Pi): 6N, per correspondence the strong direction n (4), its weight cs and n'w; else null
 };
 __host__ __device__ constexpr int pi_pp(int E) { return E * (E + 1) / 2 + E; }
 __host__ __device__ inline int pi_lds_doubles(int E, int C, int N, bool pinv_kkt) {
@@ -52,6 +53,7 @@ __device__ inline PiWork pi_carve(double* base, int E, int C, int N, bool pinv_k
     g.V = q; q += (n * n + n + 1) & ~1;
     g.xi = q; q += 6 * N;
     g.pp = q;
+    g.sn = nullptr;
     return g;
 }
 

@@ -10,7 +10,47 @@
 
 namespace tff {
 
-__host__ __device__ inline int pi_wg_lds_doubles(int E, int C, int N) { return pi_lds_doubles(E, C, N, true) + 16; }
+// + 6N: the strong direction of every 4 x 4 weight block (n, cs, n'w), see the factored weights below (Pi only; PiCol carries the room unused)
+__host__ __device__ inline int pi_wg_lds_doubles(int E, int C, int N) { return pi_lds_doubles(E, C, N, true) + 6 * N + 16; }
+
+// pinv's tolerance E N eps(max_i lambda_max(W_i)) for the block-diagonal weight matrix (Gauss_Helmert.m:57).  Only the binade of the
+// maximum enters: the eigenvalue pass is skipped when cheap upper / lower bounds agree on it.  Block-wide (contains barriers).
+template <class Model>
+__device__ inline double pi_block_tolerance(const PiWork& g, const double (&pi)[27], const int N, const int tid, double* red) {
+    constexpr int E = Model::E;
+    double umax = 0.0, lmax = 0.0;                                           // upper / lower bound on max_i lambda_max(W_i)
+    for (int i = tid; i < N; i += GH_WG_THREADS) {
+        double o[6], W[E][E];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+        PiPoint<E> pt;
+        pi_eval<Model, true>(pi, o, pt);
+        pi_block_W<E>(pt.B, W);
+        double up, lo;
+        psd_lambda_max_bounds(W, up, lo);
+        umax = (up > umax) ? up : umax;
+        lmax = (lo > lmax) ? lo : lmax;
+    }
+    umax = block_max(umax, red);
+    lmax = block_max(lmax, red);
+    double smax = umax;
+    if (eps_of(lmax) != eps_of(umax)) {
+        smax = 0.0;
+        for (int i = tid; i < N; i += GH_WG_THREADS) {
+            double o[6], W[E][E], V[E][E];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+            PiPoint<E> pt;
+            pi_eval<Model, true>(pi, o, pt);
+            pi_block_W<E>(pt.B, W);
+            jacobi_small<E, false>(W, V);
+#pragma unroll
+            for (int a = 0; a < E; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
+        }
+        smax = block_max(smax, red);
+    }
+    return (double)E * (double)N * eps_of(smax);
+}
 
 template <class Model>
 __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red, int own, const double* pts, int N, int* st, bool exact_pinv) {
@@ -49,8 +89,74 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
         }
         f2max = block_max(f2max, red);
         if (block_any(!finite, red) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
+        // ---- Pi (4 x 4 blocks, non-singular KKT): weights at the accuracy of the formulas, as in gh_wg_kernel.h -- the block
+        //      pseudo-inverse deflated by its one small eigenvalue (pinv_block_deflated<true>: regular part only in pp), the strong
+        //      direction kept apart as (n, cs, n'w) and its contributions cs a a', cs a n'w formed from a = A_i' n FIRST (a is the
+        //      inconsistency of the correspondence: tiny, while cs ~ 1e12).  Sums: 27 * 28 / 2 + 27 = 405, thirteen butterflies per
+        //      wavefront into partial slots (V, H: both dead here), combined into S = V[0 .. 405).
+        bool factored = false;
+        if constexpr (E == 4 && !Model::PINV_KKT) {
+            if (!exact_pinv && g.sn != nullptr) {
+                const double tolW = pi_block_tolerance<Model>(g, pi, N, tid, red);
+                constexpr int SLOT = 406;
+                double* slot = (wave < 3) ? g.V + wave * SLOT : g.H;
+                for (int e = lane; e < SLOT; e += WAVE) slot[e] = 0.0;
+                bool bad = false;
+#pragma unroll 1
+                for (int base = 0; base < N; base += GH_WG_THREADS) {        // block-uniform trip count (the butterflies need whole wavefronts)
+                    const int i = base + tid;
+                    double bv[27], tv = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 27; ++k) bv[k] = 0.0;
+                    if (i < N) {
+                        double o[6], W[E][E], Wp[NW], nn[4], cs = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                        PiPoint<E> pt;
+                        pi_eval<Model, true>(pi, o, pt);
+                        pi_block_W<E>(pt.B, W);
+                        const bool ok = pinv_block_deflated<true>(pt.B, W, tolW, Wp, nn, &cs);
+                        bad = !ok || bad;
+#pragma unroll
+                        for (int a = 0; a < E; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
+                        pi_store_point<E>(g, w, pts, i, o, pt, Wp);
+                        const Pt6 x = premap(load_pt(pts, i), w->nrm);
+                        double nw = 0.0;                                     // n'w,  w = -f - B (x - xi)
+#pragma unroll
+                        for (int a = 0; a < E; ++a) {
+                            double wa = -pt.f[a];
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) wa -= pt.B[a][k] * (x.v[k] - o[k]);
+                            nw += nn[a] * wa;
+                        }
+                        double* sn = g.sn + 6 * (long)i;
+                        sn[0] = nn[0]; sn[1] = nn[1]; sn[2] = nn[2]; sn[3] = nn[3]; sn[4] = ok ? cs : 0.0; sn[5] = nw;
+                        if (ok) {
+                            Model::a_quirk(pt.c);
+                            const double sc = sqrt(cs);
+#pragma unroll
+                            for (int b = 0; b < 9; ++b) {                    // a[3 b + k] = (sum_r n_r c[r][b]) p_view(b)[k]
+                                double an = 0.0;
+#pragma unroll
+                                for (int r = 0; r < E; ++r)
+                                    if (Model::nz(r, b)) an += nn[r] * pt.c[r][b];
+                                an *= sc;
+#pragma unroll
+                                for (int k = 0; k < 3; ++k) bv[3 * b + k] = an * hom_at(o, b / 3, k);
+                            }
+                            tv = sc * nw;
+                        }
+                    }
+                    strong_accumulate<27>(bv, tv, slot);
+                }
+                __syncthreads();
+                for (int e = tid; e < 405; e += GH_WG_THREADS) g.V[e] = (g.V[e] + g.V[SLOT + e]) + (g.V[2 * SLOT + e] + g.H[e]);
+                factored = !block_any(bad, red);                             // a block without the structure: the unfactored paths below for all
+            }
+        }
         bool fast = !exact_pinv && (double)E * (double)N * eps_of(sqrt(f2max)) < 0.9e-12;
-        if (fast) {
+        if (factored) {
+        } else if (fast) {
             bool bad = false;
             for (int i = tid; i < N; i += GH_WG_THREADS) {
                 double o[6], W[E][E], Wp[NW];
@@ -66,40 +172,8 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
             }
             if (block_any(bad, red)) fast = false;
         }
-        if (!fast) {
-            // only the binade of max_i lambda_max(W_i) enters pinv's tolerance: skip the eigenvalue pass when the bounds agree on it
-            double umax = 0.0, lmax = 0.0;                                   // upper / lower bound on max_i lambda_max(W_i)
-            for (int i = tid; i < N; i += GH_WG_THREADS) {
-                double o[6], W[E][E];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
-                PiPoint<E> pt;
-                pi_eval<Model, true>(pi, o, pt);
-                pi_block_W<E>(pt.B, W);
-                double up, lo;
-                psd_lambda_max_bounds(W, up, lo);
-                umax = (up > umax) ? up : umax;
-                lmax = (lo > lmax) ? lo : lmax;
-            }
-            umax = block_max(umax, red);
-            lmax = block_max(lmax, red);
-            double smax = umax;
-            if (eps_of(lmax) != eps_of(umax)) {
-                smax = 0.0;
-                for (int i = tid; i < N; i += GH_WG_THREADS) {
-                    double o[6], W[E][E], V[E][E];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
-                    PiPoint<E> pt;
-                    pi_eval<Model, true>(pi, o, pt);
-                    pi_block_W<E>(pt.B, W);
-                    jacobi_small<E, false>(W, V);
-#pragma unroll
-                    for (int a = 0; a < E; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
-                }
-                smax = block_max(smax, red);
-            }
-            const double tolW = (double)E * (double)N * eps_of(smax);
+        if (!fast && !factored) {
+            const double tolW = pi_block_tolerance<Model>(g, pi, N, tid, red);
             for (int i = tid; i < N; i += GH_WG_THREADS) {
                 double o[6], W[E][E], V[E][E];
 #pragma unroll
@@ -145,9 +219,10 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
                 const int r = e / 27, cc = e % 27;
                 const int b = r / 3, k = r % 3, bp = cc / 3, kk = cc % 3;
                 const double v = (b >= bp) ? g.H[9 * (b * (b + 1) / 2 + bp) + 3 * k + kk] : g.H[9 * (bp * (bp + 1) / 2 + b) + 3 * kk + k];
-                g.M[r * ld + cc] = v + ((r == cc) ? 1e-12 : 0.0);
+                const double sv = factored ? g.V[(r >= cc) ? tri_index(r, cc) : tri_index(cc, r)] : 0.0;
+                g.M[r * ld + cc] = (v + sv) + ((r == cc) ? 1e-12 : 0.0);
             } else {
-                g.M[(e - 729) * ld + n] = g.H[405 + e - 729];
+                g.M[(e - 729) * ld + n] = g.H[405 + e - 729] + (factored ? g.V[378 + e - 729] : 0.0);
             }
         }
         if (tid < C) {                                                       // constraints g, C   (KKT borders)
@@ -210,6 +285,14 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
                 for (int b = 0; b < E; ++b) s += sym_at<E>(pw, a, b) * Ad[b];
                 rr[a] = s;
             }
+            if constexpr (E == 4) {
+                if (factored) {                                              // + cs n (n'(A dt) - n'w): the strong direction of W+
+                    const double* sn = g.sn + 6 * (long)i;
+                    const double st = sn[4] * ((sn[0] * Ad[0] + sn[1] * Ad[1] + sn[2] * Ad[2] + sn[3] * Ad[3]) - sn[5]);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) rr[a] += sn[a] * st;
+                }
+            }
             const Pt6 x = premap(load_pt(pts, i), w->nrm);
             double vv[6];
 #pragma unroll
@@ -258,8 +341,9 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::PINV_KKT ? 4 : 2) k_pi_b
         const int N = a.N;
         const double* pts = a.corresp + b * 6 * (long)N;
         PiWork g = pi_carve(ghbase, Model::E, Model::C, a.spill ? 0 : N, true);
-        double* red = g.pp + (long)pi_pp(Model::E) * (a.spill ? 0 : N);
-        if (a.spill) { g.xi = a.spill + blockIdx.x * a.spill_stride; g.pp = g.xi + 6 * (long)N; }
+        g.sn = g.pp + (long)pi_pp(Model::E) * (a.spill ? 0 : N);
+        double* red = g.sn + 6 * (long)(a.spill ? 0 : N);
+        if (a.spill) { g.xi = a.spill + blockIdx.x * a.spill_stride; g.pp = g.xi + 6 * (long)N; g.sn = g.pp + (long)pi_pp(Model::E) * N; }
         const int own = (int)(b & (GH_WG_WAVES - 1));
         const double* r = a.rec + b * GH_REC_DOUBLES;
         if (tid < 27) w->t[tid] = r[tid];
