@@ -361,3 +361,34 @@ def test_pinv_shortcut_equals_jacobi_branch_on_graded_blocks(emu):
     a = np.zeros(10); b = np.zeros(10); ok = ctypes.c_int(1)
     emu.emu_pinv_one_null(_p(W), 1e-9, _p(a), _p(b), ctypes.byref(ok))
     assert ok.value == 0
+
+
+@pytest.mark.parametrize("model,fixture", [("ressl", "gh_mp.npz"), ("nordberg", "gh_mp_nordberg.npz"), ("pi", "gh_mp_pi.npz")])
+def test_emulated_workgroup_kernels_reproduce_the_50_digit_iteration(emu, model, fixture):
+    """The GPU-less twin of tests/test_gpu_gh_noise.py: the workgroup Gauss-Helmert kernels (factored weights), compiled against the
+    lane emulator, on the first four N = 12 scenes of the extended-precision fixtures -- T, R_t_2, R_t_3 within 1e-9 of the 50-digit
+    evaluation (observed <= 6e-11) and the same iteration count; Nordberg under one of the eight sign conventions of linearTFT's
+    singular vectors (tests/helpers.py::oracle_under_epipole_conventions)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
+    pre = "c0_"
+    C = np.ascontiguousarray(g[pre + "Corresp"][:4]); CalM = g[pre + "CalM"]
+    B, N, _ = C.shape
+    calm = calm_colmajor(CalM)
+    Rt2 = np.zeros((B, 12)); Rt3 = np.zeros((B, 12)); T = np.zeros((B, 27)); it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32)
+    if model == "pi":
+        emu.emu_pi_wg_pose(ctypes.c_int(0), _p(C), _p(calm), ctypes.c_long(0), ctypes.c_long(B), ctypes.c_int(N), ctypes.c_int(0),
+                           _p(Rt2), _p(Rt3), _p(T), None, _p(it), _p(st))
+    else:
+        emu.emu_gh_wg_pose(ctypes.c_int(0 if model == "ressl" else 1), _p(C), _p(calm), ctypes.c_long(0), ctypes.c_long(B), ctypes.c_int(N),
+                           ctypes.c_int(0), _p(Rt2), _p(Rt3), _p(T), None, _p(it), _p(st))
+    assert np.all(st == 0)
+    Tt = T.reshape(B, 3, 3, 3).transpose(0, 3, 2, 1); R2 = Rt2.reshape(B, 4, 3).transpose(0, 2, 1); R3 = Rt3.reshape(B, 4, 3).transpose(0, 2, 1)
+    for b in range(B):
+        if pre + "mp4_T" in g.files:
+            cand = [(max(rel_err_T(Tt[b], g[pre + "mp4_T"][b, c]), rel_err(R2[b], g[pre + "mp4_Rt2"][b, c]), rel_err(R3[b], g[pre + "mp4_Rt3"][b, c])),
+                     int(it[b]) - int(g[pre + "mp4_iter"][b, c])) for c in range(g[pre + "mp4_T"].shape[1])]
+            d, dit = min(cand)
+        else:
+            d = max(rel_err_T(Tt[b], g[pre + "mp_T"][b]), rel_err(R2[b], g[pre + "mp_Rt2"][b]), rel_err(R3[b], g[pre + "mp_Rt3"][b]))
+            dit = int(it[b]) - int(g[pre + "mp_iter"][b])
+        assert dit == 0 and d < 1e-9, (model, b, d, dit)
