@@ -115,3 +115,23 @@ def test_unfactored_kernels_stay_inside_the_lapack_envelope(gpu_ctx, golden_dir,
             assert np.quantile(dk, q) <= 3.0 * np.quantile(do, q) + 1e-12, (ci, q, np.quantile(dk, q), np.quantile(do, q))
         assert dk.max() < 2e-3
         assert np.abs(np.asarray(out["iter"]) - g[pre + "mp_iter"]).max() <= 2
+
+
+@pytest.mark.parametrize("method,key", [("ResslTFTPoseEstimation", "ressl"), ("NordbergTFTPoseEstimation", "nordberg"), ("PiPoseEstimation", "pi")])
+def test_kernels_reproduce_the_extended_precision_iteration_on_real_data(gpu_ctx, golden_dir, method, key):
+    """The eight EPFL triplets of tests/golden/epfl.npz (fountain-P11 / Herz-Jesu-P8, 100-inlier samples, per-triplet calibration;
+    experiments_real.m): Gauss-Helmert in 50-digit arithmetic (tests/golden/gh_mp_epfl.npz, generator make_gh_mp_epfl.py) against the
+    kernels -- 1e-9 and the same iteration count, Nordberg under one of the eight sign conventions of linearTFT's singular vectors."""
+    g = np.load(os.path.join(golden_dir, "gh_mp_epfl.npz"))
+    for t in range(int(g["n_triplets"])):
+        pre = "t%d_" % t
+        C = g[pre + "Corresp"].T[None].copy()                                    # (1, N, 6)
+        out = gpu_ctx.pose_batch(method, C, g[pre + "CalM"], reconst=False)
+        assert int(out["status"][0]) == 0
+        T, R2, R3, it = out["T"][0], out["R_t_2"][0], out["R_t_3"][0], int(out["iter"][0])
+        mT, m2, m3, mit = g[pre + key + "_T"], g[pre + key + "_Rt2"], g[pre + key + "_Rt3"], g[pre + key + "_iter"]
+        if mT.ndim == 3:
+            mT, m2, m3, mit = mT[None], m2[None], m3[None], np.array([mit])
+        cand = [(max(rel_err_T(T, mT[c]), rel_err(R2, m2[c]), rel_err(R3, m3[c])), it - int(mit[c])) for c in range(mT.shape[0])]
+        d, dit = min(cand)
+        assert dit == 0 and d < 1e-9, (method, t, d, dit)
