@@ -231,21 +231,21 @@ __device__ __forceinline__ void strong_apply_Dt(const Model& model, const GhWork
         model.apply_Dt(g, h1, gm, a);
     } else {
         constexpr int u = Model::U;
-#pragma unroll 1
-        for (int pcol = 0; pcol < u; ++pcol) {
-            double acc = 0.0;
+        // row by row of D (every lane reads the same addresses: LDS broadcasts, consecutive entries pair up in ds_read2_b64); a[] is
+        // indexed statically -- a loop over the columns instead needs a 2 u-instruction select chain per column to place its sum
 #pragma unroll
-            for (int i1 = 0; i1 < 3; ++i1) {
-                double part = 0.0;
+        for (int c = 0; c < u; ++c) a[c] = 0.0;
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
+        for (int i1 = 0; i1 < 3; ++i1)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) part += g.D[(j + 3 * k + 9 * i1) * u + pcol] * gm[j][k];
-                acc += h1[i1] * part;
-            }
+            for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int c = 0; c < u; ++c) a[c] = (c == pcol) ? acc : a[c];
-        }
+                for (int j = 0; j < 3; ++j) {
+                    const double q = h1[i1] * gm[j][k];
+                    const double* row = g.D + (j + 3 * k + 9 * i1) * u;
+#pragma unroll
+                    for (int c = 0; c < u; ++c) a[c] += row[c] * q;
+                }
     }
 }
 
