@@ -85,8 +85,8 @@ def test_kernel_is_no_noisier_than_the_lapack_evaluation(gpu_ctx, golden_dir, me
             o2, o3, _, oT, _ = getattr(O, method)(C[b].T.copy(), CalM)
             do.append(_dev(oT, o2, o3, g, pre, b))
         do = np.array(do)
-        for q in (0.5, 0.9, 1.0):
-            assert np.quantile(dk, q) <= np.quantile(do, q), (ci, q, np.quantile(dk, q), np.quantile(do, q))
+        for q in (0.5, 0.9, 1.0):                                                  # (1e-12: both at rounding level, e.g. Pi at N = 200)
+            assert np.quantile(dk, q) <= max(np.quantile(do, q), 1e-12), (ci, q, np.quantile(dk, q), np.quantile(do, q))
         # the reference-noise envelope the oracle-based tests rely on (see _ressl_tol): same-algebra noise of a LAPACK evaluation
         N = C.shape[1]
         assert np.quantile(do, 0.5) < (2e-5 if N < 50 else 1e-5) and do.max() < (1e-2 if N < 50 else 2e-3), (ci, np.quantile(do, 0.5), do.max())
