@@ -917,6 +917,70 @@ __device__ __forceinline__ void gh_store_point(const GhWork& g, const PoseLds* w
         g.pp[14 * i + 10 + a] = wp_at(Wp, a, 0) * wv[0] + wp_at(Wp, a, 1) * wv[1] + wp_at(Wp, a, 2) * wv[2] + wp_at(Wp, a, 3) * wv[3];
 }
 
+// ---- factored strong-direction terms (see pinv_block_deflated<true>) -------------------------------------------------------------
+// Per correspondence the thread holds b = sqrt(cs) a (U doubles, a = D' Ap' n) and t = sqrt(cs) n'w in registers; the sums
+//   N_s[r][c] = sum_i b_i[r] b_i[c]  (lower triangle, U (U + 1) / 2 entries)   and   r_s[r] = sum_i b_i[r] t_i  (U entries)
+// are taken 32 at a time with the halving butterfly (compile-time entry indices, so b stays in registers) and added to the calling
+// wavefront's own partial-sum slot.
+template <int U, int E>
+__device__ __forceinline__ double strong_entry(const double (&b)[U], const double t) {
+    constexpr int ntri = U * (U + 1) / 2;
+    if constexpr (E < ntri) return b[tri_row_of(E)] * b[tri_col_of(E)];
+    else if constexpr (E < ntri + U) return b[E - ntri] * t;
+    else return 0.0;
+}
+template <int U, int SW>
+__device__ __forceinline__ void strong_sweep(const double (&b)[U], const double t, double* slot) {
+    constexpr int total = U * (U + 1) / 2 + U;
+    if constexpr (32 * SW < total) {
+        double acc[32];
+        acc[0] = strong_entry<U, 32 * SW + 0>(b, t);   acc[1] = strong_entry<U, 32 * SW + 1>(b, t);   acc[2] = strong_entry<U, 32 * SW + 2>(b, t);   acc[3] = strong_entry<U, 32 * SW + 3>(b, t);
+        acc[4] = strong_entry<U, 32 * SW + 4>(b, t);   acc[5] = strong_entry<U, 32 * SW + 5>(b, t);   acc[6] = strong_entry<U, 32 * SW + 6>(b, t);   acc[7] = strong_entry<U, 32 * SW + 7>(b, t);
+        acc[8] = strong_entry<U, 32 * SW + 8>(b, t);   acc[9] = strong_entry<U, 32 * SW + 9>(b, t);   acc[10] = strong_entry<U, 32 * SW + 10>(b, t); acc[11] = strong_entry<U, 32 * SW + 11>(b, t);
+        acc[12] = strong_entry<U, 32 * SW + 12>(b, t); acc[13] = strong_entry<U, 32 * SW + 13>(b, t); acc[14] = strong_entry<U, 32 * SW + 14>(b, t); acc[15] = strong_entry<U, 32 * SW + 15>(b, t);
+        acc[16] = strong_entry<U, 32 * SW + 16>(b, t); acc[17] = strong_entry<U, 32 * SW + 17>(b, t); acc[18] = strong_entry<U, 32 * SW + 18>(b, t); acc[19] = strong_entry<U, 32 * SW + 19>(b, t);
+        acc[20] = strong_entry<U, 32 * SW + 20>(b, t); acc[21] = strong_entry<U, 32 * SW + 21>(b, t); acc[22] = strong_entry<U, 32 * SW + 22>(b, t); acc[23] = strong_entry<U, 32 * SW + 23>(b, t);
+        acc[24] = strong_entry<U, 32 * SW + 24>(b, t); acc[25] = strong_entry<U, 32 * SW + 25>(b, t); acc[26] = strong_entry<U, 32 * SW + 26>(b, t); acc[27] = strong_entry<U, 32 * SW + 27>(b, t);
+        acc[28] = strong_entry<U, 32 * SW + 28>(b, t); acc[29] = strong_entry<U, 32 * SW + 29>(b, t); acc[30] = strong_entry<U, 32 * SW + 30>(b, t); acc[31] = strong_entry<U, 32 * SW + 31>(b, t);
+        const double tot = wave_reduce_scatter<32>(acc);
+        const int lane = lane_id(), e = 32 * SW + reduce32_index(lane);
+        if ((lane & 1) == 0 && e < total) slot[e] += tot;
+        sched_fence();                                                       // keep the sweeps apart: interleaved, their 32 accumulators each would spill
+    }
+}
+template <int U>
+__device__ inline void strong_accumulate(const double (&b)[U], const double t, double* slot) {
+    static_assert(U * (U + 1) / 2 + U <= 13 * 32, "thirteen sweeps");
+    strong_sweep<U, 0>(b, t, slot); strong_sweep<U, 1>(b, t, slot); strong_sweep<U, 2>(b, t, slot); strong_sweep<U, 3>(b, t, slot);
+    strong_sweep<U, 4>(b, t, slot); strong_sweep<U, 5>(b, t, slot); strong_sweep<U, 6>(b, t, slot); strong_sweep<U, 7>(b, t, slot);
+    strong_sweep<U, 8>(b, t, slot); strong_sweep<U, 9>(b, t, slot); strong_sweep<U, 10>(b, t, slot); strong_sweep<U, 11>(b, t, slot);
+    strong_sweep<U, 12>(b, t, slot);
+}
+// a = D' q for q = h1 (x) vec(gm) (27): through the model's sparse form when it has one, else the dense 27 x U matrix in LDS
+template <class Model>
+__device__ __forceinline__ void strong_apply_Dt(const Model& model, const GhWork& g, const double (&h1)[3], const double (&gm)[3][3], double (&a)[Model::U]) {
+    if constexpr (Model::SPARSE_DT) {
+        model.apply_Dt(g, h1, gm, a);
+    } else {
+        constexpr int u = Model::U;
+        // row by row of D (every lane reads the same addresses: LDS broadcasts, consecutive entries pair up in ds_read2_b64); a[] is
+        // indexed statically -- a loop over the columns instead needs a 2 u-instruction select chain per column to place its sum
+#pragma unroll
+        for (int c = 0; c < u; ++c) a[c] = 0.0;
+#pragma unroll
+        for (int i1 = 0; i1 < 3; ++i1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double q = h1[i1] * gm[j][k];
+                    const double* row = g.D + (j + 3 * k + 9 * i1) * u;
+#pragma unroll
+                    for (int c = 0; c < u; ++c) a[c] += row[c] * q;
+                }
+    }
+}
+
 // Gauss_Helmert.m:38-83 for a trilinearity model.  xi holds x0 on entry.  Returns iterations; status via *st.
 template <class Model>
 __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, const double* pts, int N, int* st, double* dbg, bool exact_pinv) {
@@ -981,21 +1045,51 @@ __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, co
             tolW = 4.0 * (double)N * eps_of(smax);
         }
         bool jacobi = exact_pinv;
+        // Minimal parameterisations (Ressl, Nordberg): the factored strong direction of gh_wg_kernel.h -- pp holds the regular part of
+        // W+ only, the sums of cs a a' and cs a n'w (a = D' Ap' n formed first) go to S = g.V (dead until a pseudo-inverse fall-back).
+        bool factored = false;
         if (!jacobi) {
+            constexpr bool want_factored = !Model::IDENTITY_D;
+            constexpr int NS = Model::U * (Model::U + 1) / 2 + Model::U;
+            if (want_factored) for (int e = lane; e < NS; e += WAVE) g.V[e] = 0.0;
             bool bad = false;
-            for (int i = lane; i < N; i += WAVE) {
-                double o[6], f[4], B[4][6], W[4][4], Wp[10];
+#pragma unroll 1
+            for (int base = 0; base < N; base += WAVE) {                     // wave-uniform trip count (the butterflies need the whole wavefront)
+                const int i = base + lane;
+                double bv[Model::U], tv = 0.0;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
-                tril_block(T, o, f, B);
-                block_W(B, W);
-                double nn[4], cs;
-                bad = !pinv_block_deflated<false>(B, W, tolW, Wp, nn, &cs) || bad;
+                for (int k = 0; k < Model::U; ++k) bv[k] = 0.0;
+                if (i < N) {
+                    double o[6], f[4], B[4][6], W[4][4], Wp[10];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
-                gh_store_point(g, w, pts, i, o, f, B, Wp);
+                    for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                    tril_block(T, o, f, B);
+                    block_W(B, W);
+                    double nn[4], cs = 0.0;
+                    const bool ok = want_factored ? pinv_block_deflated<true>(B, W, tolW, Wp, nn, &cs) : pinv_block_deflated<false>(B, W, tolW, Wp, nn, &cs);
+                    bad = !ok || bad;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
+                    gh_store_point(g, w, pts, i, o, f, B, Wp);
+                    if constexpr (!Model::IDENTITY_D) if (ok) {
+                        double gm[3][3];
+                        tril_grad_n(o, nn, gm);
+                        const double h1[3] = {o[0], o[1], 1.0};
+                        strong_apply_Dt<Model>(model, g, h1, gm, bv);
+                        const double sc = sqrt(cs);
+#pragma unroll
+                        for (int k = 0; k < Model::U; ++k) bv[k] *= sc;
+                        const Pt6 x = premap(load_pt(pts, i), w->nrm);
+                        double nw = -(nn[0] * f[0] + nn[1] * f[1] + nn[2] * f[2] + nn[3] * f[3]);
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) nw -= (B[0][k] * nn[0] + B[1][k] * nn[1] + B[2][k] * nn[2] + B[3][k] * nn[3]) * (x.v[k] - o[k]);
+                        tv = sc * nw;
+                    }
+                }
+                if constexpr (!Model::IDENTITY_D) strong_accumulate<Model::U>(bv, tv, g.V);
             }
             if (wave_any(bad)) jacobi = true;                                // a block without the structure: eigen-decompositions for all
+            else factored = want_factored;
         }
         if (jacobi) {
             if (!(may_truncate || exact_pinv)) {                             // the tolerance was not needed so far
@@ -1066,9 +1160,11 @@ __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, co
                 double a = 0.0;
                 if (e < u * u) {
                     for (int k = 0; k < 27; ++k) a += g.D[k * u + pr] * g.Y[k * u + pc];
+                    if (factored) a += g.V[(pr >= pc) ? tri_index(pr, pc) : tri_index(pc, pr)];
                     g.M[pr * ld + pc] = a + ((pr == pc) ? 1e-12 : 0.0);
                 } else {
                     for (int k = 0; k < 27; ++k) a += g.D[k * u + pc] * g.H[270 + k];
+                    if (factored) a += g.V[u * (u + 1) / 2 + pc];
                     g.M[pc * ld + n] = a;
                 }
             }
@@ -1112,9 +1208,26 @@ __device__ inline int gauss_helmert_wave(PoseLds* w, GhWork& g, Model& model, co
             for (int a = 0; a < 4; ++a)
                 r[a] = wp_at(Wp, a, 0) * Ad[0] + wp_at(Wp, a, 1) * Ad[1] + wp_at(Wp, a, 2) * Ad[2] + wp_at(Wp, a, 3) * Ad[3] - g.pp[14 * i + 10 + a];
             const Pt6 x = premap(load_pt(pts, i), w->nrm);
+            double bn[6] = {0, 0, 0, 0, 0, 0}, sterm = 0.0;                  // strong direction: -cs (B'n) n'(A dt - w)
+            if (factored) {
+                double W[4][4], Wq[10], nn[4], cs = 0.0;
+                block_W(B, W);
+                pinv_block_deflated<true>(B, W, tolW, Wq, nn, &cs);
+                double nwv = 0.0;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    double sw = -f[a];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) sw -= B[a][k] * (x.v[k] - o[k]);
+                    nwv += nn[a] * (Ad[a] - sw);                             // n'(A dt - w)
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) bn[k] = B[0][k] * nn[0] + B[1][k] * nn[1] + B[2][k] * nn[2] + B[3][k] * nn[3];
+                sterm = cs * nwv;
+            }
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                const double v = -(B[0][k] * r[0] + B[1][k] * r[1] + B[2][k] * r[2] + B[3][k] * r[3]);
+                const double v = -(B[0][k] * r[0] + B[1][k] * r[1] + B[2][k] * r[2] + B[3][k] * r[3]) - bn[k] * sterm;
                 g.pp[14 * i + k] = v;
                 obj += v * v;
                 const double d = o[k] - x.v[k] - v;

@@ -185,70 +185,6 @@ __device__ inline void gh_sweep_part(const GhWork& g, double* Hp, int N, const d
     }
 }
 
-// ---- factored strong-direction terms (see pinv_block_deflated<true>) -------------------------------------------------------------
-// Per correspondence the thread holds b = sqrt(cs) a (U doubles, a = D' Ap' n) and t = sqrt(cs) n'w in registers; the sums
-//   N_s[r][c] = sum_i b_i[r] b_i[c]  (lower triangle, U (U + 1) / 2 entries)   and   r_s[r] = sum_i b_i[r] t_i  (U entries)
-// are taken 32 at a time with the halving butterfly (compile-time entry indices, so b stays in registers) and added to the calling
-// wavefront's own partial-sum slot.
-template <int U, int E>
-__device__ __forceinline__ double strong_entry(const double (&b)[U], const double t) {
-    constexpr int ntri = U * (U + 1) / 2;
-    if constexpr (E < ntri) return b[tri_row_of(E)] * b[tri_col_of(E)];
-    else if constexpr (E < ntri + U) return b[E - ntri] * t;
-    else return 0.0;
-}
-template <int U, int SW>
-__device__ __forceinline__ void strong_sweep(const double (&b)[U], const double t, double* slot) {
-    constexpr int total = U * (U + 1) / 2 + U;
-    if constexpr (32 * SW < total) {
-        double acc[32];
-        acc[0] = strong_entry<U, 32 * SW + 0>(b, t);   acc[1] = strong_entry<U, 32 * SW + 1>(b, t);   acc[2] = strong_entry<U, 32 * SW + 2>(b, t);   acc[3] = strong_entry<U, 32 * SW + 3>(b, t);
-        acc[4] = strong_entry<U, 32 * SW + 4>(b, t);   acc[5] = strong_entry<U, 32 * SW + 5>(b, t);   acc[6] = strong_entry<U, 32 * SW + 6>(b, t);   acc[7] = strong_entry<U, 32 * SW + 7>(b, t);
-        acc[8] = strong_entry<U, 32 * SW + 8>(b, t);   acc[9] = strong_entry<U, 32 * SW + 9>(b, t);   acc[10] = strong_entry<U, 32 * SW + 10>(b, t); acc[11] = strong_entry<U, 32 * SW + 11>(b, t);
-        acc[12] = strong_entry<U, 32 * SW + 12>(b, t); acc[13] = strong_entry<U, 32 * SW + 13>(b, t); acc[14] = strong_entry<U, 32 * SW + 14>(b, t); acc[15] = strong_entry<U, 32 * SW + 15>(b, t);
-        acc[16] = strong_entry<U, 32 * SW + 16>(b, t); acc[17] = strong_entry<U, 32 * SW + 17>(b, t); acc[18] = strong_entry<U, 32 * SW + 18>(b, t); acc[19] = strong_entry<U, 32 * SW + 19>(b, t);
-        acc[20] = strong_entry<U, 32 * SW + 20>(b, t); acc[21] = strong_entry<U, 32 * SW + 21>(b, t); acc[22] = strong_entry<U, 32 * SW + 22>(b, t); acc[23] = strong_entry<U, 32 * SW + 23>(b, t);
-        acc[24] = strong_entry<U, 32 * SW + 24>(b, t); acc[25] = strong_entry<U, 32 * SW + 25>(b, t); acc[26] = strong_entry<U, 32 * SW + 26>(b, t); acc[27] = strong_entry<U, 32 * SW + 27>(b, t);
-        acc[28] = strong_entry<U, 32 * SW + 28>(b, t); acc[29] = strong_entry<U, 32 * SW + 29>(b, t); acc[30] = strong_entry<U, 32 * SW + 30>(b, t); acc[31] = strong_entry<U, 32 * SW + 31>(b, t);
-        const double tot = wave_reduce_scatter<32>(acc);
-        const int lane = lane_id(), e = 32 * SW + reduce32_index(lane);
-        if ((lane & 1) == 0 && e < total) slot[e] += tot;
-        sched_fence();                                                       // keep the sweeps apart: interleaved, their 32 accumulators each would spill
-    }
-}
-template <int U>
-__device__ inline void strong_accumulate(const double (&b)[U], const double t, double* slot) {
-    static_assert(U * (U + 1) / 2 + U <= 13 * 32, "thirteen sweeps");
-    strong_sweep<U, 0>(b, t, slot); strong_sweep<U, 1>(b, t, slot); strong_sweep<U, 2>(b, t, slot); strong_sweep<U, 3>(b, t, slot);
-    strong_sweep<U, 4>(b, t, slot); strong_sweep<U, 5>(b, t, slot); strong_sweep<U, 6>(b, t, slot); strong_sweep<U, 7>(b, t, slot);
-    strong_sweep<U, 8>(b, t, slot); strong_sweep<U, 9>(b, t, slot); strong_sweep<U, 10>(b, t, slot); strong_sweep<U, 11>(b, t, slot);
-    strong_sweep<U, 12>(b, t, slot);
-}
-// a = D' q for q = h1 (x) vec(gm) (27): through the model's sparse form when it has one, else the dense 27 x U matrix in LDS
-template <class Model>
-__device__ __forceinline__ void strong_apply_Dt(const Model& model, const GhWork& g, const double (&h1)[3], const double (&gm)[3][3], double (&a)[Model::U]) {
-    if constexpr (Model::SPARSE_DT) {
-        model.apply_Dt(g, h1, gm, a);
-    } else {
-        constexpr int u = Model::U;
-        // row by row of D (every lane reads the same addresses: LDS broadcasts, consecutive entries pair up in ds_read2_b64); a[] is
-        // indexed statically -- a loop over the columns instead needs a 2 u-instruction select chain per column to place its sum
-#pragma unroll
-        for (int c = 0; c < u; ++c) a[c] = 0.0;
-#pragma unroll
-        for (int i1 = 0; i1 < 3; ++i1)
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const double q = h1[i1] * gm[j][k];
-                    const double* row = g.D + (j + 3 * k + 9 * i1) * u;
-#pragma unroll
-                    for (int c = 0; c < u; ++c) a[c] += row[c] * q;
-                }
-    }
-}
-
 // x_est: reprojection of the projective triangulation with P1 (Pfin[0]), P2 (P[0]), P3 (P[1])   (ResslTFT...m:72-75)
 __device__ inline void gh_block_reproject(PoseLds* w, const double* pts, int N, double* xi) {
     double PA[12], PB[12], PC[12];

@@ -644,25 +644,9 @@ __device__ inline int gauss_helmert_pi_wave(PoseLds* w, PiWork& g, const double*
         }
         f2max = wave_max(f2max);
         if (wave_any(!finite) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
-        bool fast = !exact_pinv && (double)E * (double)N * eps_of(sqrt(f2max)) < 0.9e-12;
-        if (fast) {
-            bool bad = false;
-            for (int i = lane; i < N; i += WAVE) {
-                double o[6], W[E][E], Wp[NW];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
-                PiPoint<E> pt;
-                pi_eval<Model, true>(pi, o, pt);
-                pi_block_W<E>(pt.B, W);
-                bad = !spd_inverse_packed<E>(W, Wp) || bad;
-#pragma unroll
-                for (int a = 0; a < E; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
-                pi_store_point<E>(g, w, pts, i, o, pt, Wp);
-            }
-            if (wave_any(bad)) fast = false;
-        }
-        if (!fast) {
-            // only the binade of max_i lambda_max(W_i) enters pinv's tolerance: skip the eigenvalue pass when cheap bounds agree on it
+        // pinv's tolerance E N eps(max_i lambda_max(W_i)); only the binade of the maximum enters: the eigenvalue pass is skipped when
+        // cheap bounds agree on it
+        auto tolerance = [&]() {
             double umax = 0.0, lmax = 0.0;
             for (int i = lane; i < N; i += WAVE) {
                 double o[6], W[E][E], up, lo;
@@ -693,7 +677,85 @@ __device__ inline int gauss_helmert_pi_wave(PoseLds* w, PiWork& g, const double*
                 }
                 smax = wave_max(smax);
             }
-            const double tolW = (double)E * (double)N * eps_of(smax);
+            return (double)E * (double)N * eps_of(smax);
+        };
+        // Pi (4 x 4 blocks): the deflated + factored weights of pi_wg_kernel.h; the 405 strong-direction sums go to S = g.V (dead until a
+        // pseudo-inverse fall-back), (n, cs) are recomputed in the v update
+        bool factored = false;
+        double tolF = 0.0;
+        if constexpr (E == 4 && !Model::PINV_KKT) {
+            if (!exact_pinv) {
+                tolF = tolerance();
+                for (int e = lane; e < 405; e += WAVE) g.V[e] = 0.0;
+                bool bad = false;
+#pragma unroll 1
+                for (int base = 0; base < N; base += WAVE) {                 // wave-uniform trip count (the butterflies need the whole wavefront)
+                    const int i = base + lane;
+                    double bv[27], tv = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 27; ++k) bv[k] = 0.0;
+                    if (i < N) {
+                        double o[6], W[E][E], Wp[NW], nn[4], cs = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                        PiPoint<E> pt;
+                        pi_eval<Model, true>(pi, o, pt);
+                        pi_block_W<E>(pt.B, W);
+                        const bool ok = pinv_block_deflated<true>(pt.B, W, tolF, Wp, nn, &cs);
+                        bad = !ok || bad;
+#pragma unroll
+                        for (int a = 0; a < E; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
+                        pi_store_point<E>(g, w, pts, i, o, pt, Wp);
+                        if (ok) {
+                            const Pt6 x = premap(load_pt(pts, i), w->nrm);
+                            double nw = 0.0;                                 // n'w,  w = -f - B (x - xi)
+#pragma unroll
+                            for (int a = 0; a < E; ++a) {
+                                double wa = -pt.f[a];
+#pragma unroll
+                                for (int k = 0; k < 6; ++k) wa -= pt.B[a][k] * (x.v[k] - o[k]);
+                                nw += nn[a] * wa;
+                            }
+                            Model::a_quirk(pt.c);
+                            const double sc = sqrt(cs);
+#pragma unroll
+                            for (int b = 0; b < 9; ++b) {                    // a[3 b + k] = (sum_r n_r c[r][b]) p_view(b)[k]
+                                double an = 0.0;
+#pragma unroll
+                                for (int r = 0; r < E; ++r)
+                                    if (Model::nz(r, b)) an += nn[r] * pt.c[r][b];
+                                an *= sc;
+#pragma unroll
+                                for (int k = 0; k < 3; ++k) bv[3 * b + k] = an * hom_at(o, b / 3, k);
+                            }
+                            tv = sc * nw;
+                        }
+                    }
+                    strong_accumulate<27>(bv, tv, g.V);
+                }
+                factored = !wave_any(bad);
+            }
+        }
+        bool fast = !exact_pinv && (double)E * (double)N * eps_of(sqrt(f2max)) < 0.9e-12;
+        if (factored) {
+        } else if (fast) {
+            bool bad = false;
+            for (int i = lane; i < N; i += WAVE) {
+                double o[6], W[E][E], Wp[NW];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                PiPoint<E> pt;
+                pi_eval<Model, true>(pi, o, pt);
+                pi_block_W<E>(pt.B, W);
+                bad = !spd_inverse_packed<E>(W, Wp) || bad;
+#pragma unroll
+                for (int a = 0; a < E; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
+                pi_store_point<E>(g, w, pts, i, o, pt, Wp);
+            }
+            if (wave_any(bad)) fast = false;
+        }
+        if (!fast && !factored) {
+            const double tolW = tolerance();
             // per block: W+ = pinv(W + 1e-12 I) + 1e-12 I   (:57)
             for (int i = lane; i < N; i += WAVE) {
                 double o[6], W[E][E], V[E][E];
@@ -736,9 +798,10 @@ __device__ inline int gauss_helmert_pi_wave(PoseLds* w, PiWork& g, const double*
                 const int r = e / 27, cc = e % 27;
                 const int b = r / 3, k = r % 3, bp = cc / 3, kk = cc % 3;
                 const double v = (b >= bp) ? g.H[9 * (b * (b + 1) / 2 + bp) + 3 * k + kk] : g.H[9 * (bp * (bp + 1) / 2 + b) + 3 * kk + k];
-                g.M[r * ld + cc] = v + ((r == cc) ? 1e-12 : 0.0);
+                const double sv = factored ? g.V[(r >= cc) ? tri_index(r, cc) : tri_index(cc, r)] : 0.0;
+                g.M[r * ld + cc] = (v + sv) + ((r == cc) ? 1e-12 : 0.0);
             } else {
-                g.M[(e - 729) * ld + n] = g.H[405 + e - 729];
+                g.M[(e - 729) * ld + n] = g.H[405 + e - 729] + (factored ? g.V[378 + e - 729] : 0.0);
             }
         }
         if (lane < C) {                                                      // constraints g, C   (callback; KKT borders :59-62)
@@ -798,6 +861,23 @@ __device__ inline int gauss_helmert_pi_wave(PoseLds* w, PiWork& g, const double*
                 rr[a] = s;
             }
             const Pt6 x = premap(load_pt(pts, i), w->nrm);
+            if constexpr (E == 4) {
+                if (factored) {                                              // + cs n (n'(A dt) - n'w): the strong direction of W+
+                    double W[E][E], Wq[NW], nn[4], cs = 0.0;
+                    pi_block_W<E>(pt.B, W);
+                    pinv_block_deflated<true>(pt.B, W, tolF, Wq, nn, &cs);
+                    double nwv = 0.0;
+#pragma unroll
+                    for (int a = 0; a < E; ++a) {
+                        double wa = -pt.f[a];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) wa -= pt.B[a][k] * (x.v[k] - o[k]);
+                        nwv += nn[a] * (Ad[a] - wa);
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) rr[a] += nn[a] * (cs * nwv);
+                }
+            }
             double vv[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
