@@ -53,14 +53,20 @@ def _dev_conventions(T, R2, R3, it, g, pre, b):
 CASES = [("ResslTFTPoseEstimation", "gh_mp.npz"), ("NordbergTFTPoseEstimation", "gh_mp_nordberg.npz"), ("PiPoseEstimation", "gh_mp_pi.npz")]
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("method,fixture", CASES)
-def test_kernel_reproduces_the_extended_precision_iteration(gpu_ctx, golden_dir, method, fixture):
+def test_kernel_reproduces_the_extended_precision_iteration(gpu_ctx, golden_dir, method, fixture, variant):
     """N in {12, 60, 200}: T (up to sign), R_t_2, R_t_3 within 1e-9 of the 50-digit evaluation and the SAME number of
-    Gauss-Helmert iterations, scene by scene (north_star's bar is 1e-6)."""
+    Gauss-Helmert iterations, scene by scene (north_star's bar is 1e-6).  variant: TFF_OPT_KERNEL -- 0 the library's own choice
+    between the two kernels, 1 the fused single-wavefront kernel at every N, 2 the workgroup kernel at every N."""
     g = np.load(os.path.join(golden_dir, fixture))
     for ci, pre in golden_cases(g):
         C, CalM = g[pre + "Corresp"], g[pre + "CalM"]
-        out = gpu_ctx.pose_batch(method, C, CalM, reconst=False)
+        gpu_ctx.set_kernel_variant(variant)
+        try:
+            out = gpu_ctx.pose_batch(method, C, CalM, reconst=False)
+        finally:
+            gpu_ctx.set_kernel_variant(0)
         assert np.all(out["status"] == 0)
         for b in range(C.shape[0]):
             d, dit = _dev_conventions(out["T"][b], out["R_t_2"][b], out["R_t_3"][b], out["iter"][b], g, pre, b)

@@ -242,10 +242,12 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
 template <class Model, class KFused, class KFusedJac>
 int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    // No small-N route to the fused kernel any more (Nordberg below N ~ 64 was ~1.3x faster there): only the workgroup kernel
-    // evaluates the weights in the factored form that reproduces the 50-digit iteration (gh_wg_kernel.h); the fused kernel's
-    // results carry the 1e-6 .. 1e-4 noise of an fp64 pinv(W) (measured on tests/golden/gh_mp_nordberg.npz at N = 12 and 60).
-    if (c->kernel_variant == 1)                                              // TFF_OPT_SOLVER = 1 is honoured by launch_wg's linear stage
+    // Both kernels evaluate the weights in the factored form that reproduces the 50-digit iteration (tests/test_gpu_gh_noise.py runs
+    // each of them on every fixture).  Small N: the fused single-wavefront kernel wins while a workgroup of 256 threads idles on a few
+    // correspondences -- measured (tools/time_methods.py, 10 k triplets): Ressl 2.41 vs 2.69 ms at N = 12, 2.91 vs 2.75 ms at N = 100;
+    // Nordberg never (its dense 27 x 19 D' q spills in the fused kernel: 6.2 vs 3.5 ms); FaugPapa's eigen-decomposition wants the workgroup.
+    const bool small = std::is_same<Model, tff::ResslModel>::value && N < 80 && c->kernel_variant == 0 && c->solver == 0 && !dbg;
+    if (c->kernel_variant == 1 || small)                                     // TFF_OPT_SOLVER = 1 is honoured by launch_wg's linear stage
         return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, 0, std::is_same<Model, tff::ResslModel>::value ? 8 : 4, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
     return launch_wg(c, tff::k_gh_block<Model>, wg_lds, Model::WG_PER_CU, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
@@ -253,9 +255,10 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
 template <class Model>
 int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    // Pi: every N takes the workgroup kernel -- only it evaluates the weights in the factored form that reproduces the 50-digit
-    // iteration (pi_wg_kernel.h); the fused kernel (faster below N ~ 180) carries the noise of an fp64 pinv(W), 1e-5 at N = 12.
-    if (c->kernel_variant == 1 || c->solver != 0 || c->init_p)                // the debug outputs (init_p, init_x) come from the fused kernel
+    // Pi: both kernels carry the factored weights; the fused one wins below N ~ 130 (2.49 vs 3.6 ms at N = 12 .. 64, 3.04 vs 3.54 ms at
+    // N = 100, 3.73 vs 3.70 ms at N = 140; tools/time_methods.py)
+    const bool small = !Model::PINV_KKT && N < 128 && c->kernel_variant == 0;
+    if (c->kernel_variant == 1 || c->solver != 0 || c->init_p || small)      // the debug outputs (init_p, init_x) come from the fused kernel
         return launch_pose(c, tff::k_pi_tft_pose<Model, false>, tff::k_pi_tft_pose<Model, true>, tff::pi_lds_bytes<Model>, 0, 4,
                            corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::pi_wg_lds_doubles(Model::E, Model::C, n)) * sizeof(double); };
