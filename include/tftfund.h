@@ -74,7 +74,7 @@ typedef struct tff_ctx tff_ctx;
                              * 1e-6 .. 1e-4 noise of any fp64 pinv(W) (default 0: deflated block pseudo-inverse + factored strong direction, which
                              * reproduce a 50-digit evaluation of the reference's iteration to 1e-11 for Ressl, Nordberg and Pi) */
 #define TFF_OPT_KERNEL 3    /* Kernel variants of the iterative TFT methods: 0 automatic (default: a 4-wavefront workgroup per triplet for the iteration,
-                             * the fused single-wavefront kernel below the measured crossover: N < 80 for Ressl, N < 128 for Pi);
+                             * the fused single-wavefront kernel below the measured crossover: N < 80 for Ressl, N < 72 for Nordberg, N < 128 for Pi);
                              * 1 fused kernel always;
                              * 2 workgroup kernels always */
 #define TFF_DEBUG_STRIDE 128 /* doubles per triplet written by the *_debug_dev entry points */

@@ -245,8 +245,9 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
     // Both kernels evaluate the weights in the factored form that reproduces the 50-digit iteration (tests/test_gpu_gh_noise.py runs
     // each of them on every fixture).  Small N: the fused single-wavefront kernel wins while a workgroup of 256 threads idles on a few
     // correspondences -- measured (tools/time_methods.py, 10 k triplets): Ressl 2.41 vs 2.69 ms at N = 12, 2.91 vs 2.75 ms at N = 100;
-    // Nordberg never (its dense 27 x 19 D' q spills in the fused kernel: 6.2 vs 3.5 ms); FaugPapa's eigen-decomposition wants the workgroup.
-    const bool small = std::is_same<Model, tff::ResslModel>::value && N < 80 && c->kernel_variant == 0 && c->solver == 0 && !dbg;
+    // Nordberg 3.22 vs 3.47 ms at N = 12, 4.15 vs 3.50 ms at N = 100; FaugPapa's eigen-decomposition wants the workgroup.
+    const int crossover = std::is_same<Model, tff::ResslModel>::value ? 80 : (std::is_same<Model, tff::NordbergModel>::value ? 72 : 0);
+    const bool small = N < crossover && c->kernel_variant == 0 && c->solver == 0 && !dbg;
     if (c->kernel_variant == 1 || small)                                     // TFF_OPT_SOLVER = 1 is honoured by launch_wg's linear stage
         return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, 0, std::is_same<Model, tff::ResslModel>::value ? 8 : 4, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
