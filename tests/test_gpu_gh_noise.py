@@ -123,12 +123,15 @@ def test_unfactored_kernels_stay_inside_the_lapack_envelope(gpu_ctx, golden_dir,
         assert np.abs(np.asarray(out["iter"]) - g[pre + "mp_iter"]).max() <= 2
 
 
+@pytest.mark.parametrize("fixture", ["gh_mp_epfl.npz", "gh_mp_large.npz"])
 @pytest.mark.parametrize("method,key", [("ResslTFTPoseEstimation", "ressl"), ("NordbergTFTPoseEstimation", "nordberg"), ("PiPoseEstimation", "pi")])
-def test_kernels_reproduce_the_extended_precision_iteration_on_real_data(gpu_ctx, golden_dir, method, key):
-    """The eight EPFL triplets of tests/golden/epfl.npz (fountain-P11 / Herz-Jesu-P8, 100-inlier samples, per-triplet calibration;
-    experiments_real.m): Gauss-Helmert in 50-digit arithmetic (tests/golden/gh_mp_epfl.npz, generator make_gh_mp_epfl.py) against the
-    kernels -- 1e-9 and the same iteration count, Nordberg under one of the eight sign conventions of linearTFT's singular vectors."""
-    g = np.load(os.path.join(golden_dir, "gh_mp_epfl.npz"))
+def test_kernels_reproduce_the_extended_precision_iteration_on_real_data_and_at_n_1000(gpu_ctx, golden_dir, method, key, fixture):
+    """gh_mp_epfl.npz: the eight EPFL triplets of tests/golden/epfl.npz (fountain-P11 / Herz-Jesu-P8, 100-inlier samples, per-triplet
+    calibration; experiments_real.m).  gh_mp_large.npz: two synthetic scenes of N = 1000 correspondences, the upper end of the target
+    range, where MATLAB's pinv tolerance 4 N eps(|W|) truncates the strong directions and the per-correspondence state is spilled to
+    global memory.  Gauss-Helmert in 50-digit arithmetic (generators make_gh_mp_epfl.py, make_gh_mp_large.py) against the kernels:
+    1e-9 and the same iteration count, Nordberg under one of the eight sign conventions of linearTFT's singular vectors."""
+    g = np.load(os.path.join(golden_dir, fixture))
     for t in range(int(g["n_triplets"])):
         pre = "t%d_" % t
         C = g[pre + "Corresp"].T[None].copy()                                    # (1, N, 6)
