@@ -9,7 +9,7 @@ methods = sys.argv[2:] or ["ResslTFTPoseEstimation", "NordbergTFTPoseEstimation"
 B = 10000
 C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=1)
 d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
-ctx = api.Context(0)
+ctx = api.Context(0, stage_lds=int(os.environ.get("TFF_STAGE", "-1")))
 ctx.set_kernel_variant(int(os.environ.get("TFF_VARIANT", "0")))      # 1: fused single-wavefront kernels (A/B)
 for m in methods:
     for _ in range(2):
