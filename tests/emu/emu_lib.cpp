@@ -109,6 +109,27 @@ static int emu_gh_wg_impl(const double* corresp, const double* calm, long calm_s
     emu::launch(tff::k_gh_finish, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
     return 0;
 }
+// FaugPapa through its own block kernel (gh_fp_kernel.h), then the generic one over what it handed back
+extern "C" int emu_fp_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                           double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status) {
+    std::vector<double> rec((size_t)B * tff::GH_REC_DOUBLES), topt((size_t)B * 27);
+    tff::GhWgArgs a{corresp, calm, calm_stride, B, N, (flags & ~tff::FLAG_JACOBI) | (reconst ? tff::FLAG_RECONST : 0), rec.data(), topt.data(),
+                    Rt2, Rt3, T, reconst, iter, status, nullptr, nullptr, 0};
+    emu::launch(tff::k_gh_linear<false>, emu_grid(B), 64, tff::pose_lds_bytes(N, a.flags, false), a);
+    tff::GhWgArgs m = a;
+    m.flags |= tff::FLAG_ONLY_RETRY;
+    emu::launch(tff::k_gh_linear<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
+    emu::launch(tff::k_fp_block, emu_grid(B), tff::GH_WG_THREADS, tff::fp_lds_bytes(), a);
+    int handed = 0;
+    for (long b = 0; b < B; ++b) handed += status[b] == tff::ST_RETRY;
+    if (handed) {
+        using Model = tff::FaugPapaModel;
+        const size_t lds = (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, N, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double);
+        emu::launch(tff::k_gh_block<Model>, emu_grid(B), tff::GH_WG_THREADS, lds, m);
+    }
+    emu::launch(tff::k_gh_finish, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
+    return handed;
+}
 extern "C" int emu_gh_wg_pose(int model, const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
                               double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status) {
     if (model == 0) return emu_gh_wg_impl<tff::ResslModel>(corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status);
@@ -176,6 +197,29 @@ __global__ void k_emu_eigh(EighArgs a) {
 extern "C" int emu_eigh(const double* Maug, long B, int n, double* lam, double* vecs, double* sol) {
     EighArgs a{Maug, n, lam, vecs, sol};
     emu::launch(k_emu_eigh, emu_grid(B), 64, sizeof(double) * (size_t)(2 * n * (n + 1) + n * n + 3 * n), a);
+    return 0;
+}
+
+// wave_pinv_solve_trid (wave_trid.h) on caller-supplied symmetric matrices, n <= 32: Maug B x n x (n+1) row-major (column n = right-hand
+// side), tol B -> sol B x n, kept B, fail B
+namespace {
+struct TridArgs { const double* Maug; const double* tol; int n; double* sol; int* kept; int* fail; };
+__global__ void k_emu_trid(TridArgs a) {
+    TFF_DYNAMIC_LDS(double, lds);
+    const int n = a.n, ld = n + 1, lane = tff::lane_id();
+    const long b = blockIdx.x;
+    double* M = lds; double* small = M + n * ld + 2; double* work = small + tff::TRID_SMALL_DOUBLES; double* sol = work + tff::TRID_WORK_DOUBLES;
+    for (int e = lane; e < n * ld; e += 64) M[e] = a.Maug[b * n * ld + e];
+    tff::wave_sync();
+    int kept, fail;
+    tff::wave_pinv_solve_trid(M, ld, n, a.tol[b], sol, small, work, &kept, &fail);
+    if (lane < n) a.sol[b * n + lane] = sol[lane];
+    if (lane == 0) { a.kept[b] = kept; a.fail[b] = fail; }
+}
+}
+extern "C" int emu_trid_pinv(const double* Maug, const double* tol, long B, int n, double* sol, int* kept, int* fail) {
+    TridArgs a{Maug, tol, n, sol, kept, fail};
+    emu::launch(k_emu_trid, emu_grid(B), 64, sizeof(double) * (size_t)(n * (n + 1) + 2 + tff::TRID_SMALL_DOUBLES + tff::TRID_WORK_DOUBLES + 64), a);
     return 0;
 }
 

@@ -26,6 +26,7 @@ inline lds_ptr to_lds(double* p) { return p; }
 inline double fast_rcp(double v) { return 1.0 / v; }
 inline int opaque_int(int v) { return v; }
 inline void sched_fence() {}
+inline void pin_value(double&) {}
 inline long long shader_clock() { return 0; }
 inline int wave_first_lane(bool p) {
     int c = p ? emu_lane() : 64;

@@ -191,7 +191,7 @@ int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_
 // correspondences held in LDS.
 template <class KBlock, class LdsFn>
 int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
-              double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+              double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg, bool fp_first = false) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     TFF_LOCK(c);
     if (B == 0) return 0;
@@ -222,9 +222,16 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
         hipLaunchKernelGGL(tff::k_gh_linear<true>, dim3(all_exact ? tff::pose_grid(B) : (unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID)), dim3(64), lds, c->stream, m);
         TFF_HIP(hipGetLastError());
     }
+    if (fp_first) {   // FaugPapa's own block kernel (gh_fp_kernel.h); the generic one below then redoes what it handed back (ST_RETRY: almost always nothing)
+        const size_t lds = tff::fp_lds_bytes();
+        if (int r = ensure_lds(tff::k_fp_block, lds)) return r;
+        hipLaunchKernelGGL(tff::k_fp_block, dim3(tff::pose_grid(B)), dim3(tff::GH_WG_THREADS), lds, c->stream, a);
+        TFF_HIP(hipGetLastError());
+    }
     {
         tff::GhWgArgs m = a;
-        unsigned grid = tff::pose_grid(B);
+        unsigned grid = fp_first ? (unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID) : tff::pose_grid(B);
+        if (fp_first) m.flags |= tff::FLAG_ONLY_RETRY;
         size_t lds;
         if (int r = plan_spill(c, wg_lds(N), wg_lds(0), &grid, &m.spill, &m.spill_stride, &lds, occupancy_cap)) return r;
         if (int r = ensure_lds(kblock, lds)) return r;
@@ -251,7 +258,9 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
     if (c->kernel_variant == 1 || small)                                     // TFF_OPT_SOLVER = 1 is honoured by launch_wg's linear stage
         return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, 0, std::is_same<Model, tff::ResslModel>::value ? 8 : 4, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
-    return launch_wg(c, tff::k_gh_block<Model>, wg_lds, Model::WG_PER_CU, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    // FaugPapa: the factored iteration of gh_fp_kernel.h (one correspondence per thread, N <= 256) unless an A/B switch asks for the generic kernel
+    const bool fp_first = std::is_same<Model, tff::FaugPapaModel>::value && N <= tff::FP_MAX_N && c->kernel_variant == 0 && !c->gh_exact && !dbg;
+    return launch_wg(c, tff::k_gh_block<Model>, wg_lds, Model::WG_PER_CU, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg, fp_first);
 }
 template <class Model>
 int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,

@@ -1,0 +1,654 @@
+// Faugeras-Papadopoulo's parameterisation (FaugPapaTFTPoseEstimation.m:48-153, all 27 tensor entries + 12 algebraic constraints) on
+// Gauss_Helmert.m:38-83 at the accuracy of the reference's FORMULAS, one workgroup of four wavefronts per triplet, N <= 256.
+//
+// Why this method needs its own iteration.  pinv(B_i B_i' + 1e-12 I) (Gauss_Helmert.m:57) gives every correspondence one direction
+// n_i of weight cs_i = 1 / (mu_i + 1e-12) ~ 1e9 .. 1e12.  With all 27 entries as parameters the vectors a_i = Ap_i' n_i are O(1) -- they
+// span the normal space of the trifocal variety at T -- so A'WA = R + sum_i cs_i a_i a_i' carries a rank-8/9 part of size 1e13 on top of
+// the regular part R of size N, in a subspace that is not aligned with any coordinate axis: every entry of the formed matrix is ~1e13
+// and the regular part is known to 1e-3 absolute only.  That is the 1e-6 .. 1e-4 by which ANY fp64 evaluation of the formed 39 x 39
+// KKT system (MATLAB's own included) misses the iteration the formulas define (tests/golden/gh_mp_faugpapa.npz, 50 digits).
+// Here the strong part never meets the regular part in one fp64 number:
+//   1. weights in the deflated, factored form of gh_kernel.h (pinv_block_deflated<true>): regular part K_i, strong direction (n_i, cs_i);
+//   2. R = sum Ap_i' K_i Ap_i (297 Kronecker-structured sums) and the strong Gram matrix Hs = sum cs_i a_i a_i' (270 sums), separately;
+//   3. an orthogonal Q whose first ns columns span the dominant columns of Hs (diagonally pivoted Cholesky + Householder QR, one
+//      wavefront, ~3 k instructions): in the basis Q the strong subspace is axis-aligned up to ~1e-6;
+//   4. the strong Gram matrix AGAIN, from the rotated factors g_i = sqrt(cs_i) Q' a_i (378 + 27 sums): the tangential components of
+//      a_i are ~1e-6 |a_i| and come out of the dot products with ~1e-10 relative error, so the tangential block (size N), the
+//      cross block (1e7) and the strong block (1e13) are each accurate at their OWN scale;
+//   5. M' = [Q'RQ + G'G + 1e-12 I, (CQ)'; CQ, 1e-12 I]: Cholesky elimination of the leading ns x ns block (exact algebra; the
+//      truncated pseudo-inverse of the whole differs from block elimination + truncated pseudo-inverse of the Schur complement by
+//      O((cross / strong)^2) ~ 1e-12), pinv's tolerance 39 eps(|M|_2) from the strong block's largest eigenvalue;
+//   6. truncated pseudo-inverse of the 30 / 31-dimensional Schur complement by wave_pinv_solve_trid (wave_trid.h), back-substitution,
+//      dt = Q z;  v = -B' W+ (A dt - w) with the strong term cs n n'(A dt - w) evaluated from the differences.
+// tools/proto_faugpapa_factored.py is the numpy twin (mode "kernel"): 48 fixture scenes within 4e-11 of the 50-digit iteration, equal
+// iteration counts.
+//
+// Per-correspondence state (the estimate xi, K_i, n_i, cs_i, n_i'w_i: 22 doubles) lives in REGISTERS, one correspondence per thread:
+// no LDS for it, hence four workgroups per CU with nothing spilled to global memory (the generic kernel moved 6.4 GB per 10 k x 200
+// launch through its spill slices), and every sum over correspondences is one halving butterfly per 32 sums and wavefront.
+// Triplets this kernel cannot take (a weight block without the one-small-eigenvalue structure) are handed to k_gh_block<FaugPapaModel>
+// through the status array (ST_RETRY).
+#pragma once
+#include "gh_wg_kernel.h"
+#include "wave_trid.h"
+
+namespace tff {
+
+constexpr int FP_MAX_N = GH_WG_THREADS;      // one correspondence per thread
+constexpr int FP_WG_PER_CU = 4;
+constexpr int FP_NS_MAX = 12;                // strong directions eliminated ahead of the pseudo-inverse (the normal space has dimension 9)
+constexpr int FP_SLOT = 416;                 // per-wavefront partial sums of the rotated strong Gram matrix (405)
+constexpr int FP_SLOT2 = 598;                // per-wavefront partial sums of R (297, at 0) and Hs (270, at 300)
+
+struct FpLds {
+    double p[28];          // parameters = tensor entries, t(j + 3k + 9i) = T(j,k,i)
+    double nrm[12];        // Normalize2Ddata of the three views (9)
+    double cam[3][12];     // P1, P2, P3 of the linear solution (row-major 3 x 4)
+    double gneg[12];       // -g
+    double rvec[28];       // regular part of A'Ww
+    double red[16];
+    double dt[40];         // z (basis Q), then dt at [0, 27)
+    double sm[TRID_SMALL_DOUBLES];
+    double flag[8];        // [0] ns  [1] |M|_2
+    // dead during the pseudo-inverse: A1 | A2 | fin | Cm are its TRID_WORK_DOUBLES (2112 <= 2198) or the 39 x 39 eigenvectors of the fall-back
+    double A1[729];        // R, then Q'RQ
+    double A2[729];        // Hs, then R Q
+    double fin[416];       // reflectors of the basis (12 x 27), then the rotated strong Gram sums
+    double Cm[324];        // C = dg/dT, 12 x 27
+    double Q[729];         // | partial sums of R and Hs (with Mx: 4 x FP_SLOT2 = 2392 <= 2393)
+    double Mx[1664];       // partial sums of the rotated Gram matrix (4 x FP_SLOT) | augmented M' 39 x 40
+};
+constexpr int FP_LDS_DOUBLES = (int)(sizeof(FpLds) / sizeof(double));
+static_assert(729 + 1664 >= GH_WG_WAVES * FP_SLOT2 && 1664 >= GH_WG_WAVES * FP_SLOT && 1664 >= 39 * 40, "partial-sum slots");
+static_assert(729 + 729 + 416 + 324 >= TRID_WORK_DOUBLES && 729 + 729 + 416 >= 39 * 39, "pseudo-inverse workspace");
+__host__ __device__ inline size_t fp_lds_bytes() { return sizeof(FpLds); }
+
+__device__ __forceinline__ double block_sum2(double v, double* w2, double* red) {   // two sums, one barrier pair: returns sum(v), *w2 <- sum(*w2)
+    v = wave_sum(v);
+    const double u = wave_sum(*w2);
+    if (lane_id() == 0) { red[wave_in_block()] = v; red[4 + wave_in_block()] = u; }
+    __syncthreads();
+    const double r = (red[0] + red[1]) + (red[2] + red[3]);
+    *w2 = (red[4] + red[5]) + (red[6] + red[7]);
+    __syncthreads();
+    return r;
+}
+
+// five entries of the lower triangle of s s' (s = sqrt(cs) K n, 9) times the six products of h1: 30 of the 270 sums of Hs
+template <int CH>
+__device__ __forceinline__ void fp_strong_chunk(const double (&s)[9], const double (&hh)[6], double (&acc)[32]) {
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int e = 5 * CH + t;
+        const double z = s[tri_row_of(e)] * s[tri_col_of(e)];
+#pragma unroll
+        for (int h = 0; h < 6; ++h) acc[6 * t + h] = hh[h] * z;
+    }
+    acc[30] = 0.0; acc[31] = 0.0;
+}
+// one butterfly: the wavefront's 30 (27) sums of chunk CH of R (CH < 9: Ghat entries, CH == 9: the right-hand side) -> slot
+template <int CH>
+__device__ __forceinline__ void fp_sum_regular(const GhPoint& pt, const double (&hh)[6], const bool have, double* slot) {
+    double acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+    if (have) {
+        if constexpr (CH < 9) gh_accum_chunk<CH>(pt, hh, acc);
+        else gh_accum_rhs(pt, acc);
+    }
+    const double tot = wave_reduce_scatter<32>(acc);
+    const int lane = lane_id(), idx = reduce32_index(lane);
+    if ((lane & 1) == 0) {
+        if (CH < 9) { if (idx < 30) slot[30 * CH + idx] = tot; }
+        else if (idx < 27) slot[270 + idx] = tot;
+    }
+    sched_fence();
+}
+template <int CH>
+__device__ __forceinline__ void fp_sum_strong(const double (&s)[9], const double (&hh)[6], double* slot) {
+    double acc[32];
+    fp_strong_chunk<CH>(s, hh, acc);
+    const double tot = wave_reduce_scatter<32>(acc);
+    const int lane = lane_id(), idx = reduce32_index(lane);
+    if ((lane & 1) == 0 && idx < 30) slot[30 * CH + idx] = tot;
+    sched_fence();
+}
+
+// nine components of Q' (h1 (x) sq), columns 9 CH .. 9 CH + 8 of Q.  In three chunks with a memory fence between them: left to itself the
+// compiler merges the LDS loads of the whole 27 x 27 product at its head and spills ~400 registers around them.
+template <int CH>
+__device__ __forceinline__ void fp_rotate_chunk(const double* Q, const double (&xi)[6], const double (&sq)[9], double (&bv)[27]) {
+    double acc[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) acc[c] = 0.0;
+#pragma unroll
+    for (int i1 = 0; i1 < 3; ++i1)
+#pragma unroll
+        for (int m = 0; m < 9; ++m) {
+            const double ar = ((i1 == 0) ? xi[0] : ((i1 == 1) ? xi[1] : 1.0)) * sq[m];
+            const double* qr = Q + (m + 9 * i1) * 27 + 9 * CH;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) acc[c] += qr[c] * ar;
+        }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { pin_value(acc[c]); bv[9 * CH + c] = acc[c]; }   // computed here, not sunk towards the sums that use it (243 loaded doubles would stay live)
+    wave_sync();                                                             // a memory fence: the three chunks read the same rows of Q, and merged loads live across them
+}
+
+// Step 3 on one wavefront: Hs (27 x 27, LDS) -> Q (27 x 27 row-major, LDS), returns ns.  vstore: 12 x 27 doubles for the reflectors.
+__device__ __forceinline__ int fp_strong_basis(const double* Hs, double* Qout, double* vstore) {
+    const int lane = lane_id();
+    const bool row = lane < 27;
+    const int rl = row ? lane : 0;
+    double L[FP_NS_MAX];
+#pragma unroll
+    for (int k = 0; k < FP_NS_MAX; ++k) L[k] = 0.0;
+    double d = row ? Hs[rl * 27 + rl] : -1.0;
+    bool used = !row;
+    double d0 = 0.0;
+    int ns = 0;
+#pragma unroll
+    for (int k = 0; k < FP_NS_MAX; ++k) {
+        if (ns == k) {                                                       // wave-uniform
+            const double dmax = wave_max(used ? -1.0 : d);
+            if (k == 0) d0 = dmax;
+            const double floor_ = (1e-7 * d0 > 1e7) ? 1e-7 * d0 : 1e7;
+            if (dmax > floor_) {
+                int p = wave_first_lane(!used && d == dmax);
+                p = (p < 27) ? p : 0;
+                double col = row ? Hs[rl * 27 + p] : 0.0;
+#pragma unroll
+                for (int j = 0; j < k; ++j) col -= L[j] * wave_bcast(L[j], p);
+                col = used ? 0.0 : col;
+                const double l = col * rsqrt(dmax);
+                L[k] = l;
+                d -= l * l;
+                used = used || lane == p;
+                ns = k + 1;
+            }
+        }
+    }
+    // Householder QR of L (27 x ns): reflector k -> vstore[k * 27 + .], beta_k -> betas (registers)
+    double beta[FP_NS_MAX];
+#pragma unroll
+    for (int k = 0; k < FP_NS_MAX; ++k) {
+        beta[k] = 0.0;
+        if (k < ns) {
+            const double x = (row && lane >= k) ? L[k] : 0.0;
+            const double sigma = wave_sum(x * x);
+            const double xk = wave_bcast(x, k);
+            double v = x, bk = 0.0;
+            if (sigma > 0.0) {
+                const double nr = sqrt(sigma);
+                const double alpha = (xk > 0.0) ? -nr : nr;
+                v = (lane == k) ? x - alpha : x;
+                bk = 1.0 / (sigma + fabs(xk) * nr);                          // 2 / v'v
+            }
+            beta[k] = bk;
+            if (row) vstore[k * 27 + lane] = v;
+#pragma unroll
+            for (int j = k + 1; j < FP_NS_MAX; ++j) {
+                if (j < ns) {
+                    const double sj = wave_sum(v * (row ? L[j] : 0.0));
+                    L[j] -= bk * sj * v;
+                }
+            }
+        }
+    }
+    wave_sync();
+    // Q = H_0 H_1 ... H_(ns-1): lane r owns row r
+    double q[27];
+#pragma unroll
+    for (int c = 0; c < 27; ++c) q[c] = (c == lane) ? 1.0 : 0.0;
+#pragma unroll 1
+    for (int k = 0; k < ns; ++k) {
+        const double* vk = vstore + k * 27;
+        double bk = 0.0;
+#pragma unroll
+        for (int j = 0; j < FP_NS_MAX; ++j) bk = (j == k) ? beta[j] : bk;
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < 27; ++c) s += q[c] * vk[c];
+        s *= bk;
+#pragma unroll
+        for (int c = 0; c < 27; ++c) q[c] -= s * vk[c];
+    }
+    if (row) {
+#pragma unroll
+        for (int c = 0; c < 27; ++c) Qout[lane * 27 + c] = q[c];
+    }
+    wave_sync();
+    return ns;
+}
+
+// Step 5 on one wavefront: largest eigenvalue of the leading ns x ns block of M' (-> *nrm2), its Cholesky factor (in place, lower
+// triangle) and Y = L^-1 [M12 | b1] (in place, columns ns .. 39).  M: 39 x 40 augmented.
+__device__ __forceinline__ void fp_eliminate_strong(double* M, const int ns, double* nrm2) {
+    constexpr int ld = 40;
+    const int lane = lane_id();
+    const bool row = lane < ns;
+    const int rl = row ? lane : 0;
+    double m[FP_NS_MAX];
+#pragma unroll
+    for (int c = 0; c < FP_NS_MAX; ++c) m[c] = (row && c < ns) ? M[rl * ld + c] : 0.0;
+    {   // power iteration: only the binade of the norm matters (pinv's tolerance is 39 eps(|M|_2))
+        double x = row ? 1.0 : 0.0, rho = 0.0;
+        x *= rsqrt(wave_sum(x * x));
+#pragma unroll 1
+        for (int it = 0; it < 200; ++it) {
+            double y = 0.0;
+#pragma unroll
+            for (int c = 0; c < FP_NS_MAX; ++c) y += m[c] * wave_bcast(x, c);
+            rho = wave_sum(x * y);
+            const double r = y - rho * x;
+            const double res2 = wave_sum(r * r);
+            const double up = rho + sqrt(res2);
+            if ((eps_of(rho) == eps_of(up) && res2 < 1e-2 * rho * rho) || res2 <= 1e-24 * rho * rho) break;
+            x = y * rsqrt(wave_sum(y * y));
+        }
+        *nrm2 = rho;
+    }
+    double myinv = 0.0;
+#pragma unroll
+    for (int k = 0; k < FP_NS_MAX; ++k) {                                    // right-looking Cholesky, lane r owns row r
+        if (k < ns) {
+            const double dk = wave_bcast(m[k], k);
+            const double rs = rsqrt(dk);
+            m[k] = (lane == k) ? dk * rs : m[k] * rs;
+            myinv = (lane == k) ? rs : myinv;
+#pragma unroll
+            for (int c = k + 1; c < FP_NS_MAX; ++c) m[c] -= m[k] * wave_bcast(m[k], c);
+        }
+    }
+    if (row) {
+#pragma unroll
+        for (int c = 0; c < FP_NS_MAX; ++c) if (c <= lane) M[lane * ld + c] = m[c];
+    }
+    wave_sync();
+    const int col = ns + lane;                                               // forward substitution, one column per lane
+    if (col < ld) {
+#pragma unroll 1
+        for (int k = 0; k < ns; ++k) {
+            double y = M[k * ld + col];
+            for (int j = 0; j < k; ++j) y -= M[k * ld + j] * M[j * ld + col];
+            M[k * ld + col] = y / M[k * ld + k];
+        }
+    }
+    wave_sync();
+}
+
+// Gauss_Helmert.m:38-83 with FaugPapaTFTPoseEstimation.m:87-153 as the callback, one workgroup, one correspondence per thread.
+// Returns the iteration count (:82); *st: ST_OK, ST_NONFINITE, or ST_RETRY (not this kernel's case).
+__device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pts, const int N, double (&xi)[6], int* st) {
+    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    const bool owner = wave == own, have = tid < N;
+    const int waves = (N + WAVE - 1) / WAVE;                                 // wavefronts that hold correspondences
+    const bool wave_has = wave < waves;
+    double objFunc = 0.0;                                                    // v0' v0, v0 = x0 - x   (:45-46)
+    if (have) {
+        const Pt6 x = premap(load_pt(pts, tid), s.nrm);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { const double d = xi[k] - x.v[k]; objFunc += d * d; }
+    }
+    objFunc = block_sum(objFunc, s.red);
+    int it = 0;
+#pragma unroll 1
+    for (it = 1; it <= GH_IT_MAX; ++it) {
+        // ---- func(xi, ti): constraints g, C (FaugPapaTFT...m:114-150) by the owner wavefront, through FaugPapaModel::eval into Mx ----
+        if (owner) {
+            GhWork g;
+            g.p = s.p; g.Tc = s.rvec; g.M = s.Mx; g.u = 27; g.c = 12;
+            FaugPapaModel model;
+            model.eval(g);
+            for (int e = lane; e < 324; e += WAVE) s.Cm[e] = s.Mx[(27 + e / 27) * 40 + e % 27];
+            if (lane < 12) s.gneg[lane] = s.Mx[(27 + lane) * 40 + 39];
+        }
+        double T[27];
+        load_uniform27(s.p, T);
+        // ---- W_i = B_i B_i' + 1e-12 I (:52), finite check (:53-55), pinv tolerance ----
+        double W[4][4];
+        double fro2 = 0.0;
+        if (have) {
+            double f[4], B[4][6];
+            tril_block(T, xi, f, B);
+            block_W(B, W);
+            double chk = 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { chk += W[a][b]; fro2 += W[a][b] * W[a][b]; }
+            if (!(fabs(chk) <= 1.79e308) || !(fro2 <= 1.79e308)) fro2 = 1e300 * 1e300;
+        }
+        const double f2max = block_max(fro2, s.red);                         // (also orders the owner's constraint rows before the sums reuse Mx)
+        if (!(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }
+        double tolW = 0.0;
+        if (!(4.0 * (double)N * eps_of(sqrt(f2max)) < 0.9e-12)) {            // the tolerance 4N eps(max lambda_max) can truncate: it is needed
+            double up = 0.0, lo = 0.0;
+            if (have) psd_lambda_max_bounds(W, up, lo);
+            up = block_max(up, s.red);
+            lo = block_max(lo, s.red);
+            double smax = up;
+            if (eps_of(lo) != eps_of(up)) {
+                smax = 0.0;
+                if (have) {
+                    double Wc[4][4], V[4][4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) Wc[a][b] = W[a][b];
+                    jacobi4<false>(Wc, V);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) smax = (fabs(Wc[a][a]) > smax) ? fabs(Wc[a][a]) : smax;
+                }
+                smax = block_max(smax, s.red);
+            }
+            tolW = 4.0 * (double)N * eps_of(smax);
+        }
+        // ---- weights in the deflated, factored form; R and Hs ----
+        GhPoint pt;
+        double nn[4] = {0, 0, 0, 0}, cs = 0.0, om = 0.0, sq[9], hh[6];
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pt.o[k] = xi[k];
+        if (have) {
+            double f[4], B[4][6];
+            tril_block(T, xi, f, B);
+            bad = !pinv_block_deflated<true>(B, W, tolW, pt.Wp, nn, &cs);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) pt.Wp[a * (a + 1) / 2 + a] += 1e-12;  // :57, second half
+            const Pt6 x = premap(load_pt(pts, tid), s.nrm);
+            double wv[4];
+            om = 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                double sw = -f[a];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sw -= B[a][k] * (x.v[k] - xi[k]);
+                wv[a] = sw;                                                  // w = -f - B (x - xi)   (:58)
+                om -= nn[a] * f[a];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) om -= (B[0][k] * nn[0] + B[1][k] * nn[1] + B[2][k] * nn[2] + B[3][k] * nn[3]) * (x.v[k] - xi[k]);   // n'w without forming w
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                pt.ww[a] = wp_at(pt.Wp, a, 0) * wv[0] + wp_at(pt.Wp, a, 1) * wv[1] + wp_at(pt.Wp, a, 2) * wv[2] + wp_at(pt.Wp, a, 3) * wv[3];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) pt.Wp[k] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pt.ww[k] = 0.0;
+        }
+        hh[0] = xi[0] * xi[0]; hh[1] = xi[0] * xi[1]; hh[2] = xi[0]; hh[3] = xi[1] * xi[1]; hh[4] = xi[1]; hh[5] = 1.0;
+        {
+            const double sc = sqrt(cs);
+            double kr[4];
+#define TFF_SQ(Q) K_row<Q>(xi[2], xi[3], xi[4], xi[5], kr); sq[Q] = have ? sc * (kr[0] * nn[0] + kr[1] * nn[1] + kr[2] * nn[2] + kr[3] * nn[3]) : 0.0;
+            TFF_SQ(0) TFF_SQ(1) TFF_SQ(2) TFF_SQ(3) TFF_SQ(4) TFF_SQ(5) TFF_SQ(6) TFF_SQ(7) TFF_SQ(8)
+#undef TFF_SQ
+        }
+        if (wave_has) {
+            double* slot = s.Q + wave * FP_SLOT2;                            // Q | Mx: not in use yet
+            fp_sum_regular<0>(pt, hh, have, slot); fp_sum_regular<1>(pt, hh, have, slot); fp_sum_regular<2>(pt, hh, have, slot);
+            fp_sum_regular<3>(pt, hh, have, slot); fp_sum_regular<4>(pt, hh, have, slot); fp_sum_regular<5>(pt, hh, have, slot);
+            fp_sum_regular<6>(pt, hh, have, slot); fp_sum_regular<7>(pt, hh, have, slot); fp_sum_regular<8>(pt, hh, have, slot);
+            fp_sum_regular<9>(pt, hh, have, slot);
+            double* slot2 = slot + 300;
+            fp_sum_strong<0>(sq, hh, slot2); fp_sum_strong<1>(sq, hh, slot2); fp_sum_strong<2>(sq, hh, slot2);
+            fp_sum_strong<3>(sq, hh, slot2); fp_sum_strong<4>(sq, hh, slot2); fp_sum_strong<5>(sq, hh, slot2);
+            fp_sum_strong<6>(sq, hh, slot2); fp_sum_strong<7>(sq, hh, slot2); fp_sum_strong<8>(sq, hh, slot2);
+        }
+        if (block_any(bad, s.red)) { *st = ST_RETRY; break; }                // (barrier: the partial sums are in place)
+        for (int e = tid; e < 729 + 27; e += GH_WG_THREADS) {                // Ghat[(q,i1),(q',i1')] = H[6 tri(q,q') + hht(i1,i1')], both families
+            if (e < 729) {
+                const int r = e / 27, cc = e % 27;
+                const int q = r % 9, i1 = r / 9, qq = cc % 9, i1p = cc / 9;
+                const int hi = (q > qq) ? q : qq, lo = (q > qq) ? qq : q;
+                const int src = 6 * (hi * (hi + 1) / 2 + lo) + hht_index(i1, i1p);
+                double r1 = 0.0, r2 = 0.0;
+                for (int wv_ = 0; wv_ < waves; ++wv_) { r1 += s.Q[wv_ * FP_SLOT2 + src]; r2 += s.Q[wv_ * FP_SLOT2 + 300 + src]; }
+                s.A1[e] = r1;
+                s.A2[e] = r2;
+            } else {
+                double r1 = 0.0;
+                for (int wv_ = 0; wv_ < waves; ++wv_) r1 += s.Q[wv_ * FP_SLOT2 + 270 + e - 729];
+                s.rvec[e - 729] = r1;
+            }
+        }
+        __syncthreads();
+        // ---- the orthogonal basis that aligns the strong subspace ----
+        if (owner) {
+            const int ns_ = fp_strong_basis(s.A2, s.Q, s.fin);
+            if (lane == 0) s.flag[0] = (double)ns_;
+        }
+        __syncthreads();
+        const int ns = (int)s.flag[0];
+        // ---- the strong Gram matrix from the rotated factors (378 + 27 sums); Y = R Q ----
+        if (wave_has) {
+            double* slot = s.Mx + wave * FP_SLOT;
+            for (int e = lane; e < FP_SLOT; e += WAVE) slot[e] = 0.0;
+            wave_sync();
+            double bv[27];
+            fp_rotate_chunk<0>(s.Q, xi, sq, bv); fp_rotate_chunk<1>(s.Q, xi, sq, bv); fp_rotate_chunk<2>(s.Q, xi, sq, bv);
+            strong_accumulate<27>(bv, sqrt(cs) * om, slot);
+        }
+        for (int e = tid; e < 729; e += GH_WG_THREADS) {
+            const int r = e / 27, c = e % 27;
+            double acc = 0.0;
+            for (int k = 0; k < 27; ++k) acc += s.A1[r * 27 + k] * s.Q[k * 27 + c];
+            s.A2[e] = acc;
+        }
+        __syncthreads();
+        for (int e = tid; e < 729 + 405; e += GH_WG_THREADS) {
+            if (e < 729) {                                                   // Q' (R Q)
+                const int r = e / 27, c = e % 27;
+                double acc = 0.0;
+                for (int k = 0; k < 27; ++k) acc += s.Q[k * 27 + r] * s.A2[k * 27 + c];
+                s.A1[e] = acc;
+            } else {
+                double acc = 0.0;
+                for (int wv_ = 0; wv_ < waves; ++wv_) acc += s.Mx[wv_ * FP_SLOT + e - 729];
+                s.fin[e - 729] = acc;
+            }
+        }
+        __syncthreads();
+        // ---- M' (39 x 40, augmented) ----
+        double chkM = 0.0;
+        for (int e = tid; e < 39 * 40; e += GH_WG_THREADS) {
+            const int r = e / 40, c = e % 40;
+            double v;
+            if (r < 27 && c < 27) {
+                v = s.A1[r * 27 + c] + s.fin[(r >= c) ? tri_index(r, c) : tri_index(c, r)] + ((r == c) ? 1e-12 : 0.0);
+            } else if (r < 27 && c == 39) {
+                double acc = s.fin[378 + r];
+                for (int k = 0; k < 27; ++k) acc += s.Q[k * 27 + r] * s.rvec[k];
+                v = acc;
+            } else if (r >= 27 && c == 39) {
+                v = s.gneg[r - 27];
+            } else if (r >= 27 && c >= 27) {
+                v = (r == c) ? 1e-12 : 0.0;
+            } else {                                                         // C Q and its transpose
+                const int j = (r >= 27) ? r - 27 : c - 27, cc = (r >= 27) ? c : r;
+                double acc = 0.0;
+                for (int k = 0; k < 27; ++k) acc += s.Cm[j * 27 + k] * s.Q[k * 27 + cc];
+                v = acc;
+            }
+            chkM += v;
+            s.Mx[e] = v;                                                     // (the partial-sum slots that lived here were last read before the barrier above)
+        }
+        if (!(fabs(block_sum(chkM, s.red)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
+        // ---- block elimination of the strong ns x ns block ----
+        if (owner) {
+            double nrm2 = 0.0;
+            if (ns > 0) fp_eliminate_strong(s.Mx, ns, &nrm2);
+            if (lane == 0) s.flag[1] = nrm2;
+        }
+        __syncthreads();
+        {
+            const int n2 = 39 - ns, w2 = 40 - ns;
+            for (int e = tid; e < n2 * w2; e += GH_WG_THREADS) {             // Schur complement, right-hand side included
+                const int r = ns + e / w2, c = ns + e % w2;
+                double acc = 0.0;
+                for (int k = 0; k < ns; ++k) acc += s.Mx[k * 40 + r] * s.Mx[k * 40 + c];
+                s.Mx[r * 40 + c] -= acc;
+            }
+        }
+        __syncthreads();
+        // ---- aux = pinv(M + 1e-12 I) b (:67) ----
+        if (owner) {
+            const int n2 = 39 - ns;
+            double* S = s.Mx + ns * 40 + ns;
+            if (n2 <= TRID_MAX && ns > 0) {
+                const double tol = 39.0 * eps_of(s.flag[1]);
+                int kept, fail;
+                wave_pinv_solve_trid(S, 40, n2, tol, s.dt + ns, s.sm, s.A1, &kept, &fail);
+                if (fail && lane == 0) s.flag[2] = 1.0;
+            } else {
+                // no strong block (every strong direction under pinv's tolerance for the weights, or a degenerate sample): the eigen-decomposition
+                // of the whole matrix, its own largest eigenvalue for the tolerance
+                int fail;
+                const double lam = wave_eigh_ql(S, 40, s.A1, n2, n2, s.sm, &fail);
+                double amax = wave_max((lane < n2) ? fabs(lam) : 0.0);
+                if (ns > 0 && s.flag[1] > amax) amax = s.flag[1];
+                const double tol = 39.0 * eps_of(amax);
+                if (lane < n2) {
+                    const double* vk = s.A1 + eig_row(n2, lane) * n2;
+                    double d = 0.0;
+                    for (int r = 0; r < n2; ++r) d += vk[r] * S[r * 40 + n2];
+                    s.sm[lane] = (fabs(lam) > tol) ? d / lam : 0.0;
+                }
+                wave_sync();
+                if (lane < n2) {
+                    double x = 0.0;
+                    for (int k = 0; k < n2; ++k) x += s.A1[eig_row(n2, k) * n2 + lane] * s.sm[k];
+                    s.dt[ns + lane] = x;
+                }
+                wave_sync();
+            }
+            // z1 = L^-T (y_b - Y z2)
+            double t = 0.0;
+            if (lane < ns) {
+                t = s.Mx[lane * 40 + 39];
+                for (int c = ns; c < 39; ++c) t -= s.Mx[lane * 40 + c] * s.dt[c];
+            }
+#pragma unroll 1
+            for (int k = ns - 1; k >= 0; --k) {
+                const double zk = wave_bcast(t, k) / s.Mx[k * 40 + k];
+                if (lane == k) t = zk;
+                else if (lane < k) t -= s.Mx[k * 40 + lane] * zk;
+            }
+            if (lane < ns) s.dt[lane] = t;
+            wave_sync();
+            double dtv = 0.0;
+            if (lane < 27) for (int c = 0; c < 27; ++c) dtv += s.Q[lane * 27 + c] * s.dt[c];
+            wave_sync();
+            if (lane < 27) s.dt[lane] = dtv;
+        }
+        __syncthreads();
+        double dTr[27];
+        load_uniform27(s.dt, dTr);
+        // ---- v = -B' W+ (A dt - w)   (:69) ----
+        double obj = 0.0, diff = 0.0, v6[6] = {0, 0, 0, 0, 0, 0};
+        Pt6 x;
+        if (have) {
+            x = premap(load_pt(pts, tid), s.nrm);
+            double Ad[4], wv[4], r[4], f[4], B[4][6];
+            tril_block(T, xi, f, B);                                         // recomputed: 28 doubles would otherwise stay live across the wave-serial phases
+            {
+                double m[3][3], t1[3][3], t2[3][3];
+                tril_slices(dTr, xi, m, t1, t2);
+                tril_quad(m, xi[2], xi[3], xi[4], xi[5], Ad);                // Ap_i dt
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                double sw = -f[a];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sw -= B[a][k] * (x.v[k] - xi[k]);
+                wv[a] = Ad[a] - sw;                                          // A dt - w
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                r[a] = wp_at(pt.Wp, a, 0) * wv[0] + wp_at(pt.Wp, a, 1) * wv[1] + wp_at(pt.Wp, a, 2) * wv[2] + wp_at(pt.Wp, a, 3) * wv[3];
+            const double sterm = cs * (nn[0] * wv[0] + nn[1] * wv[1] + nn[2] * wv[2] + nn[3] * wv[3]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const double bn = B[0][k] * nn[0] + B[1][k] * nn[1] + B[2][k] * nn[2] + B[3][k] * nn[3];
+                const double v = -(B[0][k] * r[0] + B[1][k] * r[1] + B[2][k] * r[2] + B[3][k] * r[3]) - bn * sterm;
+                v6[k] = v;
+                obj += v * v;
+                const double d = xi[k] - x.v[k] - v;
+                diff += d * d;
+            }
+        }
+        obj = block_sum2(obj, &diff, s.red);
+        double ndt2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) ndt2 += dTr[k] * dTr[k];
+        if (sqrt(ndt2) < GH_TOL && sqrt(diff) < GH_TOL) break;               // :71-73 (dy is empty)
+        if (obj > objFunc) break;                                            // :75-76, factor = 1
+        objFunc = obj;                                                       // :78
+        if (have) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) xi[k] = x.v[k] + v6[k];              // xi = x + v; ti = ti + dt   (:80)
+        }
+        if (tid < 27) s.p[tid] += s.dt[tid];
+        __syncthreads();
+    }
+    __syncthreads();
+    return (it > GH_IT_MAX) ? GH_IT_MAX : it;                                // :82
+}
+
+__global__ void __launch_bounds__(GH_WG_THREADS, FP_WG_PER_CU) k_fp_block(const GhWgArgs a) {
+    TFF_DYNAMIC_LDS(double, smem);
+    FpLds& s = *reinterpret_cast<FpLds*>(smem);
+    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
+        __syncthreads();
+        if (a.status[b] != ST_OK) continue;                                  // block-uniform
+        const int N = a.N;
+        const double* pts = a.corresp + b * 6 * (long)N;
+        const int own = (int)(b & (GH_WG_WAVES - 1));
+        const double* r = a.rec + b * GH_REC_DOUBLES;                        // t 27 | pa 18 | epi 6 | nrm 9   (k_gh_linear)
+        if (tid < 27) s.p[tid] = r[tid];                                     // param0 = T(:)   (FaugPapaTFT...m:65)
+        if (tid < 9) s.nrm[tid] = r[51 + tid];
+        if (tid >= 64 && tid < 76) {                                         // P1 = [I|0], P2 = [reshape(a(1:9),3,3) e21], P3 likewise   (linearTFT.m:88-90)
+            const int e = tid - 64, rr = e >> 2, c = e & 3;
+            s.cam[0][e] = (rr == c) ? 1.0 : 0.0;
+            s.cam[1][e] = (c < 3) ? r[27 + 3 * c + rr] : r[45 + rr];
+            s.cam[2][e] = (c < 3) ? r[27 + 9 + 3 * c + rr] : r[45 + 3 + rr];
+        }
+        if (tid == 0) s.flag[2] = 0.0;
+        __syncthreads();
+        double xi[6] = {0, 0, 0, 0, 0, 0};
+        if (tid < N) {                                                       // x_est: reprojection of the projective triangulation   (:58-61)
+            double PA[12], PB[12], PC[12];
+            load_uniform12(s.cam[0], PA);
+            load_uniform12(s.cam[1], PB);
+            load_uniform12(s.cam[2], PC);
+            const Pt6 p = premap(load_pt(pts, tid), s.nrm);
+            double X[4];
+            dlt_point<true>(PA, PB, PC, s.cam[0], s.cam[1], s.cam[2], true, p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], p.v[5], X);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const double (&P)[12] = (v == 0) ? PA : ((v == 1) ? PB : PC);
+                const double aa = P[0] * X[0] + P[1] * X[1] + P[2] * X[2] + P[3] * X[3];
+                const double bb = P[4] * X[0] + P[5] * X[1] + P[6] * X[2] + P[7] * X[3];
+                const double cc = P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11] * X[3];
+                xi[2 * v] = aa / cc;
+                xi[2 * v + 1] = bb / cc;
+            }
+        }
+        int gst = ST_OK;
+        const int iters = gauss_helmert_fp(s, own, pts, N, xi, &gst);
+        if (gst == ST_OK && s.flag[2] != 0.0) gst = ST_RETRY;                // an eigenpair of the pseudo-inverse did not converge (never observed)
+        if (wave == own) {
+            if (lane < 27) a.topt[b * 27 + lane] = s.p[lane];
+            if (lane == 0) {
+                if (a.iter) a.iter[b] = iters;
+                if (gst == ST_RETRY) a.status[b] = ST_RETRY;                 // k_gh_block<FaugPapaModel> redoes this triplet
+                else if (gst != ST_OK) a.status[b] = -gst;                   // negative: reported after k_gh_finish has produced the outputs
+            }
+        }
+    }
+}
+
+}  // namespace tff

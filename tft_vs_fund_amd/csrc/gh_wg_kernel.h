@@ -533,7 +533,8 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::WG_PER_CU) k_gh_block(co
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
         __syncthreads();
-        if (a.status[b] != ST_OK) continue;                                  // block-uniform (too few points, or left for nobody: see launch)
+        // block-uniform: too few points / unresolved; FLAG_ONLY_RETRY: the triplets a specialised block kernel handed over (gh_fp_kernel.h)
+        if ((a.flags & FLAG_ONLY_RETRY) ? (a.status[b] != ST_RETRY) : (a.status[b] != ST_OK)) continue;
         const int N = a.N;
         const double* pts = a.corresp + b * 6 * (long)N;
         double* red;
@@ -571,6 +572,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::WG_PER_CU) k_gh_block(co
                 int s = gst;
                 if (gh_model_bad(model)) s = ST_RANK;
                 if (s != ST_OK) a.status[b] = -s;                            // negative: reported after k_gh_finish has produced the outputs
+                else if (a.flags & FLAG_ONLY_RETRY) a.status[b] = ST_OK;
             }
         }
     }

@@ -3,9 +3,11 @@
 #include "tft_kernel.h"
 #include "f_kernel.h"
 #include "gh_kernel.h"
+#include "wave_trid.h"
 #include "blocks_kernel.h"
 #include "pi_kernel.h"
 #include "gh_wg_kernel.h"
+#include "gh_fp_kernel.h"
 #include "pi_wg_kernel.h"
 #include "ba_kernel.h"
 

@@ -43,6 +43,9 @@ __device__ __forceinline__ lds_ptr to_lds(double* p) { return (lds_ptr)p; }
 __device__ __forceinline__ double fast_rcp(double v) { return __builtin_amdgcn_rcp(v); }
 // a wave-uniform integer the optimiser cannot see through (keeps a loop with a small constant trip count rolled)
 __device__ __forceinline__ int opaque_int(int v) { asm volatile("" : "+s"(v)); return v; }
+// the value is computed HERE, in a vector register: keeps the optimiser from sinking the arithmetic that produces it towards a distant use
+// (which would stretch the live ranges of all its operands instead)
+__device__ __forceinline__ void pin_value(double& v) { asm volatile("" : "+v"(v)); }
 // the instruction scheduler does not move anything across this point
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ long long shader_clock() { return clock64(); }
