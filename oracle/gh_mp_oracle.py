@@ -2,7 +2,8 @@
 
 Extended-precision (mpmath, 50 digits) evaluation of the reference's Gauss-Helmert iteration
 (Optimization/Gauss_Helmert.m:38-83) with Ressl's callback (TFT_methods/ResslTFTPoseEstimation.m:110-177), Nordberg's
-(TFT_methods/NordbergTFTPoseEstimation.m:128-222) Faugeras-Papadopoulo's (TFT_methods/FaugPapaTFTPoseEstimation.m:87-159) and the Ponce-Hebert Pi-matrix one (TFT_methods/PiPoseEstimation.m:109-182).
+(TFT_methods/NordbergTFTPoseEstimation.m:128-222) Faugeras-Papadopoulo's (TFT_methods/FaugPapaTFTPoseEstimation.m:87-159) and the two Ponce-Hebert
+Pi-matrix ones (TFT_methods/PiPoseEstimation.m:109-182, TFT_methods/PiColPoseEstimation.m:144-216).
 
 Purpose: `pinv(W + 1e-12 I)` gives every correspondence one direction of weight ~1e12, so A'WA
 cancels ten digits in ANY fp64 evaluation -- the reference's own dense MATLAB product included.  To judge the HIP kernel
@@ -159,23 +160,25 @@ def gauss_helmert_mp(x, x_est, p0, model, u, c, it_max=400, return_history=False
             point_fn, g, C = ev
         blocks = []
         lam_max = mp.mpf(0)
+        E = 4
         for i in range(N):
             f, A, B = point_fn(xi[6 * i:6 * i + 6])
+            E = f.shape[0]                                                           # equations per correspondence (4; PiCol: 5)
             Wb = B.dot(B.T)                                                          # :52 (P = I)
-            lam, V = _eigsy(Wb + _EPS12 * np.eye(4, dtype=object))
+            lam, V = _eigsy(Wb + _EPS12 * np.eye(E, dtype=object))
             lam_max = max(lam_max, max(lam))
             blocks.append((f, A, B, lam, V))
-        tolW = _matlab_tol(4 * N, lam_max)                                           # pinv's tolerance for the 4N x 4N matrix
+        tolW = _matlab_tol(E * N, lam_max)                                           # pinv's tolerance for the EN x EN matrix
         Nm = _zeros(u, u)
         rhs = _zeros(u)
         Ws, ws = [], []
         for i in range(N):
             f, A, B, lam, V = blocks[i]
-            Wp = _zeros(4, 4)
-            for k in range(4):
+            Wp = _zeros(E, E)
+            for k in range(E):
                 if lam[k] > tolW:
                     Wp = Wp + np.outer(V[:, k], V[:, k]) / lam[k]
-            Wp = Wp + _EPS12 * np.eye(4, dtype=object)                               # :57
+            Wp = Wp + _EPS12 * np.eye(E, dtype=object)                               # :57
             w = -f - B.dot(xm[6 * i:6 * i + 6] - xi[6 * i:6 * i + 6])                 # :58
             WA = Wp.dot(A)
             Nm = Nm + A.T.dot(WA)
@@ -504,5 +507,91 @@ def PiPoseEstimation_mp(Corresp, CalM):
     P1[:, 1:4] = inv(Pi1)
     P2[:, [0, 2, 3]] = inv(Pi2)
     P3[:, [0, 1, 3]] = inv(Pi3)
+    R_t_2, R_t_3, _, T = O._pi_finish(P1, P2, P3, normals[0], normals[1], normals[2], CalM, Corresp)
+    return R_t_2, R_t_3, T, it, reason
+
+
+# ---- Ponce-Hebert Pi-matrix callback for collinear centres (PiColPoseEstimation.m:144-216): 27 parameters, 11 constraints; per
+# ---- correspondence three epipolar equations and two trilinearities (5 x 5 weight blocks).  The sign of A(ind2+4,1:3) (:186), which is
+# ---- not the derivative of f(ind2+4), is kept.
+def picol_model(ti):
+    pi = ti
+    pi21, pi31, pi41 = pi[0:3], pi[3:6], pi[6:9]
+    pi12, pi32, pi42 = pi[9:12], pi[12:15], pi[15:18]
+    w3, pi33, pi43 = pi[18:21], pi[21:24], pi[24:27]
+    F12 = np.outer(pi41, pi32) - np.outer(pi31, pi42)                                # :157-159
+    F13 = np.outer(pi41, pi33) - np.outer(pi31, pi43)
+    F23 = np.outer(pi42, pi33) - np.outer(pi32, pi43)
+    dot = lambda a, b: sum(x * y for x, y in zip(a, b))
+    g = np.array([dot(pi21, pi21) - 1, dot(pi12, pi12) - 1, dot(w3, w3) - 1, dot(pi33, pi33) - 1, dot(pi43, pi43) - 1,
+                  dot(pi21, pi31), dot(pi21, pi41), dot(pi31, pi41), dot(pi12, pi32), dot(pi12, pi42), dot(pi32, pi42)], dtype=object)   # :162-165
+    C = _zeros(11, 27)                                                               # :168-173
+    C[0, 0:3] = 2 * pi21; C[1, 9:12] = 2 * pi12
+    C[2, 18:21] = 2 * w3; C[3, 21:24] = 2 * pi33; C[4, 24:27] = 2 * pi43
+    C[5, 0:3] = pi31; C[5, 3:6] = pi21
+    C[8, 9:12] = pi32; C[8, 12:15] = pi12
+    C[6, 0:3] = pi41; C[6, 6:9] = pi21
+    C[9, 9:12] = pi42; C[9, 15:18] = pi12
+    C[7, 3:6] = pi41; C[7, 6:9] = pi31
+    C[10, 12:15] = pi42; C[10, 15:18] = pi32
+
+    def point_fn(o):
+        one = mp.mpf(1)
+        p1 = np.array([o[0], o[1], one], dtype=object)
+        p2 = np.array([o[2], o[3], one], dtype=object)
+        p3 = np.array([o[4], o[5], one], dtype=object)
+        a21, a31, a41 = dot(pi21, p1), dot(pi31, p1), dot(pi41, p1)
+        a12, a32, a42 = dot(pi12, p2), dot(pi32, p2), dot(pi42, p2)
+        aw3, a33, a43 = dot(w3, p3), dot(pi33, p3), dot(pi43, p3)
+        f = np.array([p1.dot(F12).dot(p2), p1.dot(F13).dot(p3), p2.dot(F23).dot(p3),
+                      a31 * a32 * aw3 + (a31 * a12 - a21 * a32) * a33,
+                      a41 * a42 * aw3 + (a41 * a12 - a21 * a42) * a43], dtype=object)   # :186-188
+        A = _zeros(5, 27)                                                            # :191-206
+        A[0, 3:6] = -a42 * p1; A[0, 6:9] = a32 * p1; A[0, 12:15] = a41 * p2; A[0, 15:18] = -a31 * p2
+        A[1, 3:6] = -a43 * p1; A[1, 6:9] = a33 * p1; A[1, 21:24] = a41 * p3; A[1, 24:27] = -a31 * p3
+        A[2, 12:15] = -a43 * p2; A[2, 15:18] = a33 * p2; A[2, 21:24] = a42 * p3; A[2, 24:27] = -a32 * p3
+        A[3, 0:3] = p1 * (a32 * a33); A[3, 3:6] = p1 * (a32 * aw3 + a12 * a33)
+        A[3, 9:12] = p2 * (a31 * a33); A[3, 12:15] = p2 * (a31 * aw3 - a21 * a33)
+        A[3, 18:21] = p3 * (a31 * a32); A[3, 21:24] = p3 * (a31 * a12 - a21 * a32)
+        A[4, 0:3] = -p1 * (a42 * a43); A[4, 6:9] = p1 * (a42 * aw3 + a12 * a43)
+        A[4, 9:12] = p2 * (a41 * a43); A[4, 15:18] = p2 * (a41 * aw3 - a21 * a43)
+        A[4, 18:21] = p3 * (a41 * a42); A[4, 24:27] = p3 * (a41 * a12 - a21 * a42)
+        B = _zeros(5, 6)                                                             # :208-218
+        B[0, 0:2] = F12.dot(p2)[0:2]; B[0, 2:4] = p1.dot(F12)[0:2]
+        B[1, 0:2] = F13.dot(p3)[0:2]; B[1, 4:6] = p1.dot(F13)[0:2]
+        B[2, 2:4] = F23.dot(p3)[0:2]; B[2, 4:6] = p2.dot(F23)[0:2]
+        B[3, 0:2] = (pi31 * (a32 * aw3 + a12 * a33) - pi21 * (a32 * a33))[0:2]
+        B[3, 2:4] = (pi32 * (a31 * aw3) + (pi12 * a31 - pi32 * a21) * a33)[0:2]
+        B[3, 4:6] = (w3 * (a31 * a32) + pi33 * (a31 * a12 - a21 * a32))[0:2]
+        B[4, 0:2] = (pi41 * (a42 * aw3) + (pi41 * a12 - pi21 * a42) * a43)[0:2]
+        B[4, 2:4] = (pi42 * (a41 * aw3) + (pi12 * a41 - pi42 * a21) * a43)[0:2]
+        B[4, 4:6] = (w3 * (a41 * a42) + pi43 * (a41 * a12 - a21 * a42))[0:2]
+        return f, A, B
+    return point_fn, g, C
+
+
+def picol_start(Corresp, CalM, null=None, cam_signs=(1.0, 1.0)):
+    """fp64 start of PiColPoseEstimation.m:50-115 (from the numpy oracle) under a stated convention for the null vectors / camera signs"""
+    x1, N1 = O.Normalize2Ddata(Corresp[0:2, :])
+    x2, N2 = O.Normalize2Ddata(Corresp[2:4, :])
+    x3, N3 = O.Normalize2Ddata(Corresp[4:6, :])
+    kw = dict(cam_signs=cam_signs, init_only=True)
+    if null is not None:
+        kw["null"] = null
+    pi0, x_est = O.PiColPoseEstimation(Corresp, CalM, **kw)
+    N = x1.shape[1]
+    x = np.vstack([x1[0:2, :], x2[0:2, :], x3[0:2, :]]).reshape(6 * N, order='F')
+    return x, x_est, pi0, (N1, N2, N3)
+
+
+def PiColPoseEstimation_mp(Corresp, CalM, null=None, cam_signs=(1.0, 1.0)):
+    x, x_est, p0, normals = picol_start(Corresp, CalM, null, cam_signs)
+    p_opt, _, it, reason = gauss_helmert_mp(x, x_est, p0, picol_model, 27, 11)
+    inv = np.linalg.inv
+    Pi1 = p_opt[0:9].reshape(3, 3); Pi2 = p_opt[9:18].reshape(3, 3); Pi3 = p_opt[18:27].reshape(3, 3)   # :121-123
+    P1 = np.zeros((3, 4)); P2 = np.zeros((3, 4)); P3 = np.zeros((3, 4))
+    P1[:, 1:4] = inv(Pi1)
+    P2[:, [0, 2, 3]] = inv(Pi2)
+    P3[:, 1:4] = inv(Pi3); P3[:, 0] = -P3[:, 1]                                      # :127
     R_t_2, R_t_3, _, T = O._pi_finish(P1, P2, P3, normals[0], normals[1], normals[2], CalM, Corresp)
     return R_t_2, R_t_3, T, it, reason

@@ -479,11 +479,25 @@ class MultiContext:
         record tensor (G * chunk, 51) laid out as G blocks [Rt2 (chunk x 12) | Rt3 (chunk x 12) | T (chunk x 27)] and the status."""
         import torch
         G = self.size
+        if B < 0 or len(corresp_shards) != G or len(calm_shards) != G:
+            raise ValueError("pose_batch_dev needs B >= 0 and one shard per device")
         N = int(corresp_shards[0].shape[1])
         chunk = (B + G - 1) // G
+        for g in range(G):
+            b0, b1 = self.shard(B, g)
+            c = corresp_shards[g]
+            if c.dtype != torch.float64 or not c.is_contiguous() or tuple(c.shape) != (b1 - b0, N, 6):
+                raise ValueError("shard %d must be a contiguous float64 tensor of shape (%d, %d, 6)" % (g, b1 - b0, N))
         recs = [torch.zeros(G * chunk * 51, dtype=torch.float64, device=corresp_shards[g].device) for g in range(G)]
         sts = [torch.zeros(G * chunk, dtype=torch.int32, device=corresp_shards[g].device) for g in range(G)]
         cms = [c.t().contiguous().reshape(27) for c in calm_shards]
+        # torch enqueued the allocations / transposes above on ITS current stream of each device; the library works on each context's
+        # stream.  Hand every context torch's stream of its device (tff_ctx_set_stream orders the hand-over with an event), so that
+        # zero-fill -> kernels -> all-gather are one stream's program order and later torch work on the results is ordered too.
+        for g in range(G):
+            dev = corresp_shards[g].device
+            _check(self.lib, self.lib.tff_ctx_set_stream(self.lib.tff_multi_ctx(self.handle, g), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                   "tff_ctx_set_stream")
         ptr = lambda ts: (ctypes.c_void_p * G)(*[t.data_ptr() for t in ts])
         _check(self.lib, self.lib.tff_pose_batch_dev_multi(self.handle, METHOD_IDS[method], ptr(corresp_shards), ptr(cms), 0, B, N, ptr(recs), ptr(sts)),
                "tff_pose_batch_dev_multi")

@@ -259,7 +259,7 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
         return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, 0, std::is_same<Model, tff::ResslModel>::value ? 8 : 4, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
     // FaugPapa: the factored iteration of gh_fp_kernel.h (one correspondence per thread, N <= 256) unless an A/B switch asks for the generic kernel
-    const bool fp_first = std::is_same<Model, tff::FaugPapaModel>::value && N <= tff::FP_MAX_N && c->kernel_variant == 0 && !c->gh_exact && !dbg;
+    const bool fp_first = std::is_same<Model, tff::FaugPapaModel>::value && N <= tff::FP_MAX_N && c->kernel_variant == 0 && !c->gh_exact;
     return launch_wg(c, tff::k_gh_block<Model>, wg_lds, Model::WG_PER_CU, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg, fp_first);
 }
 template <class Model>
@@ -377,8 +377,16 @@ static int switch_stream(tff_ctx* c, hipStream_t s) {
     if (s == c->stream) return 0;
     TFF_HIP(hipSetDevice(c->device));
     if (!c->handover) TFF_HIP(hipEventCreateWithFlags(&c->handover, hipEventDisableTiming));
-    TFF_HIP(hipEventRecord(c->handover, c->stream));
-    TFF_HIP(hipStreamWaitEvent(s, c->handover, 0));
+    // The previous stream must still be alive here (a caller that destroys its stream first hands the context a dangling handle).  If
+    // recording on it fails all the same -- a destroyed user stream -- the new stream is adopted anyway, after draining the context's
+    // own stream and the device: refusing would leave the context stuck on the dead stream for every later call.
+    if (hipEventRecord(c->handover, c->stream) == hipSuccess) {
+        TFF_HIP(hipStreamWaitEvent(s, c->handover, 0));
+    } else {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(c->own);
+        (void)hipDeviceSynchronize();
+    }
     c->stream = s;
     return 0;
 }
@@ -765,6 +773,7 @@ struct tff_multi {
     std::vector<int> devices;
     // RCCL (lazily): communicators of the single-process clique, one per device
     void* rccl = nullptr;
+    std::mutex rccl_mu;
     std::vector<void*> comms;
     int (*p_init_all)(void**, int, const int*) = nullptr;
     int (*p_allgather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
@@ -791,6 +800,7 @@ pose_launcher method_launcher(int32_t method) {
 }
 
 int multi_load_rccl(tff_multi* m) {
+    std::lock_guard<std::mutex> guard(m->rccl_mu);                             // concurrent first calls: one of them initialises the communicators
     if (m->rccl) return 0;
     void* h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -906,9 +916,14 @@ int tff_pose_batch_dev_multi(tff_multi* m, int32_t method, const double* const* 
     pose_launcher launch = method_launcher(method);
     if (!launch) return fail(TFF_E_INVALID, "unknown method id");
     if (!corresp || !calm || !records) return fail(TFF_E_INVALID, "null pointer array");
+    if (B < 0 || N < 0) return fail(TFF_E_INVALID, "negative batch or correspondence count");
+    if (calm_stride != 0 && calm_stride != 27) return fail(TFF_E_INVALID, "calm_stride must be 0 (shared CalM) or 27");
+    if (B == 0) return 0;
     if (int r = multi_load_rccl(m)) return r;
     const int G = (int)m->ctx.size();
     const int64_t chunk = (B + G - 1) / G;
+    int caller_device = 0;
+    TFF_HIP(hipGetDevice(&caller_device));
     std::vector<int> rc(G, 0);
     std::vector<std::string> msg(G);
     std::vector<std::thread> th;
@@ -916,10 +931,19 @@ int tff_pose_batch_dev_multi(tff_multi* m, int32_t method, const double* const* 
         th.emplace_back([&, g]() {
             int64_t b0, b1;
             tff_multi_shard(m, B, g, &b0, &b1);
-            if (b1 <= b0) return;
             double* blk = records[g] + (int64_t)g * chunk * 51;
+            int32_t* sblk = status ? status[g] + (int64_t)g * chunk : nullptr;
+            // The all-gather below sends the WHOLE block of every device: the part of it no triplet fills (an uneven last shard, or an
+            // empty one when B < G) is defined first -- quiet NaN records with status TFF_ST_TOO_FEW -- on the stream the kernels use.
+            if (b1 - b0 < chunk) {
+                hipError_t e = hipSetDevice(m->devices[g]);
+                if (e == hipSuccess) e = hipMemsetAsync(blk, 0xff, (size_t)chunk * 51 * sizeof(double), m->ctx[g]->stream);
+                if (e == hipSuccess && sblk) e = hipMemsetD32Async((hipDeviceptr_t)sblk, TFF_ST_TOO_FEW, (size_t)chunk, m->ctx[g]->stream);
+                if (e != hipSuccess) { rc[g] = hip_fail(e, "hipMemsetAsync(record block)"); msg[g] = g_err; return; }
+            }
+            if (b1 <= b0) return;
             rc[g] = launch(m->ctx[g], corresp[g], calm[g], calm_stride, b1 - b0, N, blk, blk + chunk * 12, blk + chunk * 24, nullptr, nullptr,
-                           status ? status[g] + (int64_t)g * chunk : nullptr, nullptr);
+                           sblk, nullptr);
             if (rc[g] != 0) msg[g] = g_err;
         });
     }
@@ -927,12 +951,16 @@ int tff_pose_batch_dev_multi(tff_multi* m, int32_t method, const double* const* 
     for (int g = 0; g < G; ++g) if (rc[g] != 0) { g_err = "device " + std::to_string(m->devices[g]) + ": " + msg[g]; return rc[g]; }
     // one collective per result kind, all devices in one group (single-process clique)
     int nrc = m->p_group_start();
-    for (int g = 0; g < G && nrc == 0; ++g) {
-        TFF_HIP(hipSetDevice(m->devices[g]));
+    hipError_t herr = hipSuccess;
+    for (int g = 0; g < G && nrc == 0 && herr == hipSuccess; ++g) {
+        herr = hipSetDevice(m->devices[g]);                                  // (no early return inside the group: it must be closed)
+        if (herr != hipSuccess) break;
         nrc = m->p_allgather(records[g] + (int64_t)g * chunk * 51, records[g], (size_t)(chunk * 51), 8 /* ncclFloat64 */, m->comms[g], m->ctx[g]->stream);
         if (nrc == 0 && status) nrc = m->p_allgather(status[g] + (int64_t)g * chunk, status[g], (size_t)chunk, 2 /* ncclInt32 */, m->comms[g], m->ctx[g]->stream);
     }
     const int erc = m->p_group_end();
+    (void)hipSetDevice(caller_device);                                       // the caller's current device is not ours to change
+    if (herr != hipSuccess) return hip_fail(herr, "hipSetDevice");
     if (nrc == 0) nrc = erc;
     if (nrc != 0) { g_err = std::string("ncclAllGather: ") + (m->p_err ? m->p_err(nrc) : "error"); return TFF_E_INVALID; }
     return 0;

@@ -279,7 +279,7 @@ __device__ __forceinline__ void fp_eliminate_strong(double* M, const int ns, dou
 
 // Gauss_Helmert.m:38-83 with FaugPapaTFTPoseEstimation.m:87-153 as the callback, one workgroup, one correspondence per thread.
 // Returns the iteration count (:82); *st: ST_OK, ST_NONFINITE, or ST_RETRY (not this kernel's case).
-__device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pts, const int N, double (&xi)[6], int* st) {
+__device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pts, const int N, double (&xi)[6], int* st, double* dbg) {
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
     const bool owner = wave == own, have = tid < N;
     const int waves = (N + WAVE - 1) / WAVE;                                 // wavefronts that hold correspondences
@@ -294,6 +294,8 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
     int it = 0;
 #pragma unroll 1
     for (it = 1; it <= GH_IT_MAX; ++it) {
+        double* sdbg = (owner && it == 1) ? dbg : nullptr;                   // phase stamps of the first iteration (debug entry point), slots 16 ..
+        phase_stamp(sdbg, 16);
         // ---- func(xi, ti): constraints g, C (FaugPapaTFT...m:114-150) by the owner wavefront, through FaugPapaModel::eval into Mx ----
         if (owner) {
             GhWork g;
@@ -303,6 +305,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             for (int e = lane; e < 324; e += WAVE) s.Cm[e] = s.Mx[(27 + e / 27) * 40 + e % 27];
             if (lane < 12) s.gneg[lane] = s.Mx[(27 + lane) * 40 + 39];
         }
+        phase_stamp(sdbg, 17);
         double T[27];
         load_uniform27(s.p, T);
         // ---- W_i = B_i B_i' + 1e-12 I (:52), finite check (:53-55), pinv tolerance ----
@@ -344,6 +347,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             }
             tolW = 4.0 * (double)N * eps_of(smax);
         }
+        phase_stamp(sdbg, 18);
         // ---- weights in the deflated, factored form; R and Hs ----
         GhPoint pt;
         double nn[4] = {0, 0, 0, 0}, cs = 0.0, om = 0.0, sq[9], hh[6];
@@ -386,6 +390,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             TFF_SQ(0) TFF_SQ(1) TFF_SQ(2) TFF_SQ(3) TFF_SQ(4) TFF_SQ(5) TFF_SQ(6) TFF_SQ(7) TFF_SQ(8)
 #undef TFF_SQ
         }
+        phase_stamp(sdbg, 19);
         if (wave_has) {
             double* slot = s.Q + wave * FP_SLOT2;                            // Q | Mx: not in use yet
             fp_sum_regular<0>(pt, hh, have, slot); fp_sum_regular<1>(pt, hh, have, slot); fp_sum_regular<2>(pt, hh, have, slot);
@@ -397,6 +402,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             fp_sum_strong<3>(sq, hh, slot2); fp_sum_strong<4>(sq, hh, slot2); fp_sum_strong<5>(sq, hh, slot2);
             fp_sum_strong<6>(sq, hh, slot2); fp_sum_strong<7>(sq, hh, slot2); fp_sum_strong<8>(sq, hh, slot2);
         }
+        phase_stamp(sdbg, 20);
         if (block_any(bad, s.red)) { *st = ST_RETRY; break; }                // (barrier: the partial sums are in place)
         for (int e = tid; e < 729 + 27; e += GH_WG_THREADS) {                // Ghat[(q,i1),(q',i1')] = H[6 tri(q,q') + hht(i1,i1')], both families
             if (e < 729) {
@@ -415,6 +421,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             }
         }
         __syncthreads();
+        phase_stamp(sdbg, 21);
         // ---- the orthogonal basis that aligns the strong subspace ----
         if (owner) {
             const int ns_ = fp_strong_basis(s.A2, s.Q, s.fin);
@@ -422,6 +429,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
         }
         __syncthreads();
         const int ns = (int)s.flag[0];
+        phase_stamp(sdbg, 22);
         // ---- the strong Gram matrix from the rotated factors (378 + 27 sums); Y = R Q ----
         if (wave_has) {
             double* slot = s.Mx + wave * FP_SLOT;
@@ -438,6 +446,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             s.A2[e] = acc;
         }
         __syncthreads();
+        phase_stamp(sdbg, 23);
         for (int e = tid; e < 729 + 405; e += GH_WG_THREADS) {
             if (e < 729) {                                                   // Q' (R Q)
                 const int r = e / 27, c = e % 27;
@@ -451,6 +460,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             }
         }
         __syncthreads();
+        phase_stamp(sdbg, 24);
         // ---- M' (39 x 40, augmented) ----
         double chkM = 0.0;
         for (int e = tid; e < 39 * 40; e += GH_WG_THREADS) {
@@ -476,6 +486,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             s.Mx[e] = v;                                                     // (the partial-sum slots that lived here were last read before the barrier above)
         }
         if (!(fabs(block_sum(chkM, s.red)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
+        phase_stamp(sdbg, 25);
         // ---- block elimination of the strong ns x ns block ----
         if (owner) {
             double nrm2 = 0.0;
@@ -483,6 +494,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             if (lane == 0) s.flag[1] = nrm2;
         }
         __syncthreads();
+        phase_stamp(sdbg, 26);
         {
             const int n2 = 39 - ns, w2 = 40 - ns;
             for (int e = tid; e < n2 * w2; e += GH_WG_THREADS) {             // Schur complement, right-hand side included
@@ -493,6 +505,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             }
         }
         __syncthreads();
+        phase_stamp(sdbg, 27);
         // ---- aux = pinv(M + 1e-12 I) b (:67) ----
         if (owner) {
             const int n2 = 39 - ns;
@@ -500,7 +513,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             if (n2 <= TRID_MAX && ns > 0) {
                 const double tol = 39.0 * eps_of(s.flag[1]);
                 int kept, fail;
-                wave_pinv_solve_trid(S, 40, n2, tol, s.dt + ns, s.sm, s.A1, &kept, &fail);
+                wave_pinv_solve_trid(S, 40, n2, tol, s.dt + ns, s.sm, s.A1, &kept, &fail, sdbg);
                 if (fail && lane == 0) s.flag[2] = 1.0;
             } else {
                 // no strong block (every strong direction under pinv's tolerance for the weights, or a degenerate sample): the eigen-decomposition
@@ -524,6 +537,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
                 }
                 wave_sync();
             }
+            phase_stamp(sdbg, 32);
             // z1 = L^-T (y_b - Y z2)
             double t = 0.0;
             if (lane < ns) {
@@ -544,6 +558,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             if (lane < 27) s.dt[lane] = dtv;
         }
         __syncthreads();
+        phase_stamp(sdbg, 33);
         double dTr[27];
         load_uniform27(s.dt, dTr);
         // ---- v = -B' W+ (A dt - w)   (:69) ----
@@ -580,6 +595,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             }
         }
         obj = block_sum2(obj, &diff, s.red);
+        phase_stamp(sdbg, 34);
         double ndt2 = 0.0;
 #pragma unroll
         for (int k = 0; k < 27; ++k) ndt2 += dTr[k] * dTr[k];
@@ -638,7 +654,8 @@ __global__ void __launch_bounds__(GH_WG_THREADS, FP_WG_PER_CU) k_fp_block(const 
             }
         }
         int gst = ST_OK;
-        const int iters = gauss_helmert_fp(s, own, pts, N, xi, &gst);
+        const int iters = gauss_helmert_fp(s, own, pts, N, xi, &gst, a.dbg ? a.dbg + b * DBG_STRIDE : nullptr);
+        phase_stamp((a.dbg && wave == own) ? a.dbg + b * DBG_STRIDE : nullptr, 35);
         if (gst == ST_OK && s.flag[2] != 0.0) gst = ST_RETRY;                // an eigenpair of the pseudo-inverse did not converge (never observed)
         if (wave == own) {
             if (lane < 27) a.topt[b * 27 + lane] = s.p[lane];

@@ -107,7 +107,7 @@ __device__ __forceinline__ void wave_tridiag_inplace(lds_ptr A, const int lda, c
 // work: TRID_WORK_DOUBLES.  *kept_out: eigenvalues kept; *fail: 1 when more than TRID_MAX eigenvalues are kept (cannot happen for
 // n <= TRID_MAX) or an eigenpair did not converge.
 __device__ __forceinline__ double wave_trid_pinv(const lds_ptr dS, const lds_ptr eS, const lds_ptr e2S, const int n, const lds_ptr bh, const int ldb,
-                                                 const double tol, lds_ptr work, int* kept_out, int* fail) {
+                                                 const double tol, lds_ptr work, int* kept_out, int* fail, double* dbg = nullptr) {
     const int lane = lane_id();
     lds_ptr Z = work;                                                        // Z[j * TRID_LD + lane]: pivots Dp, then the eigenvector
     lds_ptr Dm = work + TRID_MAX * TRID_LD;
@@ -179,6 +179,7 @@ __device__ __forceinline__ double wave_trid_pinv(const lds_ptr dS, const lds_ptr
         lo = right ? mid : lo; clo = right ? c : clo;
         hi = right ? hi : mid; chi = right ? chi : c;
     }
+    phase_stamp(dbg, 29);
     // ---- step 3: Rayleigh-quotient iteration with the twisted factorisation, one eigenpair per lane ----
     double sig = 0.5 * (lo + hi), lam = sig, nz2 = 1.0;
     bool done = !own;
@@ -248,6 +249,8 @@ __device__ __forceinline__ double wave_trid_pinv(const lds_ptr dS, const lds_ptr
     }
     if (wave_any(!done)) *fail = 1;
     wave_sync();
+    phase_stamp(dbg, 30);
+    if (dbg && lane_id() == 0) dbg[79] = (double)it;
     // ---- step 4: coefficients, x^ ----
     if (own) {
         double dot = 0.0;
@@ -270,12 +273,14 @@ __device__ __forceinline__ double wave_trid_pinv(const lds_ptr dS, const lds_ptr
 // Steps 1 - 4: x = pinv(S) b under the tolerance tol, S and b as for wave_tridiag_inplace (DESTROYED); sol[0 .. n) <- x.
 // small: TRID_SMALL_DOUBLES, work: TRID_WORK_DOUBLES (its first 2 n doubles double as the reduction's scratch).
 __device__ __forceinline__ void wave_pinv_solve_trid(double* A_, const int lda, const int n, const double tol, double* sol, double* small_, double* work_,
-                                                     int* kept_out, int* fail) {
+                                                     int* kept_out, int* fail, double* dbg = nullptr) {
     const lds_ptr A = to_lds(A_), small = to_lds(small_), work = to_lds(work_);
     const int lane = lane_id();
     lds_ptr dS = small, eS = small + TRID_MAX, e2S = small + 2 * TRID_MAX;
     wave_tridiag_inplace(A, lda, n, dS, eS, e2S, work);
-    double x = wave_trid_pinv(dS, eS, e2S, n, A + n, lda, tol, work, kept_out, fail);
+    phase_stamp(dbg, 28);
+    double x = wave_trid_pinv(dS, eS, e2S, n, A + n, lda, tol, work, kept_out, fail, dbg);
+    phase_stamp(dbg, 31);
     // x = H_0 ... H_(n-3) x^
 #pragma unroll 1
     for (int k = n - 3; k >= 0; --k) {

@@ -106,7 +106,13 @@ class OverlappedGather:
     """The double-buffered step / gather pipeline of bench.py: step k computes into record buffer k % nbuf and then
     all-gathers it with async_op=True, so that the gather of step k overlaps the compute of step k + 1; a buffer is reused only
     after its previous gather has completed.  `compute(record_buffer, k)` enqueues the work of one step (the HIP launch in
-    bench.py; a stub in the gloo test).  world == 1: no collective, no extra buffers."""
+    bench.py; a stub in the gloo test).  world == 1: no collective, no extra buffers.
+
+    STREAM REQUIREMENT: `compute` must enqueue its work on torch's CURRENT stream of `device` -- the stream the process group orders
+    its collectives against (all_gather_into_tensor waits for the current stream's work, Work.wait() makes the current stream wait
+    for the collective).  A tft_vs_fund_amd.api.Context launches on its own non-blocking stream by default: call
+    `ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)` first (bench.py does), or the gather reads half-written records
+    and the buffer reuse is unprotected.  The gloo CPU test cannot see a violation of this."""
 
     def __init__(self, world, numel, device, compute, nbuf=2, dtype=torch.float64):
         self.world, self.nbuf, self.compute = world, nbuf, compute
