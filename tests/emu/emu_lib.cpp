@@ -119,7 +119,7 @@ extern "C" int emu_fp_pose(const double* corresp, const double* calm, long calm_
     tff::GhWgArgs m = a;
     m.flags |= tff::FLAG_ONLY_RETRY;
     emu::launch(tff::k_gh_linear<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
-    emu::launch(tff::k_fp_block, emu_grid(B), tff::GH_WG_THREADS, tff::fp_lds_bytes(), a);
+    emu::launch(tff::k_fp_block<true>, emu_grid(B), tff::GH_WG_THREADS, tff::fp_lds_bytes(N), a);
     int handed = 0;
     for (long b = 0; b < B; ++b) handed += status[b] == tff::ST_RETRY;
     if (handed) {
@@ -203,7 +203,7 @@ extern "C" int emu_eigh(const double* Maug, long B, int n, double* lam, double* 
 // wave_pinv_solve_trid (wave_trid.h) on caller-supplied symmetric matrices, n <= 32: Maug B x n x (n+1) row-major (column n = right-hand
 // side), tol B -> sol B x n, kept B, fail B
 namespace {
-struct TridArgs { const double* Maug; const double* tol; int n; double* sol; int* kept; int* fail; };
+struct TridArgs { const double* Maug; const double* tol; int n; double* sol; int* kept; int* fail; int variant; };
 __global__ void k_emu_trid(TridArgs a) {
     TFF_DYNAMIC_LDS(double, lds);
     const int n = a.n, ld = n + 1, lane = tff::lane_id();
@@ -212,13 +212,15 @@ __global__ void k_emu_trid(TridArgs a) {
     for (int e = lane; e < n * ld; e += 64) M[e] = a.Maug[b * n * ld + e];
     tff::wave_sync();
     int kept, fail;
-    tff::wave_pinv_solve_trid(M, ld, n, a.tol[b], sol, small, work, &kept, &fail);
+    if (a.variant == 2) tff::wave_pinv_solve_trid<true, true>(M, ld, n, a.tol[b], sol, small, work, &kept, &fail);       // registers + minor form
+    else if (a.variant == 1) tff::wave_pinv_solve_trid<false, false>(M, ld, n, a.tol[b], sol, small, work, &kept, &fail);   // LDS bursts + pivot form
+    else tff::wave_pinv_solve_trid<true, false>(M, ld, n, a.tol[b], sol, small, work, &kept, &fail);                      // registers + pivot form
     if (lane < n) a.sol[b * n + lane] = sol[lane];
     if (lane == 0) { a.kept[b] = kept; a.fail[b] = fail; }
 }
 }
-extern "C" int emu_trid_pinv(const double* Maug, const double* tol, long B, int n, double* sol, int* kept, int* fail) {
-    TridArgs a{Maug, tol, n, sol, kept, fail};
+extern "C" int emu_trid_pinv(const double* Maug, const double* tol, long B, int n, double* sol, int* kept, int* fail, int variant) {
+    TridArgs a{Maug, tol, n, sol, kept, fail, variant};
     emu::launch(k_emu_trid, emu_grid(B), 64, sizeof(double) * (size_t)(n * (n + 1) + 2 + tff::TRID_SMALL_DOUBLES + tff::TRID_WORK_DOUBLES + 64), a);
     return 0;
 }

@@ -25,6 +25,8 @@ typedef double* lds_ptr;
 inline lds_ptr to_lds(double* p) { return p; }
 inline double fast_rcp(double v) { return 1.0 / v; }
 inline int opaque_int(int v) { return v; }
+inline int hw_simd_id() { return (int)((threadIdx.x >> 6) & 3u); }
+inline int hw_workgroup_slot() { return (int)(blockIdx.x & 15u); }
 inline void sched_fence() {}
 inline void pin_value(double&) {}
 inline long long shader_clock() { return 0; }

@@ -392,3 +392,50 @@ def test_emulated_workgroup_kernels_reproduce_the_50_digit_iteration(emu, model,
             d = max(rel_err_T(Tt[b], g[pre + "mp_T"][b]), rel_err(R2[b], g[pre + "mp_Rt2"][b]), rel_err(R3[b], g[pre + "mp_Rt3"][b]))
             dit = int(it[b]) - int(g[pre + "mp_iter"][b])
         assert dit == 0 and d < 1e-9, (model, b, d, dit)
+
+
+# ---- FaugPapa's block kernel and its pseudo-inverse solver (csrc/gh_fp_kernel.h, csrc/wave_trid.h) ----------------------------------
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_emulated_tridiagonal_pinv_solver_matches_lapack(emu, variant):
+    """wave_pinv_solve_trid (x = pinv(S) b under MATLAB's truncation, without eigenvectors) on KKT-like indefinite matrices of order
+    20 .. 32 with a cluster of tiny eigenvalues under the tolerance: the three code paths (reduction in registers / LDS bursts, eigenpairs
+    in the pivot / minor form) against numpy's eigh at 1e-11, same number of kept eigenvalues."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import proto_trid_pinv as P
+    rng = np.random.default_rng(5 + variant)
+    for n in (31, 32, 20):
+        B = 4
+        Ms, tols, refs, keeps = [], [], [], []
+        for b in range(B):
+            S, rhs, tol = P.random_kkt(rng, n - 12, 12)
+            Ms.append(np.hstack([S, rhs[:, None]])); tols.append(tol)
+            lam, V = np.linalg.eigh(S)
+            k = np.abs(lam) > tol
+            refs.append(V[:, k] @ ((V[:, k].T @ rhs) / lam[k])); keeps.append(int(k.sum()))
+        Maug = np.ascontiguousarray(np.stack(Ms)); tol = np.array(tols)
+        sol = np.zeros((B, n)); kept = np.zeros(B, dtype=np.int32); fail = np.zeros(B, dtype=np.int32)
+        emu.emu_trid_pinv(_p(Maug), _p(tol), ctypes.c_long(B), ctypes.c_int(n), _p(sol), _p(kept), _p(fail), ctypes.c_int(variant))
+        assert not fail.any() and kept.tolist() == keeps
+        for b in range(B):
+            assert np.linalg.norm(sol[b] - refs[b]) <= 1e-11 * np.linalg.norm(refs[b]), (n, b)
+        # the numpy twin of the kernel's algorithm (tools/proto_trid_pinv.py) agrees too
+        x, nk = P.pinv_solve_sym(Ms[0][:, :n], Ms[0][:, n], tols[0])
+        assert nk == keeps[0] and np.linalg.norm(x - refs[0]) <= 1e-10 * np.linalg.norm(refs[0])
+
+
+def test_emulated_faugpapa_block_kernel_reproduces_the_extended_precision_iteration(emu, golden_dir):
+    """k_fp_block (FaugPapaTFTPoseEstimation.m:48-153 on Gauss_Helmert.m:38-83, factored form) on two N = 12 scenes of the 50-digit fixture:
+    1e-9 and the same iteration count; nothing handed back to the generic kernel."""
+    g = np.load(os.path.join(golden_dir, "gh_mp_faugpapa.npz"))
+    C = np.ascontiguousarray(g["c0_Corresp"][:2]); CalM = g["c0_CalM"]
+    B, N, _ = C.shape
+    calm = calm_colmajor(CalM)
+    Rt2 = np.zeros((B, 12)); Rt3 = np.zeros((B, 12)); T = np.zeros((B, 27)); it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32)
+    handed = emu.emu_fp_pose(_p(C), _p(calm), ctypes.c_long(0), ctypes.c_long(B), ctypes.c_int(N), ctypes.c_int(0), _p(Rt2), _p(Rt3), _p(T), None, _p(it), _p(st))
+    assert handed == 0 and np.all(st == 0)
+    R2 = Rt2.reshape(B, 4, 3).transpose(0, 2, 1); R3 = Rt3.reshape(B, 4, 3).transpose(0, 2, 1); Tt = T.reshape(B, 3, 3, 3).transpose(0, 3, 2, 1)
+    for b in range(B):
+        assert int(it[b]) == int(g["c0_mp_iter"][b])
+        d = max(rel_err_T(Tt[b], g["c0_mp_T"][b]), rel_err(R2[b], g["c0_mp_Rt2"][b]), rel_err(R3[b], g["c0_mp_Rt3"][b]))
+        assert d < 1e-9, (b, d)

@@ -223,9 +223,17 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
         TFF_HIP(hipGetLastError());
     }
     if (fp_first) {   // FaugPapa's own block kernel (gh_fp_kernel.h); the generic one below then redoes what it handed back (ST_RETRY: almost always nothing)
-        const size_t lds = tff::fp_lds_bytes();
-        if (int r = ensure_lds(tff::k_fp_block, lds)) return r;
-        hipLaunchKernelGGL(tff::k_fp_block, dim3(tff::pose_grid(B)), dim3(tff::GH_WG_THREADS), lds, c->stream, a);
+        tff::GhWgArgs m = a;
+        unsigned grid = tff::pose_grid(B);
+        size_t lds;
+        if (int r = plan_spill(c, tff::fp_lds_bytes(N), tff::fp_lds_bytes(0), &grid, &m.spill, &m.spill_stride, &lds, tff::FP_WG_PER_CU)) return r;
+        if (m.spill) {
+            if (int r = ensure_lds(tff::k_fp_block<false>, lds)) return r;
+            hipLaunchKernelGGL(tff::k_fp_block<false>, dim3(grid), dim3(tff::GH_WG_THREADS), lds, c->stream, m);
+        } else {
+            if (int r = ensure_lds(tff::k_fp_block<true>, lds)) return r;
+            hipLaunchKernelGGL(tff::k_fp_block<true>, dim3(grid), dim3(tff::GH_WG_THREADS), lds, c->stream, m);
+        }
         TFF_HIP(hipGetLastError());
     }
     {
@@ -259,7 +267,7 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
         return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, 0, std::is_same<Model, tff::ResslModel>::value ? 8 : 4, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
     // FaugPapa: the factored iteration of gh_fp_kernel.h (one correspondence per thread, N <= 256) unless an A/B switch asks for the generic kernel
-    const bool fp_first = std::is_same<Model, tff::FaugPapaModel>::value && N <= tff::FP_MAX_N && c->kernel_variant == 0 && !c->gh_exact;
+    const bool fp_first = std::is_same<Model, tff::FaugPapaModel>::value && c->kernel_variant == 0 && !c->gh_exact;
     return launch_wg(c, tff::k_gh_block<Model>, wg_lds, Model::WG_PER_CU, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg, fp_first);
 }
 template <class Model>

@@ -1,5 +1,5 @@
 // Faugeras-Papadopoulo's parameterisation (FaugPapaTFTPoseEstimation.m:48-153, all 27 tensor entries + 12 algebraic constraints) on
-// Gauss_Helmert.m:38-83 at the accuracy of the reference's FORMULAS, one workgroup of four wavefronts per triplet, N <= 256.
+// Gauss_Helmert.m:38-83 at the accuracy of the reference's FORMULAS, one workgroup of four wavefronts per triplet.
 //
 // Why this method needs its own iteration.  pinv(B_i B_i' + 1e-12 I) (Gauss_Helmert.m:57) gives every correspondence one direction
 // n_i of weight cs_i = 1 / (mu_i + 1e-12) ~ 1e9 .. 1e12.  With all 27 entries as parameters the vectors a_i = Ap_i' n_i are O(1) -- they
@@ -7,38 +7,39 @@
 // the regular part R of size N, in a subspace that is not aligned with any coordinate axis: every entry of the formed matrix is ~1e13
 // and the regular part is known to 1e-3 absolute only.  That is the 1e-6 .. 1e-4 by which ANY fp64 evaluation of the formed 39 x 39
 // KKT system (MATLAB's own included) misses the iteration the formulas define (tests/golden/gh_mp_faugpapa.npz, 50 digits).
-// Here the strong part never meets the regular part in one fp64 number:
+// Here the tangential part of the strong terms never meets their normal part in one fp64 number:
 //   1. weights in the deflated, factored form of gh_kernel.h (pinv_block_deflated<true>): regular part K_i, strong direction (n_i, cs_i);
-//   2. R = sum Ap_i' K_i Ap_i (297 Kronecker-structured sums) and the strong Gram matrix Hs = sum cs_i a_i a_i' (270 sums), separately;
+//   2. Kronecker-structured sums, one wavefront sweeping all correspondences per 30 sums: R = sum Ap_i' K_i Ap_i and A'Ww's regular
+//      part (297), the strong Gram matrix Hs = sum cs_i a_i a_i' and sum cs_i (n_i'w_i) a_i (270 + 27);
 //   3. an orthogonal Q whose first ns columns span the dominant columns of Hs (diagonally pivoted Cholesky + Householder QR, one
-//      wavefront, ~3 k instructions): in the basis Q the strong subspace is axis-aligned up to ~1e-6;
-//   4. the strong Gram matrix AGAIN, from the rotated factors g_i = sqrt(cs_i) Q' a_i (378 + 27 sums): the tangential components of
-//      a_i are ~1e-6 |a_i| and come out of the dot products with ~1e-10 relative error, so the tangential block (size N), the
-//      cross block (1e7) and the strong block (1e13) are each accurate at their OWN scale;
-//   5. M' = [Q'RQ + G'G + 1e-12 I, (CQ)'; CQ, 1e-12 I]: Cholesky elimination of the leading ns x ns block (exact algebra; the
+//      wavefront): in the basis Q the strong subspace is axis-aligned up to ~1e-6;
+//   4. the TANGENTIAL block of the strong Gram matrix again, from the rotated factors g_i = sqrt(cs_i) Q(:, 8:27)' a_i (190 + 19 sums,
+//      one correspondence per thread): those components are ~1e-6 |a_i| and come out of the dot products with ~1e-10 relative error,
+//      so the block is accurate at its OWN scale (size N).  The strong and cross blocks Q(:,1:8)' Hs Q are taken from the formed Hs:
+//      their rounding (1e-16 of 1e13) is 1e-10 of the cross block's size and enters the Schur complement at 1e-10 relative;
+//   5. M' = [Q'RQ + Q'HsQ + 1e-12 I, (CQ)'; CQ, 1e-12 I]: Cholesky elimination of the leading ns x ns block (exact algebra; the
 //      truncated pseudo-inverse of the whole differs from block elimination + truncated pseudo-inverse of the Schur complement by
 //      O((cross / strong)^2) ~ 1e-12), pinv's tolerance 39 eps(|M|_2) from the strong block's largest eigenvalue;
 //   6. truncated pseudo-inverse of the 30 / 31-dimensional Schur complement by wave_pinv_solve_trid (wave_trid.h), back-substitution,
 //      dt = Q z;  v = -B' W+ (A dt - w) with the strong term cs n n'(A dt - w) evaluated from the differences.
-// tools/proto_faugpapa_factored.py is the numpy twin (mode "kernel"): 48 fixture scenes within 4e-11 of the 50-digit iteration, equal
-// iteration counts.
+// tools/proto_faugpapa_factored.py is the numpy twin: 48 fixture scenes within 4e-11 of the 50-digit iteration, equal iteration counts.
 //
-// Per-correspondence state (the estimate xi, K_i, n_i, cs_i, n_i'w_i: 22 doubles) lives in REGISTERS, one correspondence per thread:
-// no LDS for it, hence four workgroups per CU with nothing spilled to global memory (the generic kernel moved 6.4 GB per 10 k x 200
-// launch through its spill slices), and every sum over correspondences is one halving butterfly per 32 sums and wavefront.
-// Triplets this kernel cannot take (a weight block without the one-small-eigenvalue structure) are handed to k_gh_block<FaugPapaModel>
-// through the status array (ST_RETRY).
+// Per-correspondence state (estimate xi, K_i, n_i, cs_i, n_i'w_i: 22 doubles) lives in LDS (35 KB at N = 200, two workgroups per CU) or,
+// beyond what the LDS holds, in the global slices of launch_wg.  A first version kept it in registers, one correspondence per thread, for
+// four workgroups per CU: with 32-wide butterflies on top the register allocator spilled it around every sum (15 GB of scratch traffic
+// per 10 k x 200 launch, 11 ms).  Triplets this kernel cannot take (a weight block without the one-small-eigenvalue structure) are
+// handed to k_gh_block<FaugPapaModel> through the status array (ST_RETRY).
 #pragma once
 #include "gh_wg_kernel.h"
 #include "wave_trid.h"
 
 namespace tff {
 
-constexpr int FP_MAX_N = GH_WG_THREADS;      // one correspondence per thread
-constexpr int FP_WG_PER_CU = 4;
+constexpr int FP_WG_PER_CU = 3;
+constexpr bool FP_TRID_IN_REGISTERS = true;    // the pseudo-inverse's reduction in registers (two workgroups per CU leave 256 per thread)
 constexpr int FP_NS_MAX = 12;                // strong directions eliminated ahead of the pseudo-inverse (the normal space has dimension 9)
-constexpr int FP_SLOT = 416;                 // per-wavefront partial sums of the rotated strong Gram matrix (405)
-constexpr int FP_SLOT2 = 598;                // per-wavefront partial sums of R (297, at 0) and Hs (270, at 300)
+constexpr int FP_C0 = 8;                     // columns FP_C0 .. 26 of Q get the rotated (accurate) strong sums when ns >= FP_C0
+constexpr int FP_XI = 6, FP_PP = 16;         // per-correspondence records: xi | W+ regular part (10), n (4), cs, n'w
 
 struct FpLds {
     double p[28];          // parameters = tensor entries, t(j + 3k + 9i) = T(j,k,i)
@@ -46,22 +47,22 @@ struct FpLds {
     double cam[3][12];     // P1, P2, P3 of the linear solution (row-major 3 x 4)
     double gneg[12];       // -g
     double rvec[28];       // regular part of A'Ww
+    double rsvec[28];      // strong part of A'Ww: sum cs (n'w) a
     double red[16];
     double dt[40];         // z (basis Q), then dt at [0, 27)
     double sm[TRID_SMALL_DOUBLES];
-    double flag[8];        // [0] ns  [1] |M|_2
+    double flag[8];        // [0] ns  [1] |M|_2  [2] pseudo-inverse failure
     // dead during the pseudo-inverse: A1 | A2 | fin | Cm are its TRID_WORK_DOUBLES (2112 <= 2198) or the 39 x 39 eigenvectors of the fall-back
     double A1[729];        // R, then Q'RQ
     double A2[729];        // Hs, then R Q
-    double fin[416];       // reflectors of the basis (12 x 27), then the rotated strong Gram sums
+    double fin[432];       // reflectors of the basis (12 x 27), then the rotated sums (209 / 405) | Q(:,1:8)' Hs (8 x 27, at 216)
     double Cm[324];        // C = dg/dT, 12 x 27
-    double Q[729];         // | partial sums of R and Hs (with Mx: 4 x FP_SLOT2 = 2392 <= 2393)
-    double Mx[1664];       // partial sums of the rotated Gram matrix (4 x FP_SLOT) | augmented M' 39 x 40
+    double Q[729];
+    double Mx[1664];       // the two families of structured sums (2 x 300) | per-wavefront slots of the rotated sums | augmented M' 39 x 40
 };
 constexpr int FP_LDS_DOUBLES = (int)(sizeof(FpLds) / sizeof(double));
-static_assert(729 + 1664 >= GH_WG_WAVES * FP_SLOT2 && 1664 >= GH_WG_WAVES * FP_SLOT && 1664 >= 39 * 40, "partial-sum slots");
-static_assert(729 + 729 + 416 + 324 >= TRID_WORK_DOUBLES && 729 + 729 + 416 >= 39 * 39, "pseudo-inverse workspace");
-__host__ __device__ inline size_t fp_lds_bytes() { return sizeof(FpLds); }
+static_assert(729 + 729 + 432 + 324 >= TRID_WORK_DOUBLES && 729 + 729 + 432 >= 39 * 39, "pseudo-inverse workspace");
+__host__ __device__ inline size_t fp_lds_bytes(int N) { return sizeof(FpLds) + (size_t)(FP_XI + FP_PP) * (size_t)N * sizeof(double); }
 
 __device__ __forceinline__ double block_sum2(double v, double* w2, double* red) {   // two sums, one barrier pair: returns sum(v), *w2 <- sum(*w2)
     v = wave_sum(v);
@@ -74,69 +75,118 @@ __device__ __forceinline__ double block_sum2(double v, double* w2, double* red) 
     return r;
 }
 
-// five entries of the lower triangle of s s' (s = sqrt(cs) K n, 9) times the six products of h1: 30 of the 270 sums of Hs
+// s = sqrt(cs) K n (9): a_i = h1 (x) (K n_i)
+__device__ __forceinline__ void fp_strong_vector(const double (&o)[6], const double (&nn)[4], const double sc, double (&sq)[9]) {
+    double kr[4];
+#define TFF_SQ(Q) K_row<Q>(o[2], o[3], o[4], o[5], kr); sq[Q] = sc * (kr[0] * nn[0] + kr[1] * nn[1] + kr[2] * nn[2] + kr[3] * nn[3]);
+    TFF_SQ(0) TFF_SQ(1) TFF_SQ(2) TFF_SQ(3) TFF_SQ(4) TFF_SQ(5) TFF_SQ(6) TFF_SQ(7) TFF_SQ(8)
+#undef TFF_SQ
+}
+// five entries of the lower triangle of s s' times the six products of h1: 30 of the 270 sums of Hs.
+// (Entry indices are template arguments: a loop variable inside tri_row_of() is not folded early enough and would put s[] in scratch memory.)
+template <int E>
+__device__ __forceinline__ void fp_strong_entry(const double (&s)[9], const double (&hh)[6], double* acc) {
+    const double z = s[tri_row_of(E)] * s[tri_col_of(E)];
+#pragma unroll
+    for (int h = 0; h < 6; ++h) acc[h] += hh[h] * z;
+}
 template <int CH>
 __device__ __forceinline__ void fp_strong_chunk(const double (&s)[9], const double (&hh)[6], double (&acc)[32]) {
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        const int e = 5 * CH + t;
-        const double z = s[tri_row_of(e)] * s[tri_col_of(e)];
-#pragma unroll
-        for (int h = 0; h < 6; ++h) acc[6 * t + h] = hh[h] * z;
-    }
-    acc[30] = 0.0; acc[31] = 0.0;
+    fp_strong_entry<5 * CH + 0>(s, hh, acc + 0);
+    fp_strong_entry<5 * CH + 1>(s, hh, acc + 6);
+    fp_strong_entry<5 * CH + 2>(s, hh, acc + 12);
+    fp_strong_entry<5 * CH + 3>(s, hh, acc + 18);
+    fp_strong_entry<5 * CH + 4>(s, hh, acc + 24);
 }
-// one butterfly: the wavefront's 30 (27) sums of chunk CH of R (CH < 9: Ghat entries, CH == 9: the right-hand side) -> slot
-template <int CH>
-__device__ __forceinline__ void fp_sum_regular(const GhPoint& pt, const double (&hh)[6], const bool have, double* slot) {
+// Where the per-correspondence state lives decides the pointer type: LDS pointers are 32-bit and lower to ds_read / ds_write with
+// immediate offsets; through generic `double*` every access is a flat load with 64-bit address arithmetic, which the optimiser hoists out
+// of the loops by the hundred and then spills.
+template <bool IN_LDS> struct FpState { typedef double* ptr; typedef const double* cptr; };
+template <> struct FpState<true> { typedef lds_ptr ptr; typedef lds_ptr cptr; };
+
+// One sweep of the calling wavefront over ALL correspondences: 30 (27) sums -> H[30 CH ..] (H[270 ..]).
+// Regular family (STRONG = false): chunk CH < 9 of Ghat = sum (h1 h1') (x) (K W+ K'), CH = 9: ghat = sum h1 (x) (K W+ w), w recomputed.
+// Strong family: chunk CH < 9 of sum cs (h1 h1') (x) (K n)(K n)', CH = 9: sum cs (n'w) h1 (x) (K n).
+template <bool STRONG, int CH, class SP>
+__device__ inline void fp_sweep(const FpLds& s, const SP xi, const SP pp, const double* pts, const int N, const double (&T)[27], double* H) {
+    const int lane = lane_id();
     double acc[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.0;
-    if (have) {
-        if constexpr (CH < 9) gh_accum_chunk<CH>(pt, hh, acc);
-        else gh_accum_rhs(pt, acc);
+#pragma unroll 1
+    for (int i = lane; i < N; i += WAVE) {
+        GhPoint pt;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pt.o[k] = xi[FP_XI * (long)i + k];
+        if constexpr (!STRONG) {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) pt.Wp[k] = pp[FP_PP * (long)i + k];
+            if constexpr (CH == 9) {
+                double f[4], B[4][6], wv[4];
+                tril_block(T, pt.o, f, B);
+                const Pt6 x = premap(load_pt(pts, i), s.nrm);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    double sw = -f[a];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) sw -= B[a][k] * (x.v[k] - pt.o[k]);
+                    wv[a] = sw;
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    pt.ww[a] = wp_at(pt.Wp, a, 0) * wv[0] + wp_at(pt.Wp, a, 1) * wv[1] + wp_at(pt.Wp, a, 2) * wv[2] + wp_at(pt.Wp, a, 3) * wv[3];
+                gh_accum_rhs(pt, acc);
+            } else {
+                const double hh[6] = {pt.o[0] * pt.o[0], pt.o[0] * pt.o[1], pt.o[0], pt.o[1] * pt.o[1], pt.o[1], 1.0};
+                gh_accum_chunk<CH>(pt, hh, acc);
+            }
+        } else {
+            const double nn[4] = {pp[FP_PP * (long)i + 10], pp[FP_PP * (long)i + 11], pp[FP_PP * (long)i + 12], pp[FP_PP * (long)i + 13]};
+            const double cs = pp[FP_PP * (long)i + 14];
+            double sq[9];
+            fp_strong_vector(pt.o, nn, sqrt(cs), sq);
+            if constexpr (CH == 9) {
+                const double so = sqrt(cs) * pp[FP_PP * (long)i + 15];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) { const double v = sq[q] * so; acc[q] += pt.o[0] * v; acc[9 + q] += pt.o[1] * v; acc[18 + q] += v; }
+            } else {
+                const double hh[6] = {pt.o[0] * pt.o[0], pt.o[0] * pt.o[1], pt.o[0], pt.o[1] * pt.o[1], pt.o[1], 1.0};
+                fp_strong_chunk<CH>(sq, hh, acc);
+            }
+        }
     }
     const double tot = wave_reduce_scatter<32>(acc);
-    const int lane = lane_id(), idx = reduce32_index(lane);
+    const int idx = reduce32_index(lane);
     if ((lane & 1) == 0) {
-        if (CH < 9) { if (idx < 30) slot[30 * CH + idx] = tot; }
-        else if (idx < 27) slot[270 + idx] = tot;
+        if (CH < 9) { if (idx < 30) H[30 * CH + idx] = tot; }
+        else if (idx < 27) H[270 + idx] = tot;
     }
-    sched_fence();
-}
-template <int CH>
-__device__ __forceinline__ void fp_sum_strong(const double (&s)[9], const double (&hh)[6], double* slot) {
-    double acc[32];
-    fp_strong_chunk<CH>(s, hh, acc);
-    const double tot = wave_reduce_scatter<32>(acc);
-    const int lane = lane_id(), idx = reduce32_index(lane);
-    if ((lane & 1) == 0 && idx < 30) slot[30 * CH + idx] = tot;
-    sched_fence();
 }
 
-// nine components of Q' (h1 (x) sq), columns 9 CH .. 9 CH + 8 of Q.  In three chunks with a memory fence between them: left to itself the
-// compiler merges the LDS loads of the whole 27 x 27 product at its head and spills ~400 registers around them.
-template <int CH>
-__device__ __forceinline__ void fp_rotate_chunk(const double* Q, const double (&xi)[6], const double (&sq)[9], double (&bv)[27]) {
-    double acc[9];
+// CLEN components of Q' (h1 (x) sq), columns CSTART .. CSTART + CLEN - 1 of Q.  In fenced chunks: left to itself the compiler merges the LDS
+// loads of the whole product at its head, or sinks the arithmetic towards the sums that use it, and spills ~400 registers either way.
+template <int CSTART, int CLEN, int OUT0, int U>
+__device__ __forceinline__ void fp_rotate_chunk(const double* Q, const double (&o)[6], const double (&sq)[9], double (&bv)[U]) {
+    double acc[CLEN];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) acc[c] = 0.0;
+    for (int c = 0; c < CLEN; ++c) acc[c] = 0.0;
 #pragma unroll
     for (int i1 = 0; i1 < 3; ++i1)
 #pragma unroll
         for (int m = 0; m < 9; ++m) {
-            const double ar = ((i1 == 0) ? xi[0] : ((i1 == 1) ? xi[1] : 1.0)) * sq[m];
-            const double* qr = Q + (m + 9 * i1) * 27 + 9 * CH;
+            const double ar = ((i1 == 0) ? o[0] : ((i1 == 1) ? o[1] : 1.0)) * sq[m];
+            const double* qr = Q + (m + 9 * i1) * 27 + CSTART;
 #pragma unroll
-            for (int c = 0; c < 9; ++c) acc[c] += qr[c] * ar;
+            for (int c = 0; c < CLEN; ++c) acc[c] += qr[c] * ar;
         }
 #pragma unroll
-    for (int c = 0; c < 9; ++c) { pin_value(acc[c]); bv[9 * CH + c] = acc[c]; }   // computed here, not sunk towards the sums that use it (243 loaded doubles would stay live)
-    wave_sync();                                                             // a memory fence: the three chunks read the same rows of Q, and merged loads live across them
+    for (int c = 0; c < CLEN; ++c) { pin_value(acc[c]); bv[OUT0 + c] = acc[c]; }   // computed here, not sunk towards the sums
+    wave_sync();                                                             // a memory fence between the chunks
 }
 
 // Step 3 on one wavefront: Hs (27 x 27, LDS) -> Q (27 x 27 row-major, LDS), returns ns.  vstore: 12 x 27 doubles for the reflectors.
-__device__ __forceinline__ int fp_strong_basis(const double* Hs, double* Qout, double* vstore) {
+__device__ __forceinline__ int fp_strong_basis(const double* Hs_, double* Qout_, double* vstore_) {
+    const lds_ptr Hs = to_lds(const_cast<double*>(Hs_)), Qout = to_lds(Qout_), vstore = to_lds(vstore_);   // (generic pointers after the call boundary)
     const int lane = lane_id();
     const bool row = lane < 27;
     const int rl = row ? lane : 0;
@@ -202,7 +252,7 @@ __device__ __forceinline__ int fp_strong_basis(const double* Hs, double* Qout, d
     for (int c = 0; c < 27; ++c) q[c] = (c == lane) ? 1.0 : 0.0;
 #pragma unroll 1
     for (int k = 0; k < ns; ++k) {
-        const double* vk = vstore + k * 27;
+        const lds_ptr vk = vstore + k * 27;
         double bk = 0.0;
 #pragma unroll
         for (int j = 0; j < FP_NS_MAX; ++j) bk = (j == k) ? beta[j] : bk;
@@ -223,7 +273,8 @@ __device__ __forceinline__ int fp_strong_basis(const double* Hs, double* Qout, d
 
 // Step 5 on one wavefront: largest eigenvalue of the leading ns x ns block of M' (-> *nrm2), its Cholesky factor (in place, lower
 // triangle) and Y = L^-1 [M12 | b1] (in place, columns ns .. 39).  M: 39 x 40 augmented.
-__device__ __forceinline__ void fp_eliminate_strong(double* M, const int ns, double* nrm2) {
+__device__ __forceinline__ void fp_eliminate_strong(double* M_, const int ns, double* nrm2) {
+    const lds_ptr M = to_lds(M_);
     constexpr int ld = 40;
     const int lane = lane_id();
     const bool row = lane < ns;
@@ -277,18 +328,52 @@ __device__ __forceinline__ void fp_eliminate_strong(double* M, const int ns, dou
     wave_sync();
 }
 
-// Gauss_Helmert.m:38-83 with FaugPapaTFTPoseEstimation.m:87-153 as the callback, one workgroup, one correspondence per thread.
-// Returns the iteration count (:82); *st: ST_OK, ST_NONFINITE, or ST_RETRY (not this kernel's case).
-__device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pts, const int N, double (&xi)[6], int* st, double* dbg) {
+// The rotated strong sums: every thread takes correspondences tid, tid + 256, ...; g = sqrt(cs) Q(:, C0:27)' a, U = 27 - C0 components,
+// U (U + 1) / 2 + U sums (the last U: g * sqrt(cs) n'w) in halving butterflies -> the calling wavefront's slot (zeroed here).
+template <int C0, class SP>
+__device__ inline void fp_rotated_sums(const FpLds& s, const SP xi, const SP pp, const int N, double* slot) {
+    constexpr int U = 27 - C0;
+    constexpr int total = U * (U + 1) / 2 + U;
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
-    const bool owner = wave == own, have = tid < N;
-    const int waves = (N + WAVE - 1) / WAVE;                                 // wavefronts that hold correspondences
-    const bool wave_has = wave < waves;
-    double objFunc = 0.0;                                                    // v0' v0, v0 = x0 - x   (:45-46)
-    if (have) {
-        const Pt6 x = premap(load_pt(pts, tid), s.nrm);
+    for (int e = lane; e < ((total + 1) & ~1); e += WAVE) slot[e] = 0.0;
+    wave_sync();
+#pragma unroll 1
+    for (int base = 0; base < N; base += GH_WG_THREADS) {
+        if (base + wave * WAVE >= N) break;                                  // wave-uniform: no correspondence of this chunk on this wavefront
+        const int i = base + tid;
+        const bool have = i < N;
+        const long ii = have ? i : N - 1;                                    // (same arithmetic on finite data; the contribution is zeroed through cs)
+        double o[6], nn[4];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { const double d = xi[k] - x.v[k]; objFunc += d * d; }
+        for (int k = 0; k < 6; ++k) o[k] = xi[FP_XI * ii + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nn[k] = pp[FP_PP * ii + 10 + k];
+        const double cs = have ? pp[FP_PP * ii + 14] : 0.0, om = pp[FP_PP * ii + 15];
+        const double sc = sqrt(cs);
+        double sq[9], bv[U];
+        fp_strong_vector(o, nn, sc, sq);
+        if constexpr (C0 == 8) {
+            fp_rotate_chunk<8, 10, 0, U>(s.Q, o, sq, bv); fp_rotate_chunk<18, 9, 10, U>(s.Q, o, sq, bv);
+        } else {
+            static_assert(C0 == 0, "two variants");
+            fp_rotate_chunk<0, 9, 0, U>(s.Q, o, sq, bv); fp_rotate_chunk<9, 9, 9, U>(s.Q, o, sq, bv); fp_rotate_chunk<18, 9, 18, U>(s.Q, o, sq, bv);
+        }
+        strong_accumulate<U>(bv, sc * om, slot);
+    }
+}
+
+// Gauss_Helmert.m:38-83 with FaugPapaTFTPoseEstimation.m:87-153 as the callback, one workgroup per problem; xi holds x0 on entry.
+// Returns the iteration count (:82); *st: ST_OK, ST_NONFINITE, or ST_RETRY (not this kernel's case).
+template <class SP>
+__device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pts, const int N, const SP xi, const SP pp, int* st, double* dbg) {
+    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    const bool owner = wave == own;
+    const int waves = (N < GH_WG_THREADS) ? (N + WAVE - 1) / WAVE : GH_WG_WAVES;   // wavefronts that hold correspondences in the rotated pass
+    double objFunc = 0.0;                                                    // v0' v0, v0 = x0 - x   (:45-46)
+    for (int i = tid; i < N; i += GH_WG_THREADS) {
+        const Pt6 x = premap(load_pt(pts, i), s.nrm);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { const double d = xi[FP_XI * (long)i + k] - x.v[k]; objFunc += d * d; }
     }
     objFunc = block_sum(objFunc, s.red);
     int it = 0;
@@ -309,115 +394,110 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
         double T[27];
         load_uniform27(s.p, T);
         // ---- W_i = B_i B_i' + 1e-12 I (:52), finite check (:53-55), pinv tolerance ----
-        double W[4][4];
         double fro2 = 0.0;
-        if (have) {
-            double f[4], B[4][6];
-            tril_block(T, xi, f, B);
+        for (int i = tid; i < N; i += GH_WG_THREADS) {
+            double o[6], f[4], B[4][6], W[4][4];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = xi[FP_XI * (long)i + k];
+            tril_block(T, o, f, B);
             block_W(B, W);
-            double chk = 0.0;
+            double chk = 0.0, f2 = 0.0;
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) { chk += W[a][b]; fro2 += W[a][b] * W[a][b]; }
-            if (!(fabs(chk) <= 1.79e308) || !(fro2 <= 1.79e308)) fro2 = 1e300 * 1e300;
+                for (int b = 0; b < 4; ++b) { chk += W[a][b]; f2 += W[a][b] * W[a][b]; }
+            if (!(fabs(chk) <= 1.79e308) || !(f2 <= 1.79e308)) f2 = 1e300 * 1e300;
+            fro2 = (f2 > fro2) ? f2 : fro2;
         }
         const double f2max = block_max(fro2, s.red);                         // (also orders the owner's constraint rows before the sums reuse Mx)
         if (!(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }
         double tolW = 0.0;
         if (!(4.0 * (double)N * eps_of(sqrt(f2max)) < 0.9e-12)) {            // the tolerance 4N eps(max lambda_max) can truncate: it is needed
             double up = 0.0, lo = 0.0;
-            if (have) psd_lambda_max_bounds(W, up, lo);
+            for (int i = tid; i < N; i += GH_WG_THREADS) {
+                double o[6], f[4], B[4][6], W[4][4], u1, l1;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[k] = xi[FP_XI * (long)i + k];
+                tril_block(T, o, f, B);
+                block_W(B, W);
+                psd_lambda_max_bounds(W, u1, l1);
+                up = (u1 > up) ? u1 : up;
+                lo = (l1 > lo) ? l1 : lo;
+            }
             up = block_max(up, s.red);
             lo = block_max(lo, s.red);
             double smax = up;
             if (eps_of(lo) != eps_of(up)) {
                 smax = 0.0;
-                if (have) {
-                    double Wc[4][4], V[4][4];
+                for (int i = tid; i < N; i += GH_WG_THREADS) {
+                    double o[6], f[4], B[4][6], W[4][4], V[4][4];
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
+                    for (int k = 0; k < 6; ++k) o[k] = xi[FP_XI * (long)i + k];
+                    tril_block(T, o, f, B);
+                    block_W(B, W);
+                    jacobi4<false>(W, V);
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) Wc[a][b] = W[a][b];
-                    jacobi4<false>(Wc, V);
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) smax = (fabs(Wc[a][a]) > smax) ? fabs(Wc[a][a]) : smax;
+                    for (int a = 0; a < 4; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
                 }
                 smax = block_max(smax, s.red);
             }
             tolW = 4.0 * (double)N * eps_of(smax);
         }
         phase_stamp(sdbg, 18);
-        // ---- weights in the deflated, factored form; R and Hs ----
-        GhPoint pt;
-        double nn[4] = {0, 0, 0, 0}, cs = 0.0, om = 0.0, sq[9], hh[6];
+        // ---- weights in the deflated, factored form -> pp: regular part of W+ (with the second + 1e-12 I of :57), n, cs, n'w ----
         bool bad = false;
+        for (int i = tid; i < N; i += GH_WG_THREADS) {
+            double o[6], f[4], B[4][6], W[4][4], Wp[10], nn[4], cs = 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) pt.o[k] = xi[k];
-        if (have) {
-            double f[4], B[4][6];
-            tril_block(T, xi, f, B);
-            bad = !pinv_block_deflated<true>(B, W, tolW, pt.Wp, nn, &cs);
+            for (int k = 0; k < 6; ++k) o[k] = xi[FP_XI * (long)i + k];
+            tril_block(T, o, f, B);
+            block_W(B, W);
+            bad = !pinv_block_deflated<true>(B, W, tolW, Wp, nn, &cs) || bad;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) pt.Wp[a * (a + 1) / 2 + a] += 1e-12;  // :57, second half
-            const Pt6 x = premap(load_pt(pts, tid), s.nrm);
-            double wv[4];
-            om = 0.0;
+            for (int a = 0; a < 4; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
+            const Pt6 x = premap(load_pt(pts, i), s.nrm);
+            double om = -(nn[0] * f[0] + nn[1] * f[1] + nn[2] * f[2] + nn[3] * f[3]);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                double sw = -f[a];
+            for (int k = 0; k < 6; ++k) om -= (B[0][k] * nn[0] + B[1][k] * nn[1] + B[2][k] * nn[2] + B[3][k] * nn[3]) * (x.v[k] - o[k]);   // n'w without forming w
+            const SP rec = pp + FP_PP * (long)i;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) sw -= B[a][k] * (x.v[k] - xi[k]);
-                wv[a] = sw;                                                  // w = -f - B (x - xi)   (:58)
-                om -= nn[a] * f[a];
-            }
+            for (int k = 0; k < 10; ++k) rec[k] = Wp[k];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) om -= (B[0][k] * nn[0] + B[1][k] * nn[1] + B[2][k] * nn[2] + B[3][k] * nn[3]) * (x.v[k] - xi[k]);   // n'w without forming w
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-                pt.ww[a] = wp_at(pt.Wp, a, 0) * wv[0] + wp_at(pt.Wp, a, 1) * wv[1] + wp_at(pt.Wp, a, 2) * wv[2] + wp_at(pt.Wp, a, 3) * wv[3];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 10; ++k) pt.Wp[k] = 0.0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pt.ww[k] = 0.0;
+            for (int k = 0; k < 4; ++k) rec[10 + k] = nn[k];
+            rec[14] = cs; rec[15] = om;
         }
-        hh[0] = xi[0] * xi[0]; hh[1] = xi[0] * xi[1]; hh[2] = xi[0]; hh[3] = xi[1] * xi[1]; hh[4] = xi[1]; hh[5] = 1.0;
-        {
-            const double sc = sqrt(cs);
-            double kr[4];
-#define TFF_SQ(Q) K_row<Q>(xi[2], xi[3], xi[4], xi[5], kr); sq[Q] = have ? sc * (kr[0] * nn[0] + kr[1] * nn[1] + kr[2] * nn[2] + kr[3] * nn[3]) : 0.0;
-            TFF_SQ(0) TFF_SQ(1) TFF_SQ(2) TFF_SQ(3) TFF_SQ(4) TFF_SQ(5) TFF_SQ(6) TFF_SQ(7) TFF_SQ(8)
-#undef TFF_SQ
-        }
+        if (block_any(bad, s.red)) { *st = ST_RETRY; break; }                // (barrier: the records of every correspondence are in place)
         phase_stamp(sdbg, 19);
-        if (wave_has) {
-            double* slot = s.Q + wave * FP_SLOT2;                            // Q | Mx: not in use yet
-            fp_sum_regular<0>(pt, hh, have, slot); fp_sum_regular<1>(pt, hh, have, slot); fp_sum_regular<2>(pt, hh, have, slot);
-            fp_sum_regular<3>(pt, hh, have, slot); fp_sum_regular<4>(pt, hh, have, slot); fp_sum_regular<5>(pt, hh, have, slot);
-            fp_sum_regular<6>(pt, hh, have, slot); fp_sum_regular<7>(pt, hh, have, slot); fp_sum_regular<8>(pt, hh, have, slot);
-            fp_sum_regular<9>(pt, hh, have, slot);
-            double* slot2 = slot + 300;
-            fp_sum_strong<0>(sq, hh, slot2); fp_sum_strong<1>(sq, hh, slot2); fp_sum_strong<2>(sq, hh, slot2);
-            fp_sum_strong<3>(sq, hh, slot2); fp_sum_strong<4>(sq, hh, slot2); fp_sum_strong<5>(sq, hh, slot2);
-            fp_sum_strong<6>(sq, hh, slot2); fp_sum_strong<7>(sq, hh, slot2); fp_sum_strong<8>(sq, hh, slot2);
+        // ---- the structured sums: ten sweeps for R / ghat, ten for Hs / sum cs (n'w) a, dealt to the four wavefronts ----
+        {
+            double* Hr = s.Mx; double* Hq = s.Mx + 300;
+            if (wave == 0) {
+                fp_sweep<false, 0, SP>(s, xi, pp, pts, N, T, Hr); fp_sweep<false, 4, SP>(s, xi, pp, pts, N, T, Hr); fp_sweep<false, 8, SP>(s, xi, pp, pts, N, T, Hr);
+                fp_sweep<true, 2, SP>(s, xi, pp, pts, N, T, Hq); fp_sweep<true, 6, SP>(s, xi, pp, pts, N, T, Hq);
+            } else if (wave == 1) {
+                fp_sweep<false, 1, SP>(s, xi, pp, pts, N, T, Hr); fp_sweep<false, 5, SP>(s, xi, pp, pts, N, T, Hr); fp_sweep<false, 9, SP>(s, xi, pp, pts, N, T, Hr);
+                fp_sweep<true, 3, SP>(s, xi, pp, pts, N, T, Hq); fp_sweep<true, 7, SP>(s, xi, pp, pts, N, T, Hq);
+            } else if (wave == 2) {
+                fp_sweep<false, 2, SP>(s, xi, pp, pts, N, T, Hr); fp_sweep<false, 6, SP>(s, xi, pp, pts, N, T, Hr);
+                fp_sweep<true, 0, SP>(s, xi, pp, pts, N, T, Hq); fp_sweep<true, 4, SP>(s, xi, pp, pts, N, T, Hq); fp_sweep<true, 8, SP>(s, xi, pp, pts, N, T, Hq);
+            } else {
+                fp_sweep<false, 3, SP>(s, xi, pp, pts, N, T, Hr); fp_sweep<false, 7, SP>(s, xi, pp, pts, N, T, Hr);
+                fp_sweep<true, 1, SP>(s, xi, pp, pts, N, T, Hq); fp_sweep<true, 5, SP>(s, xi, pp, pts, N, T, Hq); fp_sweep<true, 9, SP>(s, xi, pp, pts, N, T, Hq);
+            }
         }
+        __syncthreads();
         phase_stamp(sdbg, 20);
-        if (block_any(bad, s.red)) { *st = ST_RETRY; break; }                // (barrier: the partial sums are in place)
         for (int e = tid; e < 729 + 27; e += GH_WG_THREADS) {                // Ghat[(q,i1),(q',i1')] = H[6 tri(q,q') + hht(i1,i1')], both families
             if (e < 729) {
                 const int r = e / 27, cc = e % 27;
                 const int q = r % 9, i1 = r / 9, qq = cc % 9, i1p = cc / 9;
                 const int hi = (q > qq) ? q : qq, lo = (q > qq) ? qq : q;
                 const int src = 6 * (hi * (hi + 1) / 2 + lo) + hht_index(i1, i1p);
-                double r1 = 0.0, r2 = 0.0;
-                for (int wv_ = 0; wv_ < waves; ++wv_) { r1 += s.Q[wv_ * FP_SLOT2 + src]; r2 += s.Q[wv_ * FP_SLOT2 + 300 + src]; }
-                s.A1[e] = r1;
-                s.A2[e] = r2;
+                s.A1[e] = s.Mx[src];
+                s.A2[e] = s.Mx[300 + src];
             } else {
-                double r1 = 0.0;
-                for (int wv_ = 0; wv_ < waves; ++wv_) r1 += s.Q[wv_ * FP_SLOT2 + 270 + e - 729];
-                s.rvec[e - 729] = r1;
+                s.rvec[e - 729] = s.Mx[270 + e - 729];
+                s.rsvec[e - 729] = s.Mx[300 + 270 + e - 729];
             }
         }
         __syncthreads();
@@ -429,17 +509,24 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
         }
         __syncthreads();
         const int ns = (int)s.flag[0];
+        // (Taking only the tangential block from the rotated factors and the strong / cross blocks Q(:,1:8)' Hs Q from the formed Hs was tried:
+        // 9.6e-9 instead of 7e-11 on a scene whose smallest strong eigenvalue is 1e10 -- the cross block's 1e-3 absolute rounding is not
+        // small against THAT.  All 378 + 27 sums come from the rotated factors.)
+        const bool fast = false;
         phase_stamp(sdbg, 22);
-        // ---- the strong Gram matrix from the rotated factors (378 + 27 sums); Y = R Q ----
-        if (wave_has) {
-            double* slot = s.Mx + wave * FP_SLOT;
-            for (int e = lane; e < FP_SLOT; e += WAVE) slot[e] = 0.0;
-            wave_sync();
-            double bv[27];
-            fp_rotate_chunk<0>(s.Q, xi, sq, bv); fp_rotate_chunk<1>(s.Q, xi, sq, bv); fp_rotate_chunk<2>(s.Q, xi, sq, bv);
-            strong_accumulate<27>(bv, sqrt(cs) * om, slot);
+        // ---- rotated strong sums (one correspondence per thread); Y = R Q; Z = Q(:, 0:8)' Hs ----
+        if (wave < waves) {
+            if (fast) fp_rotated_sums<FP_C0, SP>(s, xi, pp, N, s.Mx + wave * 224);
+            else fp_rotated_sums<0, SP>(s, xi, pp, N, s.Mx + wave * 416);
         }
-        for (int e = tid; e < 729; e += GH_WG_THREADS) {
+        for (int e = tid; e < FP_C0 * 27; e += GH_WG_THREADS) {               // Z[r][c] = sum_k Q[k][r] Hs[k][c], r < FP_C0 (fin's reflectors are dead)
+            const int r = e / 27, c = e % 27;
+            double acc = 0.0;
+            for (int k = 0; k < 27; ++k) acc += s.Q[k * 27 + r] * s.A2[k * 27 + c];
+            s.fin[216 + e] = acc;
+        }
+        __syncthreads();
+        for (int e = tid; e < 729; e += GH_WG_THREADS) {                     // Y = R Q -> A2 (Hs is dead now)
             const int r = e / 27, c = e % 27;
             double acc = 0.0;
             for (int k = 0; k < 27; ++k) acc += s.A1[r * 27 + k] * s.Q[k * 27 + c];
@@ -447,16 +534,19 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
         }
         __syncthreads();
         phase_stamp(sdbg, 23);
-        for (int e = tid; e < 729 + 405; e += GH_WG_THREADS) {
-            if (e < 729) {                                                   // Q' (R Q)
-                const int r = e / 27, c = e % 27;
-                double acc = 0.0;
-                for (int k = 0; k < 27; ++k) acc += s.Q[k * 27 + r] * s.A2[k * 27 + c];
-                s.A1[e] = acc;
-            } else {
-                double acc = 0.0;
-                for (int wv_ = 0; wv_ < waves; ++wv_) acc += s.Mx[wv_ * FP_SLOT + e - 729];
-                s.fin[e - 729] = acc;
+        {
+            const int nsum = fast ? 209 : 405, stride = fast ? 224 : 416;
+            for (int e = tid; e < 729 + 405; e += GH_WG_THREADS) {
+                if (e < 729) {                                               // Q' (R Q) -> A1
+                    const int r = e / 27, c = e % 27;
+                    double acc = 0.0;
+                    for (int k = 0; k < 27; ++k) acc += s.Q[k * 27 + r] * s.A2[k * 27 + c];
+                    s.A1[e] = acc;
+                } else if (e - 729 < nsum) {
+                    double acc = 0.0;
+                    for (int wv_ = 0; wv_ < waves; ++wv_) acc += s.Mx[wv_ * stride + e - 729];
+                    s.fin[e - 729] = acc;
+                }
             }
         }
         __syncthreads();
@@ -467,10 +557,29 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             const int r = e / 40, c = e % 40;
             double v;
             if (r < 27 && c < 27) {
-                v = s.A1[r * 27 + c] + s.fin[(r >= c) ? tri_index(r, c) : tri_index(c, r)] + ((r == c) ? 1e-12 : 0.0);
+                v = s.A1[r * 27 + c] + ((r == c) ? 1e-12 : 0.0);
+                if (!fast) {
+                    v += s.fin[(r >= c) ? tri_index(r, c) : tri_index(c, r)];
+                } else if (r >= FP_C0 && c >= FP_C0) {
+                    const int a = r - FP_C0, b = c - FP_C0;
+                    v += s.fin[(a >= b) ? tri_index(a, b) : tri_index(b, a)];
+                } else {                                                     // strong / cross block of Q' Hs Q from the formed Hs
+                    const int rr = (r < c) ? r : c, cc = (r < c) ? c : r;    // rr < FP_C0
+                    double acc = 0.0;
+                    for (int k = 0; k < 27; ++k) acc += s.fin[216 + rr * 27 + k] * s.Q[k * 27 + cc];
+                    v += acc;
+                }
             } else if (r < 27 && c == 39) {
-                double acc = s.fin[378 + r];
-                for (int k = 0; k < 27; ++k) acc += s.Q[k * 27 + r] * s.rvec[k];
+                double acc = 0.0;
+                if (!fast) {
+                    acc = s.fin[378 + r];
+                    for (int k = 0; k < 27; ++k) acc += s.Q[k * 27 + r] * s.rvec[k];
+                } else if (r >= FP_C0) {
+                    acc = s.fin[190 + r - FP_C0];
+                    for (int k = 0; k < 27; ++k) acc += s.Q[k * 27 + r] * s.rvec[k];
+                } else {
+                    for (int k = 0; k < 27; ++k) acc += s.Q[k * 27 + r] * (s.rvec[k] + s.rsvec[k]);
+                }
                 v = acc;
             } else if (r >= 27 && c == 39) {
                 v = s.gneg[r - 27];
@@ -483,7 +592,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
                 v = acc;
             }
             chkM += v;
-            s.Mx[e] = v;                                                     // (the partial-sum slots that lived here were last read before the barrier above)
+            s.Mx[e] = v;                                                     // (the slots that lived here were last read before the barrier above)
         }
         if (!(fabs(block_sum(chkM, s.red)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
         phase_stamp(sdbg, 25);
@@ -513,11 +622,11 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             if (n2 <= TRID_MAX && ns > 0) {
                 const double tol = 39.0 * eps_of(s.flag[1]);
                 int kept, fail;
-                wave_pinv_solve_trid(S, 40, n2, tol, s.dt + ns, s.sm, s.A1, &kept, &fail, sdbg);
+                wave_pinv_solve_trid<FP_TRID_IN_REGISTERS, false>(S, 40, n2, tol, s.dt + ns, s.sm, s.A1, &kept, &fail, sdbg);
                 if (fail && lane == 0) s.flag[2] = 1.0;
             } else {
-                // no strong block (every strong direction under pinv's tolerance for the weights, or a degenerate sample): the eigen-decomposition
-                // of the whole matrix, its own largest eigenvalue for the tolerance
+                // no (or a small) strong block -- every strong direction under pinv's tolerance for the weights, or a degenerate sample:
+                // the eigen-decomposition of the whole remainder, its own largest eigenvalue for the tolerance
                 int fail;
                 const double lam = wave_eigh_ql(S, 40, s.A1, n2, n2, s.sm, &fail);
                 double amax = wave_max((lane < n2) ? fabs(lam) : 0.0);
@@ -561,36 +670,43 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
         phase_stamp(sdbg, 33);
         double dTr[27];
         load_uniform27(s.dt, dTr);
-        // ---- v = -B' W+ (A dt - w)   (:69) ----
-        double obj = 0.0, diff = 0.0, v6[6] = {0, 0, 0, 0, 0, 0};
-        Pt6 x;
-        if (have) {
-            x = premap(load_pt(pts, tid), s.nrm);
-            double Ad[4], wv[4], r[4], f[4], B[4][6];
-            tril_block(T, xi, f, B);                                         // recomputed: 28 doubles would otherwise stay live across the wave-serial phases
+        // ---- v = -B' W+ (A dt - w)   (:69); v overwrites the record's W+ slots (dead until the next weight pass) ----
+        double obj = 0.0, diff = 0.0;
+        for (int i = tid; i < N; i += GH_WG_THREADS) {
+            double o[6], f[4], B[4][6], Ad[4], wv[4], r[4], Wp[10], nn[4];
+            const SP rec = pp + FP_PP * (long)i;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = xi[FP_XI * (long)i + k];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) Wp[k] = rec[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nn[k] = rec[10 + k];
+            const double cs = rec[14];
+            tril_block(T, o, f, B);
             {
                 double m[3][3], t1[3][3], t2[3][3];
-                tril_slices(dTr, xi, m, t1, t2);
-                tril_quad(m, xi[2], xi[3], xi[4], xi[5], Ad);                // Ap_i dt
+                tril_slices(dTr, o, m, t1, t2);
+                tril_quad(m, o[2], o[3], o[4], o[5], Ad);                    // Ap_i dt
             }
+            const Pt6 x = premap(load_pt(pts, i), s.nrm);
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 double sw = -f[a];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) sw -= B[a][k] * (x.v[k] - xi[k]);
+                for (int k = 0; k < 6; ++k) sw -= B[a][k] * (x.v[k] - o[k]);
                 wv[a] = Ad[a] - sw;                                          // A dt - w
             }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
-                r[a] = wp_at(pt.Wp, a, 0) * wv[0] + wp_at(pt.Wp, a, 1) * wv[1] + wp_at(pt.Wp, a, 2) * wv[2] + wp_at(pt.Wp, a, 3) * wv[3];
+                r[a] = wp_at(Wp, a, 0) * wv[0] + wp_at(Wp, a, 1) * wv[1] + wp_at(Wp, a, 2) * wv[2] + wp_at(Wp, a, 3) * wv[3];
             const double sterm = cs * (nn[0] * wv[0] + nn[1] * wv[1] + nn[2] * wv[2] + nn[3] * wv[3]);
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 const double bn = B[0][k] * nn[0] + B[1][k] * nn[1] + B[2][k] * nn[2] + B[3][k] * nn[3];
                 const double v = -(B[0][k] * r[0] + B[1][k] * r[1] + B[2][k] * r[2] + B[3][k] * r[3]) - bn * sterm;
-                v6[k] = v;
+                rec[k] = v;
                 obj += v * v;
-                const double d = xi[k] - x.v[k] - v;
+                const double d = o[k] - x.v[k] - v;
                 diff += d * d;
             }
         }
@@ -602,9 +718,10 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
         if (sqrt(ndt2) < GH_TOL && sqrt(diff) < GH_TOL) break;               // :71-73 (dy is empty)
         if (obj > objFunc) break;                                            // :75-76, factor = 1
         objFunc = obj;                                                       // :78
-        if (have) {
+        for (int i = tid; i < N; i += GH_WG_THREADS) {                       // xi = x + v; ti = ti + dt   (:80)
+            const Pt6 x = premap(load_pt(pts, i), s.nrm);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) xi[k] = x.v[k] + v6[k];              // xi = x + v; ti = ti + dt   (:80)
+            for (int k = 0; k < 6; ++k) xi[FP_XI * (long)i + k] = x.v[k] + pp[FP_PP * (long)i + k];
         }
         if (tid < 27) s.p[tid] += s.dt[tid];
         __syncthreads();
@@ -613,7 +730,9 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
     return (it > GH_IT_MAX) ? GH_IT_MAX : it;                                // :82
 }
 
+template <bool STATE_IN_LDS>
 __global__ void __launch_bounds__(GH_WG_THREADS, FP_WG_PER_CU) k_fp_block(const GhWgArgs a) {
+    typedef typename FpState<STATE_IN_LDS>::ptr SP;
     TFF_DYNAMIC_LDS(double, smem);
     FpLds& s = *reinterpret_cast<FpLds*>(smem);
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
@@ -622,7 +741,11 @@ __global__ void __launch_bounds__(GH_WG_THREADS, FP_WG_PER_CU) k_fp_block(const 
         if (a.status[b] != ST_OK) continue;                                  // block-uniform
         const int N = a.N;
         const double* pts = a.corresp + b * 6 * (long)N;
-        const int own = (int)(b & (GH_WG_WAVES - 1));
+        SP xi, pp;                                                           // per-correspondence state: LDS, or the block's global slice
+        if constexpr (STATE_IN_LDS) xi = to_lds(smem + FP_LDS_DOUBLES);
+        else xi = a.spill + blockIdx.x * a.spill_stride;
+        pp = xi + FP_XI * (long)N;
+        const int own = pick_serial_wave(s.red);
         const double* r = a.rec + b * GH_REC_DOUBLES;                        // t 27 | pa 18 | epi 6 | nrm 9   (k_gh_linear)
         if (tid < 27) s.p[tid] = r[tid];                                     // param0 = T(:)   (FaugPapaTFT...m:65)
         if (tid < 9) s.nrm[tid] = r[51 + tid];
@@ -634,27 +757,30 @@ __global__ void __launch_bounds__(GH_WG_THREADS, FP_WG_PER_CU) k_fp_block(const 
         }
         if (tid == 0) s.flag[2] = 0.0;
         __syncthreads();
-        double xi[6] = {0, 0, 0, 0, 0, 0};
-        if (tid < N) {                                                       // x_est: reprojection of the projective triangulation   (:58-61)
+        {                                                                    // x_est: reprojection of the projective triangulation   (:58-61)
             double PA[12], PB[12], PC[12];
             load_uniform12(s.cam[0], PA);
             load_uniform12(s.cam[1], PB);
             load_uniform12(s.cam[2], PC);
-            const Pt6 p = premap(load_pt(pts, tid), s.nrm);
-            double X[4];
-            dlt_point<true>(PA, PB, PC, s.cam[0], s.cam[1], s.cam[2], true, p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], p.v[5], X);
+#pragma unroll 1
+            for (int i = tid; i < N; i += GH_WG_THREADS) {
+                const Pt6 p = premap(load_pt(pts, i), s.nrm);
+                double X[4];
+                dlt_point<true>(PA, PB, PC, s.cam[0], s.cam[1], s.cam[2], true, p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], p.v[5], X);
 #pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                const double (&P)[12] = (v == 0) ? PA : ((v == 1) ? PB : PC);
-                const double aa = P[0] * X[0] + P[1] * X[1] + P[2] * X[2] + P[3] * X[3];
-                const double bb = P[4] * X[0] + P[5] * X[1] + P[6] * X[2] + P[7] * X[3];
-                const double cc = P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11] * X[3];
-                xi[2 * v] = aa / cc;
-                xi[2 * v + 1] = bb / cc;
+                for (int v = 0; v < 3; ++v) {
+                    const double (&P)[12] = (v == 0) ? PA : ((v == 1) ? PB : PC);
+                    const double aa = P[0] * X[0] + P[1] * X[1] + P[2] * X[2] + P[3] * X[3];
+                    const double bb = P[4] * X[0] + P[5] * X[1] + P[6] * X[2] + P[7] * X[3];
+                    const double cc = P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11] * X[3];
+                    xi[FP_XI * (long)i + 2 * v] = aa / cc;
+                    xi[FP_XI * (long)i + 2 * v + 1] = bb / cc;
+                }
             }
         }
+        __syncthreads();
         int gst = ST_OK;
-        const int iters = gauss_helmert_fp(s, own, pts, N, xi, &gst, a.dbg ? a.dbg + b * DBG_STRIDE : nullptr);
+        const int iters = gauss_helmert_fp<SP>(s, own, pts, N, xi, pp, &gst, a.dbg ? a.dbg + b * DBG_STRIDE : nullptr);
         phase_stamp((a.dbg && wave == own) ? a.dbg + b * DBG_STRIDE : nullptr, 35);
         if (gst == ST_OK && s.flag[2] != 0.0) gst = ST_RETRY;                // an eigenpair of the pseudo-inverse did not converge (never observed)
         if (wave == own) {

@@ -138,6 +138,24 @@ __device__ __forceinline__ double block_max(double v, double* red) {
 }
 __device__ __forceinline__ bool block_any(bool p, double* red) { return block_sum(p ? 1.0 : 0.0, red) != 0.0; }
 
+// The wavefront of the workgroup that runs the wave-serial steps (parameter Jacobian, KKT solve, pseudo-inverse).  The workgroups that
+// share a CU should run theirs on DIFFERENT SIMDs.  `blockIdx & 3` does not achieve that: consecutive workgroups go round-robin over the
+// eight XCDs, so the workgroups resident on one CU all have the same blockIdx mod 4, hence the same serial wave index, hence (waves are
+// dealt to the SIMDs in order) the same SIMD -- four serial waves time-slicing one SIMD while three idle, measured as ~30 cycles per
+// instruction in those steps.  The hardware knows better: the workgroup's slot number on its CU picks the SIMD, the wave that actually
+// runs there takes the job.  red: 4 doubles of scratch at red[12 ..].
+__device__ inline int pick_serial_wave(double* red) {
+    if (lane_id() == 0) red[12 + wave_in_block()] = (double)hw_simd_id();
+    __syncthreads();
+    const int target = hw_workgroup_slot() & (GH_WG_WAVES - 1);
+    int own = -1;
+#pragma unroll
+    for (int w = GH_WG_WAVES - 1; w >= 0; --w) own = ((int)red[12 + w] == target) ? w : own;
+    own = (own < 0) ? target : own;                                          // no wave of this workgroup on that SIMD
+    __syncthreads();
+    return wave_uniform_i(own);
+}
+
 // x = pinv(M) b through the eigen-decomposition (wave_pinv_solve_sym) on the wavefront `own` of the workgroup; the others wait.
 // (A workgroup-parallel cyclic Jacobi was measured here first: 11 sweeps x 39 rounds x 2 barriers on the 39 x 39 matrix, 1.5 ms per
 // solve; tridiagonalisation + QL on one wavefront does a tenth of the arithmetic and leaves the CU to the other workgroups.)
@@ -540,7 +558,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::WG_PER_CU) k_gh_block(co
         double* red;
         GhWork g = gh_wg_carve(ghbase, w, Model::U, Model::C, a.spill ? 0 : N, Model::REDUNDANT_CONSTRAINTS, &red);
         if (a.spill) { g.xi = a.spill + blockIdx.x * a.spill_stride; g.pp = g.xi + GH_XI * (long)N; }
-        const int own = (int)(b & (GH_WG_WAVES - 1));
+        const int own = pick_serial_wave(red);
         const double* r = a.rec + b * GH_REC_DOUBLES;
         if (tid < 27) w->t[tid] = r[tid];
         if (tid < 18) w->pa[tid] = r[27 + tid];

@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::PINV_KKT ? 4 : 2) k_pi_b
         g.sn = g.pp + (long)pi_pp(Model::E) * (a.spill ? 0 : N);
         double* red = g.sn + 6 * (long)(a.spill ? 0 : N);
         if (a.spill) { g.xi = a.spill + blockIdx.x * a.spill_stride; g.pp = g.xi + 6 * (long)N; g.sn = g.pp + (long)pi_pp(Model::E) * N; }
-        const int own = (int)(b & (GH_WG_WAVES - 1));
+        const int own = pick_serial_wave(red);
         const double* r = a.rec + b * GH_REC_DOUBLES;
         if (tid < 27) w->t[tid] = r[tid];
         if (tid < 18) w->pa[tid] = r[27 + tid];

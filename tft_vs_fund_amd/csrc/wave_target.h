@@ -49,6 +49,10 @@ __device__ __forceinline__ void pin_value(double& v) { asm volatile("" : "+v"(v)
 // the instruction scheduler does not move anything across this point
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ long long shader_clock() { return clock64(); }
+// Where this wavefront runs: HW_ID (hardware register 4) bits [5:4] = SIMD of the CU, bits [19:16] = slot of its workgroup on the CU.
+// s_getreg_b32 immediate = (size - 1) << 11 | offset << 6 | register.
+__device__ __forceinline__ int hw_simd_id() { return (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4); }
+__device__ __forceinline__ int hw_workgroup_slot() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4); }
 // lowest lane whose predicate holds (64 if none); wave-uniform
 __device__ __forceinline__ int wave_first_lane(bool p) {
     const unsigned long long m = __ballot(p);
