@@ -42,7 +42,7 @@ def test_shard_bounds_cover_batch():
 
 def test_gather_two_ranks_gloo():
     ctx = mp.get_context("spawn")
-    for B in (10, 11):                               # even and uneven shards
+    for B in (10, 11, 1):                            # even and uneven shards, and an empty one (B < world)
         q = ctx.Queue()
         port = _free_port()
         ps = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]

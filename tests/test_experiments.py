@@ -148,3 +148,17 @@ def test_config5_noise_trials_on_all_epfl_triplets(gpu_ctx, golden_dir):
             if tr["name"] in known and tr["name"] not in seen:
                 seen[tr["name"]] = (tr["Corresp"].shape[1], X.epfl_inliers(gpu_ctx, tr).shape[1])
     assert seen == known, seen
+
+
+@pytest.mark.gpu
+def test_config5_at_one_thousand_trials(gpu_ctx, golden_dir):
+    """BASELINE.json configs[4] at its stated trial count on one dataset: the first 50 Herz-Jesu-P8 triplets of the reference's list x 1000 noise
+    trials x the seven methods of experiments_real.m:62 (50 000 problems per method, one batched call each)."""
+    trips = X.load_epfl_all(os.path.join(golden_dir, "epfl_all.npz"), "herzjesu", 50)
+    res = X.real_trials(gpu_ctx, trips, n_trials=1000, sigma=0.5)
+    n_ok = sum(1 for i in res["triplets"] if min(100, i["inliers"]) >= 8)
+    assert len(res["summary"]) == 7
+    for m, s in res["summary"].items():
+        assert s["problems"] >= 1000 * (n_ok - 2), (m, s["problems"])
+        assert s["solved"] >= 0.97 * s["problems"], (m, s)
+        assert s["median_rot_err_deg"] < 1.0 and s["median_repr_err"] < 10.0, (m, s)

@@ -168,3 +168,42 @@ def test_config4_minimal_hypotheses_and_inlier_counts(gpu_ctx):
     # distributed gather of the counts (single process: identity)
     from tft_vs_fund_amd import dist as tdist
     assert torch.equal(tdist.all_gather_counts(torch.from_numpy(cnt), B), torch.from_numpy(cnt))
+
+
+def test_config4_at_one_million_hypotheses(gpu_ctx):
+    """BASELINE.json configs[3] at its stated size on one GPU: 1 000 000 seven-point (TFT) / eight-point (F) hypotheses of one 400-correspondence
+    scene with 25 % gross outliers + int32 inlier counts (experiments.m:99, linearF.m:35, the 1-px rule of experiments_real.m:94-98).  Properties:
+    every hypothesis finishes; a sample without outliers counts exactly the scene's uncorrupted correspondences and nothing counts more; the
+    whole-batch exact route and the flag-and-redo route (TFF_OPT_EXACT_BELOW = 0) give the same counts but for the rare hypotheses whose
+    poses differ by a resolved svd(E) tie or a residual at the threshold."""
+    import torch
+    H, Ns = 1000000, 400
+    C, CalM, Rt0, _ = _scene(1, Ns, 0.0, 7)
+    scene = C[0].copy()
+    rng = np.random.default_rng(1)
+    bad = rng.choice(Ns, Ns // 4, replace=False)
+    scene[bad, 2:6] += rng.uniform(20, 80, size=(bad.size, 4))
+    d_scene = torch.from_numpy(scene).cuda(); d_calm = torch.from_numpy(CalM).cuda()
+    is_bad = torch.zeros(Ns, dtype=torch.bool, device="cuda"); is_bad[torch.from_numpy(bad).cuda()] = True
+    for method, n in (("LinearTFTPoseEstimation", 7), ("LinearFPoseEstimation", 8)):
+        gen = torch.Generator(device="cuda"); gen.manual_seed(1234)
+        idx = torch.rand((H, Ns), device="cuda", generator=gen).argsort(dim=1)[:, :n].to(torch.int32).contiguous()
+        hyp = gpu_ctx.pose_sampled(method, d_scene, d_calm, idx)
+        cnt = gpu_ctx.inlier_count(d_scene, d_calm, hyp["R_t_2"], hyp["R_t_3"], 1.0)
+        torch.cuda.synchronize()
+        assert int((hyp["status"] != 0).sum()) == 0
+        clean = ~is_bad[idx.long()].any(dim=1)
+        assert int(clean.sum()) > 1000
+        assert int(cnt.max()) == Ns - bad.size
+        assert bool((cnt[clean] == Ns - bad.size).all()), int((cnt[clean] != Ns - bad.size).sum())
+        gpu_ctx.set_exact_below(0)                                              # fast tiers first, the exact kernel only over what they flag
+        try:
+            hyp2 = gpu_ctx.pose_sampled(method, d_scene, d_calm, idx)
+            cnt2 = gpu_ctx.inlier_count(d_scene, d_calm, hyp2["R_t_2"], hyp2["R_t_3"], 1.0)
+            torch.cuda.synchronize()
+        finally:
+            gpu_ctx.set_exact_below(12)
+        assert int((hyp2["status"] != 0).sum()) == 0
+        assert bool((cnt2[clean] == Ns - bad.size).all())
+        differ = int((cnt2 != cnt).sum())
+        assert differ <= H // 200, (method, differ)                             # both routes are exact; ties / threshold cases only
