@@ -73,6 +73,8 @@ typedef struct tff_ctx tff_ctx;
 #define TFF_OPT_GH_EXACT 4  /* Gauss-Helmert methods: 1 = always form pinv(W) through per-block eigen-decompositions -- an A/B switch: it carries the
                              * 1e-6 .. 1e-4 noise of any fp64 pinv(W) (default 0: deflated block pseudo-inverse + factored strong direction, which
                              * reproduce a 50-digit evaluation of the reference's iteration to 1e-11 for Ressl, Nordberg and Pi) */
+#define TFF_OPT_SPILL 6     /* per-correspondence state of the iterative methods: 0 (default) it leaves the LDS for the context's global slices whenever that lets
+                             * more workgroups share a CU (measured faster, at the price of HBM traffic); 1 = only when the LDS cannot hold it (large N) */
 #define TFF_OPT_KERNEL 3    /* Kernel variants of the iterative TFT methods: 0 automatic (default: a 4-wavefront workgroup per triplet for the iteration,
                              * the fused single-wavefront kernel below the measured crossover: N < 80 for Ressl, N < 72 for Nordberg, N < 128 for Pi);
                              * 1 fused kernel always;

@@ -61,6 +61,7 @@ struct tff_ctx {
     double* init_p = nullptr; double* init_x = nullptr;   // set around tff_pi_pose_batch_debug_dev
     int kernel_variant = 0;                // TFF_OPT_KERNEL
     int gh_exact = 0;                      // TFF_OPT_GH_EXACT
+    int spill_only_if_needed = 0;          // TFF_OPT_SPILL
 };
 
 namespace {
@@ -91,7 +92,7 @@ constexpr long FIXUP_GRID = 1024;
 int plan_spill(tff_ctx* c, size_t lds_full, size_t lds_fixed, unsigned* grid, double** spill, long* stride, size_t* lds, int occupancy_cap = 0) {
     *spill = nullptr; *stride = 0; *lds = lds_full;
     auto per_cu = [&](size_t bytes) { const size_t k = LDS_LIMIT / (bytes + 512); return (int)(k < (size_t)occupancy_cap ? k : (size_t)occupancy_cap); };
-    const bool for_occupancy = occupancy_cap > 0 && lds_fixed < lds_full && per_cu(lds_fixed) > per_cu(lds_full);
+    const bool for_occupancy = !c->spill_only_if_needed && occupancy_cap > 0 && lds_fixed < lds_full && per_cu(lds_fixed) > per_cu(lds_full);
     if (lds_full <= LDS_LIMIT && !for_occupancy) return 0;
     if (lds_fixed > LDS_LIMIT) return fail(TFF_E_INVALID, "LDS workspace of this method exceeds 160 KiB");
     // + 16 doubles: the kernels carve their per-correspondence arrays with small alignment pads (e.g. OptimF's v = xi + 4N + 2), so a
@@ -268,7 +269,10 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
     // FaugPapa: the factored iteration of gh_fp_kernel.h (one correspondence per thread, N <= 256) unless an A/B switch asks for the generic kernel
     const bool fp_first = std::is_same<Model, tff::FaugPapaModel>::value && c->kernel_variant == 0 && !c->gh_exact;
-    return launch_wg(c, tff::k_gh_block<Model>, wg_lds, Model::WG_PER_CU, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg, fp_first);
+    // occupancy policy of the per-correspondence state (plan_spill): Nordberg runs as fast with it in LDS at two workgroups per CU as with it in global
+    // slices at three (3.89 vs 3.87 ms per 10 k x 200) -- and moves 2x instead of 63x the algorithmic bytes through HBM
+    const int occupancy_cap = std::is_same<Model, tff::NordbergModel>::value ? 2 : Model::WG_PER_CU;
+    return launch_wg(c, tff::k_gh_block<Model>, wg_lds, occupancy_cap, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg, fp_first);
 }
 template <class Model>
 int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
@@ -418,6 +422,7 @@ int tff_ctx_set_option(tff_ctx* c, int option, long value) {
         case TFF_OPT_EXACT_BELOW: if (value < 0 || value > (1L << 30)) return fail(TFF_E_INVALID, "exact_below must be >= 0"); c->exact_below = (int)value; return 0;
         case TFF_OPT_STAGE_LDS: if (value < -1 || value > 1) return fail(TFF_E_INVALID, "stage_lds must be -1, 0 or 1"); c->stage = (int)value; return 0;
         case TFF_OPT_GH_EXACT: c->gh_exact = value != 0; return 0;
+        case TFF_OPT_SPILL: c->spill_only_if_needed = value != 0; return 0;
         case TFF_OPT_KERNEL: if (value < 0 || value > 2) return fail(TFF_E_INVALID, "kernel must be 0, 1 or 2"); c->kernel_variant = (int)value; return 0;
         default: return fail(TFF_E_INVALID, "unknown option");
     }

@@ -5,12 +5,13 @@ import numpy as np, torch
 from tft_vs_fund_amd import api
 from tft_vs_fund_amd.scenes import generate_scene_batch
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-methods = sys.argv[2:] or ["ResslTFTPoseEstimation", "NordbergTFTPoseEstimation", "FaugPapaTFTPoseEstimation", "PiPoseEstimation", "PiColPoseEstimation"]
+methods = sys.argv[2:] or ["ResslTFTPoseEstimation", "NordbergTFTPoseEstimation", "FaugPapaTFTPoseEstimation", "PiPoseEstimation", "PiColPoseEstimation", "OptimFPoseEstimation"]
 B = 10000
 C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=1)
 d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
 ctx = api.Context(0, stage_lds=int(os.environ.get("TFF_STAGE", "-1")))
 ctx.set_kernel_variant(int(os.environ.get("TFF_VARIANT", "0")))      # 1: fused single-wavefront kernels (A/B)
+ctx.set_spill_only_if_needed(int(os.environ.get("TFF_SPILL", "0")))  # 1: state stays in LDS whenever it fits
 for m in methods:
     for _ in range(2):
         out = ctx.pose_batch(m, d, calm, reconst=False)
