@@ -439,3 +439,24 @@ def test_emulated_faugpapa_block_kernel_reproduces_the_extended_precision_iterat
         assert int(it[b]) == int(g["c0_mp_iter"][b])
         d = max(rel_err_T(Tt[b], g["c0_mp_T"][b]), rel_err(R2[b], g["c0_mp_Rt2"][b]), rel_err(R3[b], g["c0_mp_Rt3"][b]))
         assert d < 1e-9, (b, d)
+
+
+def test_emulated_picol_block_kernel_reproduces_the_extended_precision_iteration(emu, golden_dir):
+    """k_pi_block<PiColModel> (PiColPoseEstimation.m:50-218; 5 x 5 weight blocks with two deflated near-null directions each,
+    pi_wg_kernel.h::pinv_block_deflated2) on two N = 12 scenes of the 50-digit fixture (the first runs six or seven iterations under every convention): 1e-9 and
+    the same iteration count under one of the four sign conventions of the start (tests/helpers.py::kernel_null_convention)."""
+    g = np.load(os.path.join(golden_dir, "gh_mp_picol.npz"))
+    pick = [6, 9]
+    C = np.ascontiguousarray(g["c0_Corresp"][pick]); CalM = g["c0_CalM"]
+    B, N, _ = C.shape
+    calm = calm_colmajor(CalM)
+    Rt2 = np.zeros((B, 12)); Rt3 = np.zeros((B, 12)); T = np.zeros((B, 27)); it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32)
+    emu.emu_pi_wg_pose(ctypes.c_int(1), _p(C), _p(calm), ctypes.c_long(0), ctypes.c_long(B), ctypes.c_int(N), ctypes.c_int(0),
+                       _p(Rt2), _p(Rt3), _p(T), None, _p(it), _p(st))
+    assert np.all(st == 0)
+    R2 = Rt2.reshape(B, 4, 3).transpose(0, 2, 1); R3 = Rt3.reshape(B, 4, 3).transpose(0, 2, 1); Tt = T.reshape(B, 3, 3, 3).transpose(0, 3, 2, 1)
+    for b, s in enumerate(pick):
+        T4, R24, R34, it4 = g["c0_mp4_T"][s], g["c0_mp4_Rt2"][s], g["c0_mp4_Rt3"][s], g["c0_mp4_iter"][s]
+        d, dit, mit = min((max(rel_err_T(Tt[b], T4[c]), rel_err(R2[b], R24[c]), rel_err(R3[b], R34[c])), abs(int(it[b]) - int(it4[c])), int(it4[c]))
+                          for c in range(4) if it4[c] >= 0)
+        assert (mit > 1 or b > 0) and dit == 0 and d < 1e-9, (s, d, dit, mit)

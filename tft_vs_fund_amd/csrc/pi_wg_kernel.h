@@ -10,8 +10,83 @@
 
 namespace tff {
 
-// + 6N: the strong direction of every 4 x 4 weight block (n, cs, n'w), see the factored weights below (Pi only; PiCol carries the room unused)
-__host__ __device__ inline int pi_wg_lds_doubles(int E, int C, int N) { return pi_lds_doubles(E, C, N, true) + 6 * N + 16; }
+// + SN N: the strong direction(s) of every weight block, see the factored weights below -- Pi (4 x 4 blocks, one near-null direction): n (4), cs,
+// n'w; PiCol (5 x 5 blocks, five equations for three independent constraints: TWO near-null directions): n1, n2 (5 each), cs1, cs2, n1'w, n2'w
+__host__ __device__ constexpr int pi_sn(int E) { return (E == 4) ? 6 : 14; }
+__host__ __device__ inline int pi_wg_lds_doubles(int E, int C, int N) { return pi_lds_doubles(E, C, N, true) + pi_sn(E) * N + 16; }
+
+// pinv(B B' + 1e-12 I) of a 5 x 5 block with TWO near-null directions, at the accuracy of the formula (the two-direction form of
+// pinv_block_deflated, gh_kernel.h).  The near-null SUBSPACE is well determined (gap to the third eigenvalue ~ O(1)); inside it the two
+// eigenvalues mu_k + 1e-12 (1e-12 .. 1e-9) are separated by less than the rounding of an fp64 B B', so their eigenvectors are taken from
+// the 2 x 2 problem G'G, G = B'[u1 u2] (6 x 2), whose entries are squared inconsistencies formed WITHOUT cancellation:
+//   u1, u2   orthonormal basis of the subspace (smallest eigenvector of W, then of W + tr(W) u1 u1')
+//   G'G = R diag(mu1, mu2) R'   (one Jacobi rotation),  n_k = [u1 u2] r_k
+//   K  = (W + n1 n1' + n2 n2')^-1                     Cholesky of a well conditioned matrix
+//   pinv = K - sum_k n_k n_k' / (1 + mu_k + 1e-12)  (REGULAR part, returned in Wp)  + sum_k cs_k n_k n_k',  cs_k = 1 / (mu_k + 1e-12) or 0 if truncated
+// false when the block does not have that structure (third-smallest eigenvalue not far above, failed factorisation, no convergence).
+template <int E>
+__device__ __forceinline__ bool pinv_block_deflated2(const double (&B)[E][6], const double (&W)[E][E], const double tolW, double* Wp,
+                                                     double (&n1)[E], double (&n2)[E], double* cs1, double* cs2) {
+    double u1[E], u2[E], W2[E][E], tr = 0.0;
+    // (eight inverse iterations each, converged or not: inside the near-null subspace the iterate may keep drifting -- the two eigenvalues can
+    // agree to many digits -- but its component outside decays by (mu / lambda_3)^8, and the structure test below bounds that ratio by 1e-3)
+    spd_min_eigvec<E>(W, u1, 8);
+#pragma unroll
+    for (int a = 0; a < E; ++a) tr += W[a][a];
+#pragma unroll
+    for (int a = 0; a < E; ++a)
+#pragma unroll
+        for (int c = 0; c < E; ++c) W2[a][c] = W[a][c] + tr * u1[a] * u1[c];
+    spd_min_eigvec<E>(W2, u2, 8);
+    double d = 0.0, nn = 0.0;
+#pragma unroll
+    for (int a = 0; a < E; ++a) d += u1[a] * u2[a];
+#pragma unroll
+    for (int a = 0; a < E; ++a) { u2[a] -= d * u1[a]; nn += u2[a] * u2[a]; }
+    const double rn = rsqrt(nn);
+#pragma unroll
+    for (int a = 0; a < E; ++a) u2[a] *= rn;
+    double m11 = 0.0, m12 = 0.0, m22 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double g1 = 0.0, g2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < E; ++a) { g1 += B[a][k] * u1[a]; g2 += B[a][k] * u2[a]; }
+        m11 += g1 * g1; m12 += g1 * g2; m22 += g2 * g2;
+    }
+    double cr = 1.0, sr = 0.0, mu1 = m11, mu2 = m22;
+    if (m12 != 0.0) {
+        const double tau = (m22 - m11) / (2.0 * m12);
+        const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+        cr = rsqrt(1.0 + t * t); sr = t * cr;
+        mu1 = m11 - t * m12; mu2 = m22 + t * m12;
+    }
+    mu1 = (mu1 > 0.0) ? mu1 : 0.0; mu2 = (mu2 > 0.0) ? mu2 : 0.0;
+#pragma unroll
+    for (int a = 0; a < E; ++a) { n1[a] = cr * u1[a] - sr * u2[a]; n2[a] = sr * u1[a] + cr * u2[a]; }
+    double Wn[E][E];
+#pragma unroll
+    for (int a = 0; a < E; ++a)
+#pragma unroll
+        for (int c = 0; c < E; ++c) Wn[a][c] = W[a][c] + n1[a] * n1[c] + n2[a] * n2[c];
+    if (!(nn > 1e-8) || !spd_inverse_packed<E>(Wn, Wp)) return false;
+    const double l1 = mu1 + 1e-12, l2 = mu2 + 1e-12, k1 = 1.0 / (1.0 + l1), k2 = 1.0 / (1.0 + l2);
+    double fro2 = 0.0;                                                       // |regular part|_F^2 = sum over the ordinary directions of 1 / (lambda_k + 1e-12)^2
+#pragma unroll
+    for (int a = 0; a < E; ++a)
+#pragma unroll
+        for (int c = 0; c <= a; ++c) {
+            const double v = Wp[a * (a + 1) / 2 + c] - n1[a] * n1[c] * k1 - n2[a] * n2[c] * k2;
+            Wp[a * (a + 1) / 2 + c] = v;
+            fro2 += (a == c) ? v * v : 2.0 * v * v;
+        }
+    const double mum = (mu1 > mu2) ? mu1 : mu2;
+    const double l3min = 1e-5 * tr + 1e3 * mum;                              // third-smallest eigenvalue >= 1 / |.|_F: far above both small ones
+    if (!(fro2 * l3min * l3min < 1.0)) return false;
+    *cs1 = (l1 > tolW) ? 1.0 / l1 : 0.0;
+    *cs2 = (l2 > tolW) ? 1.0 / l2 : 0.0;
+    return true;
+}
 
 // pinv's tolerance E N eps(max_i lambda_max(W_i)) for the block-diagonal weight matrix (Gauss_Helmert.m:57).  Only the binade of the
 // maximum enters: the eigenvalue pass is skipped when cheap upper / lower bounds agree on it.  Block-wide (contains barriers).
@@ -95,7 +170,8 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
         //      inconsistency of the correspondence: tiny, while cs ~ 1e12).  Sums: 27 * 28 / 2 + 27 = 405, thirteen butterflies per
         //      wavefront into partial slots (V, H: both dead here), combined into S = V[0 .. 405).
         bool factored = false;
-        if constexpr (E == 4 && !Model::PINV_KKT) {
+        constexpr int SN = pi_sn(E);
+        {
             if (!exact_pinv && g.sn != nullptr) {
                 const double tolW = pi_block_tolerance<Model>(g, pi, N, tid, red);
                 constexpr int SLOT = 406;
@@ -105,49 +181,64 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
 #pragma unroll 1
                 for (int base = 0; base < N; base += GH_WG_THREADS) {        // block-uniform trip count (the butterflies need whole wavefronts)
                     const int i = base + tid;
-                    double bv[27], tv = 0.0;
+                    double bv[27], tv = 0.0, bv2[27], tv2 = 0.0;
 #pragma unroll
-                    for (int k = 0; k < 27; ++k) bv[k] = 0.0;
+                    for (int k = 0; k < 27; ++k) { bv[k] = 0.0; bv2[k] = 0.0; }
                     if (i < N) {
-                        double o[6], W[E][E], Wp[NW], nn[4], cs = 0.0;
+                        double o[6], W[E][E], Wp[NW], nn[E], nm[E], cs = 0.0, cs2 = 0.0;
 #pragma unroll
                         for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
                         PiPoint<E> pt;
                         pi_eval<Model, true>(pi, o, pt);
                         pi_block_W<E>(pt.B, W);
-                        const bool ok = pinv_block_deflated<true>(pt.B, W, tolW, Wp, nn, &cs);
+                        bool ok;
+                        if constexpr (E == 4) {
+                            ok = pinv_block_deflated<true>(pt.B, W, tolW, Wp, nn, &cs);
+#pragma unroll
+                            for (int a = 0; a < E; ++a) nm[a] = 0.0;
+                        } else {
+                            ok = pinv_block_deflated2<E>(pt.B, W, tolW, Wp, nn, nm, &cs, &cs2);
+                        }
                         bad = !ok || bad;
 #pragma unroll
                         for (int a = 0; a < E; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
                         pi_store_point<E>(g, w, pts, i, o, pt, Wp);
                         const Pt6 x = premap(load_pt(pts, i), w->nrm);
-                        double nw = 0.0;                                     // n'w,  w = -f - B (x - xi)
+                        double nw = 0.0, nw2 = 0.0;                          // n'w,  w = -f - B (x - xi)
 #pragma unroll
                         for (int a = 0; a < E; ++a) {
                             double wa = -pt.f[a];
 #pragma unroll
                             for (int k = 0; k < 6; ++k) wa -= pt.B[a][k] * (x.v[k] - o[k]);
                             nw += nn[a] * wa;
+                            nw2 += nm[a] * wa;
                         }
-                        double* sn = g.sn + 6 * (long)i;
-                        sn[0] = nn[0]; sn[1] = nn[1]; sn[2] = nn[2]; sn[3] = nn[3]; sn[4] = ok ? cs : 0.0; sn[5] = nw;
+                        double* sn = g.sn + SN * (long)i;
+                        if constexpr (E == 4) {
+                            sn[0] = nn[0]; sn[1] = nn[1]; sn[2] = nn[2]; sn[3] = nn[3]; sn[4] = ok ? cs : 0.0; sn[5] = nw;
+                        } else {
+#pragma unroll
+                            for (int a = 0; a < E; ++a) { sn[a] = nn[a]; sn[E + a] = nm[a]; }
+                            sn[2 * E] = ok ? cs : 0.0; sn[2 * E + 1] = ok ? cs2 : 0.0; sn[2 * E + 2] = nw; sn[2 * E + 3] = nw2;
+                        }
                         if (ok) {
                             Model::a_quirk(pt.c);
-                            const double sc = sqrt(cs);
+                            const double sc = sqrt(cs), sc2 = sqrt(cs2);
 #pragma unroll
                             for (int b = 0; b < 9; ++b) {                    // a[3 b + k] = (sum_r n_r c[r][b]) p_view(b)[k]
-                                double an = 0.0;
+                                double an = 0.0, an2 = 0.0;
 #pragma unroll
                                 for (int r = 0; r < E; ++r)
-                                    if (Model::nz(r, b)) an += nn[r] * pt.c[r][b];
-                                an *= sc;
+                                    if (Model::nz(r, b)) { an += nn[r] * pt.c[r][b]; an2 += nm[r] * pt.c[r][b]; }
+                                an *= sc; an2 *= sc2;
 #pragma unroll
-                                for (int k = 0; k < 3; ++k) bv[3 * b + k] = an * hom_at(o, b / 3, k);
+                                for (int k = 0; k < 3; ++k) { bv[3 * b + k] = an * hom_at(o, b / 3, k); bv2[3 * b + k] = an2 * hom_at(o, b / 3, k); }
                             }
-                            tv = sc * nw;
+                            tv = sc * nw; tv2 = sc2 * nw2;
                         }
                     }
                     strong_accumulate<27>(bv, tv, slot);
+                    if constexpr (E == 5) strong_accumulate<27>(bv2, tv2, slot);   // kept apart from the first: adding the products before the butterflies saves 4 % and moves the worst fixture scene from 7e-10 to 1.7e-9
                 }
                 __syncthreads();
                 for (int e = tid; e < 405; e += GH_WG_THREADS) g.V[e] = (g.V[e] + g.V[SLOT + e]) + (g.V[2 * SLOT + e] + g.H[e]);
@@ -285,12 +376,19 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
                 for (int b = 0; b < E; ++b) s += sym_at<E>(pw, a, b) * Ad[b];
                 rr[a] = s;
             }
-            if constexpr (E == 4) {
-                if (factored) {                                              // + cs n (n'(A dt) - n'w): the strong direction of W+
-                    const double* sn = g.sn + 6 * (long)i;
+            if (factored) {                                                  // + cs n (n'(A dt) - n'w): the strong direction(s) of W+
+                const double* sn = g.sn + SN * (long)i;
+                if constexpr (E == 4) {
                     const double st = sn[4] * ((sn[0] * Ad[0] + sn[1] * Ad[1] + sn[2] * Ad[2] + sn[3] * Ad[3]) - sn[5]);
 #pragma unroll
                     for (int a = 0; a < 4; ++a) rr[a] += sn[a] * st;
+                } else {
+                    double d1 = -sn[2 * E + 2], d2 = -sn[2 * E + 3];
+#pragma unroll
+                    for (int a = 0; a < E; ++a) { d1 += sn[a] * Ad[a]; d2 += sn[E + a] * Ad[a]; }
+                    d1 *= sn[2 * E]; d2 *= sn[2 * E + 1];
+#pragma unroll
+                    for (int a = 0; a < E; ++a) rr[a] += sn[a] * d1 + sn[E + a] * d2;
                 }
             }
             const Pt6 x = premap(load_pt(pts, i), w->nrm);
@@ -342,7 +440,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::PINV_KKT ? 4 : 2) k_pi_b
         const double* pts = a.corresp + b * 6 * (long)N;
         PiWork g = pi_carve(ghbase, Model::E, Model::C, a.spill ? 0 : N, true);
         g.sn = g.pp + (long)pi_pp(Model::E) * (a.spill ? 0 : N);
-        double* red = g.sn + 6 * (long)(a.spill ? 0 : N);
+        double* red = g.sn + (long)pi_sn(Model::E) * (a.spill ? 0 : N);
         if (a.spill) { g.xi = a.spill + blockIdx.x * a.spill_stride; g.pp = g.xi + 6 * (long)N; g.sn = g.pp + (long)pi_pp(Model::E) * N; }
         const int own = pick_serial_wave(red);
         const double* r = a.rec + b * GH_REC_DOUBLES;
