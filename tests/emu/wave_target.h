@@ -25,6 +25,7 @@ typedef double* lds_ptr;
 inline lds_ptr to_lds(double* p) { return p; }
 inline double fast_rcp(double v) { return 1.0 / v; }
 inline int opaque_int(int v) { return v; }
+inline int opaque_lane_int(int v) { return v; }
 inline int hw_simd_id() { return (int)((threadIdx.x >> 6) & 3u); }
 inline int hw_workgroup_slot() { return (int)(blockIdx.x & 15u); }
 inline void sched_fence() {}
@@ -57,6 +58,14 @@ inline double dpp_mov_keep(double v) {
     const double got = emu_dbl(emu::exchange(emu_bits(v), s < 0 ? emu_lane() : s));
     return s < 0 ? v : got;
 }
+// DP-ALU DPP row_newbcast operands (csrc/wave_target.h): lane J of the caller's row of 16
+template <int J, int WAIT = 2>
+inline double fnmac_row_bcast(double acc, double src, double mul) {
+    const double got = emu_dbl(emu::exchange(emu_bits(src), (emu_lane() & ~15) | J));
+    return std::fma(got, -mul, acc);
+}
+template <int J>
+inline double row_bcast(double v) { return emu_dbl(emu::exchange(emu_bits(v), (emu_lane() & ~15) | J)); }
 // v_permlane32_swap / v_permlane16_swap followed by the sum of the two results (see csrc/wave_target.h)
 template <int MASK>
 inline double swap_sum(double a, double b) {

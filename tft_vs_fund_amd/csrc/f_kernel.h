@@ -322,15 +322,17 @@ __device__ inline bool linear_f_wave(PoseLds* w, JacobiLdsF* jw, const double* p
             x = wave_qr_min_rsv<9>(g, jw->A, jw->V, w->Lp, EIG_MAXIT, &its);
             its += 10000;
         } else {
-            double g[9], diag = 0.0;
-            const int r = (lane < 9) ? lane : 0, i = r / 3, j = r % 3;
+            double g[9], none[1] = {0.0}, diag = 0.0;                        // every row of 16 lanes holds the matrix (row_eig.h)
+            const int rp = lane & 15;
+            const bool have = rp < 9;
+            const int r = have ? rp : 0, i = r / 3, j = r % 3;
 #pragma unroll
             for (int c = 0; c < 9; ++c) {
-                g[c] = w->mom[36 * pair + 6 * hht_index(i, c / 3) + hht_index(j, c % 3)];
+                g[c] = have ? w->mom[36 * pair + 6 * hht_index(i, c / 3) + hht_index(j, c % 3)] : 0.0;
                 diag = (c == r) ? g[c] : diag;
             }
             double r2, risk;
-            x = wave_min_eigvec_reg<9>(g, diag, w->Lp, EIG_MAXIT, &its, &r2, false, 0.0, &risk);
+            x = row_min_eigvec<9>(g, none, diag, 0.0, w->Lp, EIG_MAXIT, &its, &r2, false, 0.0, 0.0, &risk);
             ok = ok && eig_converged(r2) && risk == 0.0;
         }
         if (dbg && lane == 0) dbg[69 + pair] = (double)its;

@@ -64,6 +64,8 @@ inline size_t optimf_lds_bytes(int N, int flags, bool jacobi) {
 // Batches of fewer correspondences per triplet than this go to the exact kernel as a whole (minimal samples: the two smallest singular
 // values of the design matrix nearly coincide too often for the flag-and-redo path to pay).  TFF_OPT_EXACT_BELOW overrides.
 constexpr int EXACT_BELOW_N = 12;
+// one workgroup per triplet: the hardware dispatcher balances better than a persistent grid with a stride loop (measured round 3, 10 000 x 200:
+// 0.420 ms against 0.439 ms with 2048 workgroups, 0.426 with 4096, 0.786 with 1024; LinearF 0.332 against 0.492 / 0.357 / 0.703)
 inline unsigned pose_grid(long B) { return (unsigned)((B < (1L << 30)) ? (B > 0 ? B : 1) : (1L << 30)); }
 
 }  // namespace tff

@@ -6,6 +6,7 @@
 #include "wave.h"
 #include "small_la.h"
 #include "wave_eig.h"
+#include "row_eig.h"
 #include "wave_qr.h"
 
 namespace tff {

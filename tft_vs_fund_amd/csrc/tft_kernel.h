@@ -234,11 +234,25 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double
             }
             it1 += 10000;
         } else {
-            double g[27], diag;
-            gram_row27(w->mom, (lane < 27) ? lane : 0, g, diag);
-            phase_stamp(dbg, 3, wl);
             double r2, risk;
-            x = wave_min_eigvec_reg<27, G>(g, diag, w->Lp, EIG_MAXIT, &it1, &r2, false, 0.0, &risk);
+            if constexpr (G == 64) {                                         // rows p and 16 + p of G on every position p of a row of 16 lanes (row_eig.h)
+                const int p = opaque_lane_int(lane & 15);                    // (the rows' index tables are rebuilt per triplet, not kept across the loop)
+                const bool hi = p < 11;
+                double ga[27], gb[27], g0[16], da, db;
+                gram_row27(w->mom, p, ga, da);
+                gram_row27(w->mom, hi ? 16 + p : 0, gb, db);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) g0[c] = ga[c];
+#pragma unroll
+                for (int c = 0; c < 27; ++c) gb[c] = hi ? gb[c] : 0.0;
+                phase_stamp(dbg, 3, wl);
+                x = row_min_eigvec<27>(g0, gb, da, hi ? db : 0.0, w->Lp, EIG_MAXIT, &it1, &r2, false, 0.0, 0.0, &risk);
+            } else {
+                double g[27], diag;
+                gram_row27(w->mom, (lane < 27) ? lane : 0, g, diag);
+                phase_stamp(dbg, 3, wl);
+                x = wave_min_eigvec_reg<27, G>(g, diag, w->Lp, EIG_MAXIT, &it1, &r2, false, 0.0, &risk);
+            }
             ok = ok && eig_converged(r2) && risk == 0.0;
         }
         if (lane < 27) w->t[lane] = x;
@@ -306,22 +320,29 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double
     phase_stamp(dbg, 6, wl);
     {                                                                        // :84
         double g[15], diag = 0.0, x;
-        const int r = (lane < 15) ? lane : 0;
+        const int rr = (G == 64) ? (lane & 15) : lane;                       // G == 64: every row of 16 lanes holds the matrix (row_eig.h)
+        const bool have = rr < 15;
+        const int r = have ? rr : 0;
 #pragma unroll
-        for (int c = 0; c < 15; ++c) { g[c] = (c <= r) ? Gp[tri_index(r, c)] : 0.0; diag = (c == r) ? g[c] : diag; }
+        for (int c = 0; c < 15; ++c) { g[c] = (c <= r && have) ? Gp[tri_index(r, c)] : 0.0; diag = (c == r) ? g[c] : diag; }
         wave_sync();
         // start from the unconstrained solution projected onto range(E): tp0 = Up' t (9 non-zeros per basis vector).  The
         // constrained tensor differs from it at noise level, which saves one of the four inverse iterations.
         double tp0 = 0.0;
-        if (lane < 15) {
-            const int i = lane / 5, m = lane % 5, jj = (m < 3) ? 0 : m - 2, kk = (m < 3) ? m : 0;
+        if (have) {
+            const int i = r / 5, m = r % 5, jj = (m < 3) ? 0 : m - 2, kk = (m < 3) ? m : 0;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) tp0 += w->Q[3 * j + jj] * w->Q[9 + 3 * k + kk] * w->t[j + 3 * k + 9 * i];
         }
         double r2, risk;
-        x = wave_min_eigvec_reg<15, G>(g, diag, w->Lp, EIG_MAXIT, &it2, &r2, true, tp0, &risk);
+        if constexpr (G == 64) {
+            double none[1] = {0.0};
+            x = row_min_eigvec<15>(g, none, diag, 0.0, w->Lp, EIG_MAXIT, &it2, &r2, true, tp0, 0.0, &risk);
+        } else {
+            x = wave_min_eigvec_reg<15, G>(g, diag, w->Lp, EIG_MAXIT, &it2, &r2, true, tp0, &risk);
+        }
         ok = ok && eig_converged(r2) && risk == 0.0;
         if (lane < 15) w->tp[lane] = x;
         wave_sync();
@@ -364,7 +385,7 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double
 
 // linearTFT.m:33-91 on the normalised correspondences (data pass + the rest), whole wavefront.
 template <bool JAC>
-__device__ inline bool linear_tft_wave(PoseLds* w, JacobiLds* jw, const double* pts, int N, bool want_P, double* dbg) {
+__device__ __forceinline__ bool linear_tft_wave(PoseLds* w, JacobiLds* jw, const double* pts, int N, bool want_P, double* dbg) {
     if (!JAC) accumulate_moments(w, pts, N);
     phase_stamp(dbg, 2);
     return linear_tft_middle<JAC, 64>(w, jw, pts, N, want_P, dbg);

@@ -43,6 +43,9 @@ __device__ __forceinline__ lds_ptr to_lds(double* p) { return (lds_ptr)p; }
 __device__ __forceinline__ double fast_rcp(double v) { return __builtin_amdgcn_rcp(v); }
 // a wave-uniform integer the optimiser cannot see through (keeps a loop with a small constant trip count rolled)
 __device__ __forceinline__ int opaque_int(int v) { asm volatile("" : "+s"(v)); return v; }
+// the same for a per-lane integer: index arithmetic derived from it is redone where it is used instead of being hoisted out of the
+// enclosing loop and kept (or spilled) across its whole body
+__device__ __forceinline__ int opaque_lane_int(int v) { asm volatile("" : "+v"(v)); return v; }
 // the value is computed HERE, in a vector register: keeps the optimiser from sinking the arithmetic that produces it towards a distant use
 // (which would stretch the live ranges of all its operands instead)
 __device__ __forceinline__ void pin_value(double& v) { asm volatile("" : "+v"(v)); }
@@ -75,6 +78,26 @@ __device__ __forceinline__ double dpp_mov_keep(double v) {
     lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
+}
+// DP-ALU DPP (gfx90a+): a 64-bit VALU operand read from lane J of the caller's row of 16 lanes (row_newbcast:J) inside the instruction.
+//   fnmac_row_bcast<J>(acc, src, mul) = fma(src[row | J], -mul, acc)      one v_fmac_f64_dpp
+//   row_bcast<J>(v)                   = v[row | J]                        one v_mov_b64_dpp
+// WAIT: wait states inserted in front.  A VGPR written by a VALU instruction may be read through DPP two issue slots later at the earliest
+// and nothing tells the assembler what precedes an asm statement: 2 is always safe, 0 is for a source the caller knows to be older (the
+// statements are volatile: they stay in program order among themselves).
+template <int J, int WAIT = 2>
+__device__ __forceinline__ double fnmac_row_bcast(double acc, double src, double mul) {
+    static_assert(J >= 0 && J < 16 && (WAIT == 0 || WAIT == 2), "lane of a row of 16");
+    if constexpr (WAIT == 2) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
+    else asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
+    return acc;
+}
+template <int J>
+__device__ __forceinline__ double row_bcast(double v) {
+    static_assert(J >= 0 && J < 16, "lane of a row of 16");
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(J));
+    return r;
 }
 // v_permlane32_swap / v_permlane16_swap (gfx950) do the keep/send exchange of one halving step in place:
 // swap(a, b) -> r0 = {a on the lower half-blocks, b's lower half-blocks moved up}, r1 = {a's upper half-blocks moved down,
