@@ -18,6 +18,7 @@ inline double wave_shfl_xor(double v, int mask) { return emu_dbl(emu::exchange(e
 inline int wave_shfl_xor_i(int v, int mask) { return (int)emu::exchange((uint64_t)(uint32_t)v, emu_lane() ^ mask); }
 inline double wave_bcast(double v, int src) { return emu_dbl(emu::exchange(emu_bits(v), src)); }
 inline int wave_bcast_i(int v, int src) { return (int)emu::exchange((uint64_t)(uint32_t)v, src); }
+inline double wave_shfl(double v, int src) { return emu_dbl(emu::exchange(emu_bits(v), src)); }
 inline double half_bcast(double v, int src) { return emu_dbl(emu::exchange(emu_bits(v), (emu_lane() & 32) | src)); }
 inline double wave_uniform(double v) { return v; }
 inline int wave_uniform_i(int v) { return v; }

@@ -114,6 +114,63 @@ struct RowBackward {
     }
 };
 
+// Inverse iteration with the row-scaled unit factor L' (wave_invit_unit's algorithm and tests) in the row-of-16 layout.  Lp: the factor in LDS
+// (n x n, row-major, zeros on and above the diagonal); g0 / g1: the position's rows of it (zero rows on positions without a matrix row),
+// myinv0 / myinv1 = 1 / L[r][r] of those rows (0 without one).  x0 / x1: the start on entry, the unit eigenvector on return.
+// risk[0] / risk[1] (optional): wave_invit_unit's gap_risk numerator and denominator.
+template <int n>
+__device__ __forceinline__ void row_invit_core(double (&g0)[RowEigDims<n>::N0], const double (&g1)[RowEigDims<n>::N1], const double* Lp,
+                                               const double myinv0, const double myinv1, double& x0, double& x1, const int maxit,
+                                               int* iters, double* resid2, double* risk) {
+    constexpr int N0 = RowEigDims<n>::N0;
+    constexpr bool HI = RowEigDims<n>::HI;
+    const int p = lane_id() & 15;
+    const bool valid0 = p < n, valid1 = HI && 16 + p < n;
+    const int q0 = valid0 ? p : n - 1, q1 = valid1 ? 16 + p : n - 1;         // column n - 1 of a strictly lower triangular matrix: zeros
+    double c0[n], c1[n];                                                     // (entries the substitution never touches are never loaded)
+#pragma unroll
+    for (int j = 0; j < n; ++j) { c0[j] = Lp[j * n + q0]; c1[j] = HI ? Lp[j * n + q1] : 0.0; }
+    double rprev2 = 1.0, res = 1.0, rk_r2 = 0.0, rk_rp = 1.0, rk_nn = 0.0;
+    int it = 0;
+    bool done = false;
+#pragma unroll 1
+    while (true) {
+        double y0 = x0 * myinv0, y1 = x1 * myinv1;
+        if constexpr (HI) {                                 // the lo rows come back from the LDS copy every iteration: 2 N0 fewer registers live across the
+            const double* rows = Lp + opaque_int(0);        // backward substitution, where the register demand peaks (rows + columns of both halves)
+#pragma unroll
+            for (int c = 0; c < N0; ++c) g0[c] = rows[q0 * n + c];         // (n > 16: every position has a lo row)
+        }
+        RowForward<n, 0>::run(y0, y1, g0, g1);
+        RowBackward<n, n - 1>::run(y0, y1, c0, c1);
+        y0 *= myinv0; y1 *= myinv1;
+        const double nn = row_sum16(y0 * y0 + y1 * y1);
+        const double dot = row_sum16(y0 * x0 + y1 * x1);
+        const double rn = rsqrt(nn);
+        const double sc = (dot < 0.0) ? -rn : rn;
+        const double yn0 = y0 * sc, yn1 = y1 * sc;
+        const double dd0 = yn0 - x0, dd1 = yn1 - x1;
+        const double r2 = row_sum16(dd0 * dd0 + dd1 * dd1);
+        if (!done) {                                        // the same tests as wave_invit_unit
+            x0 = yn0; x1 = yn1;
+            ++it;
+            if (r2 <= 1e-26) { res = 0.0; done = true; }
+            else if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) { res = 0.0; done = true; }
+            else if (!(r2 == r2) || it >= maxit) { res = (r2 == r2) ? r2 : 1.0; done = true; }
+            if (it >= 2 && r2 > 1e-30) { rk_r2 = r2; rk_rp = rprev2; rk_nn = nn; }
+            rprev2 = r2;
+        }
+        if (wave_uniform_i(done ? 1 : 0)) break;            // every lane holds the same r2 (replicated rows of 16): no vote needed
+    }
+    *iters = it;
+    *resid2 = res;
+    if (risk) {
+        risk[0] = 4.0 * rk_nn * rk_r2 * rk_rp;
+        const double d = rk_rp - rk_r2;
+        risk[1] = (rk_r2 < rk_rp) ? d * d : 0.0;
+    }
+}
+
 // g0[c] = G[p][c] (c <= p), g1[c] = G[16 + p][c] (c <= 16 + p; zeros when 16 + p >= n), d0 / d1 the rows' diagonal entries (0 for a row
 // that does not exist), p = lane & 15, the same in all four rows of 16 lanes.  start0 / start1 (has_start): the initial guess, components p
 // and 16 + p.  Lp: n * n doubles of LDS.  Outputs as wave_min_eigvec_reg: lane r < n returns component r of the unit eigenvector (0 on the
@@ -123,7 +180,7 @@ __device__ inline double row_min_eigvec(double (&g0)[RowEigDims<n>::N0], double 
                                         double* Lp, const int maxit, int* iters, double* resid2, const bool has_start = false,
                                         const double start0 = 0.0, const double start1 = 0.0, double* gram_risk = nullptr,
                                         const double gram_risk_limit2 = 1e14) {
-    constexpr int N0 = RowEigDims<n>::N0, N1 = RowEigDims<n>::N1;
+    constexpr int N0 = RowEigDims<n>::N0;
     constexpr bool HI = RowEigDims<n>::HI;
     const int lane = lane_id(), p = lane & 15;
     const bool valid0 = p < n, valid1 = HI && 16 + p < n;
@@ -159,56 +216,40 @@ __device__ inline double row_min_eigvec(double (&g0)[RowEigDims<n>::N0], double 
         }
     }
     wave_sync();
-    const int q0 = valid0 ? p : n - 1, q1 = valid1 ? 16 + p : n - 1;         // column n - 1 of a strictly lower triangular matrix: zeros
-    double c0[n], c1[n];                                                     // (entries the substitution never touches are never loaded)
-#pragma unroll
-    for (int j = 0; j < n; ++j) { c0[j] = Lp[j * n + q0]; c1[j] = HI ? Lp[j * n + q1] : 0.0; }
     double x0 = valid0 ? rsqrt((double)n) : 0.0, x1 = valid1 ? rsqrt((double)n) : 0.0;
     if (has_start) {                                        // a zero / non-finite guess falls back to the uniform vector
         const double s0 = valid0 ? start0 : 0.0, s1 = valid1 ? start1 : 0.0;
         const double nn0 = row_sum16(s0 * s0 + s1 * s1);
         if (nn0 > 1e-300 && nn0 < 1e300) { const double r0 = rsqrt(nn0); x0 = s0 * r0; x1 = s1 * r0; }
     }
-    double rprev2 = 1.0, res = 1.0, rk_r2 = 0.0, rk_rp = 1.0, rk_nn = 0.0;
-    int it = 0;
-    bool done = false;
-#pragma unroll 1
-    while (true) {
-        double y0 = x0 * myinv0, y1 = x1 * myinv1;
-        if constexpr (HI) {                                 // the lo rows come back from the LDS copy every iteration: 2 N0 fewer registers live across the
-            const double* rows = Lp + opaque_int(0);        // backward substitution, where the register demand peaks (rows + columns of both halves)
+    double risk[2] = {0.0, 1.0};
+    row_invit_core<n>(g0, g1, Lp, myinv0, myinv1, x0, x1, maxit, iters, resid2, gram_risk ? risk : nullptr);
+    if (gram_risk) *gram_risk = (tr * tr * risk[0] < gram_risk_limit2 * risk[1]) ? 0.0 : 1.0;
+    return (lane < 16) ? x0 : ((lane < 32 && lane < n) ? x1 : 0.0);
+}
+
+// The same iteration for a factor that already sits in LDS in wave_invit_unit's form (wave_qr.h: L = R' of a QR factorisation): Lp (n x n,
+// row-major, row-scaled, zeros on and above the diagonal), myinv = 1 / L[lane][lane] on lane `lane` < n.  Uniform start.  Lane r < n returns
+// component r of the unit eigenvector.
+template <int n>
+__device__ inline double row_invit_unit(const double* Lp, const double myinv, const int maxit, int* iters, double* resid2) {
+    constexpr int N0 = RowEigDims<n>::N0, N1 = RowEigDims<n>::N1;
+    constexpr bool HI = RowEigDims<n>::HI;
+    const int lane = lane_id(), p = lane & 15;
+    const bool valid0 = p < n, valid1 = HI && 16 + p < n;
+    const double m0 = wave_shfl(myinv, valid0 ? p : 0), m1 = wave_shfl(myinv, valid1 ? 16 + p : 0);
+    const double myinv0 = valid0 ? m0 : 0.0, myinv1 = valid1 ? m1 : 0.0;
+    double g0[N0], g1[N1];
 #pragma unroll
-            for (int c = 0; c < N0; ++c) g0[c] = rows[q0 * n + c];
-        }
-        RowForward<n, 0>::run(y0, y1, g0, g1);
-        RowBackward<n, n - 1>::run(y0, y1, c0, c1);
-        y0 *= myinv0; y1 *= myinv1;
-        const double nn = row_sum16(y0 * y0 + y1 * y1);
-        const double dot = row_sum16(y0 * x0 + y1 * x1);
-        const double rn = rsqrt(nn);
-        const double sc = (dot < 0.0) ? -rn : rn;
-        const double yn0 = y0 * sc, yn1 = y1 * sc;
-        const double dd0 = yn0 - x0, dd1 = yn1 - x1;
-        const double r2 = row_sum16(dd0 * dd0 + dd1 * dd1);
-        if (!done) {                                        // the same tests as wave_invit_unit
-            x0 = yn0; x1 = yn1;
-            ++it;
-            if (r2 <= 1e-26) { res = 0.0; done = true; }
-            else if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) { res = 0.0; done = true; }
-            else if (!(r2 == r2) || it >= maxit) { res = (r2 == r2) ? r2 : 1.0; done = true; }
-            if (it >= 2 && r2 > 1e-30) { rk_r2 = r2; rk_rp = rprev2; rk_nn = nn; }
-            rprev2 = r2;
-        }
-        if (!wave_any(!done)) break;
+    for (int c = 0; c < N0; ++c) { const double v = Lp[(valid0 ? p : 0) * n + c]; g0[c] = valid0 ? v : 0.0; }
+    if constexpr (HI) {
+#pragma unroll
+        for (int c = 0; c < n; ++c) { const double v = Lp[(valid1 ? 16 + p : 0) * n + c]; g1[c] = valid1 ? v : 0.0; }
+    } else {
+        g1[0] = 0.0;
     }
-    *iters = it;
-    *resid2 = res;
-    if (gram_risk) {
-        const double num = 4.0 * rk_nn * rk_r2 * rk_rp;
-        const double d = rk_rp - rk_r2;
-        const double den = (rk_r2 < rk_rp) ? d * d : 0.0;
-        *gram_risk = (tr * tr * num < gram_risk_limit2 * den) ? 0.0 : 1.0;
-    }
+    double x0 = valid0 ? rsqrt((double)n) : 0.0, x1 = valid1 ? rsqrt((double)n) : 0.0;
+    row_invit_core<n>(g0, g1, Lp, myinv0, myinv1, x0, x1, maxit, iters, resid2, nullptr);
     return (lane < 16) ? x0 : ((lane < 32 && lane < n) ? x1 : 0.0);
 }
 

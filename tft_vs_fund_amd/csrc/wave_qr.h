@@ -16,6 +16,7 @@
 #pragma once
 #include "wave.h"
 #include "wave_eig.h"
+#include "row_eig.h"
 
 namespace tff {
 
@@ -181,7 +182,7 @@ __device__ inline double wave_qr_min_rsv(const double (&g)[n], double* Rm, doubl
     const double myinv = wave_qr_to_factor<n>(g, Rm, Lp);
     int it = 0;
     double r2 = 0.0;
-    double x = wave_invit_unit<n, 64>(Lp, myinv, maxit, &it, &r2);
+    double x = row_invit_unit<n>(Lp, myinv, maxit, &it, &r2);                 // (row_eig.h: the DPP form of wave_invit_unit)
     if (!eig_converged(r2)) {
         wave_sync();
         int sw = 0;

@@ -24,6 +24,8 @@ __device__ __forceinline__ double wave_bcast(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int wave_bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+// any lane's value, the source chosen per lane: ds_bpermute (LDS crossbar)
+__device__ __forceinline__ double wave_shfl(double v, int src) { return __shfl(v, src, 64); }
 // lane (l & 32) | src of the caller's own half-wavefront: the source differs between the halves -> ds_bpermute
 __device__ __forceinline__ double half_bcast(double v, int src) { return __shfl(v, ((int)(threadIdx.x & 32u)) | src, 64); }
 // v holds the same value in every lane: move it to scalar registers (v_readfirstlane) so that it costs SGPRs, not VGPRs,
