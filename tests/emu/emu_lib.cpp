@@ -225,6 +225,56 @@ extern "C" int emu_trid_pinv(const double* Maug, const double* tol, long B, int 
     return 0;
 }
 
+// row_min_eigvec<n> (csrc/row_eig.h: Cholesky + inverse iteration with DP-ALU DPP row_newbcast operands, two matrix rows per position of a
+// row of 16 lanes) and wave_min_eigvec_reg<n> (csrc/wave_eig.h: the v_readlane form it replaced, one matrix row per lane) on the same
+// symmetric positive semi-definite matrices G (B x n x n, row-major): smallest eigenvectors (B x n), iteration counts, convergence flags.
+namespace {
+struct RowEigArgs { const double* G; int n; double* x_row; double* x_lane; int* its_row; int* its_lane; int* conv_row; int* conv_lane; };
+template <int n>
+__device__ void emu_row_eig_one(const RowEigArgs& a, double* Lp) {
+    const int b = blockIdx.x, lane = tff::lane_id(), p = lane & 15;
+    const double* G = a.G + (long)b * n * n;
+    {
+        constexpr int N0 = tff::RowEigDims<n>::N0, N1 = tff::RowEigDims<n>::N1;
+        double g0[N0], g1[N1], d0 = 0.0, d1 = 0.0;
+        const bool v0 = p < n, v1 = n > 16 && 16 + p < n;
+        for (int c = 0; c < N0; ++c) g0[c] = v0 ? G[(v0 ? p : 0) * n + c] : 0.0;
+        for (int c = 0; c < N1; ++c) g1[c] = (v1 && c < n) ? G[(16 + p) * n + c] : 0.0;
+        if (v0) d0 = G[p * n + p];
+        if (v1) d1 = G[(16 + p) * n + 16 + p];
+        int it = 0; double r2 = 1.0, risk = 0.0;
+        const double x = tff::row_min_eigvec<n>(g0, g1, d0, d1, Lp, 40, &it, &r2, false, 0.0, 0.0, &risk);
+        if (lane < n) a.x_row[(long)b * n + lane] = x;
+        if (lane == 0) { a.its_row[b] = it; a.conv_row[b] = (r2 == 0.0) ? 1 : 0; }
+    }
+    tff::wave_sync();
+    {
+        double g[n], diag = 0.0;
+        const int r = (lane < n) ? lane : 0;
+        for (int c = 0; c < n; ++c) { g[c] = G[r * n + c]; if (c == r) diag = g[c]; }
+        int it = 0; double r2 = 1.0, risk = 0.0;
+        const double x = tff::wave_min_eigvec_reg<n>(g, diag, Lp, 40, &it, &r2, false, 0.0, &risk);
+        if (lane < n) a.x_lane[(long)b * n + lane] = x;
+        if (lane == 0) { a.its_lane[b] = it; a.conv_lane[b] = (r2 == 0.0) ? 1 : 0; }
+    }
+}
+__global__ void k_emu_row_eig(RowEigArgs a) {
+    TFF_DYNAMIC_LDS(double, smem);
+    if (a.n == 27) emu_row_eig_one<27>(a, smem);
+    else if (a.n == 15) emu_row_eig_one<15>(a, smem);
+    else if (a.n == 9) emu_row_eig_one<9>(a, smem);
+    else if (a.n == 16) emu_row_eig_one<16>(a, smem);
+    else if (a.n == 17) emu_row_eig_one<17>(a, smem);
+    else emu_row_eig_one<32>(a, smem);
+}
+}  // namespace
+extern "C" int emu_row_eig(const double* G, long B, int n, double* x_row, double* x_lane, int* its_row, int* its_lane, int* conv_row, int* conv_lane) {
+    if (n != 27 && n != 15 && n != 9 && n != 16 && n != 17 && n != 32) return -1;
+    RowEigArgs a{G, n, x_row, x_lane, its_row, its_lane, conv_row, conv_lane};
+    emu::launch(k_emu_row_eig, (unsigned)B, 64, sizeof(double) * (size_t)(n * n + 64), a);
+    return 0;
+}
+
 // NordbergModel::init on caller-supplied linearTFT output (t 27, a 18, epipoles 6): the initial 19 parameters and the
 // rank flag -- exercises the projective fix-up for a rank-deficient P2(:,1:3) / P3(:,1:3) (NordbergTFTPoseEstimation.m:56-62),
 // which no correspondence set reaches through the whole pipeline (it needs sigma_3 <= 3 eps(sigma_1) in the linear solution).

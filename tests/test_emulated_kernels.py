@@ -460,3 +460,36 @@ def test_emulated_picol_block_kernel_reproduces_the_extended_precision_iteration
         d, dit, mit = min((max(rel_err_T(Tt[b], T4[c]), rel_err(R2[b], R24[c]), rel_err(R3[b], R34[c])), abs(int(it[b]) - int(it4[c])), int(it4[c]))
                           for c in range(4) if it4[c] >= 0)
         assert (mit > 1 or b > 0) and dit == 0 and d < 1e-9, (s, d, dit, mit)
+
+
+@pytest.mark.parametrize("n", [9, 15, 16, 17, 27, 32])
+def test_emulated_row_eigvec_dpp_form_matches_the_readlane_form_and_lapack(emu, n):
+    """row_min_eigvec<n> (csrc/row_eig.h: every cross-lane operand through v_fmac_f64 row_newbcast, two matrix rows per position of a row of
+    16 lanes, the four rows of 16 bit-identical replicas) against wave_min_eigvec_reg<n> (the v_readlane form, one row per lane) and
+    numpy.linalg.eigh: V(:,end) of the reference's svd calls (linearTFT.m:64-67, :84, linearF.m:54-55).  Sizes in use: 9, 15, 27; 16 / 17 / 32
+    are the layout's edge cases (a full lo half, a hi half of one row, both halves full).  The two forms perform the same operations per matrix
+    entry in the same order -- only the reductions (norms) are summed in a different order -- so they agree to a few ulps and iterate equally."""
+    rng = np.random.default_rng(n)
+    B = 6
+    Gs = []
+    for b in range(B):
+        A = rng.standard_normal((4 * n, n))
+        U, sv, Vt = np.linalg.svd(A, full_matrices=False)
+        sv[-1] = sv[-2] * (0.02 if b < 4 else 0.3)                                           # sigma_n / sigma_(n-1): the kernels' typical gap, and a slow one
+        if b == 5: sv[-1] = 0.0                                                              # exactly singular (minimal samples)
+        A = (U * sv) @ Vt
+        Gs.append(A.T @ A)
+    G = np.ascontiguousarray(np.stack(Gs))
+    xr = np.zeros((B, n)); xl = np.zeros((B, n))
+    ir = np.zeros(B, dtype=np.int32); il = np.zeros(B, dtype=np.int32); cr = np.zeros(B, dtype=np.int32); cl = np.zeros(B, dtype=np.int32)
+    assert emu.emu_row_eig(_p(G), ctypes.c_long(B), ctypes.c_int(n), _p(xr), _p(xl), _p(ir), _p(il), _p(cr), _p(cl)) == 0
+    for b in range(B):
+        w, V = np.linalg.eigh(G[b])
+        v = V[:, 0]
+        assert cr[b] == 1 and cl[b] == 1, (b, ir[b], il[b])
+        assert abs(np.linalg.norm(xr[b]) - 1.0) < 1e-14
+        gap = (w[1] - w[0]) / w[-1]
+        tol = 1e-15 / gap + 1e-13                                                            # eigenvector of a formed Gram matrix: eps |G| / gap
+        assert min(np.abs(xr[b] - v).max(), np.abs(xr[b] + v).max()) < tol, (b, gap)
+        assert min(np.abs(xr[b] - xl[b]).max(), np.abs(xr[b] + xl[b]).max()) < 1e-13 + tol
+        assert abs(int(ir[b]) - int(il[b])) <= 1, (b, ir[b], il[b])
