@@ -41,12 +41,13 @@ def test_host_multi_equals_single_device(method):
     m.close()
 
 
-def test_dev_multi_gathers_records_on_every_device():
+@pytest.mark.parametrize("B", [37, 1])                                         # 37: uneven last shard for G >= 2; 1: empty shards for G >= 2 (B < G)
+def test_dev_multi_gathers_records_on_every_device(B):
     import torch
     from tft_vs_fund_amd import api
     from tft_vs_fund_amd.scenes import generate_scene_batch
     G = _devices()
-    B, N = 37, 30
+    N = 30
     C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=23)
     ref = api.Context(0).pose_batch("LinearTFTPoseEstimation", C, CalM, reconst=False)
     m = api.MultiContext(list(range(G)))
