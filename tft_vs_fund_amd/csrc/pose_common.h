@@ -561,6 +561,97 @@ __device__ __attribute__((noinline)) int tri_vote_fast(PoseLds* w, const double*
     }
     return 2 * wave_sum_i(score) + (wave_any(!all_certain) ? 1 : 0);
 }
+// The fast tier for the TWO rotation candidates of one essential matrix in one pass over the correspondences (same second view, same
+// camera K1 [I|0]): the point is loaded once and camera 1's two rows and their share of S11 are formed once -- a quarter of the per-point
+// instructions of the second candidate.  Same arithmetic per candidate as tri_vote_fast.  Returns tri_vote_fast's value for candidate 0 in
+// the low and for candidate 1 in the high 16 bits (|score| <= 2 N <= 2^14 is the caller's business: it falls back to two single passes beyond).
+struct VoteCam { double PB[12], R3[4]; };
+__device__ __forceinline__ void vote_one(const double (&SA)[6], const VoteCam& cam, const double x2, const double y2, int& score, bool& all_certain) {
+    double b0[4], b1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { b0[c] = y2 * cam.PB[8 + c] - cam.PB[4 + c]; b1[c] = cam.PB[c] - x2 * cam.PB[8 + c]; }
+    double S[4][3];                                                          // lower triangle of A'A, columns 0..2
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (c > r) continue;
+            double v = b0[r] * b0[c] + b1[r] * b1[c];
+            if (r < 3) v += SA[r * (r + 1) / 2 + c];
+            S[r][c] = v;
+        }
+    const double S33 = b0[3] * b0[3] + b1[3] * b1[3];
+    const double tr3 = S[0][0] + S[1][1] + S[2][2];
+    const double delta = 1e-14 * (tr3 + S33), pfloor = 1e-3 * delta + 1e-300;
+    double L[4][3], inv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double d = S[j][j] + delta;
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        d = (d > pfloor) ? d : pfloor;
+        inv[j] = rsqrt(d);
+#pragma unroll
+        for (int r = j + 1; r < 4; ++r) {
+            double sv = S[r][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sv -= L[r][k] * L[j][k];
+            L[r][j] = sv * inv[j];
+        }
+    }
+    double z[3];
+#pragma unroll
+    for (int r = 2; r >= 0; --r) {
+        double sum = -L[3][r];
+#pragma unroll
+        for (int k = r + 1; k < 3; ++k) sum -= L[k][r] * z[k];
+        z[r] = sum * inv[r];
+    }
+    const double d1 = z[2], d2 = cam.R3[0] * z[0] + cam.R3[1] * z[1] + cam.R3[2] * z[2] + cam.R3[3];
+    const double d4 = S33 + delta - (L[3][0] * L[3][0] + L[3][1] * L[3][1] + L[3][2] * L[3][2]);
+    const double zz = z[0] * z[0] + z[1] * z[1] + z[2] * z[2];
+    const double idet = (inv[0] * inv[1]) * (inv[0] * inv[1]) * (inv[2] * inv[2]);
+    const double trs = tr3 + 3.0 * delta;
+    const double e = trs * trs * idet;
+    const double Gp = 4.0 * (1.0 + zz) - d4 * e;
+    const double rhs = 2.0 * d4 * e + 2.5e-14 * trs * e * Gp;
+    const double dmin2 = fmin(d1 * d1, d2 * d2);
+    const bool certain = Gp > 0.0 && dmin2 * Gp * Gp > rhs * rhs * zz;      // false for NaN / inf
+    all_certain = all_certain && certain;
+    score += (int)sgn(d1) + (int)sgn(d2);
+}
+__device__ __attribute__((noinline)) int tri_vote_fast2(PoseLds* w, const double* pts, int N, int view, const double* camB0, const double* Rt0,
+                                                        const double* camB1, const double* Rt1) {
+    const int lane = lane_id();
+    double PA[12];
+    VoteCam c0, c1;
+    load_uniform12(w->Pfin[0], PA);                                          // PA[3] = PA[7] = PA[11] = 0
+    load_uniform12(camB0, c0.PB);
+#pragma unroll
+    for (int c = 0; c < 12; ++c) c1.PB[c] = camB1[c];                        // (the second camera stays in vector registers: three cameras do not fit the scalar file)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { c0.R3[c] = wave_uniform(Rt0[8 + c]); c1.R3[c] = Rt1[8 + c]; }
+    int score0 = 0, score1 = 0;
+    bool certain0 = true, certain1 = true;
+    Pt6 pnext = load_pt(pts, (lane < N) ? lane : 0);
+#pragma unroll 1
+    for (int i = lane; i < N; i += WAVE) {
+        const Pt6 p = pnext;
+        if (i + WAVE < N) pnext = load_pt(pts, i + WAVE);
+        const double x1 = p.v[0], y1 = p.v[1], x2 = (view == 1) ? p.v[2] : p.v[4], y2 = (view == 1) ? p.v[3] : p.v[5];
+        double a0[3], a1[3], SA[6];                                          // rows [0 -1 y; 1 0 -x] * P1 and their A'A   (triangulation3D.m:58-59)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a0[c] = y1 * PA[8 + c] - PA[4 + c]; a1[c] = PA[c] - x1 * PA[8 + c]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) SA[r * (r + 1) / 2 + c] = a0[r] * a0[c] + a1[r] * a1[c];
+        vote_one(SA, c0, x2, y2, score0, certain0);
+        vote_one(SA, c1, x2, y2, score1, certain1);
+    }
+    const int r0 = 2 * wave_sum_i(score0) + (wave_any(!certain0) ? 1 : 0), r1 = 2 * wave_sum_i(score1) + (wave_any(!certain1) ? 1 : 0);
+    return (int)(((unsigned)r1 << 16) | ((unsigned)r0 & 0xffffu));
+}
 // exact tier: every correspondence from its converged homogeneous point  (R_t_from_TFT.m:98-99)
 __device__ __attribute__((noinline)) int tri_vote_exact(PoseLds* w, const double* pts, int N, int view, const double* camB, const double* Rt) {
     const int lane = lane_id();
@@ -772,8 +863,17 @@ __device__ inline int recover_vote(PoseLds* w, const double* pts, int N, double*
     bool certified = true;
 #pragma unroll 1
     for (int call = 0; call < 2; ++call) {
-        const int sR = tri_vote<EXACT>(w, pts, N, call + 1, w->P[2 * call], w->candRt[2 * call], &certified);
-        const int sRp = tri_vote<EXACT>(w, pts, N, call + 1, w->P[2 * call + 1], w->candRt[2 * call + 1], &certified);
+        int sR, sRp;
+        if (N <= 4096) {                                                     // both candidates in one pass (|2 score + 1| < 2^15)
+            const int both = tri_vote_fast2(w, pts, N, call + 1, w->P[2 * call], w->candRt[2 * call], w->P[2 * call + 1], w->candRt[2 * call + 1]);
+            const int r0 = (int)(short)(both & 0xffff), r1 = both >> 16;     // wave-uniform
+            sR = r0 >> 1; sRp = r1 >> 1;
+            if (r0 & 1) { if (EXACT) sR = tri_vote_exact(w, pts, N, call + 1, w->P[2 * call], w->candRt[2 * call]); else certified = false; }
+            if (r1 & 1) { if (EXACT) sRp = tri_vote_exact(w, pts, N, call + 1, w->P[2 * call + 1], w->candRt[2 * call + 1]); else certified = false; }
+        } else {
+            sR = tri_vote<EXACT>(w, pts, N, call + 1, w->P[2 * call], w->candRt[2 * call], &certified);
+            sRp = tri_vote<EXACT>(w, pts, N, call + 1, w->P[2 * call + 1], w->candRt[2 * call + 1], &certified);
+        }
         // reference order: k=1 (R,t), k=2 (R,-t), k=3 (Rp,-t), k=4 (Rp,t)   (:92-104)
         const int score[4] = {sR, -sR, -sRp, sRp};
         int seen = 0, pick = -1;
