@@ -855,7 +855,10 @@ __device__ inline void recover_prepare(PoseLds* w, const double* Ein) {
 }
 
 // ok (optional, EXACT = false): set to false when a score could not be certified by the fast tier.
-template <bool EXACT = true>
+// FUSE: both rotation candidates of a call in one pass (tri_vote_fast2).  That function needs 194 registers and a callee's count is its
+// callers': right for the kernels that run two wavefronts per SIMD anyway (the trifocal ones), wrong for the fundamental-matrix kernels,
+// which run three at <= 168 (measured: LinearF 291 -> 314 us, OptimF 1219 -> 1345 us with it) -- they keep the single passes.
+template <bool EXACT = true, bool FUSE = true>
 __device__ inline int recover_vote(PoseLds* w, const double* pts, int N, double* dbg, bool* ok = nullptr) {
     const int lane = lane_id();
     phase_stamp(dbg, 10);
@@ -864,7 +867,7 @@ __device__ inline int recover_vote(PoseLds* w, const double* pts, int N, double*
 #pragma unroll 1
     for (int call = 0; call < 2; ++call) {
         int sR, sRp;
-        if (N <= 4096) {                                                     // both candidates in one pass (|2 score + 1| < 2^15)
+        if (FUSE && N <= 4096) {                                             // both candidates in one pass (|2 score + 1| < 2^15)
             const int both = tri_vote_fast2(w, pts, N, call + 1, w->P[2 * call], w->candRt[2 * call], w->P[2 * call + 1], w->candRt[2 * call + 1]);
             const int r0 = (int)(short)(both & 0xffff), r1 = both >> 16;     // wave-uniform
             sR = r0 >> 1; sRp = r1 >> 1;
@@ -893,10 +896,10 @@ __device__ inline int recover_vote(PoseLds* w, const double* pts, int N, double*
     return status;
 }
 
-template <bool EXACT = true>
+template <bool EXACT = true, bool FUSE = true>
 __device__ inline int recover_poses(PoseLds* w, const double* Ein, const double* pts, int N, double* dbg, bool* ok = nullptr) {
     recover_prepare<64>(w, Ein);
-    return recover_vote<EXACT>(w, pts, N, dbg, ok);
+    return recover_vote<EXACT, FUSE>(w, pts, N, dbg, ok);
 }
 
 // t3 scale, R_t_from_TFT.m:68-74 == LinearFPoseEstimation.m:64-70.  Scales w->Rt[1](:,4) in place.
