@@ -14,7 +14,10 @@ namespace tff {
 
 constexpr int WAVE = 64;
 
-__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+// (opaque: one workgroup handles one triplet, so what the optimiser hoists out of the kernels' triplet loops -- dozens of lane predicates as
+// 64-bit scalar masks -- is used once and has to be spilled to vector lanes and read back: ~1000 v_writelane / v_readlane per triplet in
+// k_linear_tft_pose.  A lane index the optimiser cannot see through stays where it is asked for; loops INSIDE a function still see it as invariant.)
+__device__ __forceinline__ int lane_id() { return opaque_lane_int((int)(threadIdx.x & 63u)); }
 __device__ __forceinline__ int wave_in_block() { return (int)(threadIdx.x >> 6); }
 
 // Coarse phase stamps for the *_debug_dev entry points (shader clock, lane 0):
