@@ -334,7 +334,7 @@ template <int C0, class SP>
 __device__ inline void fp_rotated_sums(const FpLds& s, const SP xi, const SP pp, const int N, double* slot) {
     constexpr int U = 27 - C0;
     constexpr int total = U * (U + 1) / 2 + U;
-    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    const int tid = thread_in_block(), lane = lane_id(), wave = wave_in_block();
     for (int e = lane; e < ((total + 1) & ~1); e += WAVE) slot[e] = 0.0;
     wave_sync();
 #pragma unroll 1
@@ -366,7 +366,7 @@ __device__ inline void fp_rotated_sums(const FpLds& s, const SP xi, const SP pp,
 // Returns the iteration count (:82); *st: ST_OK, ST_NONFINITE, or ST_RETRY (not this kernel's case).
 template <class SP>
 __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pts, const int N, const SP xi, const SP pp, int* st, double* dbg) {
-    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    const int tid = thread_in_block(), lane = lane_id(), wave = wave_in_block();
     const bool owner = wave == own;
     const int waves = (N < GH_WG_THREADS) ? (N + WAVE - 1) / WAVE : GH_WG_WAVES;   // wavefronts that hold correspondences in the rotated pass
     double objFunc = 0.0;                                                    // v0' v0, v0 = x0 - x   (:45-46)
@@ -735,7 +735,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, FP_WG_PER_CU) k_fp_block(const 
     typedef typename FpState<STATE_IN_LDS>::ptr SP;
     TFF_DYNAMIC_LDS(double, smem);
     FpLds& s = *reinterpret_cast<FpLds*>(smem);
-    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    const int tid = thread_in_block(), lane = lane_id(), wave = wave_in_block();
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
         __syncthreads();
         if (a.status[b] != ST_OK) continue;                                  // block-uniform

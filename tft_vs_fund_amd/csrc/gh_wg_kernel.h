@@ -210,7 +210,7 @@ __device__ inline void gh_block_reproject(PoseLds* w, const double* pts, int N, 
     load_uniform12(w->P[0], PB);
     load_uniform12(w->P[1], PC);
 #pragma unroll 1
-    for (int i = threadIdx.x; i < N; i += GH_WG_THREADS) {
+    for (int i = thread_in_block(); i < N; i += GH_WG_THREADS) {
         const Pt6 p = premap(load_pt(pts, i), w->nrm);
         double X[4];
         dlt_point<true>(PA, PB, PC, w->Pfin[0], w->P[0], w->P[1], true, p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], p.v[5], X);
@@ -230,7 +230,7 @@ __device__ inline void gh_block_reproject(PoseLds* w, const double* pts, int N, 
 template <class Model>
 __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Model& model, int own, const double* pts, int N,
                                           int* st, bool exact_pinv, double* dbg) {
-    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    const int tid = thread_in_block(), lane = lane_id(), wave = wave_in_block();
     constexpr int u = Model::U, c = Model::C, n = u + c, ld = n + 1;
     const bool owner = wave == own;
     double* sdbg = owner ? dbg : nullptr;                                    // phase stamps of the first iteration (debug entry point)
@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::WG_PER_CU) k_gh_block(co
     PoseLds* w = reinterpret_cast<PoseLds*>(smem);
     constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
     double* ghbase = smem + base;
-    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    const int tid = thread_in_block(), lane = lane_id(), wave = wave_in_block();
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
         __syncthreads();
         // block-uniform: too few points / unresolved; FLAG_ONLY_RETRY: the triplets a specialised block kernel handed over (gh_fp_kernel.h)

@@ -130,7 +130,7 @@ __device__ inline double pi_block_tolerance(const PiWork& g, const double (&pi)[
 template <class Model>
 __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red, int own, const double* pts, int N, int* st, bool exact_pinv) {
     constexpr int E = Model::E, C = Model::C, u = 27, n = u + C, ld = n + 1, PP = pi_pp(E), NW = E * (E + 1) / 2;
-    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    const int tid = thread_in_block(), lane = lane_id(), wave = wave_in_block();
     const bool owner = wave == own;
     double objFunc = 0.0;                                                    // v0' v0, v0 = x0 - x   (:45-46)
     for (int i = tid; i < N; i += GH_WG_THREADS) {
@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::PINV_KKT ? 4 : 2) k_pi_b
     PoseLds* w = reinterpret_cast<PoseLds*>(smem);
     constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
     double* ghbase = smem + base;
-    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    const int tid = thread_in_block(), lane = lane_id(), wave = wave_in_block();
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
         __syncthreads();
         if (a.status[b] != ST_OK) continue;

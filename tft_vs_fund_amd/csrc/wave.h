@@ -18,7 +18,8 @@ constexpr int WAVE = 64;
 // 64-bit scalar masks -- is used once and has to be spilled to vector lanes and read back: ~1000 v_writelane / v_readlane per triplet in
 // k_linear_tft_pose.  A lane index the optimiser cannot see through stays where it is asked for; loops INSIDE a function still see it as invariant.)
 __device__ __forceinline__ int lane_id() { return opaque_lane_int((int)(threadIdx.x & 63u)); }
-__device__ __forceinline__ int wave_in_block() { return (int)(threadIdx.x >> 6); }
+__device__ __forceinline__ int wave_in_block() { return opaque_lane_int((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ int thread_in_block() { return opaque_lane_int((int)threadIdx.x); }
 
 // Coarse phase stamps for the *_debug_dev entry points (shader clock, lane 0):
 // dbg[80 + slot].  A null dbg (every production entry point) skips them.
