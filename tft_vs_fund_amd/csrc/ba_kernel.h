@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(64, 1) k_bundle_adjust(const BaArgs a) {
     double* Xc = smem + base + ((BA_LDS_DOUBLES + 1) & ~1);                  // current points (3N), then trial points (3N)
     const int lane = lane_id();
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
-        const int N = a.N;
+        const int N = opaque_int(a.N);                                       // (not hoisted out of the one-trip triplet loop: tft_kernel.h)
         double* Xt = Xc + 3 * N;
         const double* pts = a.corresp + b * 6 * (long)N;
         wave_sync();

@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(64, (METHOD == 1 && !JAC) ? 3 : 2) k_f_pose(co
     const int lane = lane_id();
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
         if ((a.flags & FLAG_ONLY_RETRY) && a.status[b] != ST_RETRY) continue;      // wave-uniform
-        const int N = a.N;
+        const int N = opaque_int(a.N);                                       // (not hoisted out of the one-trip triplet loop: tft_kernel.h)
         double* dbg = a.dbg ? a.dbg + b * DBG_STRIDE : nullptr;
         const double* src = a.corresp + b * 6 * (long)N;
         const double* pts = src;
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(64, 2) k_linear_f(const LinearFOnlyArgs a) {
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
         if ((a.flags & FLAG_ONLY_RETRY) && a.status[b] != ST_RETRY) continue;
         wave_sync();
-        const int N = a.N;
+        const int N = opaque_int(a.N);                                       // (not hoisted out of the one-trip triplet loop: tft_kernel.h)
         const double* pts = a.corresp + b * 6 * (long)N;
         int st = ST_OK, iters = 0;
         if (N < 8) {                                                         // linearF.m:35-37, optimF.m:36-38

@@ -739,7 +739,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, FP_WG_PER_CU) k_fp_block(const 
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
         __syncthreads();
         if (a.status[b] != ST_OK) continue;                                  // block-uniform
-        const int N = a.N;
+        const int N = opaque_int(a.N);                                       // (not hoisted out of the one-trip triplet loop: tft_kernel.h)
         const double* pts = a.corresp + b * 6 * (long)N;
         SP xi, pp;                                                           // per-correspondence state: LDS, or the block's global slice
         if constexpr (STATE_IN_LDS) xi = to_lds(smem + FP_LDS_DOUBLES);

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(64, 2) k_gh_linear(const GhWgArgs a) {
     const int lane = lane_id();
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
         if ((a.flags & FLAG_ONLY_RETRY) && a.status[b] != ST_RETRY) continue;
-        const int N = a.N;
+        const int N = opaque_int(a.N);                                       // (not hoisted out of the one-trip triplet loop: tft_kernel.h)
         const double* pts = a.corresp + b * 6 * (long)N;
         wave_sync();
         if (a.flags & FLAG_STAGE_LDS) { stage_points(pts, lds_pts, N); pts = lds_pts; }
@@ -553,7 +553,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::WG_PER_CU) k_gh_block(co
         __syncthreads();
         // block-uniform: too few points / unresolved; FLAG_ONLY_RETRY: the triplets a specialised block kernel handed over (gh_fp_kernel.h)
         if ((a.flags & FLAG_ONLY_RETRY) ? (a.status[b] != ST_RETRY) : (a.status[b] != ST_OK)) continue;
-        const int N = a.N;
+        const int N = opaque_int(a.N);                                       // (not hoisted out of the one-trip triplet loop: tft_kernel.h)
         const double* pts = a.corresp + b * 6 * (long)N;
         double* red;
         GhWork g = gh_wg_carve(ghbase, w, Model::U, Model::C, a.spill ? 0 : N, Model::REDUNDANT_CONSTRAINTS, &red);
@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(64, 2) k_gh_finish(const GhWgArgs a) {
     const int lane = lane_id();
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
-        const int N = a.N;
+        const int N = opaque_int(a.N);                                       // (not hoisted out of the one-trip triplet loop: tft_kernel.h)
         const double* pts = a.corresp + b * 6 * (long)N;
         wave_sync();
         const int s0 = a.status[b];

@@ -921,7 +921,7 @@ __global__ void __launch_bounds__(64, 1) k_pi_tft_pose(const LinearTftArgs a) {
     const int lane = lane_id();
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
         if ((a.flags & FLAG_ONLY_RETRY) && a.status[b] != ST_RETRY) continue;
-        const int N = a.N;
+        const int N = opaque_int(a.N);                                       // (not hoisted out of the one-trip triplet loop: tft_kernel.h)
         double* dbg = a.dbg ? a.dbg + b * DBG_STRIDE : nullptr;
         const double* pts = a.corresp + b * 6 * (long)N;
         wave_sync();

@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::PINV_KKT ? 4 : 2) k_pi_b
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
         __syncthreads();
         if (a.status[b] != ST_OK) continue;
-        const int N = a.N;
+        const int N = opaque_int(a.N);                                       // (not hoisted out of the one-trip triplet loop: tft_kernel.h)
         const double* pts = a.corresp + b * 6 * (long)N;
         PiWork g = pi_carve(ghbase, Model::E, Model::C, a.spill ? 0 : N, true);
         g.sn = g.pp + (long)pi_pp(Model::E) * (a.spill ? 0 : N);

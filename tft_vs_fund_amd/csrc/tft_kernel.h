@@ -451,8 +451,10 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose(const LinearTftArgs a
     double* lds_pts = smem + base + (JAC ? ((JACOBI_LDS_DOUBLES + 1) & ~1) : 0);
     const int lane = lane_id();
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
-        if ((a.flags & FLAG_ONLY_RETRY) && a.status[b] != ST_RETRY) continue;      // wave-uniform
-        const int N = a.N;
+        // (opaque: the loop makes one trip per workgroup; what the optimiser derives from N and the flags ahead of it -- N * 6, N < 7,
+        // flag tests as scalar masks, ... -- would be computed in the pre-header and spilled across the whole body, see wave.h::lane_id)
+        const int N = opaque_int(a.N), flags = opaque_int(a.flags);
+        if ((flags & FLAG_ONLY_RETRY) && a.status[b] != ST_RETRY) continue;        // wave-uniform
         double* dbg = a.dbg ? a.dbg + b * DBG_STRIDE : nullptr;
         const double* src = a.corresp + b * 6 * (long)N;
         const double* pts = src;
@@ -461,7 +463,7 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose(const LinearTftArgs a
         if (a.sample_idx) {
             bad_index = gather_points(a.corresp, a.sample_idx + b * (long)N, lds_pts, N, a.sample_ns);
             pts = lds_pts;
-        } else if (a.flags & FLAG_STAGE_LDS) {
+        } else if (flags & FLAG_STAGE_LDS) {
             stage_points(src, lds_pts, N);
             pts = lds_pts;
         }
