@@ -617,7 +617,11 @@ __global__ void __launch_bounds__(64, 2) k_gh_finish(const GhWgArgs a) {
         if (lane < 9) w->nrm[lane] = a.rec[b * GH_REC_DOUBLES + 51 + lane];
         wave_sync();
         transform_tft_inverse(w->t, w->T1, w->Lp, [w](int v) { return normal_matrix(w->nrm, v); });
-        int status = rt_from_tft_wave(w, pts, N, nullptr);
+        // fast tiers first (certified votes, inverse-iteration null vectors and DLT points: what k_linear_tft_pose<false> runs); the exact
+        // tiers redo the triplet only when one of them could not finish or certify its part (wave-uniform)
+        bool fine = true;
+        int status = rt_from_tft_wave<false>(w, pts, N, nullptr, &fine);
+        if (!fine) status = rt_from_tft_wave<true>(w, pts, N, nullptr);
         if (s0 < 0) status = -s0;
         write_poses(w, a.Rt2 + b * 12, a.Rt3 + b * 12);
         if (lane < 27) a.T[b * 27 + lane] = w->T1[lane];

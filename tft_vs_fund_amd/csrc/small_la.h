@@ -524,6 +524,18 @@ __device__ __forceinline__ bool null3(const Mat3& M, double (&x)[3]) {
         });
     } else {
         spd_min_eigvec<3>(S, x, 40, &conv);
+        // The eigenvector of a FORMED M'M carries eps tr / (lambda_2 - lambda_3): fine for generic slices (lambda_2 ~ 1e-2 tr), seven digits
+        // short for the nearly rank-one slices of collinear camera centres (R_t_3 4.7e-7 off at N = 200 before this test).  Report a gap
+        // under 1e-7 tr -- the limit of the 27 x 27 solve's gram_risk flag -- as "not finished": with s = lambda_1 + lambda_2 = tr - rho and
+        // p = lambda_1 lambda_2 = c2 - rho s (c2: the sum of the principal 2 x 2 minors), z = rho + 1e-7 tr lies below lambda_2 iff
+        // q(z) = z^2 - s z + p > 0 and z < s / 2.  No square root, ~25 operations.
+        const double tr = S[0][0] + S[1][1] + S[2][2];
+        double rho = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rho += x[i] * (S[i][0] * x[0] + S[i][1] * x[1] + S[i][2] * x[2]);
+        const double c2 = (S[0][0] * S[1][1] - S[0][1] * S[0][1]) + (S[0][0] * S[2][2] - S[0][2] * S[0][2]) + (S[1][1] * S[2][2] - S[1][2] * S[1][2]);
+        const double sm = tr - rho, z = rho + 1e-7 * tr;
+        conv = conv && (z * z - sm * z + (c2 - rho * sm) > 0.0) && (z + z < sm);
     }
     if (EXACT && !conv) {
         double A[3][3];
