@@ -270,7 +270,8 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
     // FaugPapa: the factored iteration of gh_fp_kernel.h (one correspondence per thread, N <= 256) unless an A/B switch asks for the generic kernel
     const bool fp_first = std::is_same<Model, tff::FaugPapaModel>::value && c->kernel_variant == 0 && !c->gh_exact;
     // occupancy policy of the per-correspondence state (plan_spill): Nordberg runs as fast with it in LDS at two workgroups per CU as with it in global
-    // slices at three (3.89 vs 3.87 ms per 10 k x 200) -- and moves 2x instead of 63x the algorithmic bytes through HBM
+    // slices at three (3.89 vs 3.87 ms per 10 k x 200) -- without the state's HBM round trips (what is left of its 52x algorithmic traffic is scratch:
+    // the 168-register build spills 368 registers, and is still faster than the 256-register one, 3.69 vs 3.90 ms)
     const int occupancy_cap = std::is_same<Model, tff::NordbergModel>::value ? 2 : Model::WG_PER_CU;
     return launch_wg(c, tff::k_gh_block<Model>, wg_lds, occupancy_cap, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg, fp_first);
 }
