@@ -185,7 +185,7 @@ __device__ __attribute__((noinline)) bool epipoles_from_tensor(const double* t, 
                 if (lane < 3) M.m[j][k] = v; else M.m[k][j] = v;             // T(:,:,i) or its transpose
             }
         double x[3];
-        ok = null3<EXACT>(M, x);
+        ok = null3<EXACT, true>(M, x);
         nullv[3 * lane + 0] = x[0]; nullv[3 * lane + 1] = x[1]; nullv[3 * lane + 2] = x[2];
     }
     wave_sync();
@@ -196,7 +196,7 @@ __device__ __attribute__((noinline)) bool epipoles_from_tensor(const double* t, 
 #pragma unroll
             for (int k = 0; k < 3; ++k) M.m[i][k] = nullv[9 * lane + 3 * i + k];
         double x[3];
-        ok = null3<EXACT>(M, x) && ok;
+        ok = null3<EXACT, true>(M, x) && ok;
         if (fix_sign) { const double sg = sgn(x[2]); x[0] *= sg; x[1] *= sg; x[2] *= sg; }
         double* dst = (lane == 0) ? (epi + 3) : epi;                         // lane 0: right nulls -> e31; lane 1: left -> e21
         dst[0] = x[0]; dst[1] = x[1]; dst[2] = x[2];

@@ -505,7 +505,10 @@ __device__ __forceinline__ void svd3(const Mat3& E, Mat3& U, Mat3& V, double (&s
 // right null vector of a 3x3 matrix M: smallest eigenvector of M'M.  When its inverse iteration hits the cap (nearly
 // coincident smallest singular values, rare), EXACT = true finishes with the one-sided Jacobi on M itself, EXACT = false
 // only reports it (returns false) so that the caller can hand the triplet to the exact kernel.
-template <bool EXACT = true>
+// GAP_CHECK (fast tier only): see below -- for the callers whose matrices are well scaled (calibrated tensor slices, unit null vectors).  The
+// fundamental-matrix kernels project pixel-coordinate F matrices (singular values 1, 1e-5, 0: lambda_2 ~ 1e-10 tr by construction, and a
+// null vector that only enters a correction of size sigma_3) and do not ask for it.
+template <bool EXACT = true, bool GAP_CHECK = false>
 __device__ __forceinline__ bool null3(const Mat3& M, double (&x)[3]) {
     double S[3][3];
 #pragma unroll
@@ -524,6 +527,7 @@ __device__ __forceinline__ bool null3(const Mat3& M, double (&x)[3]) {
         });
     } else {
         spd_min_eigvec<3>(S, x, 40, &conv);
+        if constexpr (GAP_CHECK) {
         // The eigenvector of a FORMED M'M carries eps tr / (lambda_2 - lambda_3): fine for generic slices (lambda_2 ~ 1e-2 tr), seven digits
         // short for the nearly rank-one slices of collinear camera centres (R_t_3 4.7e-7 off at N = 200 before this test).  Report a gap
         // under 1e-7 tr -- the limit of the 27 x 27 solve's gram_risk flag -- as "not finished": with s = lambda_1 + lambda_2 = tr - rho and
@@ -536,6 +540,7 @@ __device__ __forceinline__ bool null3(const Mat3& M, double (&x)[3]) {
         const double c2 = (S[0][0] * S[1][1] - S[0][1] * S[0][1]) + (S[0][0] * S[2][2] - S[0][2] * S[0][2]) + (S[1][1] * S[2][2] - S[1][2] * S[1][2]);
         const double sm = tr - rho, z = rho + 1e-7 * tr;
         conv = conv && (z * z - sm * z + (c2 - rho * sm) > 0.0) && (z + z < sm);
+        }
     }
     if (EXACT && !conv) {
         double A[3][3];
