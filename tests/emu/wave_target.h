@@ -32,6 +32,11 @@ inline int hw_workgroup_slot() { return (int)(blockIdx.x & 15u); }
 inline void sched_fence() {}
 inline void pin_value(double&) {}
 inline long long shader_clock() { return 0; }
+inline bool wave_vote_any(bool p) {
+    int c = p ? 1 : 0;
+    for (int m = 32; m >= 1; m >>= 1) c |= wave_shfl_xor_i(c, m);
+    return c != 0;
+}
 inline int wave_first_lane(bool p) {
     int c = p ? emu_lane() : 64;
     for (int m = 32; m >= 1; m >>= 1) { const int o = wave_shfl_xor_i(c, m); c = (o < c) ? o : c; }

@@ -64,7 +64,7 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     for (int m = 32; m >= 1; m >>= 1) v += wave_shfl_xor_i(v, m);
     return v;
 }
-__device__ __forceinline__ bool wave_any(bool p) { return wave_sum_i(p ? 1 : 0) != 0; }
+__device__ __forceinline__ bool wave_any(bool p) { return wave_vote_any(p); }          // (one v_cmp + a scalar compare on the GPU: wave_target.h)
 
 // ---- lane groups ------------------------------------------------------------------------------
 // The lane-sparse stages (27x27 / 15x15 eigen-solves, epipoles, 3x3 SVDs: 27, 15, 6 or 2 busy

@@ -58,6 +58,8 @@ __device__ __forceinline__ long long shader_clock() { return clock64(); }
 // s_getreg_b32 immediate = (size - 1) << 11 | offset << 6 | register.
 __device__ __forceinline__ int hw_simd_id() { return (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4); }
 __device__ __forceinline__ int hw_workgroup_slot() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4); }
+// does the predicate hold on any lane?  wave-uniform
+__device__ __forceinline__ bool wave_vote_any(bool p) { return __ballot(p) != 0ull; }
 // lowest lane whose predicate holds (64 if none); wave-uniform
 __device__ __forceinline__ int wave_first_lane(bool p) {
     const unsigned long long m = __ballot(p);
