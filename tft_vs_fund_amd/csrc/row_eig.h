@@ -57,23 +57,26 @@ struct RowCholUpdate {
 template <int n, int K>
 struct RowChol {
     template <int N0, int N1>
-    static __device__ __forceinline__ void run(double (&g0)[N0], double (&g1)[N1], double& myinv0, double& myinv1, const double pfloor, const int p) {
+    static __device__ __forceinline__ void run(double (&g0)[N0], double (&g1)[N1], double& myinv0, double& myinv1, const double delta, const double pfloor, const int p) {
         if constexpr (K < n) {
             constexpr int Q = K & 15;
             double d;
             if constexpr (K < 16) d = row_bcast<Q>(g0[K]); else d = row_bcast<Q>(g1[K]);      // pivot: row K's diagonal, fully updated
+            d += delta;                                                      // the shift of G + delta I enters here: the diagonal is only ever read as a pivot
             d = (d > pfloor) ? d : pfloor;
             const double rs = rsqrt(d);
+            // column K of L: rows > K are meaningful.  Row K's own entry (the diagonal of L) is never read again -- 1 / L[K][K] = rs is what the
+            // substitutions use, and the factor's diagonal is masked out below -- so the whole column is scaled without a select
             if constexpr (K < 16) {
-                g0[K] = (p == Q) ? d * rs : g0[K] * rs;                       // column K of L (rows >= K meaningful)
+                g0[K] *= rs;
                 if constexpr (RowEigDims<n>::HI) g1[K] *= rs;
                 myinv0 = (p == Q) ? rs : myinv0;
             } else {
-                g1[K] = (p == Q) ? d * rs : g1[K] * rs;
+                g1[K] *= rs;
                 myinv1 = (p == Q) ? rs : myinv1;
             }
             RowCholUpdate<n, K, K + 1>::run(g0, g1);
-            RowChol<n, K + 1>::run(g0, g1, myinv0, myinv1, pfloor, p);
+            RowChol<n, K + 1>::run(g0, g1, myinv0, myinv1, delta, pfloor, p);
         }
     }
 };
@@ -187,14 +190,8 @@ __device__ inline double row_min_eigvec(double (&g0)[RowEigDims<n>::N0], double 
     const double tr = row_sum16((valid0 ? d0 : 0.0) + (valid1 ? d1 : 0.0));
     const double delta = 1e-14 * tr;
     const double pfloor = 1e-3 * delta + 1e-300;
-#pragma unroll
-    for (int c = 0; c < N0; ++c) g0[c] += (c == p) ? delta : 0.0;
-    if constexpr (HI) {
-#pragma unroll
-        for (int c = 16; c < n; ++c) g1[c] += (c == 16 + p) ? delta : 0.0;
-    }
     double myinv0 = 0.0, myinv1 = 0.0;                                       // 1 / L[r][r] of the position's rows
-    RowChol<n, 0>::run(g0, g1, myinv0, myinv1, pfloor, p);
+    RowChol<n, 0>::run(g0, g1, myinv0, myinv1, delta, pfloor, p);
     // row-scaled unit factor L' = D^-1 L in place (zeros on and above the diagonal); its transpose goes through LDS once
 #pragma unroll
     for (int c = 0; c < N0; ++c) g0[c] = (c < p && valid0) ? g0[c] * myinv0 : 0.0;
