@@ -25,6 +25,7 @@ inline int wave_uniform_i(int v) { return v; }
 typedef double* lds_ptr;
 inline lds_ptr to_lds(double* p) { return p; }
 inline double fast_rcp(double v) { return 1.0 / v; }
+inline double rsqrt_pos(double v) { return rsqrt(v); }
 inline int opaque_int(int v) { return v; }
 inline int opaque_lane_int(int v) { return v; }
 inline int hw_simd_id() { return (int)((threadIdx.x >> 6) & 3u); }

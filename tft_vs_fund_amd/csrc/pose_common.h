@@ -528,7 +528,7 @@ __device__ __attribute__((noinline)) int tri_vote_fast(PoseLds* w, const double*
 #pragma unroll
             for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
             d = (d > pfloor) ? d : pfloor;
-            inv[j] = rsqrt(d);
+            inv[j] = rsqrt_pos(d);
 #pragma unroll
             for (int r = j + 1; r < 4; ++r) {
                 double sv = S[r][j];
@@ -590,7 +590,7 @@ __device__ __forceinline__ void vote_one(const double (&SA)[6], const VoteCam& c
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
         d = (d > pfloor) ? d : pfloor;
-        inv[j] = rsqrt(d);
+        inv[j] = rsqrt_pos(d);
 #pragma unroll
         for (int r = j + 1; r < 4; ++r) {
             double sv = S[r][j];

@@ -85,7 +85,7 @@ __device__ __forceinline__ int spd_min_eigvec(const double (&S)[n][n], double (&
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
         d = (d > pfloor) ? d : pfloor;
-        const double rs = rsqrt(d);
+        const double rs = rsqrt_pos(d);
         L[j][j] = d * rs;
         inv[j] = rs;
 #pragma unroll
@@ -188,7 +188,7 @@ __device__ __forceinline__ bool chol_shifted(const double (&S)[n][n], const doub
         for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
         pd = pd && ((j == n - 1) ? (d > 0.0) : (d > pfloor));
         d = (d > pfloor) ? d : pfloor;
-        const double rs = rsqrt(d);
+        const double rs = rsqrt_pos(d);
         L[j][j] = d * rs;
         inv[j] = rs;
 #pragma unroll

@@ -125,7 +125,7 @@ __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, 
     for (int k = 0; k < n; ++k) {
         double d = Grp::bcast(g[k], k);                     // pivot (lane k's diagonal, fully updated)
         d = (d > pfloor) ? d : pfloor;
-        const double rs = rsqrt(d);
+        const double rs = rsqrt_pos(d);
         g[k] = (lane == k) ? d * rs : g[k] * rs;            // column k of L (rows >= k meaningful)
         myinv = (lane == k) ? rs : myinv;
 #pragma unroll
