@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(64, (METHOD == 1 && !JAC) ? 3 : 2) k_f_pose(co
                 wave_sync();
                 fine = !wave_any(!fine);
                 if (fine) {
-                    status = recover_poses<JAC, false>(w, Ein, pts, N, dbg, &fine);   // (single vote passes: pose_common.h::recover_vote)
+                    status = recover_poses<JAC, 2>(w, Ein, pts, N, dbg, &fine);       // (fused votes, second camera from LDS: pose_common.h::recover_vote)
                     if (gst != ST_OK) status = gst;
                 }
                 if (fine) fine = scale_t3<JAC>(w, pts, N, dbg);

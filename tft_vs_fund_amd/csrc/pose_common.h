@@ -620,17 +620,24 @@ __device__ __forceinline__ void vote_one(const double (&SA)[6], const VoteCam& c
     all_certain = all_certain && certain;
     score += (int)sgn(d1) + (int)sgn(d2);
 }
+// CAM1_IN_REGISTERS: the second camera in vector registers (194 registers: for kernels that run two wavefronts per SIMD anyway) or re-read from
+// LDS per trip (132: for the fundamental-matrix kernels, three wavefronts per SIMD at <= 168; 1 % slower inside the trifocal kernel).
+template <bool CAM1_IN_REGISTERS>
 __device__ __attribute__((noinline)) int tri_vote_fast2(PoseLds* w, const double* pts, int N, int view, const double* camB0, const double* Rt0,
                                                         const double* camB1, const double* Rt1) {
     const int lane = lane_id();
     double PA[12];
-    VoteCam c0, c1;
+    VoteCam c0, c1r;
     load_uniform12(w->Pfin[0], PA);                                          // PA[3] = PA[7] = PA[11] = 0
     load_uniform12(camB0, c0.PB);
 #pragma unroll
-    for (int c = 0; c < 12; ++c) c1.PB[c] = camB1[c];                        // (the second camera stays in vector registers: three cameras do not fit the scalar file)
+    for (int c = 0; c < 4; ++c) c0.R3[c] = wave_uniform(Rt0[8 + c]);
+    if constexpr (CAM1_IN_REGISTERS) {                                       // (vector registers: three cameras do not fit the scalar file)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { c0.R3[c] = wave_uniform(Rt0[8 + c]); c1.R3[c] = Rt1[8 + c]; }
+        for (int c = 0; c < 12; ++c) c1r.PB[c] = camB1[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) c1r.R3[c] = Rt1[8 + c];
+    }
     int score0 = 0, score1 = 0;
     bool certain0 = true, certain1 = true;
     Pt6 pnext = load_pt(pts, (lane < N) ? lane : 0);
@@ -647,7 +654,18 @@ __device__ __attribute__((noinline)) int tri_vote_fast2(PoseLds* w, const double
 #pragma unroll
             for (int c = 0; c <= r; ++c) SA[r * (r + 1) / 2 + c] = a0[r] * a0[c] + a1[r] * a1[c];
         vote_one(SA, c0, x2, y2, score0, certain0);
-        vote_one(SA, c1, x2, y2, score1, certain1);
+        if constexpr (CAM1_IN_REGISTERS) {
+            vote_one(SA, c1r, x2, y2, score1, certain1);
+        } else {
+            VoteCam c1;                                                      // the second camera is re-read from LDS per trip (uniform address: one broadcast read each)
+            const double* pb = camB1 + opaque_int(0);
+            const double* pr = Rt1 + opaque_int(0);
+#pragma unroll
+            for (int c = 0; c < 12; ++c) c1.PB[c] = pb[c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) c1.R3[c] = pr[8 + c];
+            vote_one(SA, c1, x2, y2, score1, certain1);
+        }
     }
     const int r0 = 2 * wave_sum_i(score0) + (wave_any(!certain0) ? 1 : 0), r1 = 2 * wave_sum_i(score1) + (wave_any(!certain1) ? 1 : 0);
     return (int)(((unsigned)r1 << 16) | ((unsigned)r0 & 0xffffu));
@@ -855,10 +873,10 @@ __device__ inline void recover_prepare(PoseLds* w, const double* Ein) {
 }
 
 // ok (optional, EXACT = false): set to false when a score could not be certified by the fast tier.
-// FUSE: both rotation candidates of a call in one pass (tri_vote_fast2).  That function needs 194 registers and a callee's count is its
-// callers': right for the kernels that run two wavefronts per SIMD anyway (the trifocal ones), wrong for the fundamental-matrix kernels,
-// which run three at <= 168 (measured: LinearF 291 -> 314 us, OptimF 1219 -> 1345 us with it) -- they keep the single passes.
-template <bool EXACT = true, bool FUSE = true>
+// FUSE: both rotation candidates of a call in one pass (tri_vote_fast2) -- 1: second camera in registers, 2: re-read from LDS; 0: two single
+// passes (A/B).  A callee's register count is its callers': the register form needs 194 and cost the fundamental-matrix kernels (three wavefronts
+// per SIMD at <= 168) a wavefront -- LinearF 291 -> 314 us; the LDS form needs 132 and serves them (LinearF 34.3 -> 35.7 M/s).
+template <bool EXACT = true, int FUSE = 1>
 __device__ inline int recover_vote(PoseLds* w, const double* pts, int N, double* dbg, bool* ok = nullptr) {
     const int lane = lane_id();
     phase_stamp(dbg, 10);
@@ -867,8 +885,8 @@ __device__ inline int recover_vote(PoseLds* w, const double* pts, int N, double*
 #pragma unroll 1
     for (int call = 0; call < 2; ++call) {
         int sR, sRp;
-        if (FUSE && N <= 4096) {                                             // both candidates in one pass (|2 score + 1| < 2^15)
-            const int both = tri_vote_fast2(w, pts, N, call + 1, w->P[2 * call], w->candRt[2 * call], w->P[2 * call + 1], w->candRt[2 * call + 1]);
+        if (FUSE != 0 && N <= 4096) {                                             // both candidates in one pass (|2 score + 1| < 2^15)
+            const int both = tri_vote_fast2<FUSE == 1>(w, pts, N, call + 1, w->P[2 * call], w->candRt[2 * call], w->P[2 * call + 1], w->candRt[2 * call + 1]);
             const int r0 = (int)(short)(both & 0xffff), r1 = both >> 16;     // wave-uniform
             sR = r0 >> 1; sRp = r1 >> 1;
             if (r0 & 1) { if (EXACT) sR = tri_vote_exact(w, pts, N, call + 1, w->P[2 * call], w->candRt[2 * call]); else certified = false; }
@@ -896,7 +914,7 @@ __device__ inline int recover_vote(PoseLds* w, const double* pts, int N, double*
     return status;
 }
 
-template <bool EXACT = true, bool FUSE = true>
+template <bool EXACT = true, int FUSE = 1>
 __device__ inline int recover_poses(PoseLds* w, const double* Ein, const double* pts, int N, double* dbg, bool* ok = nullptr) {
     recover_prepare<64>(w, Ein);
     return recover_vote<EXACT, FUSE>(w, pts, N, dbg, ok);
