@@ -527,7 +527,7 @@ __device__ __attribute__((noinline)) int tri_vote_fast(PoseLds* w, const double*
             double d = S[j][j] + delta;
 #pragma unroll
             for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-            d = (d > pfloor) ? d : pfloor;
+            d = fmax(d, pfloor);                                               // (NaN -> pfloor, as the select did)
             inv[j] = rsqrt_pos(d);
 #pragma unroll
             for (int r = j + 1; r < 4; ++r) {
@@ -589,7 +589,7 @@ __device__ __forceinline__ void vote_one(const double (&SA)[6], const VoteCam& c
         double d = S[j][j] + delta;
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-        d = (d > pfloor) ? d : pfloor;
+        d = fmax(d, pfloor);                                               // (NaN -> pfloor, as the select did)
         inv[j] = rsqrt_pos(d);
 #pragma unroll
         for (int r = j + 1; r < 4; ++r) {

@@ -63,7 +63,7 @@ struct RowChol {
             double d;
             if constexpr (K < 16) d = row_bcast<Q>(g0[K]); else d = row_bcast<Q>(g1[K]);      // pivot: row K's diagonal, fully updated
             d += delta;                                                      // the shift of G + delta I enters here: the diagonal is only ever read as a pivot
-            d = (d > pfloor) ? d : pfloor;
+            d = fmax(d, pfloor);                                               // (NaN -> pfloor, as the select did)
             const double rs = rsqrt_pos(d);
             // column K of L: rows > K are meaningful.  Row K's own entry (the diagonal of L) is never read again -- 1 / L[K][K] = rs is what the
             // substitutions use, and the factor's diagonal is masked out below -- so the whole column is scaled without a select

@@ -84,7 +84,7 @@ __device__ __forceinline__ int spd_min_eigvec(const double (&S)[n][n], double (&
         double d = S[j][j] + delta;
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-        d = (d > pfloor) ? d : pfloor;
+        d = fmax(d, pfloor);                                               // (NaN -> pfloor, as the select did)
         const double rs = rsqrt_pos(d);
         L[j][j] = d * rs;
         inv[j] = rs;
@@ -187,7 +187,7 @@ __device__ __forceinline__ bool chol_shifted(const double (&S)[n][n], const doub
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
         pd = pd && ((j == n - 1) ? (d > 0.0) : (d > pfloor));
-        d = (d > pfloor) ? d : pfloor;
+        d = fmax(d, pfloor);                                               // (NaN -> pfloor, as the select did)
         const double rs = rsqrt_pos(d);
         L[j][j] = d * rs;
         inv[j] = rs;

@@ -124,7 +124,7 @@ __device__ inline double wave_min_eigvec_reg(double (&g)[n], const double diag, 
 #pragma unroll
     for (int k = 0; k < n; ++k) {
         double d = Grp::bcast(g[k], k);                     // pivot (lane k's diagonal, fully updated)
-        d = (d > pfloor) ? d : pfloor;
+        d = fmax(d, pfloor);                                               // (NaN -> pfloor, as the select did)
         const double rs = rsqrt_pos(d);
         g[k] = (lane == k) ? d * rs : g[k] * rs;            // column k of L (rows >= k meaningful)
         myinv = (lane == k) ? rs : myinv;
