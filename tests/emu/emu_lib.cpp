@@ -40,6 +40,22 @@ extern "C" int emu_linear_tft_pose(const double* corresp, const double* calm, lo
     return emu_pose(tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, true, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T,
                     reconst, iter, status, dbg);
 }
+// the four-triplets-per-wavefront kernel (tft_rows_kernel.h), then the exact kernel over what it handed back
+extern "C" int emu_linear_tft_pose_rows(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                                        double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
+    tff::LinearTftArgs a{corresp, calm, calm_stride, B, N, flags & ~tff::FLAG_JACOBI, Rt2, Rt3, T, reconst, iter, status, dbg, nullptr, nullptr, nullptr};
+    if (reconst) a.flags |= tff::FLAG_RECONST;
+    unsigned grid = tff::rows_grid(B);
+    if (g_grid_cap && grid > g_grid_cap) grid = g_grid_cap;
+    emu::launch(tff::k_linear_tft_pose_rows, grid, 64, tff::rows_lds_bytes(), a);
+    bool any = false;
+    for (long b = 0; b < B; ++b) any = any || status[b] == tff::ST_RETRY;
+    if (!any) return 0;
+    a.flags |= tff::FLAG_ONLY_RETRY;
+    a.flags = tff::pose_auto_flags(N, a.flags, true);
+    emu::launch(tff::k_linear_tft_pose<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, a.flags, true), a);
+    return 1;
+}
 extern "C" int emu_linear_f_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
                                  double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
     return emu_pose(tff::k_f_pose<false, 0>, tff::k_f_pose<true, 0>, tff::f_pose_lds_bytes, true, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T,

@@ -38,6 +38,11 @@ inline bool wave_vote_any(bool p) {
     for (int m = 32; m >= 1; m >>= 1) c |= wave_shfl_xor_i(c, m);
     return c != 0;
 }
+inline unsigned long long wave_ballot(bool p) {
+    uint64_t c = p ? (1ull << emu_lane()) : 0ull;
+    for (int m = 32; m >= 1; m >>= 1) c |= emu::exchange(c, emu_lane() ^ m);
+    return c;
+}
 inline int wave_first_lane(bool p) {
     int c = p ? emu_lane() : 64;
     for (int m = 32; m >= 1; m >>= 1) { const int o = wave_shfl_xor_i(c, m); c = (o < c) ? o : c; }

@@ -35,6 +35,7 @@ TFF_OPT_KERNEL = 3
 TFF_OPT_GH_EXACT = 4
 TFF_OPT_EXACT_BELOW = 5
 TFF_OPT_SPILL = 6
+TFF_OPT_ROWS = 7
 DEBUG_STRIDE = 128
 
 ST_OK, ST_TOO_FEW, ST_NONFINITE, ST_NO_POSE, ST_RANK, ST_NO_PARAM = 0, 1, 2, 3, 4, 5
@@ -183,6 +184,10 @@ class Context:
         """TFF_OPT_SPILL: True = the per-correspondence state of the iterative methods stays in LDS whenever it fits (fewer workgroups per CU,
         HBM traffic near the algorithmic bytes); False (default) = it goes to global slices when that raises the occupancy."""
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_SPILL, int(bool(on))), "set_option")
+
+    def set_rows(self, on):
+        """TFF_OPT_ROWS: True (default) = LinearTFT runs four triplets per wavefront (one per row of 16 lanes); False = one per wavefront."""
+        _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_ROWS, int(bool(on))), "set_option")
 
     def set_gh_exact(self, on):
         """Gauss-Helmert methods: True = pinv(W) always through per-block eigen-decompositions (A/B; slower)."""

@@ -62,6 +62,7 @@ struct tff_ctx {
     int kernel_variant = 0;                // TFF_OPT_KERNEL
     int gh_exact = 0;                      // TFF_OPT_GH_EXACT
     int spill_only_if_needed = 0;          // TFF_OPT_SPILL
+    int rows = 1;                          // TFF_OPT_ROWS
 };
 
 namespace {
@@ -170,9 +171,42 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_
     return 0;
 }
 
+// LinearTFTPoseEstimation, default route: four triplets per wavefront (tft_rows_kernel.h, fast tiers), then the exact kernel
+// (one wavefront per triplet) over what they could not finish or certify.
+int launch_linear_tft_rows(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
+                           double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+    if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
+    TFF_LOCK(c);
+    if (B == 0) return 0;
+    if (!Rt2 || !Rt3 || !T) return fail(TFF_E_INVALID, "null output pointer");
+    TFF_HIP(hipSetDevice(c->device));
+    if (!status) {                         // the kernels hand ST_RETRY over through the status array
+        if (int r = c->scratch_status.reserve((size_t)B * sizeof(int32_t))) return r;
+        status = (int32_t*)c->scratch_status.p;
+    }
+    tff::LinearTftArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr),
+                         Rt2, Rt3, T, reconst, iter, status, dbg, c->sample_idx, c->init_p, c->init_x, nullptr, 0, c->sample_ns};
+    hipLaunchKernelGGL(tff::k_linear_tft_pose_rows, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, a);
+    TFF_HIP(hipGetLastError());
+    a.flags |= tff::FLAG_ONLY_RETRY;
+    if (c->sample_idx) a.flags |= tff::FLAG_STAGE_LDS;   // the exact kernel gathers samples into LDS
+    else a.flags = staged_flags(c, N, a.flags, true, tff::STAGE_MAX_N_TFT);
+    if ((a.flags & tff::FLAG_STAGE_LDS) && tff::pose_lds_bytes(N, a.flags, true) > LDS_LIMIT) {
+        if (c->sample_idx) return fail(TFF_E_INVALID, "sample too large for the LDS (sampled hypotheses are gathered into LDS)");
+        a.flags &= ~tff::FLAG_STAGE_LDS;
+    }
+    const size_t lds = tff::pose_lds_bytes(N, a.flags, true);
+    if (int r = ensure_lds(tff::k_linear_tft_pose<true>, lds)) return r;
+    hipLaunchKernelGGL(tff::k_linear_tft_pose<true>, dim3((unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID)), dim3(64), lds, c->stream, a);
+    TFF_HIP(hipGetLastError());
+    return 0;
+}
+
 // LinearTFTPoseEstimation: one wavefront per triplet (fast tiers) + the exact kernel over what they could not finish.
 int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+    if (c && c->rows && c->solver == 0 && N >= c->exact_below)
+        return launch_linear_tft_rows(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     return launch_pose(c, tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, 0, corresp, calm, calm_stride,
                        B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
@@ -424,6 +458,7 @@ int tff_ctx_set_option(tff_ctx* c, int option, long value) {
         case TFF_OPT_STAGE_LDS: if (value < -1 || value > 1) return fail(TFF_E_INVALID, "stage_lds must be -1, 0 or 1"); c->stage = (int)value; return 0;
         case TFF_OPT_GH_EXACT: c->gh_exact = value != 0; return 0;
         case TFF_OPT_SPILL: c->spill_only_if_needed = value != 0; return 0;
+        case TFF_OPT_ROWS: c->rows = value != 0; return 0;
         case TFF_OPT_KERNEL: if (value < 0 || value > 2) return fail(TFF_E_INVALID, "kernel must be 0, 1 or 2"); c->kernel_variant = (int)value; return 0;
         default: return fail(TFF_E_INVALID, "unknown option");
     }

@@ -1,6 +1,7 @@
 // Launch geometry shared by the C ABI (hipcc) and the emulator test library.
 #pragma once
 #include "tft_kernel.h"
+#include "tft_rows_kernel.h"
 #include "f_kernel.h"
 #include "gh_kernel.h"
 #include "wave_trid.h"

@@ -23,15 +23,6 @@ template <int n> struct RowEigDims {
     static constexpr bool HI = n > 16;
 };
 
-// every lane: the sum over its row of 16 lanes
-__device__ __forceinline__ double row_sum16(double v) {
-    v += dpp_mov<0x111>(v);            // row_shr:1
-    v += dpp_mov<0x112>(v);            // row_shr:2
-    v += dpp_mov<0x114>(v);            // row_shr:4
-    v += dpp_mov<0x118>(v);            // row_shr:8   -> position 15 holds the row sum
-    return row_bcast<15>(v);
-}
-
 // right-looking Cholesky, the updates of pivot column K: entry C of every row r >= C loses L[r][K] L[C][K]; L[C][K] sits in row C's
 // (position C & 15, half C >> 4) entry K
 template <int n, int K, int C>

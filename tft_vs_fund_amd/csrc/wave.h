@@ -66,6 +66,20 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 }
 __device__ __forceinline__ bool wave_any(bool p) { return wave_vote_any(p); }          // (one v_cmp + a scalar compare on the GPU: wave_target.h)
 
+// every lane: the sum over its row of 16 lanes (DPP row shifts + one DP-ALU row broadcast; nothing leaves the row)
+__device__ __forceinline__ double row_sum16(double v) {
+    v += dpp_mov<0x111>(v);            // row_shr:1
+    v += dpp_mov<0x112>(v);            // row_shr:2
+    v += dpp_mov<0x114>(v);            // row_shr:4
+    v += dpp_mov<0x118>(v);            // row_shr:8   -> position 15 holds the row sum
+    return row_bcast<15>(v);
+}
+// does the predicate hold on any lane of the caller's row of 16 lanes?  (one ballot for the wavefront, each row looks at its own 16 bits)
+__device__ __forceinline__ bool row_any(bool p) {
+    const unsigned long long m = wave_ballot(p);
+    return ((m >> (lane_id() & 48)) & 0xffffull) != 0ull;
+}
+
 // ---- lane groups ------------------------------------------------------------------------------
 // The lane-sparse stages (27x27 / 15x15 eigen-solves, epipoles, 3x3 SVDs: 27, 15, 6 or 2 busy
 // lanes) are written against a lane GROUP: Group<64> is the whole wavefront, Group<32> one half of it.
@@ -90,6 +104,15 @@ template <> struct Group<32> {
         v += dpp_mov<0x118>(v);        // row_shr:8 -> lane 15 of every 16-lane row holds its row sum
         return half_bcast(v, 15) + half_bcast(v, 31);
     }
+};
+
+// One row of 16 lanes: the unit of the four-triplets-per-wavefront kernels (tft_rows_kernel.h).  Every cross-lane operation stays inside the
+// row (DPP), so the four rows of a wavefront work on four different problems in the same instruction stream.
+template <> struct Group<16> {
+    static constexpr int size = 16;
+    __device__ static __forceinline__ int lane() { return lane_id() & 15; }
+    __device__ static __forceinline__ int index() { return lane_id() >> 4; }
+    __device__ static __forceinline__ double sum(double v) { return row_sum16(v); }
 };
 
 // Reduce K (= 32) per-lane values over the 64 lanes with a halving ("transposing") butterfly: K exchanges instead of 6K.

@@ -68,6 +68,8 @@ __device__ __forceinline__ int hw_simd_id() { return (int)__builtin_amdgcn_s_get
 __device__ __forceinline__ int hw_workgroup_slot() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4); }
 // does the predicate hold on any lane?  wave-uniform
 __device__ __forceinline__ bool wave_vote_any(bool p) { return __ballot(p) != 0ull; }
+// bit l = the predicate of lane l; wave-uniform
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __ballot(p); }
 // lowest lane whose predicate holds (64 if none); wave-uniform
 __device__ __forceinline__ int wave_first_lane(bool p) {
     const unsigned long long m = __ballot(p);
