@@ -28,14 +28,14 @@ def _p(a):
     return ctypes.c_void_p(a.ctypes.data) if a is not None else None
 
 
-def run_linear_tft(lib, C, CalM, flags=0, reconst=True, entry="emu_linear_tft_pose"):
+def run_linear_tft(lib, C, CalM, flags=0, reconst=True, entry="emu_linear_tft_pose", debug=True):
     B, N, _ = C.shape
     calm = calm_colmajor(CalM)
     Rt2 = np.zeros((B, 12)); Rt3 = np.zeros((B, 12)); T = np.zeros((B, 27))
     Rec = np.zeros((B, N, 3)) if reconst else None
     it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32); dbg = np.zeros((B, 128))
     getattr(lib, entry)(_p(C), _p(calm), ctypes.c_long(0), ctypes.c_long(B), ctypes.c_int(N), ctypes.c_int(flags),
-                            _p(Rt2), _p(Rt3), _p(T), _p(Rec), _p(it), _p(st), _p(dbg))
+                            _p(Rt2), _p(Rt3), _p(T), _p(Rec), _p(it), _p(st), _p(dbg) if debug else None)
     return dict(R_t_2=Rt2.reshape(B, 4, 3).transpose(0, 2, 1), R_t_3=Rt3.reshape(B, 4, 3).transpose(0, 2, 1),
                 T=T.reshape(B, 3, 3, 3).transpose(0, 3, 2, 1), Reconst=None if Rec is None else Rec.transpose(0, 2, 1),
                 iter=it, status=st, debug=dbg)

@@ -487,45 +487,129 @@ __device__ __forceinline__ bool rows_rt_prepare(RowLds* w, RowRt* rt, double* db
     return ok;
 }
 
-// Pass 3: cheirality votes of all four (R, t) candidates -- the two rotations of E21 against view 2 and the two of E31 against view 3 -- in one
-// pass over the row's correspondences (pose_common.h::tri_vote_fast2 per essential matrix: certified sign-only fast tier, vote_one).  Camera 1's
-// rows and their share of S11 are formed once per correspondence; the candidate cameras are re-read from the row's LDS workspace per trip
-// (row-uniform addresses: broadcast reads that cost no VALU slot; 64 doubles would not fit the register file beside vote_one).
-// r[k] = 2 * score + (1 if some correspondence was not certified), candidates in the order of RowRt::P.
-__device__ __forceinline__ void rows_vote4(const RowSrc& s, const int N, const RowRt* rt, int (&r)[4]) {
+// Pass 3: cheirality votes (R_t_from_TFT.m:91-104) for both essential matrices in one pass over the row's correspondences, with the certified
+// sign-only fast tier of pose_common.h (vote_one).  score(R,-t) = -score(R,t) exactly (pose_common.h), so each essential matrix has two scores
+// to find: sR = score(R,t) and sRp = score(Rp,t).  The reference's selection loop needs them only as far as this:
+//     |score| = 2 N  <=>  every correspondence votes +2, or every one -2;
+//     if one candidate of the pair reaches |s| = 2 N and the other is KNOWN to stay below 2 N in magnitude, the loop's pick (order k = 1..4,
+//     `>=`, start 0) does not depend on the other's value: it takes the sign variant of the first that scores +2 N.
+// Hence: the first trip (16 correspondences) evaluates all four candidates; a candidate that shows a certified vote != +2 AND a certified vote
+// != -2 there is proven |s| < 2 N.  When exactly one candidate of a pair is proven so, only its partner ("main", A) is evaluated over the
+// remaining trips -- half the work of the pass on well-posed triplets, whose true rotation votes 2 N and whose twisted partner splits at once.
+// If the main candidate then fails to reach 2 N (noisy or degenerate data), the other one (B) is evaluated in a second sweep: every outcome is
+// decided on exact, certified scores.  all4 (debug entry points): always evaluate all four, so that the four scores can be reported.
+// The trip loops are wave-uniform (lanes past the end work on correspondence 0 and are masked out): the four rows decide independently, the
+// wavefront skips a candidate only when no row needs it.  Cameras are re-read from the row's LDS workspace per trip (row-uniform addresses:
+// broadcast reads that cost no VALU slot).
+// Returns false (per row) when a needed vote could not be certified.  sc[call][0] = sR, sc[call][1] = sRp; a score that was not needed is
+// reported as 0 (it is below 2 N in magnitude and its partner is +-2 N: same pick).
+__device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const RowRt* rt, const bool all4, int (&sc)[2][2]) {
     const int p = rows_p();
     double PA[12];
 #pragma unroll
     for (int c = 0; c < 12; ++c) PA[c] = rt->Pfin[0][c];                     // PA[3] = PA[7] = PA[11] = 0
-    int score[4] = {0, 0, 0, 0};
-    bool certain[4] = {true, true, true, true};
-    Pt6 pnext = rows_load(s, (p < N) ? p : 0);
+    int scA[2] = {0, 0}, scB[2] = {0, 0};
+    bool certA[2] = {true, true}, certB[2] = {true, true};
+    int offA[2] = {0, 24}, offB[2] = {12, 36};                              // doubles into RowRt::P / RowRt::candRt: A = (R,t), B = (Rp,t) to begin with
+    bool main1[2] = {false, false};                                          // the row's main candidate is Rp
+    bool evalA = true, evalB[2] = {true, true};                              // wave-uniform: what the running sweep evaluates
+    bool fullB[2] = {true, true};                                            // wave-uniform: B covers every trip
 #pragma unroll 1
-    for (int i = p; i < N; i += ROWL) {
-        const Pt6 q = pnext;
-        if (i + ROWL < N) pnext = rows_load(s, i + ROWL);
-        const double x1 = q.v[0], y1 = q.v[1];
-        double a0[3], a1[3], SA[6];                                          // rows [0 -1 y; 1 0 -x] * P1 and their A'A   (triangulation3D.m:58-59)
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        const int start = (sweep == 0) ? 0 : ROWL;
+        Pt6 pnext = rows_load(s, (start + p < N) ? start + p : 0);
+#pragma unroll 1
+        for (int i0 = start; i0 < N; i0 += ROWL) {
+            const Pt6 q = pnext;
+            const bool have = i0 + p < N;
+            pnext = rows_load(s, (i0 + ROWL + p < N) ? i0 + ROWL + p : 0);
+            const double x1 = q.v[0], y1 = q.v[1];
+            double a0[3], a1[3], SA[6];                                      // rows [0 -1 y; 1 0 -x] * P1 and their A'A   (triangulation3D.m:58-59)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { a0[c] = y1 * PA[8 + c] - PA[4 + c]; a1[c] = PA[c] - x1 * PA[8 + c]; }
+            for (int c = 0; c < 3; ++c) { a0[c] = y1 * PA[8 + c] - PA[4 + c]; a1[c] = PA[c] - x1 * PA[8 + c]; }
 #pragma unroll
-        for (int rr = 0; rr < 3; ++rr)
+            for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-            for (int c = 0; c <= rr; ++c) SA[rr * (rr + 1) / 2 + c] = a0[rr] * a0[c] + a1[rr] * a1[c];
+                for (int c = 0; c <= rr; ++c) SA[rr * (rr + 1) / 2 + c] = a0[rr] * a0[c] + a1[rr] * a1[c];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            VoteCam cam;
-            const double* pb = rt->P[k] + opaque_int(0);
-            const double* pr = rt->candRt[k] + opaque_int(0);
+            for (int call = 0; call < 2; ++call) {
+                const double x2 = (call == 0) ? q.v[2] : q.v[4], y2 = (call == 0) ? q.v[3] : q.v[5];
+                if (evalA) {
+                    VoteCam cam;
+                    const int off = opaque_lane_int(offA[call]);
+                    const double* pb = rt->P[0] + off;
+                    const double* pr = rt->candRt[0] + off;
 #pragma unroll
-            for (int c = 0; c < 12; ++c) cam.PB[c] = pb[c];
+                    for (int c = 0; c < 12; ++c) cam.PB[c] = pb[c];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) cam.R3[c] = pr[8 + c];
-            vote_one(SA, cam, (k < 2) ? q.v[2] : q.v[4], (k < 2) ? q.v[3] : q.v[5], score[k], certain[k]);
+                    for (int c = 0; c < 4; ++c) cam.R3[c] = pr[8 + c];
+                    int term = 0;
+                    bool cert = true;
+                    vote_one(SA, cam, x2, y2, term, cert);
+                    scA[call] += have ? term : 0;
+                    certA[call] = certA[call] && (cert || !have);
+                }
+                if (evalB[call]) {
+                    VoteCam cam;
+                    const int off = opaque_lane_int(offB[call]);
+                    const double* pb = rt->P[0] + off;
+                    const double* pr = rt->candRt[0] + off;
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) cam.PB[c] = pb[c];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) cam.R3[c] = pr[8 + c];
+                    int term = 0;
+                    bool cert = true;
+                    vote_one(SA, cam, x2, y2, term, cert);
+                    scB[call] += have ? term : 0;
+                    certB[call] = certB[call] && (cert || !have);
+                }
+            }
+            if (sweep == 0 && i0 == 0) {                                     // after the first trip: which candidates are already out of the race?
+#pragma unroll
+                for (int call = 0; call < 2; ++call) {
+                    // the accumulators hold the vote of this lane's first correspondence
+                    // (every ballot is taken by the whole wavefront: no short-circuit between them)
+                    const bool a0 = row_any(have && certA[call] && scA[call] != 2), a1 = row_any(have && certA[call] && scA[call] != -2);
+                    const bool b0 = row_any(have && certB[call] && scB[call] != 2), b1 = row_any(have && certB[call] && scB[call] != -2);
+                    const bool mixA = a0 && a1, mixB = b0 && b1;
+                    const bool single = !all4 && (mixA != mixB);
+                    main1[call] = single && mixA;                            // (R,t) is out: (Rp,t) is the row's main candidate
+                    if (main1[call]) {
+                        const int ts = scA[call]; scA[call] = scB[call]; scB[call] = ts;
+                        const bool tc = certA[call]; certA[call] = certB[call]; certB[call] = tc;
+                        offA[call] = 12 + 24 * call; offB[call] = 24 * call;
+                    }
+                    evalB[call] = wave_any(!single);                         // some row of the wavefront needs both candidates of this pair
+                    fullB[call] = evalB[call];
+                }
+            }
         }
-    }
+        if (sweep == 1) break;
+        // a main candidate that did not reach 2 N: its partner's score decides, evaluate it over the trips it skipped (rare)
+        bool again = false;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = 2 * (int)row_sum16((double)score[k]) + (row_any(!certain[k]) ? 1 : 0);   // |score| <= 2 N: exact
+        for (int call = 0; call < 2; ++call) {
+            const int tA = (int)row_sum16((double)scA[call]);                // |score| <= 2 N: exact
+            const bool need = wave_any(!fullB[call] && tA != 2 * N && tA != -2 * N);
+            evalB[call] = need;
+            fullB[call] = fullB[call] || need;
+            again = again || need;
+        }
+        evalA = false;
+        if (!again) break;
+    }
+    bool ok = true;
+#pragma unroll
+    for (int call = 0; call < 2; ++call) {
+        const int tA = (int)row_sum16((double)scA[call]);
+        const int tB = fullB[call] ? (int)row_sum16((double)scB[call]) : 0;
+        const bool badA = row_any(!certA[call]), badB = row_any(!certB[call]);
+        ok = ok && !badA && (!fullB[call] || !badB);
+        sc[call][0] = main1[call] ? tB : tA;
+        sc[call][1] = main1[call] ? tA : tB;
+    }
+    return ok;
 }
 
 // One pass over the row's correspondences with the fast DLT tier (pose_common.h::tri_pass_fast): MODE TRI_SCALE -> num / den of
@@ -626,12 +710,11 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose_rows(const LinearTftA
             ok = rows_rt_prepare(w, rt, dbg) && ok;                          // :56
             rows_stamp(dbg, 10);
             {                                                                // recover_R_t (R_t_from_TFT.m:82-106), see pose_common.h::recover_vote
-                int r4[4];
-                rows_vote4(src, N, rt, r4);
-                if ((r4[0] | r4[1] | r4[2] | r4[3]) & 1) ok = false;         // an uncertified sign: the exact kernel's business
+                int sc[2][2];
+                ok = rows_votes(src, N, rt, dbg != nullptr, sc) && ok;       // an uncertified sign: the exact kernel's business
 #pragma unroll
                 for (int call = 0; call < 2; ++call) {
-                    const int sR = r4[2 * call] >> 1, sRp = r4[2 * call + 1] >> 1;
+                    const int sR = sc[call][0], sRp = sc[call][1];
                     // reference order: k=1 (R,t), k=2 (R,-t), k=3 (Rp,-t), k=4 (Rp,t)   (:92-104)
                     const int score[4] = {sR, -sR, -sRp, sRp};
                     int seen = 0, pick = -1;
@@ -679,7 +762,9 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose_rows(const LinearTftA
                 }
             } else if (!ok) {
                 status = ST_RETRY;                                           // redone by k_linear_tft_pose<true>
-            } else {
+            }
+            {
+                const bool store = valid && ok && !bad_index;                // per row
                 bool bad = false;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {                                // poses (row-major in LDS) -> MATLAB column-major 3x4 arrays
@@ -688,17 +773,18 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose_rows(const LinearTftA
                         const int which = e24 / 12, e = e24 % 12, c = e / 3, r = e % 3;
                         const double v = rt->Rt[which][4 * r + c];
                         bad = bad || !(fabs(v) <= 1.79e308);
-                        if (valid) (which ? a.Rt3 : a.Rt2)[b * 12 + e] = v;
+                        if (store) (which ? a.Rt3 : a.Rt2)[b * 12 + e] = v;
                     }
                     const int e27 = 16 * h + p;
                     if (e27 < 27) {
                         const double v = rt->T1[e27];
                         bad = bad || !(fabs(v) <= 1.79e308);
-                        if (valid) a.T[b * 27 + e27] = v;
+                        if (store) a.T[b * 27 + e27] = v;
                     }
                 }
                 rows_stamp(dbg, 13);
-                if (row_any(bad) && status == ST_OK) status = ST_NONFINITE;  // non-finite outputs -> status 2
+                const bool nonfinite = row_any(bad);                         // (the ballot is the whole wavefront's: outside every per-row branch)
+                if (nonfinite && status == ST_OK) status = ST_NONFINITE;     // non-finite outputs -> status 2
             }
         }
         if (p == 0 && valid) {
