@@ -13,6 +13,15 @@ process per GPU, every rank owns a batch of its own (weak scaling, independent
 triplets, no collective on the data path) and the fixed-size result records are
 all-gathered over RCCL, overlapped with the next step's compute.
 
+Steps are independent batches, so they are issued round-robin on `--streams`
+HIP streams (default 2, one library context per stream, result records
+double-buffered): 10 000 triplets are 2 500 wavefronts of four triplets on
+2 048 wavefront slots, and the next batch's wavefronts fill the slots the
+previous batch's 452-wavefront tail leaves idle.  Every step still runs whole
+inside the timed region; `roofline.kernel_ms` is the launches' own HIP-event
+duration on their streams (longer than ms_per_step when two overlap), and the
+one-stream, nothing-overlapped figure is reported beside it (`single_stream`).
+
 Rank 0 prints ONE JSON line (metric, value, roofline, cpu_baseline, ...).
 """
 import argparse
@@ -71,6 +80,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="triplets timed on the CPU (default: 40 per host core, at least 1024, at most the batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary blocks (other methods, N sweep, config 4; 1 GPU, rank 0)")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the steps alternate between (1 = strictly one batch at a time)")
     args = ap.parse_args()
 
     import torch
@@ -89,7 +99,9 @@ def main():
         build_library()
     if world > 1:
         dist.barrier()
-    ctx = api.Context(local)
+    S = max(1, args.streams)
+    ctxs = [api.Context(local) for _ in range(S)]
+    ctx = ctxs[0]
 
     B, N = args.batch, args.ncorr
     C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=1000 + rank)
@@ -97,32 +109,54 @@ def main():
     d_calm = torch.from_numpy(np.ascontiguousarray(CalM.T).reshape(27)).to(dev)
 
     # result records, double-buffered so that the gather of step k overlaps the compute of step k+1 (tdist.OverlappedGather)
-    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    statuses = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(S)]
+    status = statuses[0]
     import ctypes
     lib = ctx.lib
-    stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)
+    stream = torch.cuda.current_stream(dev)                # the stream the process group orders its gathers against
+    if S > 1:
+        # every context launches on the stream the library created for it (hipStreamNonBlocking); measured: two of torch's pool streams
+        # do not overlap their kernels on this stack, the contexts' own streams do (tools/ab_streams2.py)
+        for c in ctxs:
+            c.use_own_stream()
+        side = [torch.cuda.ExternalStream(c.stream_ptr(), device=dev) for c in ctxs]
+    else:
+        side = [stream]
+        ctx.set_stream(stream.cuda_stream)
     p = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + 8 * off)
     timing = {"events": None}
+    done = [torch.cuda.Event() for _ in range(S)]
 
     def compute(r, k):
+        # step k runs on stream k % S (result buffer k % S: a stream only ever reuses its own buffer); the gather stream waits for it
+        j = k % S
         ev = timing["events"][k] if timing["events"] is not None else None
-        if ev is not None:
-            ev[0].record(stream)
-        rc = lib.tff_linear_tft_pose_batch_dev(ctx.handle, p(d_C), p(d_calm), 0, B, N, p(r, 0), p(r, 12 * B), p(r, 24 * B),
-                                               None, None, ctypes.c_void_p(status.data_ptr()))
-        if ev is not None:
-            ev[1].record(stream)
+        if S > 1 and world > 1:
+            side[j].wait_stream(stream)                   # the gather that last read this buffer was ordered on the main stream
+        if ev is not None and not os.environ.get("TFF_BENCH_NOEV"):
+            ev[0].record(side[j])
+        rc = lib.tff_linear_tft_pose_batch_dev(ctxs[j].handle, p(d_C), p(d_calm), 0, B, N, p(r, 0), p(r, 12 * B), p(r, 24 * B),
+                                               None, None, ctypes.c_void_p(statuses[j].data_ptr()))
+        if ev is not None and not os.environ.get("TFF_BENCH_NOEV"):
+            ev[1].record(side[j])
         if rc != 0:
             raise RuntimeError("tff_linear_tft_pose_batch_dev failed: %s" % lib.tff_last_error().decode())
+        if S > 1 and (world > 1 or os.environ.get("TFF_BENCH_JOIN")):
+            done[j].record(side[j])
+            stream.wait_event(done[j])                    # anything enqueued on the main stream after this (the gather) sees the records
 
-    pipe = tdist.OverlappedGather(world, tdist.RECORD_DOUBLES * B, dev, compute)
+    pipe = tdist.OverlappedGather(world, tdist.RECORD_DOUBLES * B, dev, compute, nbuf=max(2, S))
     step, drain = pipe.step, pipe.drain
+
+    def sync_all():
+        for c in ctxs:
+            c.synchronize()
+        torch.cuda.synchronize(dev)
 
     for k in range(args.warmup):
         step(k)
     drain()
-    torch.cuda.synchronize(dev)
+    sync_all()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -133,7 +167,7 @@ def main():
         step(k)
     drain()
     timing["events"] = None
-    torch.cuda.synchronize(dev)
+    sync_all()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -142,8 +176,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    n_bad = int((status != 0).sum().item())
-    step_ms = np.array([a.elapsed_time(b) for a, b in events]) if events else np.array([float("nan")])
+    n_bad = sum(int((st_ != 0).sum().item()) for st_ in statuses)
+    for c in ctxs:                                          # the secondary blocks below run on the main stream, one call at a time
+        c.set_stream(stream.cuda_stream)
+    step_ms = np.array([a.elapsed_time(b) for a, b in events]) if events and not os.environ.get("TFF_BENCH_NOEV") else np.array([float("nan")])
     kern_ms = float(step_ms.mean())
 
     # secondary metrics of SURVEY 8(d) on the same resident batch (rank 0, outside the contract's timed region)
@@ -161,6 +197,15 @@ def main():
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) / reps
 
+    single = None
+    if rank == 0:
+        # the same launch, strictly one batch at a time on one stream (no overlap between consecutive batches)
+        r0 = pipe.recs[0]
+        call = lambda: lib.tff_linear_tft_pose_batch_dev(ctx.handle, p(d_C), p(d_calm), 0, B, N, p(r0, 0), p(r0, 12 * B), p(r0, 24 * B), None, None,
+                                                         ctypes.c_void_p(status.data_ptr()))
+        ms1 = time_calls(call, max(10, args.steps))
+        single = {"ms_per_batch": ms1, "value": B / (ms1 * 1e-3), "unit": "triplet-hypotheses/s",
+                  "achieved_GBs": algorithmic_bytes_per_triplet(N) * B / (ms1 * 1e-3) / 1e9}
     if rank == 0 and world == 1 and not args.no_secondary:
         it32 = torch.zeros(B, dtype=torch.int32, device=dev)
         r = pipe.recs[0]
@@ -229,7 +274,7 @@ def main():
                     simds, clock_hz = 256 * 4, 2.4e9
                     valu = {"instructions_per_triplet": ipt, "busy_fraction": pj.get("valu_busy_fraction"),
                             "issue_limited_triplets_per_s": simds * clock_hz / 4.0 / ipt, "source": "profiles/pmc_latest.json (rocprofv3 --pmc, same command)"}
-                    valu["frac_of_issue_limit"] = (B / (kern_ms * 1e-3)) / valu["issue_limited_triplets_per_s"]
+                    valu["frac_of_issue_limit"] = (value / world) / valu["issue_limited_triplets_per_s"]       # of the per-GPU rate actually delivered
             except Exception:
                 traffic, valu = None, None
         out = {
@@ -240,16 +285,23 @@ def main():
             "config": {"workload": "configs[1]: batch of %d synthetic triplets x %d correspondences, sigma=1px, "
                                    "linearTFT + R_t_from_TFT (LinearTFTPoseEstimation without Reconst), one batch per GPU" % (B, N),
                        "batch_per_gpu": B, "correspondences": N,
+                       "streams": "%d (consecutive batches alternate between streams and may overlap)" % S if S > 1 else "1",
                        "gather": "RCCL all_gather of 408-B result records, overlapped" if world > 1 else "none (1 GPU)",
                        "failed_triplets": n_bad},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_linear_tft_pose", "kernel_ms": kern_ms,
-                         # the timed region is short (steps x 0.4 ms) and `value` moves a few per cent with the clock state: the steps' own HIP-event
-                         # times, minimum and median beside the mean that `achieved` uses
+                         "traffic": traffic, "kernel": "k_linear_tft_pose_rows", "kernel_ms": kern_ms,
+                         # kernel_ms: HIP events around each step's launches on the step's own stream, mean over the timed region (with two
+                         # streams a launch shares the GPU with its neighbour, so it is LONGER than ms_per_step); minimum and median beside it
                          "kernel_ms_min": float(step_ms.min()), "kernel_ms_median": float(np.median(step_ms)),
-                         "value_at_median_step": world * B / (float(np.median(step_ms)) * 1e-3),
-                         "algorithmic_bytes_per_launch": alg},
+                         "value_at_median_step": (world * B / (float(np.median(step_ms)) * 1e-3)) if S == 1 else None,
+                         "algorithmic_bytes_per_launch": alg,
+                         # with two streams a launch shares the GPU with its neighbour: `achieved` above prices ONE launch over its own (longer)
+                         # duration; the rate the device delivers is the algorithmic bytes of a step over ms_per_step
+                         "delivered": {"achieved": alg * world / (1e3 * elapsed / args.steps * 1e-3) / 1e9 / world,
+                                       "frac": alg / (1e3 * elapsed / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s per GPU"}},
         }
+        if single:
+            out["single_stream"] = single
         if valu:
             out["fp64_valu"] = valu
         if secondary:

@@ -205,6 +205,10 @@ class Context:
     def use_own_stream(self):
         _check(self.lib, self.lib.tff_ctx_use_own_stream(self.handle), "use_own_stream")
 
+    def stream_ptr(self):
+        """The hipStream_t the context launches on (its own stream unless set_stream was called), as an integer."""
+        return int(self.lib.tff_ctx_get_stream(self.handle) or 0)
+
     def synchronize(self):
         _check(self.lib, self.lib.tff_ctx_synchronize(self.handle), "synchronize")
 
