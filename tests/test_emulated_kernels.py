@@ -493,3 +493,74 @@ def test_emulated_row_eigvec_dpp_form_matches_the_readlane_form_and_lapack(emu, 
         assert min(np.abs(xr[b] - v).max(), np.abs(xr[b] + v).max()) < tol, (b, gap)
         assert min(np.abs(xr[b] - xl[b]).max(), np.abs(xr[b] + xl[b]).max()) < 1e-13 + tol
         assert abs(int(ir[b]) - int(il[b])) <= 1, (b, ir[b], il[b])
+
+
+# ---- four triplets per wavefront (csrc/tft_rows_kernel.h) -----------------------------------------------------------------------
+FLAG_DBG_ADAPTIVE = 32
+
+
+@pytest.mark.parametrize("B,N,sigma", [(5, 12, 1.0), (4, 70, 0.0), (3, 130, 1.0), (6, 200, 1.0)])
+def test_rows_kernel_matches_oracle(emu, B, N, sigma):
+    """One triplet per row of 16 lanes: batches that do and do not fill the last wavefront (tail rows repeat the last triplet and store
+    nothing), one to thirteen trips per data pass.  Production route (adaptive votes) and debug route (all four scores)."""
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=sigma, seed=100 + N)
+    for debug in (False, True):
+        out = run_linear_tft(emu, C, CalM, entry="emu_linear_tft_pose_rows", debug=debug)
+        assert np.all(out["status"] == 0) and np.all(out["iter"] == 0)
+        for b in range(B):
+            R2, R3, Rec, T, _ = O.LinearTFTPoseEstimation(C[b].T.copy(), CalM)
+            assert rel_err_T(out["T"][b], T) < 1e-9
+            assert rel_err(out["R_t_2"][b], R2) < 1e-9 and rel_err(out["R_t_3"][b], R3) < 1e-9
+            assert rel_err(out["Reconst"][b], Rec) < 1e-9
+    wave = run_linear_tft(emu, C, CalM)
+    # the four cheirality scores of both essential matrices, up to the candidate order (the signs svd(E) gives U(:,3), V(:,3) permute the list)
+    so, sw = out["debug"][:, 60:68].reshape(B, 2, 4), wave["debug"][:, 60:68].reshape(B, 2, 4)
+    assert np.array_equal(np.sort(so, axis=2), np.sort(sw, axis=2))
+    assert np.abs(out["debug"][:, 33:60] - wave["debug"][:, 33:60]).max() < 1e-12     # linearTFT's constrained tensor (normalised frame)
+
+
+def test_rows_kernel_grid_stride_and_too_few(emu):
+    C, CalM, _, _ = generate_scene_batch(9, 20, noise=1.0, seed=77)
+    ref = run_linear_tft(emu, C, CalM, entry="emu_linear_tft_pose_rows", debug=False)
+    emu.emu_set_grid_cap(1)                                  # one wavefront takes all three quads through the same LDS
+    try:
+        out = run_linear_tft(emu, C, CalM, entry="emu_linear_tft_pose_rows", debug=False)
+    finally:
+        emu.emu_set_grid_cap(0)
+    for k in ("T", "R_t_2", "R_t_3", "Reconst", "iter", "status"):
+        assert np.array_equal(ref[k], out[k], equal_nan=True), k
+    C6, _, _, _ = generate_scene_batch(5, 6, noise=1.0, seed=1)
+    few = run_linear_tft(emu, C6, CalM, entry="emu_linear_tft_pose_rows", debug=False)
+    assert np.all(few["status"] == 1) and np.all(np.isnan(few["T"])) and np.all(np.isnan(few["R_t_3"]))
+
+
+def test_rows_kernel_adaptive_votes_second_sweep(emu):
+    """Three consistent correspondences of points BEHIND the three cameras, past the first 16: the candidate that looked unanimous after the
+    first trip ends at 2 N - 12, so its partner's score decides and is evaluated in a second sweep.  Scores and poses must equal those of
+    the one-triplet kernel, which evaluates every candidate over every correspondence."""
+    from tft_vs_fund_amd.scenes import scene_cameras
+    B, N = 5, 40
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=0.5, seed=5)
+    _, Ps, _, _ = scene_cameras()
+    C = C.copy()
+    rng = np.random.default_rng(3)
+    for b in range(B - 1):                                   # the last triplet stays clean: its row must not be disturbed by the others' second sweep
+        X = np.array([0.0, -3000.0, 700.0]) + rng.uniform(-150, 150, size=(3, 3))
+        for v in range(3):
+            x = (Ps[v] @ np.c_[X, np.ones(3)].T).T
+            assert np.all(x[:, 2] * np.sign(np.linalg.det(Ps[v][:, :3])) < 0)      # behind camera v
+            C[b, 20:23, 2 * v:2 * v + 2] = x[:, :2] / x[:, 2:3]
+    wave = run_linear_tft(emu, C, CalM, reconst=False)
+    scores = wave["debug"][:, 60:68].reshape(B, 2, 4)
+    assert np.all(np.abs(scores[:-1]).max(axis=2) == 2 * N - 12) and np.all(np.abs(scores[-1]).max(axis=1) == 2 * N)
+    for flags, debug in ((0, False), (FLAG_DBG_ADAPTIVE, True)):
+        out = run_linear_tft(emu, C, CalM, flags=flags, reconst=False, entry="emu_linear_tft_pose_rows", debug=debug)
+        assert np.all(out["status"] == 0) and np.all(wave["status"] == 0)
+        assert np.abs(out["R_t_2"] - wave["R_t_2"]).max() < 1e-9 and np.abs(out["R_t_3"] - wave["R_t_3"]).max() < 1e-9
+    sweeps = out["debug"][:, 94].astype(int)
+    assert np.all((sweeps[:4] & 15) == 2) and np.all(sweeps[:4] >= 48)     # the first wavefront made the second sweep, both pairs complete
+    assert (sweeps[4] & 15) == 1 and sweeps[4] < 16                        # the second wavefront (the clean triplet alone) did not
+    got = out["debug"][:, 60:68].reshape(B, 2, 4)
+    assert np.array_equal(np.sort(got[:4], axis=2), np.sort(scores[:4], axis=2))
+    # a score that was not needed is reported as 0: same pick
+    assert np.array_equal(np.argmax(got[4], axis=1), np.argmax(scores[4], axis=1)) and np.all(np.abs(got[4]).max(axis=1) == 2 * N)

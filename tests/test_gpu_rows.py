@@ -1,0 +1,117 @@
+"""
+The four-triplets-per-wavefront LinearTFT kernel (csrc/tft_rows_kernel.h, TFF_OPT_ROWS = 1, the default) on the MI355X against the
+one-triplet-per-wavefront kernel (TFF_OPT_ROWS = 0) and the oracle: same arithmetic per matrix entry and correspondence, sums taken in
+a different order, so the two routes must agree to rounding on every batch shape -- full and ragged last wavefronts, one to many trips
+per data pass, well-posed and outlier-ridden data (adaptive cheirality votes: second sweep), sampled hypotheses (config 4).
+The oracle comparisons of tests/test_gpu_parity.py run through the rows kernel as well, since it is the default route.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from helpers import rel_err_T, rel_err   # noqa: E402
+
+TOL = 1e-9
+
+
+def _both_routes(ctx, *args, **kw):
+    out = {}
+    for rows in (1, 0):
+        ctx.set_rows(rows)
+        try:
+            o = ctx.pose_batch(*args, **kw)
+        finally:
+            ctx.set_rows(1)
+        out[rows] = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in o.items() if k != "_raw" and v is not None}
+    return out[1], out[0]
+
+
+@pytest.mark.parametrize("B,N,sigma", [(10000, 200, 1.0), (3001, 33, 0.5), (1000, 500, 1.0), (2047, 16, 2.0), (5, 100, 1.0), (1, 64, 1.0)])
+def test_rows_and_wave_routes_agree(gpu_ctx, B, N, sigma):
+    import torch
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=sigma, seed=7 * N + B)
+    d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
+    r, w = _both_routes(gpu_ctx, "LinearTFTPoseEstimation", d, calm, reconst=True)
+    assert np.array_equal(r["status"], w["status"]) and np.all(r["status"] == 0) and np.all(r["iter"] == 0)
+    sg = np.sign(np.sum(r["T"] * w["T"], axis=(1, 2, 3)))[:, None, None, None]
+    assert np.abs(r["T"] * sg - w["T"]).max() < TOL
+    assert np.abs(r["R_t_2"] - w["R_t_2"]).max() < TOL
+    assert np.abs(r["R_t_3"] - w["R_t_3"]).max() < TOL * max(1.0, np.abs(w["R_t_3"]).max())
+    assert np.abs(r["Reconst"] - w["Reconst"]).max() < 1e-8 * np.abs(w["Reconst"]).max()
+    # and against the oracle, first and last triplets (the last wavefront is ragged unless B is a multiple of four)
+    from oracle import tft_oracle as O
+    for b in sorted(set([0, B // 2, max(B - 2, 0), B - 1])):
+        R2, R3, Rec, T, _ = O.LinearTFTPoseEstimation(C[b].T.copy(), CalM)
+        assert rel_err_T(r["T"][b], T) < TOL and rel_err(r["R_t_2"][b], R2) < TOL and rel_err(r["R_t_3"][b], R3) < TOL
+        assert rel_err(r["Reconst"][b], Rec) < TOL
+
+
+def test_rows_result_does_not_depend_on_the_row_or_the_neighbours(gpu_ctx):
+    """A triplet gives bit-identical results in every row of a wavefront, whatever the other rows hold."""
+    import torch
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    C, CalM, _, _ = generate_scene_batch(9, 200, noise=1.0, seed=99)
+    calm = torch.from_numpy(CalM).cuda()
+    base = gpu_ctx.pose_batch("LinearTFTPoseEstimation", torch.from_numpy(C[:1].copy()).cuda(), calm, reconst=True)
+    for pos in range(4):
+        idx = [1, 2, 3, 4, 5, 6, 7, 8]
+        idx.insert(pos, 0)
+        out = gpu_ctx.pose_batch("LinearTFTPoseEstimation", torch.from_numpy(np.ascontiguousarray(C[idx])).cuda(), calm, reconst=True)
+        for k in ("T", "R_t_2", "R_t_3", "Reconst"):
+            assert torch.equal(out[k][pos], base[k][0]), (pos, k)
+
+
+def test_rows_adaptive_votes_on_outlier_data(gpu_ctx):
+    """A fifth of the correspondences replaced by random image points, noise 2 px, N = 30: cheirality scores fall short of 2 N, votes go
+    uncertified, triplets are handed to the exact kernel -- on both routes alike."""
+    import torch
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    B, N = 8000, 30
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=2.0, seed=31)
+    rng = np.random.default_rng(8)
+    C = C.copy()
+    for b in range(B):
+        bad = rng.choice(N, 6, replace=False)
+        C[b, bad, 2:6] = rng.uniform([0, 0, 0, 0], [1800, 1200, 1800, 1200], size=(6, 4))
+    d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
+    r, w = _both_routes(gpu_ctx, "LinearTFTPoseEstimation", d, calm, reconst=False)
+    assert np.array_equal(r["status"], w["status"])
+    ok = r["status"] == 0
+    assert ok.mean() > 0.5
+    e2 = np.abs(r["R_t_2"] - w["R_t_2"]).reshape(B, -1).max(axis=1)[ok]
+    e3 = np.abs(r["R_t_3"] - w["R_t_3"]).reshape(B, -1).max(axis=1)[ok]
+    # rounding-level cheirality ties between the two rotations may fall differently (the reference leaves them open: tests/helpers.py)
+    assert (e2 > 1e-7).mean() < 2e-3 and (e3 > 1e-6 * np.abs(w["R_t_3"]).reshape(B, -1).max(axis=1)[ok].clip(1.0)).mean() < 2e-3
+
+
+def test_rows_sampled_hypotheses(gpu_ctx):
+    """Config-4 style index gathering through the rows kernel (TFF_OPT_EXACT_BELOW = 0, 12-point samples): same poses as the
+    one-triplet kernel's LDS gather, and an index outside the scene is reported for its own hypothesis only."""
+    import torch
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    Ns, H, n = 300, 4001, 12
+    Cs, CalM, _, _ = generate_scene_batch(1, Ns, noise=0.5, seed=11)
+    scene = torch.from_numpy(Cs[0].copy()).cuda(); calm = torch.from_numpy(CalM).cuda()
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    idx = torch.rand((H, Ns), device="cuda", generator=g).argsort(dim=1)[:, :n].to(torch.int32).contiguous()
+    idx[17, 3] = Ns            # outside the scene
+    idx[18, 0] = -1
+    res = {}
+    gpu_ctx.set_exact_below(0)
+    try:
+        for rows in (1, 0):
+            gpu_ctx.set_rows(rows)
+            o = gpu_ctx.pose_sampled("LinearTFTPoseEstimation", scene, calm, idx)
+            res[rows] = {k: v.cpu().numpy() for k, v in o.items() if k != "_raw"}
+    finally:
+        gpu_ctx.set_rows(1)
+        gpu_ctx.set_exact_below(12)
+    r, w = res[1], res[0]
+    assert np.array_equal(r["status"], w["status"])
+    assert r["status"][17] == 1 and r["status"][18] == 1 and np.all(np.isnan(r["T"][17])) and (r["status"] == 1).sum() == 2
+    ok = r["status"] == 0
+    assert ok.sum() >= H - 2 - 40
+    e3 = np.abs(r["R_t_3"] - w["R_t_3"]).reshape(H, -1).max(axis=1)[ok]
+    assert (e3 > 1e-6).mean() < 5e-3

@@ -503,7 +503,7 @@ __device__ __forceinline__ bool rows_rt_prepare(RowLds* w, RowRt* rt, double* db
 // broadcast reads that cost no VALU slot).
 // Returns false (per row) when a needed vote could not be certified.  sc[call][0] = sR, sc[call][1] = sRp; a score that was not needed is
 // reported as 0 (it is below 2 N in magnitude and its partner is +-2 N: same pick).
-__device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const RowRt* rt, const bool all4, int (&sc)[2][2]) {
+__device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const RowRt* rt, const bool all4, int (&sc)[2][2], int* sweeps_out = nullptr) {
     const int p = rows_p();
     double PA[12];
 #pragma unroll
@@ -514,8 +514,10 @@ __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const R
     bool main1[2] = {false, false};                                          // the row's main candidate is Rp
     bool evalA = true, evalB[2] = {true, true};                              // wave-uniform: what the running sweep evaluates
     bool fullB[2] = {true, true};                                            // wave-uniform: B covers every trip
+    int sweeps = 0;
 #pragma unroll 1
     for (int sweep = 0; sweep < 2; ++sweep) {
+        ++sweeps;
         const int start = (sweep == 0) ? 0 : ROWL;
         Pt6 pnext = rows_load(s, (start + p < N) ? start + p : 0);
 #pragma unroll 1
@@ -609,6 +611,7 @@ __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const R
         sc[call][0] = main1[call] ? tB : tA;
         sc[call][1] = main1[call] ? tA : tB;
     }
+    if (sweeps_out) *sweeps_out = sweeps + (fullB[0] ? 16 : 0) + (fullB[1] ? 32 : 0);   // (debug: sweeps made, which pairs were evaluated in full)
     return ok;
 }
 
@@ -711,7 +714,9 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose_rows(const LinearTftA
             rows_stamp(dbg, 10);
             {                                                                // recover_R_t (R_t_from_TFT.m:82-106), see pose_common.h::recover_vote
                 int sc[2][2];
-                ok = rows_votes(src, N, rt, dbg != nullptr, sc) && ok;       // an uncertified sign: the exact kernel's business
+                int sweeps = 0;
+                ok = rows_votes(src, N, rt, dbg != nullptr && !(a.flags & FLAG_DBG_ADAPTIVE), sc, &sweeps) && ok;   // an uncertified sign: the exact kernel's business
+                if (dbg && p == 0) dbg[94] = (double)sweeps;
 #pragma unroll
                 for (int call = 0; call < 2; ++call) {
                     const int sR = sc[call][0], sRp = sc[call][1];
