@@ -424,6 +424,33 @@ def test_emulated_tridiagonal_pinv_solver_matches_lapack(emu, variant):
         assert nk == keeps[0] and np.linalg.norm(x - refs[0]) <= 1e-10 * np.linalg.norm(refs[0])
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_emulated_tridiagonal_pinv_solver_reports_clustered_eigenvalues(emu, variant):
+    """Two kept eigenvalues 1e-9 |T| apart: the eigenvectors come from independent iterations and need not be orthogonal inside the cluster.
+    The solver must either still be right or say so (fail = 1: the caller takes the orthogonalising eigen-decomposition) -- never silently
+    wrong.  Well separated spectra (the test above) must not trip the guard."""
+    rng = np.random.default_rng(11 + variant)
+    n, B = 24, 4
+    Ms, tols, refs = [], [], []
+    for b in range(B):
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        lam = np.concatenate([-np.geomspace(1e-3, 1.0, 6), np.geomspace(1e-2, 50.0, n - 6)])
+        lam[10] = lam[9] * (1.0 + (1e-9 if b % 2 == 0 else 3e-13) * 50.0 / lam[9])          # a pair 1e-9 |T| (3e-13 |T|) apart
+        S = (Q * lam) @ Q.T
+        S = 0.5 * (S + S.T)
+        rhs = rng.standard_normal(n)
+        Ms.append(np.hstack([S, rhs[:, None]])); tols.append(1e-9)
+        w, V = np.linalg.eigh(S)
+        refs.append(V @ ((V.T @ rhs) / w))
+    Maug = np.ascontiguousarray(np.stack(Ms)); tol = np.array(tols)
+    sol = np.zeros((B, n)); kept = np.zeros(B, dtype=np.int32); fail = np.zeros(B, dtype=np.int32)
+    emu.emu_trid_pinv(_p(Maug), _p(tol), ctypes.c_long(B), ctypes.c_int(n), _p(sol), _p(kept), _p(fail), ctypes.c_int(variant))
+    assert np.all(kept == n)
+    for b in range(B):
+        err = np.linalg.norm(sol[b] - refs[b]) / np.linalg.norm(refs[b])
+        assert fail[b] == 1 or err <= 1e-9, (b, err, fail[b])
+
+
 def test_emulated_faugpapa_block_kernel_reproduces_the_extended_precision_iteration(emu, golden_dir):
     """k_fp_block (FaugPapaTFTPoseEstimation.m:48-153 on Gauss_Helmert.m:38-83, factored form) on an N = 12 scene of the 50-digit fixture:
     1e-9 and the same iteration count; nothing handed back to the generic kernel."""

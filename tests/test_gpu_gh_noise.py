@@ -147,8 +147,8 @@ def test_generic_block_kernel_stays_inside_the_lapack_envelope(gpu_ctx, golden_d
             o2, o3, _, oT, _ = getattr(O, method)(C[b].T.copy(), CalM)
             do.append(_dev(oT, o2, o3, g, pre, b))
         do = np.array(do)
-        for q in (0.5, 0.9, 1.0):
-            assert np.quantile(dk, q) <= 10.0 * np.quantile(do, q) + 1e-12, (ci, q, np.quantile(dk, q), np.quantile(do, q))
+        for q, factor in ((0.5, 3.0), (0.9, 3.0), (1.0, 10.0)):              # (the maximum is one scene's last-bit luck; the bulk is held to 3x)
+            assert np.quantile(dk, q) <= factor * np.quantile(do, q) + 1e-12, (ci, q, np.quantile(dk, q), np.quantile(do, q))
         assert dk.max() < 2e-3
         assert np.abs(np.asarray(out["iter"]) - g[pre + "mp_iter"]).max() <= 2
 

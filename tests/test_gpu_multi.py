@@ -71,6 +71,38 @@ def test_dev_multi_gathers_records_on_every_device(B):
     m.close()
 
 
+def test_dev_multi_gives_the_streams_back_and_leaves_the_device_alone():
+    """pose_batch_dev lends every context torch's current stream for the call only: afterwards the contexts launch on their own streams
+    again (a user stream destroyed after the call must not be touched), and the calling thread's current device is what it was."""
+    import ctypes
+    import torch
+    from tft_vs_fund_amd import api
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    G = _devices()
+    B, N = 9, 20
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=3)
+    m = api.MultiContext(list(range(G)))
+    own = [int(m.lib.tff_ctx_get_stream(m.lib.tff_multi_ctx(m.handle, g)) or 0) for g in range(G)]
+    shards, calms = [], []
+    for g in range(G):
+        b0, b1 = m.shard(B, g)
+        dev = torch.device("cuda", g)
+        shards.append(torch.from_numpy(np.ascontiguousarray(C[b0:b1])).to(dev))
+        calms.append(torch.from_numpy(CalM).to(dev))
+    torch.cuda.set_device(0)
+    user = torch.cuda.Stream(torch.device("cuda", 0))
+    with torch.cuda.stream(user):
+        recs, sts, chunk = m.pose_batch_dev("LinearTFTPoseEstimation", shards, calms, B)
+    assert torch.cuda.current_device() == 0
+    now = [int(m.lib.tff_ctx_get_stream(m.lib.tff_multi_ctx(m.handle, g)) or 0) for g in range(G)]
+    assert now == own and user.cuda_stream not in now
+    del user
+    out = m.pose_batch("LinearTFTPoseEstimation", C, CalM, reconst=False)      # runs on the contexts' own streams
+    ref = api.Context(0).pose_batch("LinearTFTPoseEstimation", C, CalM, reconst=False)
+    assert np.array_equal(out["T"], ref["T"]) and torch.cuda.current_device() == 0
+    m.close()
+
+
 def test_multi_rejects_bad_arguments():
     from tft_vs_fund_amd import api
     with pytest.raises(api.TffError):

@@ -716,6 +716,27 @@ def test_spilled_batches_are_bit_identical_to_single_triplets(gpu_ctx, method, N
             assert np.array_equal(np.asarray(full[k][b]), np.asarray(one[k][0]), equal_nan=True), (method, N, b, k)
 
 
+@pytest.mark.parametrize("method", ["ResslTFTPoseEstimation", "FaugPapaTFTPoseEstimation", "PiPoseEstimation", "OptimFPoseEstimation"])
+def test_spill_only_if_needed_route_agrees_with_the_default(gpu_ctx, method):
+    """TFF_OPT_SPILL = 1 keeps the per-correspondence state of the iterative methods in LDS whenever it fits (the default moves it to global
+    slices when that buys occupancy): same arithmetic, so the same results and iteration counts."""
+    import torch
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    B, N = 96, 200
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=314)
+    d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
+    ref = gpu_ctx.pose_batch(method, d, calm, reconst=False)
+    gpu_ctx.set_spill_only_if_needed(True)
+    try:
+        out = gpu_ctx.pose_batch(method, d, calm, reconst=False)
+    finally:
+        gpu_ctx.set_spill_only_if_needed(False)
+    torch.cuda.synchronize()
+    assert torch.equal(out["status"], ref["status"]) and torch.equal(out["iter"], ref["iter"])
+    for k in ("T", "R_t_2", "R_t_3"):
+        assert (out[k] - ref[k]).abs().max().item() < 1e-9 * max(1.0, ref[k].abs().max().item()), k
+
+
 def test_exact_fixup_pass_finds_every_retry_in_a_large_batch(gpu_ctx):
     """Minimal noisy samples with the whole-batch routing switched off (TFF_OPT_EXACT_BELOW = 0): the fast tiers flag the triplets
     they cannot finish or certify (status ST_RETRY inside the library) and the exact kernel, whose fixed 1024-block grid strides

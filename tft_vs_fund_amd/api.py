@@ -518,6 +518,10 @@ class MultiContext:
                "tff_pose_batch_dev_multi")
         for g in range(G):
             _check(self.lib, self.lib.tff_ctx_synchronize(self.lib.tff_multi_ctx(self.handle, g)), "synchronize")
+        # everything is complete: give the borrowed torch streams back (a later call on these contexts -- pose_batch, another thread's
+        # pose_batch_dev under a different torch stream -- must not run on a stream the caller may have destroyed meanwhile)
+        for g in range(G):
+            _check(self.lib, self.lib.tff_ctx_use_own_stream(self.lib.tff_multi_ctx(self.handle, g)), "tff_ctx_use_own_stream")
         return recs, sts, chunk
 
     def close(self):

@@ -301,7 +301,7 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
     if (c->kernel_variant == 1 || small)                                     // TFF_OPT_SOLVER = 1 is honoured by launch_wg's linear stage
         return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, 0, std::is_same<Model, tff::ResslModel>::value ? 8 : 4, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
-    // FaugPapa: the factored iteration of gh_fp_kernel.h (one correspondence per thread, N <= 256) unless an A/B switch asks for the generic kernel
+    // FaugPapa: the factored iteration of gh_fp_kernel.h (the threads stride over the correspondences: any N) unless an A/B switch asks for the generic kernel
     const bool fp_first = std::is_same<Model, tff::FaugPapaModel>::value && c->kernel_variant == 0 && !c->gh_exact;
     // occupancy policy of the per-correspondence state (plan_spill): Nordberg runs as fast with it in LDS at two workgroups per CU as with it in global
     // slices at three (3.89 vs 3.87 ms per 10 k x 200) -- without the state's HBM round trips (what is left of its 52x algorithmic traffic is scratch:
@@ -422,6 +422,10 @@ void tff_ctx_destroy(tff_ctx* c) {
 // old stream, waited for by the new one (no host synchronisation).
 static int switch_stream(tff_ctx* c, hipStream_t s) {
     if (s == c->stream) return 0;
+    // the hand-over touches the context's device; the calling thread's current device is the caller's business and is put back
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{caller_device};
     TFF_HIP(hipSetDevice(c->device));
     if (!c->handover) TFF_HIP(hipEventCreateWithFlags(&c->handover, hipEventDisableTiming));
     // The previous stream must still be alive here (a caller that destroys its stream first hands the context a dangling handle).  If

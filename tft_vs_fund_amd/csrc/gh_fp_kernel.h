@@ -24,8 +24,9 @@
 //      dt = Q z;  v = -B' W+ (A dt - w) with the strong term cs n n'(A dt - w) evaluated from the differences.
 // tools/proto_faugpapa_factored.py is the numpy twin: 48 fixture scenes within 4e-11 of the 50-digit iteration, equal iteration counts.
 //
-// Per-correspondence state (estimate xi, K_i, n_i, cs_i, n_i'w_i: 22 doubles) lives in LDS (35 KB at N = 200, two workgroups per CU) or,
-// beyond what the LDS holds, in the global slices of launch_wg.  A first version kept it in registers, one correspondence per thread, for
+// Per-correspondence state (estimate xi, K_i, n_i, cs_i, n_i'w_i: 22 doubles) lives in the global slices of launch_wg whenever that lets
+// more workgroups share a CU (the default, plan_spill: three per CU at N = 200) or in LDS (35 KB at N = 200, two workgroups per CU;
+// TFF_OPT_SPILL = 1 keeps it there whenever it fits).  A first version kept it in registers, one correspondence per thread, for
 // four workgroups per CU: with 32-wide butterflies on top the register allocator spilled it around every sum (15 GB of scratch traffic
 // per 10 k x 200 launch, 11 ms).  Triplets this kernel cannot take (a weight block without the one-small-eigenvalue structure) are
 // handed to k_gh_block<FaugPapaModel> through the status array (ST_RETRY).
@@ -512,19 +513,9 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
         // (Taking only the tangential block from the rotated factors and the strong / cross blocks Q(:,1:8)' Hs Q from the formed Hs was tried:
         // 9.6e-9 instead of 7e-11 on a scene whose smallest strong eigenvalue is 1e10 -- the cross block's 1e-3 absolute rounding is not
         // small against THAT.  All 378 + 27 sums come from the rotated factors.)
-        const bool fast = false;
         phase_stamp(sdbg, 22);
-        // ---- rotated strong sums (one correspondence per thread); Y = R Q; Z = Q(:, 0:8)' Hs ----
-        if (wave < waves) {
-            if (fast) fp_rotated_sums<FP_C0, SP>(s, xi, pp, N, s.Mx + wave * 224);
-            else fp_rotated_sums<0, SP>(s, xi, pp, N, s.Mx + wave * 416);
-        }
-        for (int e = tid; e < FP_C0 * 27; e += GH_WG_THREADS) {               // Z[r][c] = sum_k Q[k][r] Hs[k][c], r < FP_C0 (fin's reflectors are dead)
-            const int r = e / 27, c = e % 27;
-            double acc = 0.0;
-            for (int k = 0; k < 27; ++k) acc += s.Q[k * 27 + r] * s.A2[k * 27 + c];
-            s.fin[216 + e] = acc;
-        }
+        // ---- rotated strong sums (one correspondence per thread); Y = R Q ----
+        if (wave < waves) fp_rotated_sums<0, SP>(s, xi, pp, N, s.Mx + wave * 416);
         __syncthreads();
         for (int e = tid; e < 729; e += GH_WG_THREADS) {                     // Y = R Q -> A2 (Hs is dead now)
             const int r = e / 27, c = e % 27;
@@ -535,7 +526,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
         __syncthreads();
         phase_stamp(sdbg, 23);
         {
-            const int nsum = fast ? 209 : 405, stride = fast ? 224 : 416;
+            const int nsum = 405, stride = 416;
             for (int e = tid; e < 729 + 405; e += GH_WG_THREADS) {
                 if (e < 729) {                                               // Q' (R Q) -> A1
                     const int r = e / 27, c = e % 27;
@@ -558,28 +549,10 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             double v;
             if (r < 27 && c < 27) {
                 v = s.A1[r * 27 + c] + ((r == c) ? 1e-12 : 0.0);
-                if (!fast) {
-                    v += s.fin[(r >= c) ? tri_index(r, c) : tri_index(c, r)];
-                } else if (r >= FP_C0 && c >= FP_C0) {
-                    const int a = r - FP_C0, b = c - FP_C0;
-                    v += s.fin[(a >= b) ? tri_index(a, b) : tri_index(b, a)];
-                } else {                                                     // strong / cross block of Q' Hs Q from the formed Hs
-                    const int rr = (r < c) ? r : c, cc = (r < c) ? c : r;    // rr < FP_C0
-                    double acc = 0.0;
-                    for (int k = 0; k < 27; ++k) acc += s.fin[216 + rr * 27 + k] * s.Q[k * 27 + cc];
-                    v += acc;
-                }
+                v += s.fin[(r >= c) ? tri_index(r, c) : tri_index(c, r)];
             } else if (r < 27 && c == 39) {
-                double acc = 0.0;
-                if (!fast) {
-                    acc = s.fin[378 + r];
-                    for (int k = 0; k < 27; ++k) acc += s.Q[k * 27 + r] * s.rvec[k];
-                } else if (r >= FP_C0) {
-                    acc = s.fin[190 + r - FP_C0];
-                    for (int k = 0; k < 27; ++k) acc += s.Q[k * 27 + r] * s.rvec[k];
-                } else {
-                    for (int k = 0; k < 27; ++k) acc += s.Q[k * 27 + r] * (s.rvec[k] + s.rsvec[k]);
-                }
+                double acc = s.fin[378 + r];
+                for (int k = 0; k < 27; ++k) acc += s.Q[k * 27 + r] * s.rvec[k];
                 v = acc;
             } else if (r >= 27 && c == 39) {
                 v = s.gneg[r - 27];
@@ -629,6 +602,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
                 // the eigen-decomposition of the whole remainder, its own largest eigenvalue for the tolerance
                 int fail;
                 const double lam = wave_eigh_ql(S, 40, s.A1, n2, n2, s.sm, &fail);
+                if (fail && lane == 0) s.flag[2] = 1.0;                      // (an eigenvalue that did not converge: the triplet goes to the generic kernel)
                 double amax = wave_max((lane < n2) ? fabs(lam) : 0.0);
                 if (ns > 0 && s.flag[1] > amax) amax = s.flag[1];
                 const double tol = 39.0 * eps_of(amax);

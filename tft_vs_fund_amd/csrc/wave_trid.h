@@ -371,6 +371,21 @@ __device__ __forceinline__ double wave_trid_pinv(const lds_ptr dS, const lds_ptr
     wave_sync();
     phase_stamp(dbg, 30);
     if (dbg && lane_id() == 0) dbg[79] = (double)it;
+    // Guard for clustered kept eigenvalues: the eigenvectors come from INDEPENDENT iterations (no re-orthogonalisation), so two of them that
+    // belong to nearly coincident eigenvalues may both be good Ritz vectors of the cluster and yet not orthogonal -- the sum over the cluster
+    // would then be wrong by their overlap (eps |T| / gap).  Neighbouring eigenvalues are the closest ones: the cosine between the vectors of
+    // lanes l and l + 1 is measured, and anything above 1e-9 (the parity gate of the callers) reports failure -- the caller redoes the system
+    // with an eigen-decomposition that orthogonalises (wave_eigh_ql) or hands the triplet on.
+    {
+        const int lane_ = lane_id();
+        const bool pair = own && lane_ + 1 < kept;
+        double dotn = 0.0;
+        const int zn = pair ? zl + 1 : zl;
+#pragma unroll 4
+        for (int j = 0; j < n; ++j) dotn += Z[j * TRID_LD + zl] * Z[j * TRID_LD + zn];
+        const double nz2n = wave_shfl(nz2, (lane_ + 1) & 63);
+        if (wave_any(pair && !(dotn * dotn <= 1e-18 * nz2 * nz2n))) *fail = 1;
+    }
     // ---- step 4: coefficients, x^ ----
     if (own) {
         double dot = 0.0;
@@ -600,8 +615,17 @@ __device__ __forceinline__ double wave_trid_pinv_fast(const double dreg, const d
     if (wave_any(!done) || wave_any(risky && own)) *fail = 1;
     phase_stamp(dbg, 30);
     if (dbg && lane == 0) dbg[79] = (double)it;
-    // ---- step 4: coefficients, x^ ----
     wave_sync();
+    {                                                                        // guard for clustered kept eigenvalues: see wave_trid_pinv
+        const bool pair = own && lane + 1 < kept;
+        double dotn = 0.0;
+        const int zn = pair ? zl + 1 : zl;
+#pragma unroll 4
+        for (int j = 0; j < n; ++j) dotn += Zt[j * TRID_LD + zl] * Zt[j * TRID_LD + zn];
+        const double nz2n = wave_shfl(nz2, (lane + 1) & 63);
+        if (wave_any(pair && !(dotn * dotn <= 1e-18 * nz2 * nz2n))) *fail = 1;
+    }
+    // ---- step 4: coefficients, x^ ----
     if (own) {
         double dot = 0.0;
 #pragma unroll 4
