@@ -56,6 +56,7 @@ extern "C" int emu_linear_tft_pose_rows(const double* corresp, const double* cal
     emu::launch(tff::k_linear_tft_pose<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, a.flags, true), a);
     return 1;
 }
+#ifndef TFF_EMU_LINEAR_TFT_ONLY   // (the sanitizer build of tests/test_emulated_kernels.py compiles the linear trifocal kernels only: minutes less)
 extern "C" int emu_linear_f_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
                                  double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
     return emu_pose(tff::k_f_pose<false, 0>, tff::k_f_pose<true, 0>, tff::f_pose_lds_bytes, true, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T,
@@ -337,3 +338,4 @@ extern "C" int emu_pinv_one_null(const double* W16, double tolW, double* wp_shor
         }
     return 0;
 }
+#endif  // TFF_EMU_LINEAR_TFT_ONLY

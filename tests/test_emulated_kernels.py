@@ -591,3 +591,35 @@ def test_rows_kernel_adaptive_votes_second_sweep(emu):
     assert np.array_equal(np.sort(got[:4], axis=2), np.sort(scores[:4], axis=2))
     # a score that was not needed is reported as 0: same pick
     assert np.array_equal(np.argmax(got[4], axis=1), np.argmax(scores[4], axis=1)) and np.all(np.abs(got[4]).max(axis=1) == 2 * N)
+
+
+def test_linear_tft_kernels_under_address_and_ub_sanitizers():
+    """tests/emu/emu_build.build(sanitize=True): the rows kernel, the one-triplet kernel and the exact kernel compiled with
+    -fsanitize=address,undefined and run in a child process that has the sanitizer runtimes preloaded -- ragged last wavefront, grid-stride
+    reuse of the LDS, a batch that sends triplets to the exact kernel.  Any out-of-bounds LDS index, use of an uninitialised overlay or signed
+    overflow aborts the child."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import ctypes, sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import numpy as np
+        from emu import emu_build
+        from test_emulated_kernels import run_linear_tft
+        from tft_vs_fund_amd.scenes import generate_scene_batch
+        lib = ctypes.CDLL(emu_build.build(sanitize=True))
+        C, CalM, _, _ = generate_scene_batch(5, 20, noise=1.0, seed=3)
+        a = run_linear_tft(lib, C, CalM, entry="emu_linear_tft_pose_rows", debug=False)
+        lib.emu_set_grid_cap(1)
+        b = run_linear_tft(lib, C, CalM, entry="emu_linear_tft_pose_rows", debug=True)
+        lib.emu_set_grid_cap(0)
+        w = run_linear_tft(lib, C, CalM)
+        C7, _, _, _ = generate_scene_batch(2, 7, noise=1.0, seed=4)          # minimal samples: the exact kernel
+        e = run_linear_tft(lib, C7, CalM)
+        assert np.all(a["status"] == 0) and np.all(b["status"] == 0) and np.all(w["status"] == 0) and np.all(e["status"] == 0)
+        assert np.abs(a["R_t_3"] - w["R_t_3"]).max() < 1e-9 and np.array_equal(a["T"], b["T"])
+        print("sanitized run ok")
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=emu_build.sanitizer_env(), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "sanitized run ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
