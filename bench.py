@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary blocks (other methods, N sweep, config 4; 1 GPU, rank 0)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the steps alternate between (1 = strictly one batch at a time)")
+    ap.add_argument("--stub-compute", action="store_true",
+                    help="TEST SEAM (tests/test_bench_flow_gloo.py): CPU tensors + gloo, the HIP launch replaced by a tagged fill -- everything around it "
+                         "(rendezvous, rank-0 build + barrier, step / gather pipeline, weak-scaling accounting, the JSON line) runs as on the GPUs")
     args = ap.parse_args()
 
     import torch
@@ -89,19 +92,24 @@ def main():
     from tft_vs_fund_amd.build import build_library
     from tft_vs_fund_amd.scenes import generate_scene_batch
 
-    rank, world, local = tdist.init_from_env("cuda")
+    stub = args.stub_compute
+    rank, world, local = tdist.init_from_env("cpu" if stub else "cuda")
     if world != args.gpus:
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if rank == 0:
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    if rank == 0 and not stub:
         build_library()
     if world > 1:
         dist.barrier()
     S = max(1, args.streams)
-    ctxs = [api.Context(local) for _ in range(S)]
-    ctx = ctxs[0]
+    ctxs = [api.Context(local) for _ in range(S)] if not stub else []
+    ctx = ctxs[0] if ctxs else None
+    dsync = (lambda: None) if stub else (lambda: torch.cuda.synchronize(dev))
 
     B, N = args.batch, args.ncorr
     C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=1000 + rank)
@@ -112,9 +120,11 @@ def main():
     statuses = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(S)]
     status = statuses[0]
     import ctypes
-    lib = ctx.lib
-    stream = torch.cuda.current_stream(dev)                # the stream the process group orders its gathers against
-    if S > 1:
+    lib = ctx.lib if ctx else None
+    stream = torch.cuda.current_stream(dev) if not stub else None   # the stream the process group orders its gathers against
+    if stub:
+        side = []
+    elif S > 1:
         # every context launches on the stream the library created for it (hipStreamNonBlocking); measured: two of torch's pool streams
         # do not overlap their kernels on this stack, the contexts' own streams do (tools/ab_streams2.py)
         for c in ctxs:
@@ -125,7 +135,14 @@ def main():
         ctx.set_stream(stream.cuda_stream)
     p = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + 8 * off)
     timing = {"events": None}
-    done = [torch.cuda.Event() for _ in range(S)]
+    done = [torch.cuda.Event() for _ in range(S)] if not stub else []
+    stub_ms = []
+
+    def compute_stub(r, k):                                # the records of (rank, step): what the gather check at the end looks for
+        t_ = time.perf_counter()
+        r.copy_(torch.full((r.numel(),), float(1000 * rank + k), dtype=torch.float64) + torch.arange(r.numel(), dtype=torch.float64) * 1e-9)
+        if timing["events"] is not None:
+            stub_ms.append(1e3 * (time.perf_counter() - t_))
 
     def compute(r, k):
         # step k runs on stream k % S (result buffer k % S: a stream only ever reuses its own buffer); the gather stream waits for it
@@ -145,13 +162,13 @@ def main():
             done[j].record(side[j])
             stream.wait_event(done[j])                    # anything enqueued on the main stream after this (the gather) sees the records
 
-    pipe = tdist.OverlappedGather(world, tdist.RECORD_DOUBLES * B, dev, compute, nbuf=max(2, S))
+    pipe = tdist.OverlappedGather(world, tdist.RECORD_DOUBLES * B, dev, compute_stub if stub else compute, nbuf=max(2, S))
     step, drain = pipe.step, pipe.drain
 
     def sync_all():
         for c in ctxs:
             c.synchronize()
-        torch.cuda.synchronize(dev)
+        dsync()
 
     for k in range(args.warmup):
         step(k)
@@ -159,8 +176,8 @@ def main():
     sync_all()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize(dev)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    dsync()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if not stub else [None] * args.steps
     t0 = time.perf_counter()
     timing["events"] = events
     for k in range(args.steps):
@@ -170,7 +187,7 @@ def main():
     sync_all()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    dsync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -179,8 +196,18 @@ def main():
     n_bad = sum(int((st_ != 0).sum().item()) for st_ in statuses)
     for c in ctxs:                                          # the secondary blocks below run on the main stream, one call at a time
         c.set_stream(stream.cuda_stream)
-    step_ms = np.array([a.elapsed_time(b) for a, b in events]) if events and not os.environ.get("TFF_BENCH_NOEV") else np.array([float("nan")])
+    if stub:
+        step_ms = np.array(stub_ms) if stub_ms else np.array([float("nan")])
+    else:
+        step_ms = np.array([a.elapsed_time(b) for a, b in events]) if events and not os.environ.get("TFF_BENCH_NOEV") else np.array([float("nan")])
     kern_ms = float(step_ms.mean())
+    gather_check = None
+    if stub and world > 1:                                  # every rank's records of the last step arrived complete and in rank order
+        kl = args.steps - 1
+        g_ = pipe.gathered[kl % pipe.nbuf]
+        n_ = g_.shape[1]
+        gather_check = all(torch.equal(g_[src], torch.full((n_,), float(1000 * src + kl), dtype=torch.float64) + torch.arange(n_, dtype=torch.float64) * 1e-9)
+                           for src in range(world))
 
     # secondary metrics of SURVEY 8(d) on the same resident batch (rank 0, outside the contract's timed region)
     secondary, n_sweep, config4 = {}, {}, {}
@@ -198,7 +225,7 @@ def main():
         return e0.elapsed_time(e1) / reps
 
     single = None
-    if rank == 0:
+    if rank == 0 and not stub:
         # the same launch, strictly one batch at a time on one stream (no overlap between consecutive batches)
         r0 = pipe.recs[0]
         call = lambda: lib.tff_linear_tft_pose_batch_dev(ctx.handle, p(d_C), p(d_calm), 0, B, N, p(r0, 0), p(r0, 12 * B), p(r0, 24 * B), None, None,
@@ -206,7 +233,7 @@ def main():
         ms1 = time_calls(call, max(10, args.steps))
         single = {"ms_per_batch": ms1, "value": B / (ms1 * 1e-3), "unit": "triplet-hypotheses/s",
                   "achieved_GBs": algorithmic_bytes_per_triplet(N) * B / (ms1 * 1e-3) / 1e9}
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if rank == 0 and world == 1 and not args.no_secondary and not stub:
         it32 = torch.zeros(B, dtype=torch.int32, device=dev)
         r = pipe.recs[0]
         for name in ("LinearFPoseEstimation", "OptimFPoseEstimation", "ResslTFTPoseEstimation", "NordbergTFTPoseEstimation",
@@ -286,7 +313,7 @@ def main():
                                    "linearTFT + R_t_from_TFT (LinearTFTPoseEstimation without Reconst), one batch per GPU" % (B, N),
                        "batch_per_gpu": B, "correspondences": N,
                        "streams": "%d (consecutive batches alternate between streams and may overlap)" % S if S > 1 else "1",
-                       "gather": "RCCL all_gather of 408-B result records, overlapped" if world > 1 else "none (1 GPU)",
+                       "gather": ("%s all_gather of 408-B result records, overlapped" % ("gloo (stub)" if stub else "RCCL")) if world > 1 else "none (1 GPU)",
                        "failed_triplets": n_bad},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_linear_tft_pose_rows", "kernel_ms": kern_ms,
@@ -310,7 +337,9 @@ def main():
             out["n_sweep"] = n_sweep
         if config4:
             out["config4"] = config4
-        if world == 1 and not args.no_cpu_baseline:
+        if stub:
+            out["stub"] = {"compute": "tagged fill on CPU tensors (test seam, not a measurement)", "gather_check": gather_check}
+        if world == 1 and not args.no_cpu_baseline and not stub:
             sample = args.cpu_sample or max(1024, 40 * (os.cpu_count() or 1))   # ~10 s of wall time on the box's host cores
             out["cpu_baseline"] = cpu_baseline(C, CalM, min(sample, B))
             out["cpu_baseline_lapack"] = cpu_baseline_lapack(C, CalM)

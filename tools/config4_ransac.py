@@ -22,9 +22,24 @@ def main():
     ap.add_argument("--scene", type=int, default=400)
     ap.add_argument("--outliers", type=float, default=0.25)
     ap.add_argument("--variant", type=int, default=0, help="TFF_OPT_KERNEL (1: paired kernel, A/B)")
+    ap.add_argument("--stub", action="store_true", help="TEST SEAM (tests/test_bench_flow_gloo.py): CPU + gloo, the counts replaced by a function of "
+                                                        "the global hypothesis index -- the sharding and the count gather run as on the GPUs")
     args = ap.parse_args()
     from tft_vs_fund_amd import api, dist as tdist
     from tft_vs_fund_amd.scenes import generate_scene_batch
+    if args.stub:
+        rank, world, _ = tdist.init_from_env("cpu")
+        lo, hi = tdist.shard_bounds(args.hyp, world, rank)
+        cnt = ((torch.arange(lo, hi, dtype=torch.int64) * 7919) % 401).to(torch.int32)      # this rank's block of "inlier counts"
+        allc = tdist.all_gather_counts(cnt, args.hyp)
+        exp = ((torch.arange(args.hyp, dtype=torch.int64) * 7919) % 401).to(torch.int32)
+        if rank == 0:
+            print(json.dumps({"config": "config4", "stub": True, "hypotheses": args.hyp, "n_gpus": world, "shard": [lo, hi],
+                              "gathered": int(allc.numel()), "order_ok": bool(torch.equal(allc, exp)), "best_inliers": int(allc.max())}))
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
     rank, world, local = tdist.init_from_env("cuda")
     torch.cuda.set_device(local)
     ctx = api.Context(local)
