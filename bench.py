@@ -70,6 +70,35 @@ def cpu_baseline_lapack(C, CalM, budget_s=8.0):
                        "triangulation loops in Python), one core" % (n, C.shape[1], dt))
 
 
+def cpu_baseline_reference(N):
+    """The reference's OWN timing, when someone with MATLAB has produced tests/golden/reference_golden.mat (matlab/reference_pin/
+    make_reference_golden.m: tic/toc around the reference's LinearTFTPoseEstimation on the committed fixture inputs).  Measured on that
+    person's machine, not on this GPU box -- reported as such, beside the port's figure measured here."""
+    path = os.path.join(ROOT, "tests", "golden", "reference_golden.mat")
+    if not os.path.exists(path):
+        return None
+    try:
+        from scipy.io import loadmat
+        m = loadmat(path, squeeze_me=True, struct_as_record=False)
+        rows = []
+        for r in np.atleast_1d(m["results"]):
+            o = getattr(r, "LinearTFTPoseEstimation", None)
+            if o is not None and np.isfinite(float(o.seconds)):
+                rows.append((abs(int(r.N) - N), int(r.N), float(o.seconds)))
+        if not rows:
+            return None
+        d0 = min(rows)[0]
+        secs = [s_ for d_, n_, s_ in rows if d_ == d0]
+        n_used = [n_ for d_, n_, s_ in rows if d_ == d0][0]
+        info = m.get("info")
+        return dict(value=1.0 / float(np.median(secs)), unit="triplet-hypotheses/s", cores=float(getattr(info, "threads", float("nan"))), kind="reference",
+                    sample="%d calls of the reference's LinearTFTPoseEstimation at N=%d (full wrapper incl. Reconst), best-of-%s tic/toc each, %s on %s -- "
+                           "timed by matlab/reference_pin/make_reference_golden.m on the file author's machine, NOT on this GPU box"
+                           % (len(secs), n_used, getattr(info, "repeats", "?"), getattr(info, "release", "?"), getattr(info, "computer", "?")))
+    except Exception as ex:
+        return {"error": repr(ex)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -343,6 +372,9 @@ def main():
             sample = args.cpu_sample or max(1024, 40 * (os.cpu_count() or 1))   # ~10 s of wall time on the box's host cores
             out["cpu_baseline"] = cpu_baseline(C, CalM, min(sample, B))
             out["cpu_baseline_lapack"] = cpu_baseline_lapack(C, CalM)
+            ref_t = cpu_baseline_reference(N)
+            if ref_t:
+                out["cpu_baseline_reference"] = ref_t
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
