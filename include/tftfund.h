@@ -79,8 +79,9 @@ typedef struct tff_ctx tff_ctx;
                              * the fused single-wavefront kernel below the measured crossover: N < 80 for Ressl, N < 72 for Nordberg, N < 128 for Pi);
                              * 1 fused kernel always;
                              * 2 workgroup kernels always */
-#define TFF_OPT_ROWS 7      /* linear TFT pose kernel: 1 (default) four triplets per wavefront, one per row of 16 lanes (csrc/tft_rows_kernel.h);
-                             * 0 one triplet per wavefront (csrc/tft_kernel.h) -- an A/B switch, results agree to rounding */
+#define TFF_OPT_ROWS 7      /* LinearTFT / LinearF pose kernels and the linear stage of the iterative TFT methods: 1 (default) four triplets per wavefront,
+                             * one per row of 16 lanes (csrc/tft_rows_kernel.h, f_rows_kernel.h, gh_rows_kernel.h); 0 one triplet per wavefront
+                             * (csrc/tft_kernel.h, f_kernel.h) -- an A/B switch, results agree to rounding */
 #define TFF_DEBUG_STRIDE 128 /* doubles per triplet written by the *_debug_dev entry points */
 
 int tff_version(void);

@@ -9,6 +9,7 @@
 // batch items through the same LDS (stale state between items is what that catches).
 static unsigned g_grid_cap = 0;
 extern "C" void emu_set_grid_cap(int cap) { g_grid_cap = cap > 0 ? (unsigned)cap : 0u; }
+static unsigned emu_rows_grid(long B) { const unsigned g = tff::rows_grid(B); return (g_grid_cap && g > g_grid_cap) ? g_grid_cap : g; }
 static unsigned emu_grid(long B) { const unsigned g = tff::pose_grid(B); return (g_grid_cap && g > g_grid_cap) ? g_grid_cap : g; }
 
 // Same two-pass structure as the C ABI: inverse-iteration kernel, then the
@@ -45,15 +46,27 @@ extern "C" int emu_linear_tft_pose_rows(const double* corresp, const double* cal
                                         double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
     tff::LinearTftArgs a{corresp, calm, calm_stride, B, N, flags & ~tff::FLAG_JACOBI, Rt2, Rt3, T, reconst, iter, status, dbg, nullptr, nullptr, nullptr};
     if (reconst) a.flags |= tff::FLAG_RECONST;
-    unsigned grid = tff::rows_grid(B);
-    if (g_grid_cap && grid > g_grid_cap) grid = g_grid_cap;
-    emu::launch(tff::k_linear_tft_pose_rows, grid, 64, tff::rows_lds_bytes(), a);
+    emu::launch(tff::k_linear_tft_pose_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);
     bool any = false;
     for (long b = 0; b < B; ++b) any = any || status[b] == tff::ST_RETRY;
     if (!any) return 0;
     a.flags |= tff::FLAG_ONLY_RETRY;
     a.flags = tff::pose_auto_flags(N, a.flags, true);
     emu::launch(tff::k_linear_tft_pose<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, a.flags, true), a);
+    return 1;
+}
+// LinearF with four triplets per wavefront (f_rows_kernel.h), then the exact kernel over what it handed back
+extern "C" int emu_linear_f_pose_rows(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                                      double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
+    tff::LinearTftArgs a{corresp, calm, calm_stride, B, N, flags & ~tff::FLAG_JACOBI, Rt2, Rt3, T, reconst, iter, status, dbg, nullptr, nullptr, nullptr};
+    if (reconst) a.flags |= tff::FLAG_RECONST;
+    emu::launch(tff::k_linear_f_pose_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);
+    bool any = false;
+    for (long b = 0; b < B; ++b) any = any || status[b] == tff::ST_RETRY;
+    if (!any) return 0;
+    a.flags |= tff::FLAG_ONLY_RETRY;
+    a.flags = tff::pose_auto_flags(N, a.flags, true, tff::STAGE_MAX_N_F);
+    emu::launch(tff::k_f_pose<true, 0>, emu_grid(B), 64, tff::f_pose_lds_bytes(N, a.flags, true), a);
     return 1;
 }
 #ifndef TFF_EMU_LINEAR_TFT_ONLY   // (the sanitizer build of tests/test_emulated_kernels.py compiles the linear trifocal kernels only: minutes less)
@@ -93,7 +106,7 @@ static int emu_wg_run(KBlock kblock, size_t lds_block, const double* corresp, co
     std::vector<double> rec((size_t)B * tff::GH_REC_DOUBLES), topt((size_t)B * 27);
     tff::GhWgArgs a{corresp, calm, calm_stride, B, N, (flags & ~tff::FLAG_JACOBI) | (reconst ? tff::FLAG_RECONST : 0), rec.data(), topt.data(),
                     Rt2, Rt3, T, reconst, iter, status, nullptr, nullptr, 0};
-    emu::launch(tff::k_gh_linear<false>, emu_grid(B), 64, tff::pose_lds_bytes(N, a.flags, false), a);
+    emu::launch(tff::k_gh_linear_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);     // (as the C ABI: four triplets per wavefront)
     tff::GhWgArgs m = a;
     m.flags |= tff::FLAG_ONLY_RETRY;
     emu::launch(tff::k_gh_linear<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
@@ -117,7 +130,7 @@ static int emu_gh_wg_impl(const double* corresp, const double* calm, long calm_s
     std::vector<double> rec((size_t)B * tff::GH_REC_DOUBLES), topt((size_t)B * 27);
     tff::GhWgArgs a{corresp, calm, calm_stride, B, N, (flags & ~tff::FLAG_JACOBI) | (reconst ? tff::FLAG_RECONST : 0), rec.data(), topt.data(),
                     Rt2, Rt3, T, reconst, iter, status, nullptr, nullptr, 0};
-    emu::launch(tff::k_gh_linear<false>, emu_grid(B), 64, tff::pose_lds_bytes(N, a.flags, false), a);
+    emu::launch(tff::k_gh_linear_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);     // (as the C ABI: four triplets per wavefront)
     tff::GhWgArgs m = a;
     m.flags |= tff::FLAG_ONLY_RETRY;
     emu::launch(tff::k_gh_linear<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
@@ -132,7 +145,7 @@ extern "C" int emu_fp_pose(const double* corresp, const double* calm, long calm_
     std::vector<double> rec((size_t)B * tff::GH_REC_DOUBLES), topt((size_t)B * 27);
     tff::GhWgArgs a{corresp, calm, calm_stride, B, N, (flags & ~tff::FLAG_JACOBI) | (reconst ? tff::FLAG_RECONST : 0), rec.data(), topt.data(),
                     Rt2, Rt3, T, reconst, iter, status, nullptr, nullptr, 0};
-    emu::launch(tff::k_gh_linear<false>, emu_grid(B), 64, tff::pose_lds_bytes(N, a.flags, false), a);
+    emu::launch(tff::k_gh_linear_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);     // (as the C ABI: four triplets per wavefront)
     tff::GhWgArgs m = a;
     m.flags |= tff::FLAG_ONLY_RETRY;
     emu::launch(tff::k_gh_linear<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);

@@ -623,3 +623,19 @@ def test_linear_tft_kernels_under_address_and_ub_sanitizers():
     """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=emu_build.sanitizer_env(), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "sanitized run ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("B,N,sigma", [(5, 12, 1.0), (3, 70, 0.0), (2, 130, 1.0)])
+def test_rows_linear_f_kernel_matches_oracle(emu, B, N, sigma):
+    """LinearFPoseEstimation with one triplet per row of 16 lanes (csrc/f_rows_kernel.h): moments of the centred coordinates scaled
+    afterwards, 9 x 9 eigen-solves in the row layout, the pose tail shared with the trifocal rows kernel, T from the cameras."""
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=sigma, seed=100 + N)
+    out = run_linear_tft(emu, C, CalM, entry="emu_linear_f_pose_rows", debug=False)
+    assert np.all(out["status"] == 0) and np.all(out["iter"] == 0)
+    for b in range(B):
+        R2, R3, Rec, T, _ = O.LinearFPoseEstimation(C[b].T.copy(), CalM)
+        assert rel_err_T(out["T"][b], T) < 1e-9
+        assert rel_err(out["R_t_2"][b], R2) < 1e-9 and rel_err(out["R_t_3"][b], R3) < 1e-9 and rel_err(out["Reconst"][b], Rec) < 1e-9
+    C7, _, _, _ = generate_scene_batch(3, 7, noise=1.0, seed=2)              # linearF.m:35-37
+    few = run_linear_tft(emu, C7, CalM, entry="emu_linear_f_pose_rows", debug=False)
+    assert np.all(few["status"] == 1) and np.all(np.isnan(few["T"]))

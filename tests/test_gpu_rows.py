@@ -1,6 +1,6 @@
 """
-The four-triplets-per-wavefront LinearTFT kernel (csrc/tft_rows_kernel.h, TFF_OPT_ROWS = 1, the default) on the MI355X against the
-one-triplet-per-wavefront kernel (TFF_OPT_ROWS = 0) and the oracle: same arithmetic per matrix entry and correspondence, sums taken in
+The four-triplets-per-wavefront kernels (csrc/tft_rows_kernel.h, f_rows_kernel.h, gh_rows_kernel.h; TFF_OPT_ROWS = 1, the default) on the MI355X
+against the one-triplet-per-wavefront kernels (TFF_OPT_ROWS = 0) and the oracle: same arithmetic per matrix entry and correspondence, sums taken in
 a different order, so the two routes must agree to rounding on every batch shape -- full and ragged last wavefronts, one to many trips
 per data pass, well-posed and outlier-ridden data (adaptive cheirality votes: second sweep), sampled hypotheses (config 4).
 The oracle comparisons of tests/test_gpu_parity.py run through the rows kernel as well, since it is the default route.
@@ -27,13 +27,14 @@ def _both_routes(ctx, *args, **kw):
     return out[1], out[0]
 
 
+@pytest.mark.parametrize("method", ["LinearTFTPoseEstimation", "LinearFPoseEstimation"])
 @pytest.mark.parametrize("B,N,sigma", [(10000, 200, 1.0), (3001, 33, 0.5), (1000, 500, 1.0), (2047, 16, 2.0), (5, 100, 1.0), (1, 64, 1.0)])
-def test_rows_and_wave_routes_agree(gpu_ctx, B, N, sigma):
+def test_rows_and_wave_routes_agree(gpu_ctx, method, B, N, sigma):
     import torch
     from tft_vs_fund_amd.scenes import generate_scene_batch
     C, CalM, _, _ = generate_scene_batch(B, N, noise=sigma, seed=7 * N + B)
     d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
-    r, w = _both_routes(gpu_ctx, "LinearTFTPoseEstimation", d, calm, reconst=True)
+    r, w = _both_routes(gpu_ctx, method, d, calm, reconst=True)
     assert np.array_equal(r["status"], w["status"]) and np.all(r["status"] == 0) and np.all(r["iter"] == 0)
     sg = np.sign(np.sum(r["T"] * w["T"], axis=(1, 2, 3)))[:, None, None, None]
     assert np.abs(r["T"] * sg - w["T"]).max() < TOL
@@ -43,9 +44,27 @@ def test_rows_and_wave_routes_agree(gpu_ctx, B, N, sigma):
     # and against the oracle, first and last triplets (the last wavefront is ragged unless B is a multiple of four)
     from oracle import tft_oracle as O
     for b in sorted(set([0, B // 2, max(B - 2, 0), B - 1])):
-        R2, R3, Rec, T, _ = O.LinearTFTPoseEstimation(C[b].T.copy(), CalM)
+        R2, R3, Rec, T, _ = getattr(O, method)(C[b].T.copy(), CalM)
         assert rel_err_T(r["T"][b], T) < TOL and rel_err(r["R_t_2"][b], R2) < TOL and rel_err(r["R_t_3"][b], R3) < TOL
         assert rel_err(r["Reconst"][b], Rec) < TOL
+
+
+@pytest.mark.parametrize("method", ["ResslTFTPoseEstimation", "NordbergTFTPoseEstimation", "FaugPapaTFTPoseEstimation", "PiPoseEstimation"])
+def test_iterative_methods_do_not_depend_on_the_layout_of_their_linear_stage(gpu_ctx, method):
+    """k_gh_linear_rows (four triplets per wavefront) against k_gh_linear<false>: the start of the Gauss-Helmert iteration agrees to rounding,
+    so do the results -- same iteration counts, 1e-7 (the iteration amplifies the start's last bits; the 50-digit gates of
+    tests/test_gpu_gh_noise.py run on the rows route, the default)."""
+    import torch
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    B, N = 1001, 200
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=606)
+    d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
+    r, w = _both_routes(gpu_ctx, method, d, calm, reconst=False)
+    assert np.array_equal(r["status"], w["status"]) and np.all(r["status"] == 0)
+    assert (r["iter"] != w["iter"]).mean() < 0.01
+    same = r["iter"] == w["iter"]
+    sg = np.sign(np.sum(r["T"] * w["T"], axis=(1, 2, 3)))[:, None, None, None]
+    assert np.abs(r["T"] * sg - w["T"])[same].max() < 1e-7 and np.abs(r["R_t_3"] - w["R_t_3"])[same].max() < 1e-7 * max(1.0, np.abs(w["R_t_3"]).max())
 
 
 def test_rows_result_does_not_depend_on_the_row_or_the_neighbours(gpu_ctx):

@@ -171,10 +171,11 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_
     return 0;
 }
 
-// LinearTFTPoseEstimation, default route: four triplets per wavefront (tft_rows_kernel.h, fast tiers), then the exact kernel
-// (one wavefront per triplet) over what they could not finish or certify.
-int launch_linear_tft_rows(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
-                           double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+// LinearTFTPoseEstimation / LinearFPoseEstimation, default route: four triplets per wavefront (tft_rows_kernel.h / f_rows_kernel.h, fast
+// tiers), then the exact kernel (one wavefront per triplet) over what they could not finish or certify.
+template <class KRows, class KExact>
+int launch_pose_rows(tff_ctx* c, KRows krows, KExact kexact, lds_fn exact_lds, int stage_max_n, const double* corresp, const double* calm, int64_t calm_stride,
+                     int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     TFF_LOCK(c);
     if (B == 0) return 0;
@@ -186,18 +187,18 @@ int launch_linear_tft_rows(tff_ctx* c, const double* corresp, const double* calm
     }
     tff::LinearTftArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr),
                          Rt2, Rt3, T, reconst, iter, status, dbg, c->sample_idx, c->init_p, c->init_x, nullptr, 0, c->sample_ns};
-    hipLaunchKernelGGL(tff::k_linear_tft_pose_rows, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, a);
+    hipLaunchKernelGGL(krows, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, a);
     TFF_HIP(hipGetLastError());
     a.flags |= tff::FLAG_ONLY_RETRY;
     if (c->sample_idx) a.flags |= tff::FLAG_STAGE_LDS;   // the exact kernel gathers samples into LDS
-    else a.flags = staged_flags(c, N, a.flags, true, tff::STAGE_MAX_N_TFT);
-    if ((a.flags & tff::FLAG_STAGE_LDS) && tff::pose_lds_bytes(N, a.flags, true) > LDS_LIMIT) {
+    else a.flags = staged_flags(c, N, a.flags, true, stage_max_n);
+    if ((a.flags & tff::FLAG_STAGE_LDS) && exact_lds(N, a.flags, true) > LDS_LIMIT) {
         if (c->sample_idx) return fail(TFF_E_INVALID, "sample too large for the LDS (sampled hypotheses are gathered into LDS)");
         a.flags &= ~tff::FLAG_STAGE_LDS;
     }
-    const size_t lds = tff::pose_lds_bytes(N, a.flags, true);
-    if (int r = ensure_lds(tff::k_linear_tft_pose<true>, lds)) return r;
-    hipLaunchKernelGGL(tff::k_linear_tft_pose<true>, dim3((unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID)), dim3(64), lds, c->stream, a);
+    const size_t lds = exact_lds(N, a.flags, true);
+    if (int r = ensure_lds(kexact, lds)) return r;
+    hipLaunchKernelGGL(kexact, dim3((unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID)), dim3(64), lds, c->stream, a);
     TFF_HIP(hipGetLastError());
     return 0;
 }
@@ -206,12 +207,16 @@ int launch_linear_tft_rows(tff_ctx* c, const double* corresp, const double* calm
 int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     if (c && c->rows && c->solver == 0 && N >= c->exact_below)
-        return launch_linear_tft_rows(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+        return launch_pose_rows(c, tff::k_linear_tft_pose_rows, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, corresp, calm, calm_stride,
+                                B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     return launch_pose(c, tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, 0, corresp, calm, calm_stride,
                        B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }
 int launch_linear_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+    if (c && c->rows && c->solver == 0 && N >= c->exact_below)                // four triplets per wavefront (f_rows_kernel.h)
+        return launch_pose_rows(c, tff::k_linear_f_pose_rows, tff::k_f_pose<true, 0>, tff::f_pose_lds_bytes, tff::STAGE_MAX_N_F, corresp, calm, calm_stride,
+                                B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     return launch_pose(c, tff::k_f_pose<false, 0>, tff::k_f_pose<true, 0>, tff::f_pose_lds_bytes, tff::STAGE_MAX_N_F, 0, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
                        reconst, iter, status, dbg);
 }
@@ -226,7 +231,8 @@ int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_
 // correspondences held in LDS.
 template <class KBlock, class LdsFn>
 int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
-              double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg, bool fp_first = false) {
+              double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg, bool fp_first = false,
+              bool rows_linear = true) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     TFF_LOCK(c);
     if (B == 0) return 0;
@@ -244,7 +250,10 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
         const bool all_exact = c->solver != 0 || N < c->exact_below;
         tff::GhWgArgs m = a;
         size_t lds;
-        if (!all_exact) {
+        if (!all_exact && c->rows && rows_linear) {                          // four triplets per wavefront (gh_rows_kernel.h)
+            hipLaunchKernelGGL(tff::k_gh_linear_rows, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, m);
+            TFF_HIP(hipGetLastError());
+        } else if (!all_exact) {
             m.flags = staged_flags(c, N, a.flags, false);
             lds = tff::pose_lds_bytes(N, m.flags, false);
             if (int r = ensure_lds(tff::k_gh_linear<false>, lds)) return r;
@@ -319,7 +328,11 @@ int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64
         return launch_pose(c, tff::k_pi_tft_pose<Model, false>, tff::k_pi_tft_pose<Model, true>, tff::pi_lds_bytes<Model>, 0, 4,
                            corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::pi_wg_lds_doubles(Model::E, Model::C, n)) * sizeof(double); };
-    return launch_wg(c, tff::k_pi_block<Model>, wg_lds, Model::PINV_KKT ? 4 : 2, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    // PiCol keeps the one-triplet-per-wavefront linear stage: its scenes that take seven Gauss-Helmert iterations amplify a last-bit difference
+    // of the start a million times (tools/diag_gh_noise_picol.py: 3.3e-10 from the 50-digit iteration with this start, 2.5e-9 with the rows
+    // kernel's on the same N = 60 scene -- both draws of the same rounding noise, one of them over the 1e-9 gate of tests/test_gpu_gh_noise.py)
+    return launch_wg(c, tff::k_pi_block<Model>, wg_lds, Model::PINV_KKT ? 4 : 2, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg,
+                     false, !Model::PINV_KKT);
 }
 int launch_ressl_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {

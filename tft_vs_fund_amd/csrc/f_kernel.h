@@ -56,15 +56,6 @@ __device__ inline void accumulate_moments_f(PoseLds* w, const double* pts, int N
 }
 
 // TFT_from_P.m:25-33 with P1 = K1 [I|0]:  T(j,k,i) = (-1)^(i+1) det[P1 without row i; P2(j,:); P3(k,:)]
-__device__ __forceinline__ double det4(const double (&m)[4][4]) {
-    const double s0 = m[0][0] * m[1][1] - m[1][0] * m[0][1], s1 = m[0][0] * m[1][2] - m[1][0] * m[0][2];
-    const double s2 = m[0][0] * m[1][3] - m[1][0] * m[0][3], s3 = m[0][1] * m[1][2] - m[1][1] * m[0][2];
-    const double s4 = m[0][1] * m[1][3] - m[1][1] * m[0][3], s5 = m[0][2] * m[1][3] - m[1][2] * m[0][3];
-    const double c5 = m[2][2] * m[3][3] - m[3][2] * m[2][3], c4 = m[2][1] * m[3][3] - m[3][1] * m[2][3];
-    const double c3 = m[2][1] * m[3][2] - m[3][1] * m[2][2], c2 = m[2][0] * m[3][3] - m[3][0] * m[2][3];
-    const double c1 = m[2][0] * m[3][2] - m[3][0] * m[2][2], c0 = m[2][0] * m[3][1] - m[3][0] * m[2][1];
-    return s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
-}
 __device__ inline void tft_from_cameras(PoseLds* w, double* tout) {     // cameras w->Pfin[0..2] (row-major 3x4)
     const int lane = lane_id();
     double val = 0.0;

@@ -3,11 +3,13 @@
 #include "tft_kernel.h"
 #include "tft_rows_kernel.h"
 #include "f_kernel.h"
+#include "f_rows_kernel.h"
 #include "gh_kernel.h"
 #include "wave_trid.h"
 #include "blocks_kernel.h"
 #include "pi_kernel.h"
 #include "gh_wg_kernel.h"
+#include "gh_rows_kernel.h"
 #include "gh_fp_kernel.h"
 #include "pi_wg_kernel.h"
 #include "ba_kernel.h"

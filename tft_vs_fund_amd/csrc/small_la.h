@@ -57,6 +57,17 @@ __device__ __forceinline__ void cross3(const double* a, const double* b, double*
     c[2] = a[0] * b[1] - a[1] * b[0];
 }
 
+// 4 x 4 determinant by 2 x 2 minors (TFT_from_P.m:25-33 takes 27 of them)
+__device__ __forceinline__ double det4(const double (&m)[4][4]) {
+    const double s0 = m[0][0] * m[1][1] - m[1][0] * m[0][1], s1 = m[0][0] * m[1][2] - m[1][0] * m[0][2];
+    const double s2 = m[0][0] * m[1][3] - m[1][0] * m[0][3], s3 = m[0][1] * m[1][2] - m[1][1] * m[0][2];
+    const double s4 = m[0][1] * m[1][3] - m[1][1] * m[0][3], s5 = m[0][2] * m[1][3] - m[1][2] * m[0][3];
+    const double c5 = m[2][2] * m[3][3] - m[3][2] * m[2][3], c4 = m[2][1] * m[3][3] - m[3][1] * m[2][3];
+    const double c3 = m[2][1] * m[3][2] - m[3][1] * m[2][2], c2 = m[2][0] * m[3][3] - m[3][0] * m[2][3];
+    const double c1 = m[2][0] * m[3][2] - m[3][0] * m[2][2], c0 = m[2][0] * m[3][1] - m[3][0] * m[2][1];
+    return s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+}
+
 // --------------------------------------------------------------------------
 // Eigenvector of the smallest eigenvalue of a symmetric positive
 // semi-definite n x n matrix S (n = 3, 4): Cholesky of S + delta*I followed by

@@ -48,6 +48,7 @@ struct RowLds {
     double epi[6];
     double Q[18];
     double tp[15];
+    double pa[18];         // linearTFT's a (-> P2, P3 of the constrained solution), for the iterative methods' linear stage
     double ov[ROW_OV_DOUBLES];   // overlay: packed Cholesky factor | slice null vectors | Gp | RowRt
 };
 constexpr int ROW_LDS_DOUBLES = (int)(sizeof(RowLds) / sizeof(double));
@@ -318,7 +319,7 @@ __device__ __forceinline__ void rows_transform_tft_inverse(const double* to, dou
 
 // linearTFT.m:64-91 from the moment sums of the row's triplet (tft_kernel.h::linear_tft_middle, fast tier): w->t = the constrained tensor.
 // Returns (per lane, the same on every lane of a row) false when a fast tier could not finish.
-__device__ __forceinline__ bool rows_linear_tft_middle(RowLds* w, double* dbg) {
+__device__ __forceinline__ bool rows_linear_tft_middle(RowLds* w, double* dbg, const bool want_P = false) {
     const int p = opaque_lane_int(rows_p());
     bool ok = true;
     int it1 = 0, it2 = 0;
@@ -411,9 +412,29 @@ __device__ __forceinline__ bool rows_linear_tft_middle(RowLds* w, double* dbg) {
         if (p < 11) dbg[33 + 16 + p] = w->t[16 + p];
         if (p == 0) { dbg[69] = (double)it1; dbg[70] = (double)it2; }
     }
+    if (want_P) {                                                            // a = pinv(E) t (:86), see tft_kernel.h::linear_tft_middle
+        if (p < 3) {
+            const int i = p;
+            const double* e21 = w->epi; const double* e31 = w->epi + 3;
+            double ai[3], bi[3];
+            for (int j = 0; j < 3; ++j) ai[j] = w->t[j + 9 * i] * e31[0] + w->t[j + 3 + 9 * i] * e31[1] + w->t[j + 6 + 9 * i] * e31[2];
+            const double ae = ai[0] * e21[0] + ai[1] * e21[1] + ai[2] * e21[2];
+            for (int k = 0; k < 3; ++k) {
+                const double tte = w->t[3 * k + 9 * i] * e21[0] + w->t[1 + 3 * k + 9 * i] * e21[1] + w->t[2 + 3 * k + 9 * i] * e21[2];
+                bi[k] = e31[k] * ae - tte;
+            }
+            const double be = bi[0] * e31[0] + bi[1] * e31[1] + bi[2] * e31[2];
+            const double n21 = e21[0] * e21[0] + e21[1] * e21[1] + e21[2] * e21[2];
+            const double n31 = e31[0] * e31[0] + e31[1] * e31[1] + e31[2] * e31[2];
+            const double c = -(ae + be) / (n21 + n31);
+            for (int j = 0; j < 3; ++j) { w->pa[3 * i + j] = ai[j] + c * e21[j]; w->pa[9 + 3 * i + j] = bi[j] + c * e31[j]; }
+        }
+        wave_sync();
+    }
     return ok;
 }
 
+__device__ __forceinline__ void rows_recover_prepare(RowLds* w, RowRt* rt);
 // R_t_from_TFT.m:44-58 and svd(E), candidate poses and cameras (:85-88) for the row's triplet (tft_kernel.h::rt_prepare + recover_prepare)
 __device__ __forceinline__ bool rows_rt_prepare(RowLds* w, RowRt* rt, double* dbg) {
     const int p = rows_p();
@@ -443,7 +464,14 @@ __device__ __forceinline__ bool rows_rt_prepare(RowLds* w, RowRt* rt, double* db
     }
     wave_sync();
     rows_stamp(dbg, 9);
-    if (p < 2) {                                                             // recover_R_t: svd(E), R = U W V', Rp = U W' V', t = U(:,3)   (:84-88)
+    rows_recover_prepare(w, rt);
+    return ok;
+}
+
+// recover_R_t up to the candidate cameras (R_t_from_TFT.m:84-88 == LinearFPoseEstimation.m:86-90) from the two essential matrices in rt->Ein
+__device__ __forceinline__ void rows_recover_prepare(RowLds* w, RowRt* rt) {
+    const int p = rows_p();
+    if (p < 2) {                                                             // svd(E), R = U W V', Rp = U W' V', t = U(:,3)
         Mat3 E, U, V;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -484,7 +512,6 @@ __device__ __forceinline__ bool rows_rt_prepare(RowLds* w, RowRt* rt, double* db
         for (int r = 0; r < 3; ++r) { rt->Pfin[0][4 * r] = K1.m[r][0]; rt->Pfin[0][4 * r + 1] = K1.m[r][1]; rt->Pfin[0][4 * r + 2] = K1.m[r][2]; rt->Pfin[0][4 * r + 3] = 0.0; }
     }
     wave_sync();
-    return ok;
 }
 
 // Pass 3: cheirality votes (R_t_from_TFT.m:91-104) for both essential matrices in one pass over the row's correspondences, with the certified
@@ -661,48 +688,178 @@ __device__ __forceinline__ bool rows_tri_pass(const RowSrc& s, const int N, cons
     return !row_any(!all_conv);
 }
 
+// ---- what the rows kernels share around their linear stage ------------------------------------------------------------------------
+struct RowJob {
+    long b;                // the row's triplet (a tail row repeats the last one)
+    bool valid;            // ... and stores nothing
+    bool bad_index;        // sampled hypotheses: an index outside the scene
+    double* dbg;
+    RowSrc src;
+};
+// the row's triplet, its correspondences and calibration (-> w->calm)
+__device__ __forceinline__ RowJob rows_begin(const LinearTftArgs& a, RowLds* w, const long blk, const int N) {
+    const int lane = lane_id(), p = lane & 15, row = lane >> 4;
+    RowJob j;
+    const long b_raw = blk * ROW_TRIPLETS + row;
+    j.valid = b_raw < a.B;
+    j.b = j.valid ? b_raw : a.B - 1;
+    j.dbg = a.dbg ? a.dbg + j.b * DBG_STRIDE : nullptr;
+    j.src.idx = a.sample_idx ? a.sample_idx + j.b * (long)N : nullptr;
+    j.src.pts = a.sample_idx ? a.corresp : a.corresp + j.b * 6 * (long)N;
+    j.src.ns = a.sample_ns;
+    j.src.sampled = a.sample_idx != nullptr;
+    wave_sync();
+    j.bad_index = false;
+    if (a.sample_idx) {
+        bool bad = false;
+        for (int i = p; i < N; i += ROWL) { const int k = j.src.idx[i]; bad = bad || !(k >= 0 && k < j.src.ns); }
+        j.bad_index = row_any(bad);
+    }
+    w->calm[p] = a.calm[j.b * a.calm_stride + p];
+    if (p < 11) w->calm[16 + p] = a.calm[j.b * a.calm_stride + 16 + p];
+    return j;
+}
+__device__ __forceinline__ void rows_store_nan(const LinearTftArgs& a, const RowJob& j, const int N) {
+    const int p = rows_p();
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    if (j.valid) {
+        if (p < 12) { a.Rt2[j.b * 12 + p] = qnan; a.Rt3[j.b * 12 + p] = qnan; }
+        a.T[j.b * 27 + p] = qnan;
+        if (p < 11) a.T[j.b * 27 + 16 + p] = qnan;
+        if (a.reconst) for (int i = p; i < 3 * N; i += ROWL) a.reconst[j.b * 3 * (long)N + i] = qnan;
+    }
+}
+
+// Everything after the candidate cameras (rows_recover_prepare): cheirality votes and the reference's selection (R_t_from_TFT.m:91-104 ==
+// LinearFPoseEstimation.m:93-107), t3 scale (:68-74 == :64-70), optional Reconst, stores.  T_FROM_CAMERAS: T = TFT_from_P(K1 [I|0], K2 R_t_2,
+// K3 R_t_3) (LinearFPoseEstimation.m:78, TFT_from_P.m:25-33); else the tensor in rt->T1.  Returns the row's status.
+template <bool T_FROM_CAMERAS>
+__device__ __forceinline__ int rows_pose_tail(const LinearTftArgs& a, RowLds* w, RowRt* rt, const RowJob& j, const int N, bool ok) {
+    const int p = rows_p();
+    double* dbg = j.dbg;
+    const long b = j.b;
+    int status = ST_OK;
+    {                                                                        // recover_R_t, see pose_common.h::recover_vote
+        int sc[2][2];
+        int sweeps = 0;
+        ok = rows_votes(j.src, N, rt, dbg != nullptr && !(a.flags & FLAG_DBG_ADAPTIVE), sc, &sweeps) && ok;   // an uncertified sign: the exact kernel's business
+        if (dbg && p == 0) dbg[94] = (double)sweeps;
+#pragma unroll
+        for (int call = 0; call < 2; ++call) {
+            const int sR = sc[call][0], sRp = sc[call][1];
+            // reference order: k=1 (R,t), k=2 (R,-t), k=3 (Rp,-t), k=4 (Rp,t)   (:92-104)
+            const int score[4] = {sR, -sR, -sRp, sRp};
+            int seen = 0, pick = -1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (score[k] >= seen) { pick = k; seen = score[k]; }
+            if (pick < 0) status = ST_NO_POSE;
+            if (dbg && p < 4) dbg[60 + 4 * call + p] = (double)((p == 0) ? score[0] : (p == 1) ? score[1] : (p == 2) ? score[2] : score[3]);
+            if (p < 12) {
+                const int r = p >> 2, c = p & 3;
+                const double* R = rt->cand[call] + ((pick >= 2) ? 9 : 0);
+                const double tsign = (pick == 1 || pick == 2) ? -1.0 : 1.0;
+                rt->Rt[call][p] = (c < 3) ? R[3 * r + c] : tsign * rt->cand[call][18 + r];
+            }
+        }
+        wave_sync();
+    }
+    rows_stamp(dbg, 11);
+    {                                                                        // t3 scale, R_t_from_TFT.m:68-74
+        if (p < 2) compose_camera_from_pose(load_K(w->calm, p + 1), rt->Rt[p], rt->Pfin[p + 1]);   // Pfin[1] = K2 [R2|t2]; Pfin[2] = [K3*R3 | K3*t3]
+        wave_sync();
+        double num, den;
+        const bool conv = rows_tri_pass<TRI_SCALE>(j.src, N, rt->Pfin[0], rt->Pfin[1], rt->Pfin[2], nullptr, num, den);
+        ok = ok && conv;
+        const double lam = -num / den;                                       // :72-73
+        if (dbg && p == 0) dbg[68] = lam;
+        if (p < 3) rt->Rt[1][4 * p + 3] *= lam;                              // :74
+        wave_sync();
+    }
+    rows_stamp(dbg, 12);
+    if (a.reconst || T_FROM_CAMERAS) {
+        if (p == 0) compose_camera_from_pose(load_K(w->calm, 2), rt->Rt[1], rt->Pfin[2]);           // K3 [R3 | lam t3]
+        wave_sync();
+    }
+    if (a.reconst) {                                                         // LinearTFTPoseEstimation.m:59-60
+        double n0, d0;
+        // (a tail row repeats triplet B - 1 and stores the same values to the same places)
+        const bool conv = rows_tri_pass<TRI_RECONST>(j.src, N, rt->Pfin[0], rt->Pfin[1], rt->Pfin[2], a.reconst + b * 3 * (long)N, n0, d0);
+        ok = ok && conv;
+    }
+    if constexpr (T_FROM_CAMERAS) {                                          // TFT_from_P.m:25-33 (f_kernel.h::tft_from_cameras): 27 determinants, positions p and 16 + p
+        double val[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = (16 * h + p < 27) ? 16 * h + p : 0;
+            const int i = e / 9, k = (e % 9) / 3, jj = e % 3;
+            const int r0 = (i == 0) ? 1 : 0, r1 = (i == 2) ? 1 : 2;         // rows of P1 kept
+            double m[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                m[0][c] = rt->Pfin[0][4 * r0 + c];
+                m[1][c] = rt->Pfin[0][4 * r1 + c];
+                m[2][c] = rt->Pfin[1][4 * jj + c];
+                m[3][c] = rt->Pfin[2][4 * k + c];
+            }
+            val[h] = (16 * h + p < 27) ? ((i == 1) ? -1.0 : 1.0) * det4(m) : 0.0;
+        }
+        const double rs = rsqrt(row_sum16(val[0] * val[0] + val[1] * val[1]));                     // :33
+        rt->T1[p] = val[0] * rs;
+        if (p < 11) rt->T1[16 + p] = val[1] * rs;
+        wave_sync();
+    }
+    if (j.bad_index) {
+        status = ST_TOO_FEW;
+        rows_store_nan(a, j, N);
+    } else if (!ok) {
+        status = ST_RETRY;                                                   // redone by the exact kernel
+    }
+    {
+        const bool store = j.valid && ok && !j.bad_index;                    // per row
+        bool bad = false;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                                        // poses (row-major in LDS) -> MATLAB column-major 3x4 arrays
+            const int e24 = 16 * h + p;
+            if (e24 < 24) {
+                const int which = e24 / 12, e = e24 % 12, c = e / 3, r = e % 3;
+                const double v = rt->Rt[which][4 * r + c];
+                bad = bad || !(fabs(v) <= 1.79e308);
+                if (store) (which ? a.Rt3 : a.Rt2)[b * 12 + e] = v;
+            }
+            const int e27 = 16 * h + p;
+            if (e27 < 27) {
+                const double v = rt->T1[e27];
+                bad = bad || !(fabs(v) <= 1.79e308);
+                if (store) a.T[b * 27 + e27] = v;
+            }
+        }
+        rows_stamp(dbg, 13);
+        const bool nonfinite = row_any(bad);                                 // (the ballot is the whole wavefront's: outside every per-row branch)
+        if (nonfinite && status == ST_OK) status = ST_NONFINITE;             // non-finite outputs -> status 2
+    }
+    return status;
+}
+
 __global__ void __launch_bounds__(64, 2) k_linear_tft_pose_rows(const LinearTftArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
-    const int lane = lane_id();
-    const int p = lane & 15, row = lane >> 4;
+    const int p = lane_id() & 15, row = lane_id() >> 4;
     RowLds* w = reinterpret_cast<RowLds*>(smem) + row;
     RowRt* rt = reinterpret_cast<RowRt*>(w->ov);
     for (long blk = blockIdx.x; blk * ROW_TRIPLETS < a.B; blk += gridDim.x) {
         const int N = opaque_int(a.N);
-        const long b_raw = blk * ROW_TRIPLETS + row;
-        const bool valid = b_raw < a.B;                                      // (a tail row repeats the last triplet and stores nothing)
-        const long b = valid ? b_raw : a.B - 1;
-        double* dbg = a.dbg ? a.dbg + b * DBG_STRIDE : nullptr;
-        RowSrc src;
-        src.idx = a.sample_idx ? a.sample_idx + b * (long)N : nullptr;
-        src.pts = a.sample_idx ? a.corresp : a.corresp + b * 6 * (long)N;
-        src.ns = a.sample_ns;
-        src.sampled = a.sample_idx != nullptr;
-        wave_sync();
-        bool bad_index = false;
-        if (a.sample_idx) {
-            for (int i = p; i < N; i += ROWL) { const int k = src.idx[i]; bad_index = bad_index || !(k >= 0 && k < src.ns); }
-            bad_index = row_any(bad_index);
-        }
-        w->calm[p] = a.calm[b * a.calm_stride + p];
-        if (p < 11) w->calm[16 + p] = a.calm[b * a.calm_stride + 16 + p];
+        const RowJob j = rows_begin(a, w, blk, N);
+        double* dbg = j.dbg;
         rows_stamp(dbg, 0);
-        int status = ST_OK;
-        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        int status;
         if (N < 7) {                                                         // experiments.m:99 (wave-uniform: N is the batch's)
             status = ST_TOO_FEW;
-            if (valid) {
-                if (p < 12) { a.Rt2[b * 12 + p] = qnan; a.Rt3[b * 12 + p] = qnan; }
-                a.T[b * 27 + p] = qnan;
-                if (p < 11) a.T[b * 27 + 16 + p] = qnan;
-                if (a.reconst) for (int i = p; i < 3 * N; i += ROWL) a.reconst[b * 3 * (long)N + i] = qnan;
-            }
+            rows_store_nan(a, j, N);
         } else {
             {
                 double cen[6], nr[9];
-                rows_centroids(src, N, cen);                                 // LinearTFTPoseEstimation.m:45-47
+                rows_centroids(j.src, N, cen);                               // LinearTFTPoseEstimation.m:45-47
                 rows_stamp(dbg, 1);
-                rows_distances_moments(src, N, cen, w->nrm, nr, w->mom);
+                rows_distances_moments(j.src, N, cen, w->nrm, nr, w->mom);
                 if (dbg && p < 9) dbg[71 + p] = w->nrm[p];
             }
             wave_sync();
@@ -712,89 +869,11 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose_rows(const LinearTftA
             rows_transform_tft_inverse(w->t, rt->T1, rt->mats, [w](int v) { return normal_matrix(w->nrm, v); });   // :53
             ok = rows_rt_prepare(w, rt, dbg) && ok;                          // :56
             rows_stamp(dbg, 10);
-            {                                                                // recover_R_t (R_t_from_TFT.m:82-106), see pose_common.h::recover_vote
-                int sc[2][2];
-                int sweeps = 0;
-                ok = rows_votes(src, N, rt, dbg != nullptr && !(a.flags & FLAG_DBG_ADAPTIVE), sc, &sweeps) && ok;   // an uncertified sign: the exact kernel's business
-                if (dbg && p == 0) dbg[94] = (double)sweeps;
-#pragma unroll
-                for (int call = 0; call < 2; ++call) {
-                    const int sR = sc[call][0], sRp = sc[call][1];
-                    // reference order: k=1 (R,t), k=2 (R,-t), k=3 (Rp,-t), k=4 (Rp,t)   (:92-104)
-                    const int score[4] = {sR, -sR, -sRp, sRp};
-                    int seen = 0, pick = -1;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) if (score[k] >= seen) { pick = k; seen = score[k]; }
-                    if (pick < 0) status = ST_NO_POSE;
-                    if (dbg && p < 4) dbg[60 + 4 * call + p] = (double)((p == 0) ? score[0] : (p == 1) ? score[1] : (p == 2) ? score[2] : score[3]);
-                    if (p < 12) {
-                        const int r = p >> 2, c = p & 3;
-                        const double* R = rt->cand[call] + ((pick >= 2) ? 9 : 0);
-                        const double tsign = (pick == 1 || pick == 2) ? -1.0 : 1.0;
-                        rt->Rt[call][p] = (c < 3) ? R[3 * r + c] : tsign * rt->cand[call][18 + r];
-                    }
-                }
-                wave_sync();
-            }
-            rows_stamp(dbg, 11);
-            {                                                                // t3 scale, R_t_from_TFT.m:68-74
-                if (p < 2) compose_camera_from_pose(load_K(w->calm, p + 1), rt->Rt[p], rt->Pfin[p + 1]);   // Pfin[1] = K2 [R2|t2]; Pfin[2] = [K3*R3 | K3*t3]
-                wave_sync();
-                double num, den;
-                const bool conv = rows_tri_pass<TRI_SCALE>(src, N, rt->Pfin[0], rt->Pfin[1], rt->Pfin[2], nullptr, num, den);
-                ok = ok && conv;
-                const double lam = -num / den;                               // :72-73
-                if (dbg && p == 0) dbg[68] = lam;
-                if (p < 3) rt->Rt[1][4 * p + 3] *= lam;                      // :74
-                wave_sync();
-            }
-            rows_stamp(dbg, 12);
-            if (a.reconst) {                                                 // LinearTFTPoseEstimation.m:59-60
-                if (p == 0) compose_camera_from_pose(load_K(w->calm, 2), rt->Rt[1], rt->Pfin[2]);
-                wave_sync();
-                double n0, d0;
-                // (a tail row repeats triplet B - 1 and stores the same values to the same places)
-                const bool conv = rows_tri_pass<TRI_RECONST>(src, N, rt->Pfin[0], rt->Pfin[1], rt->Pfin[2], a.reconst + b * 3 * (long)N, n0, d0);
-                ok = ok && conv;
-            }
-            if (bad_index) {
-                status = ST_TOO_FEW;
-                if (valid) {
-                    if (p < 12) { a.Rt2[b * 12 + p] = qnan; a.Rt3[b * 12 + p] = qnan; }
-                    a.T[b * 27 + p] = qnan;
-                    if (p < 11) a.T[b * 27 + 16 + p] = qnan;
-                    if (a.reconst) for (int i = p; i < 3 * N; i += ROWL) a.reconst[b * 3 * (long)N + i] = qnan;
-                }
-            } else if (!ok) {
-                status = ST_RETRY;                                           // redone by k_linear_tft_pose<true>
-            }
-            {
-                const bool store = valid && ok && !bad_index;                // per row
-                bool bad = false;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {                                // poses (row-major in LDS) -> MATLAB column-major 3x4 arrays
-                    const int e24 = 16 * h + p;
-                    if (e24 < 24) {
-                        const int which = e24 / 12, e = e24 % 12, c = e / 3, r = e % 3;
-                        const double v = rt->Rt[which][4 * r + c];
-                        bad = bad || !(fabs(v) <= 1.79e308);
-                        if (store) (which ? a.Rt3 : a.Rt2)[b * 12 + e] = v;
-                    }
-                    const int e27 = 16 * h + p;
-                    if (e27 < 27) {
-                        const double v = rt->T1[e27];
-                        bad = bad || !(fabs(v) <= 1.79e308);
-                        if (store) a.T[b * 27 + e27] = v;
-                    }
-                }
-                rows_stamp(dbg, 13);
-                const bool nonfinite = row_any(bad);                         // (the ballot is the whole wavefront's: outside every per-row branch)
-                if (nonfinite && status == ST_OK) status = ST_NONFINITE;     // non-finite outputs -> status 2
-            }
+            status = rows_pose_tail<false>(a, w, rt, j, N, ok);
         }
-        if (p == 0 && valid) {
-            if (a.iter) a.iter[b] = 0;                                       // :62
-            a.status[b] = status;
+        if (p == 0 && j.valid) {
+            if (a.iter) a.iter[j.b] = 0;                                     // :62
+            a.status[j.b] = status;
         }
     }
 }

@@ -1,6 +1,6 @@
-"""A/B of the two LinearTFT fast kernels on one GPU: four triplets per wavefront (TFF_OPT_ROWS = 1, default) against one triplet per
+"""A/B of the two LinearTFT (or, 4th argument, LinearF) fast kernels on one GPU: four triplets per wavefront (TFF_OPT_ROWS = 1, default) against one triplet per
 wavefront (0).  Prints per-launch time (HIP events around K launches), the agreement of the two routes and, for a few triplets,
-the deviation from the oracle (test infrastructure).  Usage: python tools/ab_rows.py [B] [N] [K]"""
+the deviation from the oracle (test infrastructure).  Usage: python tools/ab_rows.py [B] [N] [K] [method]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,6 +10,7 @@ from tft_vs_fund_amd.scenes import generate_scene_batch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+METHOD = sys.argv[4] if len(sys.argv) > 4 else "LinearTFTPoseEstimation"
 C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=1)
 d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
 ctx = api.Context(0)
@@ -18,12 +19,12 @@ for reconst in (False, True):
     for rows in (1, 0):
         ctx.set_rows(rows)
         for _ in range(3):
-            out = ctx.pose_batch("LinearTFTPoseEstimation", d, calm, reconst=reconst)
+            out = ctx.pose_batch(METHOD, d, calm, reconst=reconst)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(K):
-            out = ctx.pose_batch("LinearTFTPoseEstimation", d, calm, reconst=reconst)
+            out = ctx.pose_batch(METHOD, d, calm, reconst=reconst)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / K
         res[(reconst, rows)] = {k: (v.cpu().numpy() if v is not None else None) for k, v in out.items() if k != "_raw"}
@@ -41,7 +42,7 @@ try:
     a = res[(True, 1)]
     worst = 0.0
     for b in list(range(6)) + [B - 1, B - 2, B - 3]:
-        o2, o3, orec, oT, _ = O.LinearTFTPoseEstimation(C[b].T.copy(), CalM)
+        o2, o3, orec, oT, _ = getattr(O, METHOD)(C[b].T.copy(), CalM)
         s = np.sign(np.sum(a["T"][b] * oT))
         worst = max(worst, np.abs(s * a["T"][b] - oT).max(), np.abs(a["R_t_2"][b] - o2).max(), np.abs(a["R_t_3"][b] - o3).max(),
                     np.abs(a["Reconst"][b] - orec).max() / np.abs(orec).max())

@@ -14,6 +14,7 @@ ctx = None
 if "--no-gpu" not in sys.argv:
     from tft_vs_fund_amd import api
     ctx = api.Context(0)
+    ctx.set_rows(int(os.environ.get("TFF_ROWS", "1")))       # 0: one-triplet-per-wavefront linear stage (A/B)
 fmt = lambda d: "p50 %.1e  p90 %.1e  max %.1e" % (np.quantile(d, 0.5), np.quantile(d, 0.9), np.max(d))
 for ci, pre in golden_cases(g):
     N, B, _ = g[pre + "meta"]; N, B = int(N), int(B)
@@ -42,3 +43,4 @@ for ci, pre in golden_cases(g):
             d, di = min(cand)
             dk.append(d); dik.append(di)
         print("                   HIP kernel (best convention per scene)                  : %s  iter diff %s  (status != 0: %d)" % (fmt(np.array(dk)), np.bincount(dik).tolist(), int((st != 0).sum())))
+        print("                   per scene: " + " ".join("%.1e" % v for v in dk) + "   iterations " + str(np.asarray(out["iter"]).tolist()))

@@ -12,6 +12,7 @@ d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
 ctx = api.Context(0, stage_lds=int(os.environ.get("TFF_STAGE", "-1")))
 ctx.set_kernel_variant(int(os.environ.get("TFF_VARIANT", "0")))      # 1: fused single-wavefront kernels (A/B)
 ctx.set_spill_only_if_needed(int(os.environ.get("TFF_SPILL", "0")))  # 1: state stays in LDS whenever it fits
+ctx.set_rows(int(os.environ.get("TFF_ROWS", "1")))                   # 0: one triplet per wavefront in the linear stage (A/B)
 for m in methods:
     for _ in range(2):
         out = ctx.pose_batch(m, d, calm, reconst=False)
