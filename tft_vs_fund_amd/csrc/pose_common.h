@@ -424,9 +424,12 @@ __device__ __forceinline__ bool dlt_point(const double (&PA)[12], const double (
 }
 // ... from the normal matrix S = M'M of the system (lower triangle), for callers that need S themselves.
 // CERT (with EXACT): the gap-independent certified tier of small_la.h between the three-iteration fast tier and the one-sided Jacobi
-// -- for the kernels that triangulate many correspondences of unknown consistency (k_repr_error, k_triangulate).  The passes over a
-// triplet's own correspondences keep the plain ladder: the extra level of calls raised the register count of every kernel that
-// reaches tri_pass_exact / tri_vote_exact (168 -> 231, three -> two wavefronts per SIMD for the F kernels) for no measured gain.
+// -- for the kernels that triangulate many correspondences of unknown consistency (k_repr_error, k_triangulate) and, since round 4, for
+// the exact passes over a triplet's own correspondences (tri_vote_exact, tri_pass_exact): on minimal samples a tenth of those triangulations
+// used to fall through to the one-sided Jacobi, whose rolled copy lives in scratch memory -- 57 GB of scratch traffic per million eight-point
+// hypotheses (profiles/r3_config4f_summary.json: 129 x the algorithmic bytes).  The certified tier settles all but ~7e-4 of them in registers:
+// eight-point hypotheses 33.9 -> 29.3 ms per million, seven-point 60.7 -> 58.4 ms, identical inlier counts.  (The fast kernels never reach these
+// functions -- EXACT = false only reports -- so their register budgets are untouched; the exact kernels stay at two wavefronts per SIMD.)
 template <bool EXACT, bool CERT>
 __device__ __forceinline__ bool dlt_point_solve(const double (&S)[4][4], const double* camA, const double* camB, const double* camC, const bool three,
                                                 const double xa, const double ya, const double xb, const double yb, const double xc, const double yc,
@@ -685,7 +688,7 @@ __device__ __attribute__((noinline)) int tri_vote_exact(PoseLds* w, const double
     for (int i = lane; i < N; i += WAVE) {
         const Pt6 p = load_pt(pts, i);
         double X[4];
-        dlt_point<true>(PA, PB, PB, w->Pfin[0], camB, camB, false, p.v[0], p.v[1], (view == 1) ? p.v[2] : p.v[4],
+        dlt_point<true, true>(PA, PB, PB, w->Pfin[0], camB, camB, false, p.v[0], p.v[1], (view == 1) ? p.v[2] : p.v[4],
                         (view == 1) ? p.v[3] : p.v[5], 0.0, 0.0, X);
         const double s4 = sgn(X[3]);                                         // X1 = X ./ X(4)
         const double d1 = X[2] * s4, d2 = (R3[0] * X[0] + R3[1] * X[1] + R3[2] * X[2] + R3[3] * X[3]) * s4;
@@ -745,7 +748,7 @@ __device__ __forceinline__ int tri_pass_impl(PoseLds* w, const double* pts, int 
         const Pt6 p = premap(pnext, pre);
         if (i + WAVE < N) pnext = load_pt(pts, i + WAVE);
         double X[4];
-        const bool conv = dlt_point<EXACT>(PA, PB, AX, w->Pfin[0], camB, aux, mode == TRI_RECONST || mode == TRI_REPROJECT, p.v[0], p.v[1],
+        const bool conv = dlt_point<EXACT, EXACT>(PA, PB, AX, w->Pfin[0], camB, aux, mode == TRI_RECONST || mode == TRI_REPROJECT, p.v[0], p.v[1],
                                            (view == 1) ? p.v[2] : p.v[4], (view == 1) ? p.v[3] : p.v[5], p.v[4], p.v[5], X);
         all_conv = all_conv && conv;
         if (mode == TRI_REPROJECT2) {
