@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 rocprofv3 evidence for every method bench.py reports (kernel trace + four separate PMC passes each; program directly after `--`).
-# Usage: bash tools/gpu_profile_r4.sh [tags...]   tags: headline ressl nordberg faugpapa pi picol linearf optimf config4tft config4f
+# Usage: bash tools/gpu_profile_r4.sh [tags...]   tags: headline headline1 ressl nordberg faugpapa pi picol linearf optimf config4tft config4f
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/r4
 run_one() {   # tag, command, kernel substring, units per launch, algorithmic bytes per launch, waves per SIMD
@@ -22,15 +22,16 @@ print("$TAG: %.1f us, VALU/unit %.0f, busy %.2f, waiting %.2f, lanes %.2f, HBM x
 PY
 }
 ALG=$((10000 * (48 * 200 + 216 + 216 + 192)))
-for T in ${@:-headline ressl nordberg faugpapa pi picol linearf optimf config4tft config4f}; do
+for T in ${@:-headline headline1 ressl nordberg faugpapa pi picol linearf optimf config4tft config4f}; do
   case $T in
-    headline)   run_one headline "python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 3" "k_linear_tft_pose_rows" 10000 $ALG 2;;
+    headline)   run_one headline "python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 3" "k_linear_tft_pose_rows" 10000 $ALG 2;;          # bench.py as the driver runs it: two streams, consecutive batches overlap
+    headline1)  run_one headline1 "python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 3 --streams 1" "k_linear_tft_pose_rows" 10000 $ALG 2;;   # one stream: a launch has the GPU to itself
     ressl)      run_one ressl "python3 $R/tools/bench_one.py ResslTFTPoseEstimation 8" "k_gh_block" 10000 $ALG 2;;
     nordberg)   run_one nordberg "python3 $R/tools/bench_one.py NordbergTFTPoseEstimation 8" "k_gh_block" 10000 $ALG 3;;
     faugpapa)   run_one faugpapa "python3 $R/tools/bench_one.py FaugPapaTFTPoseEstimation 6" "k_fp_block" 10000 $ALG 3;;
     pi)         run_one pi "python3 $R/tools/bench_one.py PiPoseEstimation 8" "k_pi_block" 10000 $ALG 2;;
     picol)      run_one picol "python3 $R/tools/bench_one.py PiColPoseEstimation 6" "k_pi_block" 10000 $ALG 4;;
-    linearf)    run_one linearf "python3 $R/tools/bench_one.py LinearFPoseEstimation 20" "k_f_pose<false, 0>" 10000 $ALG 3;;
+    linearf)    run_one linearf "python3 $R/tools/bench_one.py LinearFPoseEstimation 20" "k_linear_f_pose_rows" 10000 $ALG 2;;
     optimf)     run_one optimf "python3 $R/tools/bench_one.py OptimFPoseEstimation 10" "k_f_pose<false, 1>" 10000 $ALG 3;;
     config4tft) run_one config4tft "python3 $R/tools/config4_split.py 1000000" "k_linear_tft_pose<true>" 1000000 $((1000000 * 440)) 2;;
     config4f)   run_one config4f "python3 $R/tools/config4_split.py 1000000" "k_f_pose<true, 0>" 1000000 $((1000000 * 444)) 2;;
