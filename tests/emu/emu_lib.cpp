@@ -4,6 +4,7 @@
 // Never linked into libtftfund.so.
 #include <vector>
 #include "../../tft_vs_fund_amd/csrc/launch.h"
+#include "../../tft_vs_fund_amd/csrc/rows_qr.h"
 
 // Optional cap on the grid of every launch below (0 = none): exercises the grid-stride loops, in which one block takes several
 // batch items through the same LDS (stale state between items is what that catches).
@@ -68,6 +69,48 @@ extern "C" int emu_linear_f_pose_rows(const double* corresp, const double* calm,
     a.flags = tff::pose_auto_flags(N, a.flags, true, tff::STAGE_MAX_N_F);
     emu::launch(tff::k_f_pose<true, 0>, emu_grid(B), 64, tff::f_pose_lds_bytes(N, a.flags, true), a);
     return 1;
+}
+// rows_qr.h: streaming Householder QR + inverse iteration in the row layout, four systems per wavefront.  A: B x rows x n (row-major) ->
+// x: B x n (right singular vector of the smallest singular value), its, conv (1 = converged)
+namespace {
+struct RowsQrArgs { const double* A; long B; int rows; double* x; int* its; int* conv; double* Rout; };
+template <int n, int M>
+__global__ void k_emu_rows_qr(RowsQrArgs a) {
+    TFF_DYNAMIC_LDS(double, lds);
+    const int lane = tff::lane_id(), p = lane & 15, row = lane >> 4;
+    constexpr int RP = tff::rows_up_doubles<n>();
+    double* Rp = lds + row * (RP + M + n + 3);
+    double* xch = Rp + RP; double* dinv = xch + M;
+    long b = (long)blockIdx.x * 4 + row;
+    if (b >= a.B) b = a.B - 1;
+    tff::rows_qr_clear<n>(Rp);
+    for (int base = 0; base < a.rows; base += M) {
+        double a0[M], a1[M];
+        for (int i = 0; i < M; ++i) {
+            const bool have = base + i < a.rows;
+            a0[i] = (have && p < n) ? a.A[(b * a.rows + base + i) * n + p] : 0.0;
+            a1[i] = (have && 16 + p < n) ? a.A[(b * a.rows + base + i) * n + 16 + p] : 0.0;
+        }
+        tff::rows_qr_append<n, M>(a0, a1, Rp, xch);
+    }
+    if (a.Rout && (long)blockIdx.x * 4 + row < a.B) for (int e = p; e < RP; e += 16) a.Rout[b * RP + e] = Rp[e];
+    int its; double r2, x0, x1;
+    tff::rows_invit_from_R<n>(Rp, dinv, 300, &its, &r2, x0, x1);
+    if ((long)blockIdx.x * 4 + row < a.B) {
+        if (p < n) a.x[b * n + p] = x0;
+        if (16 + p < n) a.x[b * n + 16 + p] = x1;
+        if (p == 0) { a.its[b] = its; a.conv[b] = (r2 == 0.0) ? 1 : 0; }
+    }
+}
+}
+extern "C" int emu_rows_qr(const double* A, long B, int rows, int n, double* x, int* its, int* conv, double* Rout) {
+    RowsQrArgs a{A, B, rows, x, its, conv, Rout};
+    const unsigned grid = (unsigned)((B + 3) / 4);
+    if (n == 27) emu::launch(k_emu_rows_qr<27, 28>, grid, 64, sizeof(double) * 4 * (tff::rows_up_doubles<27>() + 28 + 27 + 3), a);
+    else if (n == 15) emu::launch(k_emu_rows_qr<15, 27>, grid, 64, sizeof(double) * 4 * (tff::rows_up_doubles<15>() + 27 + 15 + 3), a);
+    else if (n == 9) emu::launch(k_emu_rows_qr<9, 16>, grid, 64, sizeof(double) * 4 * (tff::rows_up_doubles<9>() + 16 + 9 + 3), a);
+    else return -1;
+    return 0;
 }
 #ifndef TFF_EMU_LINEAR_TFT_ONLY   // (the sanitizer build of tests/test_emulated_kernels.py compiles the linear trifocal kernels only: minutes less)
 extern "C" int emu_linear_f_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
