@@ -4,7 +4,6 @@
 // Never linked into libtftfund.so.
 #include <vector>
 #include "../../tft_vs_fund_amd/csrc/launch.h"
-#include "../../tft_vs_fund_amd/csrc/rows_qr.h"
 
 // Optional cap on the grid of every launch below (0 = none): exercises the grid-stride loops, in which one block takes several
 // batch items through the same LDS (stale state between items is what that catches).
@@ -48,6 +47,20 @@ extern "C" int emu_linear_tft_pose_rows(const double* corresp, const double* cal
     tff::LinearTftArgs a{corresp, calm, calm_stride, B, N, flags & ~tff::FLAG_JACOBI, Rt2, Rt3, T, reconst, iter, status, dbg, nullptr, nullptr, nullptr};
     if (reconst) a.flags |= tff::FLAG_RECONST;
     emu::launch(tff::k_linear_tft_pose_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);
+    bool any = false;
+    for (long b = 0; b < B; ++b) any = any || status[b] == tff::ST_RETRY;
+    if (!any) return 0;
+    a.flags |= tff::FLAG_ONLY_RETRY;
+    a.flags = tff::pose_auto_flags(N, a.flags, true);
+    emu::launch(tff::k_linear_tft_pose<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, a.flags, true), a);
+    return 1;
+}
+// the exact tiers with four triplets per wavefront (tft_rows_exact_kernel.h), then the one-triplet exact kernel over what it handed back
+extern "C" int emu_linear_tft_pose_rows_exact(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                                              double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
+    tff::LinearTftArgs a{corresp, calm, calm_stride, B, N, flags & ~tff::FLAG_JACOBI, Rt2, Rt3, T, reconst, iter, status, dbg, nullptr, nullptr, nullptr};
+    if (reconst) a.flags |= tff::FLAG_RECONST;
+    emu::launch(tff::k_linear_tft_pose_rows_exact, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);
     bool any = false;
     for (long b = 0; b < B; ++b) any = any || status[b] == tff::ST_RETRY;
     if (!any) return 0;

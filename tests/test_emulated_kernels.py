@@ -639,3 +639,48 @@ def test_rows_linear_f_kernel_matches_oracle(emu, B, N, sigma):
     C7, _, _, _ = generate_scene_batch(3, 7, noise=1.0, seed=2)              # linearF.m:35-37
     few = run_linear_tft(emu, C7, CalM, entry="emu_linear_f_pose_rows", debug=False)
     assert np.all(few["status"] == 1) and np.all(np.isnan(few["T"]))
+
+
+@pytest.mark.parametrize("B,N,sigma", [(6, 7, 1.0), (5, 9, 2.0), (2, 30, 1.0)])
+def test_rows_exact_kernel_matches_oracle(emu, B, N, sigma):
+    """The exact tiers with one triplet per row of 16 lanes (csrc/tft_rows_exact_kernel.h, rows_qr.h): Householder QR of the explicit 4N x 27
+    system with the owner of a column publishing its chunk through LDS, inverse iteration straight from the packed R, the 27 x 15 re-solve from
+    R * Up, certified null vectors, all four votes with the exact re-score behind them -- minimal samples (one chunk), two chunks, and N = 30
+    (five chunks, two trips per data pass).  Agreement with the oracle and with the one-triplet exact kernel."""
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=sigma, seed=100 + N)
+    out = run_linear_tft(emu, C, CalM, entry="emu_linear_tft_pose_rows_exact", debug=True)
+    ref = run_linear_tft(emu, C, CalM, flags=FLAG_JACOBI)
+    assert np.all(out["status"] == 0) and np.all(ref["status"] == 0)
+    assert np.all(out["debug"][:, 69] >= 20000) and np.all(out["debug"][:, 70] >= 20000)          # this kernel's stamp: nothing was handed on
+    for b in range(B):
+        R2, R3, Rec, T, _ = O.LinearTFTPoseEstimation(C[b].T.copy(), CalM)
+        assert rel_err_T(out["T"][b], T) < 1e-9 and rel_err(out["R_t_2"][b], R2) < 1e-9 and rel_err(out["R_t_3"][b], R3) < 1e-9
+        assert rel_err(out["Reconst"][b], Rec) < 1e-9
+        assert rel_err_T(out["T"][b], ref["T"][b]) < 1e-11 and rel_err(out["R_t_3"][b], ref["R_t_3"][b]) < 1e-11
+    so, sw = out["debug"][:, 60:68].reshape(B, 2, 4), ref["debug"][:, 60:68].reshape(B, 2, 4)
+    assert np.array_equal(np.sort(so, axis=2), np.sort(sw, axis=2))
+
+
+def test_rows_qr_and_inverse_iteration_match_lapack(emu):
+    """rows_qr.h on random tall systems, four per wavefront: 28 x 27 and 44 x 27 (one and two chunks), 27 x 15, N x 9; well separated and
+    close smallest singular values (ratio 0.02 / 0.7); a rank-deficient system (8 x 9) returns a null vector."""
+    rng = np.random.default_rng(1)
+    for n, rows in ((27, 28), (27, 44), (15, 27), (9, 8), (9, 40)):
+        B = 6
+        A = rng.standard_normal((B, rows, n))
+        for b in range(B):
+            U, s, Vt = np.linalg.svd(A[b], full_matrices=False)
+            if s.size == n:
+                s[-1] = s[-2] * (0.02 if b % 2 == 0 else 0.7)
+            A[b] = (U * s) @ Vt
+        A = np.ascontiguousarray(A)
+        x = np.zeros((B, n)); its = np.zeros(B, dtype=np.int32); conv = np.zeros(B, dtype=np.int32)
+        assert emu.emu_rows_qr(_p(A), ctypes.c_long(B), ctypes.c_int(rows), ctypes.c_int(n), _p(x), _p(its), _p(conv), None) == 0
+        assert np.all(conv == 1)
+        for b in range(B):
+            if rows < n:
+                assert np.linalg.norm(A[b] @ x[b]) < 1e-12 and abs(np.linalg.norm(x[b]) - 1) < 1e-12
+            else:
+                v = np.linalg.svd(A[b])[2][-1]
+                assert min(np.abs(x[b] - v).max(), np.abs(x[b] + v).max()) < 1e-11
+                assert its[b] <= (8 if b % 2 == 0 else 60)

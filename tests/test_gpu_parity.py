@@ -116,9 +116,17 @@ def test_collinear_camera_centres_take_the_exact_tiers(gpu_ctx, method, N):
     B = 24
     C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=300 + N, angle=180)
     out = gpu_ctx.pose_batch(method, C, CalM, reconst=False)
-    exact = api.Context(0, solver="jacobi").pose_batch(method, C, CalM, reconst=False)
+    ectx = api.Context(0, solver="jacobi")
+    ectx.set_rows(False)                                    # the one-triplet exact kernel for all: the kernel that redoes what the default route flags
+    exact = ectx.pose_batch(method, C, CalM, reconst=False)
     assert np.all(out["status"] == 0) and np.all(exact["status"] == 0)
     tol = 2e-8 if method != "OptimFPoseEstimation" else 2e-7
+    if method == "LinearTFTPoseEstimation":                 # the exact tiers with four triplets per wavefront (TFF_OPT_SOLVER = 1, rows on): a second
+        ectx.set_rows(True)                                 # implementation of the same tiers, equal within the conditioning of the configuration
+        rex = ectx.pose_batch(method, C, CalM, reconst=False)
+        assert np.all(rex["status"] == 0)
+        for b in range(B):
+            assert rel_err_T(rex["T"][b], exact["T"][b]) < tol and rel_err(rex["R_t_2"][b], exact["R_t_2"][b]) < tol and rel_err(rex["R_t_3"][b], exact["R_t_3"][b]) < tol, b
     for b in range(B):
         assert rel_err_T(out["T"][b], exact["T"][b]) < 1e-10 and rel_err(out["R_t_2"][b], exact["R_t_2"][b]) < 1e-10
         assert rel_err(out["R_t_3"][b], exact["R_t_3"][b]) < 1e-10, (b, rel_err(out["R_t_3"][b], exact["R_t_3"][b]))

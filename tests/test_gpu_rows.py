@@ -134,3 +134,22 @@ def test_rows_sampled_hypotheses(gpu_ctx):
     assert ok.sum() >= H - 2 - 40
     e3 = np.abs(r["R_t_3"] - w["R_t_3"]).reshape(H, -1).max(axis=1)[ok]
     assert (e3 > 1e-6).mean() < 5e-3
+
+
+def test_exact_rows_kernel_against_the_one_triplet_exact_kernel(gpu_ctx):
+    """40 000 seven-point samples at 3 px noise through the exact tiers: four triplets per wavefront (tft_rows_exact_kernel.h, the default for
+    N < TFF_OPT_EXACT_BELOW) against one per wavefront (TFF_OPT_ROWS = 0).  Same statuses; the same poses wherever the reference's answer is
+    unique (cheirality ties between the two rotations, ~0.2 % of minimal samples, may fall differently: tests/helpers.py)."""
+    import torch
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    B = 40000
+    C, CalM, _, _ = generate_scene_batch(B, 7, noise=3.0, seed=5)
+    d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
+    r, w = _both_routes(gpu_ctx, "LinearTFTPoseEstimation", d, calm, reconst=True)
+    assert np.array_equal(r["status"], w["status"])
+    ok = r["status"] == 0
+    assert ok.mean() > 0.99
+    sg = np.sign(np.sum(r["T"] * w["T"], axis=(1, 2, 3)))[:, None, None, None]
+    eT = np.abs(r["T"] * sg - w["T"]).reshape(B, -1).max(axis=1)[ok]
+    e3 = (np.abs(r["R_t_3"] - w["R_t_3"]).reshape(B, -1).max(axis=1) / np.abs(w["R_t_3"]).reshape(B, -1).max(axis=1).clip(1.0))[ok]
+    assert np.quantile(eT, 0.999) < 1e-7 and (e3 > 1e-6).mean() < 3e-3, (np.quantile(eT, 0.999), (e3 > 1e-6).mean())

@@ -209,6 +209,9 @@ int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int
     if (c && c->rows && c->solver == 0 && N >= c->exact_below)
         return launch_pose_rows(c, tff::k_linear_tft_pose_rows, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, corresp, calm, calm_stride,
                                 B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    if (c && c->rows)     // whole batches for the exact tiers (minimal samples, TFF_OPT_SOLVER = 1): four triplets per wavefront there too (tft_rows_exact_kernel.h)
+        return launch_pose_rows(c, tff::k_linear_tft_pose_rows_exact, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, corresp, calm,
+                                calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     return launch_pose(c, tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, 0, corresp, calm, calm_stride,
                        B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include "tft_kernel.h"
 #include "tft_rows_kernel.h"
+#include "tft_rows_exact_kernel.h"
 #include "f_kernel.h"
 #include "f_rows_kernel.h"
 #include "gh_kernel.h"

@@ -52,9 +52,11 @@ __device__ __forceinline__ void rows_qr_append(double (&a0)[M], double (&a1)[M],
             }
         }
         wave_sync();
-        double s[M], sigma = 0.0;
+        // (the owner's entries are re-read from LDS in each of the three loops below: broadcast reads cost no VALU slot, M more live doubles would)
+        const double* s = xch + opaque_int(0);
+        double sigma = 0.0;
 #pragma unroll
-        for (int i = 0; i < M; ++i) { s[i] = xch[i]; sigma = fma(s[i], s[i], sigma); }
+        for (int i = 0; i < M; ++i) sigma = fma(s[i], s[i], sigma);
         const int kk = rows_up_index(n, k, k);
         const double rkk = Rp[kk];
         const bool in0 = own0 && p >= k, in1 = own1 && 16 + p >= k;          // the columns of row k of R this position holds

@@ -38,7 +38,7 @@ struct RowRt {
     double Rt[2][12];      // chosen poses, row-major 3x4
     double Pfin[3][12];    // final cameras
 };
-constexpr int ROW_OV_DOUBLES = 352;      // >= 27 * 26 / 2 + 1 (packed factor + the zero slot), >= sizeof(RowRt)
+constexpr int ROW_OV_DOUBLES = 380;      // >= 27 * 26 / 2 + 1 (packed factor + the zero slot), >= 27 * 28 / 2 (R of the exact tier, rows_qr.h), >= sizeof(RowRt)
 static_assert(sizeof(RowRt) <= ROW_OV_DOUBLES * sizeof(double), "overlay");
 struct RowLds {
     double mom[96];        // moment sums (tft_kernel.h)
@@ -435,11 +435,13 @@ __device__ __forceinline__ bool rows_linear_tft_middle(RowLds* w, double* dbg, c
 }
 
 __device__ __forceinline__ void rows_recover_prepare(RowLds* w, RowRt* rt);
+// (EXACT: the certified / one-sided-Jacobi null vectors of small_la.h instead of the fast tier that only reports)
 // R_t_from_TFT.m:44-58 and svd(E), candidate poses and cameras (:85-88) for the row's triplet (tft_kernel.h::rt_prepare + recover_prepare)
+template <bool EXACT = false>
 __device__ __forceinline__ bool rows_rt_prepare(RowLds* w, RowRt* rt, double* dbg) {
     const int p = rows_p();
     rows_transform_tft_inverse(rt->T1, rt->T2, rt->mats, [w](int v) { return load_K(w->calm, v); });   // :44
-    const bool eok = epipoles_from_tensor<16, false>(rt->T2, rt->nullv, w->epi, true);                 // :47-55
+    const bool eok = epipoles_from_tensor<16, EXACT>(rt->T2, rt->nullv, w->epi, true);                 // :47-55
     const bool ok = !row_any(!eok);
     if (p < 2) {
         const double* e21 = w->epi; const double* e31 = w->epi + 3;
@@ -530,7 +532,8 @@ __device__ __forceinline__ void rows_recover_prepare(RowLds* w, RowRt* rt) {
 // broadcast reads that cost no VALU slot).
 // Returns false (per row) when a needed vote could not be certified.  sc[call][0] = sR, sc[call][1] = sRp; a score that was not needed is
 // reported as 0 (it is below 2 N in magnitude and its partner is +-2 N: same pick).
-__device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const RowRt* rt, const bool all4, int (&sc)[2][2], int* sweeps_out = nullptr) {
+__device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const RowRt* rt, const bool all4, int (&sc)[2][2], int* sweeps_out = nullptr,
+                                           bool* cert_out = nullptr) {
     const int p = rows_p();
     double PA[12];
 #pragma unroll
@@ -635,6 +638,10 @@ __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const R
         const int tB = fullB[call] ? (int)row_sum16((double)scB[call]) : 0;
         const bool badA = row_any(!certA[call]), badB = row_any(!certB[call]);
         ok = ok && !badA && (!fullB[call] || !badB);
+        if (cert_out) {                                                      // (with all4: A = (R,t), B = (Rp,t), both evaluated over every trip)
+            cert_out[2 * call] = main1[call] ? !badB : !badA;
+            cert_out[2 * call + 1] = main1[call] ? !badA : !badB;
+        }
         sc[call][0] = main1[call] ? tB : tA;
         sc[call][1] = main1[call] ? tA : tB;
     }
@@ -645,13 +652,21 @@ __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const R
 // One pass over the row's correspondences with the fast DLT tier (pose_common.h::tri_pass_fast): MODE TRI_SCALE -> num / den of
 // R_t_from_TFT.m:72-73 (every lane of the row), TRI_RECONST -> dehomogenised points to out (3 x N).  Returns false (per row) when some
 // correspondence's inverse iteration hit its cap.
-template <int MODE>
+template <int MODE, bool EXACT = false>
 __device__ __forceinline__ bool rows_tri_pass(const RowSrc& s, const int N, const double* camA, const double* camB, const double* aux,
                                               double* out, double& num_out, double& den_out) {
     const int p = rows_p();
-    double PA[12], PB[12], AX[12];
+    // EXACT: the cameras are read from LDS where they are used, so that none of their 36 values stays live across the out-of-line tiers of
+    // dlt_point (pose_common.h::tri_pass_impl)
+    double PAr[12], PBr[12], AXr[12];
+    if (!EXACT) {
 #pragma unroll
-    for (int c = 0; c < 12; ++c) { PA[c] = camA[c]; PB[c] = camB[c]; AX[c] = aux[c]; }
+        for (int c = 0; c < 12; ++c) { PAr[c] = camA[c]; PBr[c] = camB[c]; AXr[c] = aux[c]; }
+    }
+    typedef const double (&cam_ref)[12];
+    cam_ref PA = EXACT ? *reinterpret_cast<const double(*)[12]>(camA) : PAr;
+    cam_ref PB = EXACT ? *reinterpret_cast<const double(*)[12]>(camB) : PBr;
+    cam_ref AX = EXACT ? *reinterpret_cast<const double(*)[12]>(aux) : AXr;
     bool all_conv = true;
     double num = 0.0, den = 0.0;
     Pt6 pnext = rows_load(s, (p < N) ? p : 0);
@@ -660,7 +675,7 @@ __device__ __forceinline__ bool rows_tri_pass(const RowSrc& s, const int N, cons
         const Pt6 q = pnext;
         if (i + ROWL < N) pnext = rows_load(s, i + ROWL);
         double X[4];
-        const bool conv = dlt_point<false>(PA, PB, AX, camA, camB, aux, MODE == TRI_RECONST, q.v[0], q.v[1], q.v[2], q.v[3], q.v[4], q.v[5], X);
+        const bool conv = dlt_point<EXACT, EXACT>(PA, PB, AX, camA, camB, aux, MODE == TRI_RECONST, q.v[0], q.v[1], q.v[2], q.v[3], q.v[4], q.v[5], X);
         all_conv = all_conv && conv;
         const double iw = 1.0 / X[3];
         const double X0 = X[0] * iw, X1 = X[1] * iw, X2 = X[2] * iw;         // X./X(4)
@@ -733,7 +748,31 @@ __device__ __forceinline__ void rows_store_nan(const LinearTftArgs& a, const Row
 // Everything after the candidate cameras (rows_recover_prepare): cheirality votes and the reference's selection (R_t_from_TFT.m:91-104 ==
 // LinearFPoseEstimation.m:93-107), t3 scale (:68-74 == :64-70), optional Reconst, stores.  T_FROM_CAMERAS: T = TFT_from_P(K1 [I|0], K2 R_t_2,
 // K3 R_t_3) (LinearFPoseEstimation.m:78, TFT_from_P.m:25-33); else the tensor in rt->T1.  Returns the row's status.
-template <bool T_FROM_CAMERAS>
+// exact tier of one candidate's cheirality score for the row (pose_common.h::tri_vote_exact: every correspondence from its converged homogeneous
+// DLT point, R_t_from_TFT.m:98-99).  Rolled, cameras from LDS: it runs for the candidates whose fast vote was not certified.
+__device__ __forceinline__ int rows_vote_exact(const RowSrc& s, const int N, const RowRt* rt, const int cand_off, const int view) {
+    const int p = rows_p();
+    typedef const double (&cam_ref)[12];
+    cam_ref PA = *reinterpret_cast<const double(*)[12]>(rt->Pfin[0]);
+    const double* camB = rt->P[0] + cand_off;
+    cam_ref PB = *reinterpret_cast<const double(*)[12]>(camB);
+    const double* pr = rt->candRt[0] + cand_off;
+    double score = 0.0;
+#pragma unroll 1
+    for (int i = p; i < N; i += ROWL) {
+        const Pt6 q = rows_load(s, i);
+        double X[4];
+        dlt_point<true, true>(PA, PB, PB, rt->Pfin[0], camB, camB, false, q.v[0], q.v[1], (view == 1) ? q.v[2] : q.v[4], (view == 1) ? q.v[3] : q.v[5], 0.0, 0.0, X);
+        const double s4 = sgn(X[3]);                                         // X1 = X ./ X(4)
+        const double d1 = X[2] * s4, d2 = (pr[8] * X[0] + pr[9] * X[1] + pr[10] * X[2] + pr[11] * X[3]) * s4;
+        score += sgn(d1) + sgn(d2);
+    }
+    return (int)row_sum16(score);
+}
+
+// EXACT: every score is evaluated (all four candidates), an uncertified one is recomputed by rows_vote_exact, the t3 scale and Reconst take the
+// certified DLT ladder -- the row then fails only on what the caller's exact tiers reported.
+template <bool T_FROM_CAMERAS, bool EXACT = false>
 __device__ __forceinline__ int rows_pose_tail(const LinearTftArgs& a, RowLds* w, RowRt* rt, const RowJob& j, const int N, bool ok) {
     const int p = rows_p();
     double* dbg = j.dbg;
@@ -742,7 +781,19 @@ __device__ __forceinline__ int rows_pose_tail(const LinearTftArgs& a, RowLds* w,
     {                                                                        // recover_R_t, see pose_common.h::recover_vote
         int sc[2][2];
         int sweeps = 0;
-        ok = rows_votes(j.src, N, rt, dbg != nullptr && !(a.flags & FLAG_DBG_ADAPTIVE), sc, &sweeps) && ok;   // an uncertified sign: the exact kernel's business
+        if constexpr (EXACT) {
+            bool cert4[4];
+            rows_votes(j.src, N, rt, true, sc, &sweeps, cert4);             // all four fast scores and which of them are certified
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {                                    // (wave-uniform loop; a row joins when its candidate k needs the exact tier)
+                const bool need = !((k == 0) ? cert4[0] : (k == 1) ? cert4[1] : (k == 2) ? cert4[2] : cert4[3]);
+                if (!wave_any(need)) continue;
+                const int ex = rows_vote_exact(j.src, N, rt, 12 * k, (k < 2) ? 1 : 2);
+                if (need) { if (k == 0) sc[0][0] = ex; else if (k == 1) sc[0][1] = ex; else if (k == 2) sc[1][0] = ex; else sc[1][1] = ex; }
+            }
+        } else {
+            ok = rows_votes(j.src, N, rt, dbg != nullptr && !(a.flags & FLAG_DBG_ADAPTIVE), sc, &sweeps) && ok;   // an uncertified sign: the exact kernel's business
+        }
         if (dbg && p == 0) dbg[94] = (double)sweeps;
 #pragma unroll
         for (int call = 0; call < 2; ++call) {
@@ -768,7 +819,7 @@ __device__ __forceinline__ int rows_pose_tail(const LinearTftArgs& a, RowLds* w,
         if (p < 2) compose_camera_from_pose(load_K(w->calm, p + 1), rt->Rt[p], rt->Pfin[p + 1]);   // Pfin[1] = K2 [R2|t2]; Pfin[2] = [K3*R3 | K3*t3]
         wave_sync();
         double num, den;
-        const bool conv = rows_tri_pass<TRI_SCALE>(j.src, N, rt->Pfin[0], rt->Pfin[1], rt->Pfin[2], nullptr, num, den);
+        const bool conv = rows_tri_pass<TRI_SCALE, EXACT>(j.src, N, rt->Pfin[0], rt->Pfin[1], rt->Pfin[2], nullptr, num, den);
         ok = ok && conv;
         const double lam = -num / den;                                       // :72-73
         if (dbg && p == 0) dbg[68] = lam;
@@ -783,7 +834,7 @@ __device__ __forceinline__ int rows_pose_tail(const LinearTftArgs& a, RowLds* w,
     if (a.reconst) {                                                         // LinearTFTPoseEstimation.m:59-60
         double n0, d0;
         // (a tail row repeats triplet B - 1 and stores the same values to the same places)
-        const bool conv = rows_tri_pass<TRI_RECONST>(j.src, N, rt->Pfin[0], rt->Pfin[1], rt->Pfin[2], a.reconst + b * 3 * (long)N, n0, d0);
+        const bool conv = rows_tri_pass<TRI_RECONST, EXACT>(j.src, N, rt->Pfin[0], rt->Pfin[1], rt->Pfin[2], a.reconst + b * 3 * (long)N, n0, d0);
         ok = ok && conv;
     }
     if constexpr (T_FROM_CAMERAS) {                                          // TFT_from_P.m:25-33 (f_kernel.h::tft_from_cameras): 27 determinants, positions p and 16 + p
