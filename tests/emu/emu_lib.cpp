@@ -125,6 +125,19 @@ extern "C" int emu_rows_qr(const double* A, long B, int rows, int n, double* x, 
     else return -1;
     return 0;
 }
+extern "C" int emu_linear_f_pose_rows_exact(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                                            double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
+    tff::LinearTftArgs a{corresp, calm, calm_stride, B, N, flags & ~tff::FLAG_JACOBI, Rt2, Rt3, T, reconst, iter, status, dbg, nullptr, nullptr, nullptr};
+    if (reconst) a.flags |= tff::FLAG_RECONST;
+    emu::launch(tff::k_linear_f_pose_rows_exact, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);
+    bool any = false;
+    for (long b = 0; b < B; ++b) any = any || status[b] == tff::ST_RETRY;
+    if (!any) return 0;
+    a.flags |= tff::FLAG_ONLY_RETRY;
+    a.flags = tff::pose_auto_flags(N, a.flags, true, tff::STAGE_MAX_N_F);
+    emu::launch(tff::k_f_pose<true, 0>, emu_grid(B), 64, tff::f_pose_lds_bytes(N, a.flags, true), a);
+    return 1;
+}
 #ifndef TFF_EMU_LINEAR_TFT_ONLY   // (the sanitizer build of tests/test_emulated_kernels.py compiles the linear trifocal kernels only: minutes less)
 extern "C" int emu_linear_f_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
                                  double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {

@@ -684,3 +684,18 @@ def test_rows_qr_and_inverse_iteration_match_lapack(emu):
                 v = np.linalg.svd(A[b])[2][-1]
                 assert min(np.abs(x[b] - v).max(), np.abs(x[b] + v).max()) < 1e-11
                 assert its[b] <= (8 if b % 2 == 0 else 60)
+
+
+@pytest.mark.parametrize("B,N,sigma", [(6, 8, 1.0), (5, 9, 2.0), (3, 20, 0.5)])
+def test_rows_exact_linear_f_kernel_matches_oracle(emu, B, N, sigma):
+    """LinearFPoseEstimation's exact tiers with one triplet per row of 16 lanes (csrc/f_rows_kernel.h::k_linear_f_pose_rows_exact): QR of the explicit
+    N x 9 systems, linearF's own normalisation computed from the normalised points, certified null vectors and votes."""
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=sigma, seed=100 + N)
+    out = run_linear_tft(emu, C, CalM, entry="emu_linear_f_pose_rows_exact", debug=True)
+    ref = run_linear_tft(emu, C, CalM, flags=FLAG_JACOBI, entry="emu_linear_f_pose")
+    assert np.all(out["status"] == 0) and np.all(out["debug"][:, 69:71] >= 20000)
+    for b in range(B):
+        R2, R3, Rec, T, _ = O.LinearFPoseEstimation(C[b].T.copy(), CalM)
+        assert rel_err_T(out["T"][b], T) < 1e-9 and rel_err(out["R_t_2"][b], R2) < 1e-9 and rel_err(out["R_t_3"][b], R3) < 1e-9
+        assert rel_err(out["Reconst"][b], Rec) < 1e-9
+        assert rel_err_T(out["T"][b], ref["T"][b]) < 1e-10 and rel_err(out["R_t_3"][b], ref["R_t_3"][b]) < 1e-10

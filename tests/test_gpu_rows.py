@@ -136,16 +136,17 @@ def test_rows_sampled_hypotheses(gpu_ctx):
     assert (e3 > 1e-6).mean() < 5e-3
 
 
-def test_exact_rows_kernel_against_the_one_triplet_exact_kernel(gpu_ctx):
-    """40 000 seven-point samples at 3 px noise through the exact tiers: four triplets per wavefront (tft_rows_exact_kernel.h, the default for
+@pytest.mark.parametrize("method,n", [("LinearTFTPoseEstimation", 7), ("LinearFPoseEstimation", 8)])
+def test_exact_rows_kernel_against_the_one_triplet_exact_kernel(gpu_ctx, method, n):
+    """40 000 seven- / eight-point samples at 3 px noise through the exact tiers: four triplets per wavefront (tft_rows_exact_kernel.h, the default for
     N < TFF_OPT_EXACT_BELOW) against one per wavefront (TFF_OPT_ROWS = 0).  Same statuses; the same poses wherever the reference's answer is
     unique (cheirality ties between the two rotations, ~0.2 % of minimal samples, may fall differently: tests/helpers.py)."""
     import torch
     from tft_vs_fund_amd.scenes import generate_scene_batch
     B = 40000
-    C, CalM, _, _ = generate_scene_batch(B, 7, noise=3.0, seed=5)
+    C, CalM, _, _ = generate_scene_batch(B, n, noise=3.0, seed=5)
     d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
-    r, w = _both_routes(gpu_ctx, "LinearTFTPoseEstimation", d, calm, reconst=True)
+    r, w = _both_routes(gpu_ctx, method, d, calm, reconst=True)
     assert np.array_equal(r["status"], w["status"])
     ok = r["status"] == 0
     assert ok.mean() > 0.99

@@ -198,7 +198,11 @@ int launch_pose_rows(tff_ctx* c, KRows krows, KExact kexact, lds_fn exact_lds, i
     }
     const size_t lds = exact_lds(N, a.flags, true);
     if (int r = ensure_lds(kexact, lds)) return r;
-    hipLaunchKernelGGL(kexact, dim3((unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID)), dim3(64), lds, c->stream, a);
+    // the fix-up grid: 1024 wavefronts scan the status array (resident in one go; almost always nothing to redo).  Whole batches of minimal
+    // samples hand ~2 % on when the scene has gross outliers (config 4): a block then redoes its share one after the other, a lone wavefront at
+    // ~0.4 ms each -- a grid that grows with the batch (one block per 64 triplets) keeps that share at one or two
+    const long fix = (B / 64 > FIXUP_GRID) ? ((B / 64 < 65536) ? B / 64 : 65536) : FIXUP_GRID;
+    hipLaunchKernelGGL(kexact, dim3((unsigned)(B < fix ? B : fix)), dim3(64), lds, c->stream, a);
     TFF_HIP(hipGetLastError());
     return 0;
 }
@@ -217,9 +221,12 @@ int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int
 }
 int launch_linear_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    if (c && c->rows && c->solver == 0 && N >= c->exact_below)                // four triplets per wavefront (f_rows_kernel.h)
-        return launch_pose_rows(c, tff::k_linear_f_pose_rows, tff::k_f_pose<true, 0>, tff::f_pose_lds_bytes, tff::STAGE_MAX_N_F, corresp, calm, calm_stride,
-                                B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+    if (c && c->rows)                                                         // four triplets per wavefront (f_rows_kernel.h): fast tiers, or -- whole batches for the exact tiers -- the exact ones
+        return (c->solver == 0 && N >= c->exact_below)
+            ? launch_pose_rows(c, tff::k_linear_f_pose_rows, tff::k_f_pose<true, 0>, tff::f_pose_lds_bytes, tff::STAGE_MAX_N_F, corresp, calm, calm_stride,
+                               B, N, Rt2, Rt3, T, reconst, iter, status, dbg)
+            : launch_pose_rows(c, tff::k_linear_f_pose_rows_exact, tff::k_f_pose<true, 0>, tff::f_pose_lds_bytes, tff::STAGE_MAX_N_F, corresp, calm, calm_stride,
+                               B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     return launch_pose(c, tff::k_f_pose<false, 0>, tff::k_f_pose<true, 0>, tff::f_pose_lds_bytes, tff::STAGE_MAX_N_F, 0, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
                        reconst, iter, status, dbg);
 }

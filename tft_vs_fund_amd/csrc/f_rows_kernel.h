@@ -13,6 +13,7 @@
 // Reference: F_methods/LinearFPoseEstimation.m:42-109, F_methods/linearF.m:32-62, TFT_methods/TFT_from_P.m:25-33.
 #pragma once
 #include "tft_rows_kernel.h"
+#include "tft_rows_exact_kernel.h"
 #include "f_kernel.h"
 
 namespace tff {
@@ -157,6 +158,132 @@ __global__ void __launch_bounds__(64, 2) k_linear_f_pose_rows(const LinearTftArg
             bool ok = rows_linear_f_middle(w, rt, w->t, w->pa, j.dbg);       // (w->t: F21, F31)
             rows_recover_prepare(w, rt);
             status = rows_pose_tail<true>(a, w, rt, j, N, ok);
+        }
+        if (p == 0 && j.valid) {
+            if (a.iter) a.iter[j.b] = 0;                                     // LinearFPoseEstimation.m:77
+            a.status[j.b] = status;
+        }
+    }
+}
+
+// ---- the exact tiers of LinearFPoseEstimation, four triplets per wavefront (k_f_pose<true, 0> in the row layout; minimal samples / TFF_OPT_SOLVER = 1) ----
+// Streaming Householder QR of the explicit N x 9 system of each view pair (rows_qr.h: position p < 9 owns column p, 16 rows per chunk), inverse
+// iteration with L = R', certified 3 x 3 null vectors, all four votes with the exact re-score behind them, certified DLT ladder for t3 scale and
+// Reconst.  linearF's own normalisation of the normalised points (linearF.m:45-46) is computed from them as the reference does.
+// A row whose inverse iteration hits its cap is marked ST_RETRY for k_f_pose<true, 0> (one-sided Jacobi on R).
+__device__ __forceinline__ bool rows_linear_f_middle_exact(RowLds* w, RowRt* rt, const RowSrc& s, const int N, double* Fm, double* nrm2, double* dbg) {
+    const int p = opaque_lane_int(rows_p());
+    double* Rp = w->ov;
+    double* xch = w->mom;
+    double* dinv = w->mom + 32;
+    {                                                                        // linearF.m:45-46: Normalize2Ddata of the already normalised points
+        double sm[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+        for (int i = p; i < N; i += ROWL) {
+            const Pt6 q = premap(rows_load(s, i), w->nrm);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sm[k] += q.v[k];
+        }
+        double c[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c[k] = row_sum16(sm[k]) / (double)N;
+        double d[3] = {0.0, 0.0, 0.0};
+#pragma unroll 1
+        for (int i = p; i < N; i += ROWL) {
+            const Pt6 q = premap(rows_load(s, i), w->nrm);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const double dx = q.v[2 * v] - c[2 * v], dy = q.v[2 * v + 1] - c[2 * v + 1];
+                d[v] += sqrt(dx * dx + dy * dy);
+            }
+        }
+        const double r2c = sqrt(2.0);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const double norm0 = row_sum16(d[v]) / (double)N;
+            if (p == 3 * v) nrm2[3 * v] = r2c / norm0;
+            if (p == 3 * v + 1) nrm2[3 * v + 1] = -r2c * c[2 * v] / norm0;
+            if (p == 3 * v + 2) nrm2[3 * v + 2] = -r2c * c[2 * v + 1] / norm0;
+        }
+        wave_sync();
+    }
+    bool ok = true;
+#pragma unroll 1
+    for (int pair = 0; pair < 2; ++pair) {                                   // linearF(x1,x2), linearF(x1,x3): rows h1 (x) h2, position 3a + b (linearF.m:48-53)
+        rows_qr_clear<9>(Rp);
+        const int col = (p < 9) ? p : 0, ca = col / 3, cb = col % 3;
+#pragma unroll 1
+        for (int base = 0; base < N; base += 16) {
+            double a0[16], a1[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = base + r;                                      // row-uniform: every lane of the row reads the same correspondence
+                const Pt6 q = premap(premap(rows_load(s, (i < N) ? i : 0), w->nrm), nrm2);
+                const double h1 = (ca == 0) ? q.v[0] : (ca == 1) ? q.v[1] : 1.0;
+                const double h2 = (cb == 0) ? (pair ? q.v[4] : q.v[2]) : (cb == 1) ? (pair ? q.v[5] : q.v[3]) : 1.0;
+                a0[r] = (i < N && p < 9) ? h1 * h2 : 0.0;
+                a1[r] = 0.0;
+            }
+            rows_qr_append<9, 16>(a0, a1, Rp, xch);
+        }
+        int its = 0;
+        double x0, x1, r2;
+        rows_invit_from_R<9>(Rp, dinv, EIG_MAXIT, &its, &r2, x0, x1);
+        ok = ok && eig_converged(r2);
+        if (dbg && p == 0) dbg[69 + pair] = (double)(20000 + its);
+        if (p < 9) Fm[9 * pair + 3 * (p % 3) + p / 3] = x0;                  // F = reshape(V(:,9),3,3), row-major
+        wave_sync();
+    }
+    if (p < 2) {
+        const int v2 = p + 1;
+        Mat3 F;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) F.m[r][c] = Fm[9 * p + 3 * r + c];
+        F = mat3_mul(mat3_mul(mat3_T(normal_matrix(nrm2, v2)), F), normal_matrix(nrm2, 0));          // linearF.m:58
+        double v3[3], fv[3];
+        null3<true>(F, v3);                                                  // :61-62 (certified tier, one-sided Jacobi behind it)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) fv[r] = F.m[r][0] * v3[0] + F.m[r][1] * v3[1] + F.m[r][2] * v3[2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) F.m[r][c] -= fv[r] * v3[c];
+        F = mat3_mul(mat3_mul(mat3_T(normal_matrix(w->nrm, v2)), F), normal_matrix(w->nrm, 0));      // LinearFPoseEstimation.m:55-56
+        const Mat3 E = mat3_mul(mat3_mul(mat3_T(load_K(w->calm, v2)), F), load_K(w->calm, 0));       // E = K2' F K1
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rt->Ein[9 * p + 3 * r + c] = E.m[r][c];
+    }
+    wave_sync();
+    return ok;
+}
+
+__global__ void __launch_bounds__(64, 2) k_linear_f_pose_rows_exact(const LinearTftArgs a) {
+    TFF_DYNAMIC_LDS(double, smem);
+    const int p = lane_id() & 15, row = lane_id() >> 4;
+    RowLds* w = reinterpret_cast<RowLds*>(smem) + row;
+    RowRt* rt = reinterpret_cast<RowRt*>(w->ov);
+    for (long blk = blockIdx.x; blk * ROW_TRIPLETS < a.B; blk += gridDim.x) {
+        const int N = opaque_int(a.N);
+        const RowJob j = rows_begin(a, w, blk, N);
+        int status;
+        if (N < 8) {                                                         // linearF.m:35-37
+            status = ST_TOO_FEW;
+            rows_store_nan(a, j, N);
+        } else {
+            {
+                double cen[6];
+                rows_centroids(j.src, N, cen);                               // LinearFPoseEstimation.m:46-48
+                rows_distances(j.src, N, cen, w->nrm);
+            }
+            // (the rank-2 F matrices go to w->t, linearF's inner normalisation to w->pa; the packed R lives in the overlay until E is formed --
+            //  rt->Ein overlaps it, so E is written after the last solve)
+            bool ok = rows_linear_f_middle_exact(w, rt, j.src, N, w->t, w->pa, j.dbg);
+            rows_recover_prepare(w, rt);
+            status = rows_pose_tail<true, true>(a, w, rt, j, N, ok);
         }
         if (p == 0 && j.valid) {
             if (a.iter) a.iter[j.b] = 0;                                     // LinearFPoseEstimation.m:77
