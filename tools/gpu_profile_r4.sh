@@ -34,6 +34,6 @@ for T in ${@:-headline headline1 ressl nordberg faugpapa pi picol linearf optimf
     linearf)    run_one linearf "python3 $R/tools/bench_one.py LinearFPoseEstimation 20" "k_linear_f_pose_rows" 10000 $ALG 2;;
     optimf)     run_one optimf "python3 $R/tools/bench_one.py OptimFPoseEstimation 10" "k_f_pose<false, 1>" 10000 $ALG 3;;
     config4tft) run_one config4tft "python3 $R/tools/config4_split.py 1000000" "k_linear_tft_pose_rows_exact" 1000000 $((1000000 * 440)) 2;;
-    config4f)   run_one config4f "python3 $R/tools/config4_split.py 1000000" "k_f_pose<true, 0>" 1000000 $((1000000 * 444)) 2;;
+    config4f)   run_one config4f "python3 $R/tools/config4_split.py 1000000" "k_linear_f_pose_rows_exact" 1000000 $((1000000 * 444)) 2;;
   esac
 done
