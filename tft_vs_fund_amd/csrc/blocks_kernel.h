@@ -169,6 +169,73 @@ __global__ void __launch_bounds__(64, 4) k_repr_error(const ReprErrorArgs a) {
     }
 }
 
+// The int32 inlier counts of many hypotheses against ONE shared scene (config 4: experiments_real.m:94-98's rule per hypothesis) with the scene
+// staged in LDS once per workgroup: k_repr_error re-reads the scene through L1 / L2 for every hypothesis (a million hypotheses x 19 KB = 3.8 TB/s
+// of cache traffic at 5 ms per launch, more than twice what the arithmetic needs).  Four wavefronts share one copy of the scene and walk the
+// hypotheses with a grid stride; same arithmetic per correspondence as k_repr_error's count-only path (certain-outlier pivot test, then the
+// certified DLT ladder for the correspondences that could be inliers), so the counts are identical.
+constexpr int INLIER_WG_WAVES = 4;
+__global__ void __launch_bounds__(64 * INLIER_WG_WAVES, 4) k_inlier_count_staged(const ReprErrorArgs a) {
+    TFF_DYNAMIC_LDS(double, smem);
+    double* scene = smem;                                                    // 6 N doubles
+    double* camw = smem + 6 * (size_t)a.N + 36 * wave_in_block();            // the wavefront's three cameras (row-major 3 x 4)
+    const int lane = lane_id();
+    {
+        const double2* s2 = reinterpret_cast<const double2*>(a.corresp);
+        double2* d2 = reinterpret_cast<double2*>(scene);
+        for (int i = thread_in_block(); i < 3 * a.N; i += 64 * INLIER_WG_WAVES) d2[i] = s2[i];
+    }
+    __syncthreads();
+    for (long b = (long)blockIdx.x * INLIER_WG_WAVES + wave_in_block(); b < a.B; b += (long)gridDim.x * INLIER_WG_WAVES) {
+        wave_sync();
+        if (lane < 3) {
+            const Mat3 K = load_K(a.calm, lane);
+            double Rt[12];                                                   // row-major pose of view `lane`
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                const int r = e >> 2, c = e & 3;
+                Rt[e] = (lane == 0) ? ((r == c) ? 1.0 : 0.0) : ((lane == 1) ? a.Rt2[b * 12 + r + 3 * c] : a.Rt3[b * 12 + r + 3 * c]);
+            }
+            compose_camera_from_pose(K, Rt, camw + 12 * lane);
+        }
+        wave_sync();
+        double P[3][12];
+        load_uniform12(camw, P[0]);
+        load_uniform12(camw + 12, P[1]);
+        load_uniform12(camw + 24, P[2]);
+        double Zt[4][4];
+        const double k2 = 2.0 * a.thr * a.thr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) Zt[i][j] = k2 * (P[0][8 + i] * P[0][8 + j] + P[1][8 + i] * P[1][8 + j] + P[2][8 + i] * P[2][8 + j]);
+        int cnt = 0;
+#pragma unroll 1
+        for (int i = lane; i < a.N; i += WAVE) {
+            const Pt6 p = load_pt(scene, i);
+            double S[4][4], X[4];
+            tri_zero(S);
+            tri_accum(S, P[0], p.v[0], p.v[1]);
+            tri_accum(S, P[1], p.v[2], p.v[3]);
+            tri_accum(S, P[2], p.v[4], p.v[5]);
+            if (certainly_positive_definite(S, Zt)) continue;
+            dlt_point_solve<true, true>(S, camw, camw + 12, camw + 24, true, p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], p.v[5], X);
+            bool in = true;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const double u = P[v][0] * X[0] + P[v][1] * X[1] + P[v][2] * X[2] + P[v][3] * X[3];
+                const double w2 = P[v][4] * X[0] + P[v][5] * X[1] + P[v][6] * X[2] + P[v][7] * X[3];
+                const double z = P[v][8] * X[0] + P[v][9] * X[1] + P[v][10] * X[2] + P[v][11] * X[3];
+                const double dx = u / z - p.v[2 * v], dy = w2 / z - p.v[2 * v + 1];
+                in = in && (fabs(dx) <= a.thr) && (fabs(dy) <= a.thr);     // sum(abs(residuals) > th, 1) == 0
+            }
+            cnt += in ? 1 : 0;
+        }
+        cnt = wave_sum_i(cnt);
+        if (lane == 0) a.inliers[b] = cnt;
+    }
+}
+
 // ---- transform_TFT ----------------------------------------------------------------------------
 struct TransformArgs {
     const double* T;         // B x 27

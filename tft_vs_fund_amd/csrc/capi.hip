@@ -658,7 +658,16 @@ int tff_inlier_count_batch_dev(tff_ctx* c, const double* scene, int32_t Ns, cons
     if (!scene || !calm || !Rt2 || !Rt3 || !counts) return fail(TFF_E_INVALID, "null pointer");
     TFF_HIP(hipSetDevice(c->device));
     tff::ReprErrorArgs a{nullptr, 0, calm, Rt2, Rt3, scene, 0, nullptr, (long)B, Ns, threshold, err, counts};
-    hipLaunchKernelGGL(tff::k_repr_error, dim3(tff::pose_grid(B)), dim3(64), 0, c->stream, a);
+    const size_t staged = ((size_t)6 * Ns + 36 * tff::INLIER_WG_WAVES) * sizeof(double);
+    if (!err && staged <= 48 * 1024 && B >= 4096) {
+        // counts only, many hypotheses, a scene that fits the LDS a few times over: stage it once per workgroup (blocks_kernel.h)
+        const int per_cu = (int)((LDS_LIMIT / (staged + 512) < 4) ? LDS_LIMIT / (staged + 512) : 4);
+        long grid = 256L * per_cu;
+        if (grid * tff::INLIER_WG_WAVES > B) grid = (B + tff::INLIER_WG_WAVES - 1) / tff::INLIER_WG_WAVES;
+        hipLaunchKernelGGL(tff::k_inlier_count_staged, dim3((unsigned)grid), dim3(64 * tff::INLIER_WG_WAVES), staged, c->stream, a);
+    } else {
+        hipLaunchKernelGGL(tff::k_repr_error, dim3(tff::pose_grid(B)), dim3(64), 0, c->stream, a);
+    }
     TFF_HIP(hipGetLastError());
     return 0;
 }
