@@ -164,7 +164,6 @@ def main():
         ctx.set_stream(stream.cuda_stream)
     p = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + 8 * off)
     timing = {"events": None}
-    done = [torch.cuda.Event() for _ in range(S)] if not stub else []
     stub_ms = []
 
     def compute_stub(r, k):                                # the records of (rank, step): what the gather check at the end looks for
@@ -174,11 +173,11 @@ def main():
             stub_ms.append(1e3 * (time.perf_counter() - t_))
 
     def compute(r, k):
-        # step k runs on stream k % S (result buffer k % S: a stream only ever reuses its own buffer); the gather stream waits for it
+        # step k runs on stream k % S (result buffer k % S: a stream only ever reuses its own buffer).  While a step is issued its stream is
+        # torch's CURRENT stream (step() below), so the process group orders the step's gather against that stream only: Work.wait() of the
+        # gather that last read this buffer blocks this stream, the new gather waits for this stream's launch -- the other stream is not involved
         j = k % S
         ev = timing["events"][k] if timing["events"] is not None else None
-        if S > 1 and world > 1:
-            side[j].wait_stream(stream)                   # the gather that last read this buffer was ordered on the main stream
         if ev is not None and not os.environ.get("TFF_BENCH_NOEV"):
             ev[0].record(side[j])
         rc = lib.tff_linear_tft_pose_batch_dev(ctxs[j].handle, p(d_C), p(d_calm), 0, B, N, p(r, 0), p(r, 12 * B), p(r, 24 * B),
@@ -187,12 +186,15 @@ def main():
             ev[1].record(side[j])
         if rc != 0:
             raise RuntimeError("tff_linear_tft_pose_batch_dev failed: %s" % lib.tff_last_error().decode())
-        if S > 1 and (world > 1 or os.environ.get("TFF_BENCH_JOIN")):
-            done[j].record(side[j])
-            stream.wait_event(done[j])                    # anything enqueued on the main stream after this (the gather) sees the records
 
     pipe = tdist.OverlappedGather(world, tdist.RECORD_DOUBLES * B, dev, compute_stub if stub else compute, nbuf=max(2, S))
-    step, drain = pipe.step, pipe.drain
+    drain = pipe.drain
+    if stub or S == 1:
+        step = pipe.step
+    else:
+        def step(k):
+            with torch.cuda.stream(side[k % S]):
+                return pipe.step(k)
 
     def sync_all():
         for c in ctxs:

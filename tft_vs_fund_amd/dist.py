@@ -108,6 +108,9 @@ class OverlappedGather:
     after its previous gather has completed.  `compute(record_buffer, k)` enqueues the work of one step (the HIP launch in
     bench.py; a stub in the gloo test).  world == 1: no collective, no extra buffers.
 
+    Several compute streams (bench.py --streams 2): call `step(k)` inside `with torch.cuda.stream(stream_of_step_k)` -- the requirement below then
+    holds per step, and a step's gather is ordered against that step's stream only.
+
     STREAM REQUIREMENT: `compute` must enqueue its work on torch's CURRENT stream of `device` -- the stream the process group orders
     its collectives against (all_gather_into_tensor waits for the current stream's work, Work.wait() makes the current stream wait
     for the collective).  A tft_vs_fund_amd.api.Context launches on its own non-blocking stream by default: call
