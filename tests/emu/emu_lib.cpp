@@ -180,7 +180,8 @@ static int emu_wg_run(KBlock kblock, size_t lds_block, const double* corresp, co
     m.flags |= tff::FLAG_ONLY_RETRY;
     emu::launch(tff::k_gh_linear<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
     emu::launch(kblock, emu_grid(B), tff::GH_WG_THREADS, lds_block, a);
-    emu::launch(tff::k_gh_finish, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
+    if (N >= 12) emu::launch(tff::k_gh_finish_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);     // (as the C ABI)
+    else emu::launch(tff::k_gh_finish, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
     return 0;
 }
 // Pi / PiCol through the workgroup path (pi_wg_kernel.h)
@@ -205,7 +206,8 @@ static int emu_gh_wg_impl(const double* corresp, const double* calm, long calm_s
     emu::launch(tff::k_gh_linear<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
     const size_t lds = (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, N, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double);
     emu::launch(tff::k_gh_block<Model>, emu_grid(B), tff::GH_WG_THREADS, lds, a);
-    emu::launch(tff::k_gh_finish, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
+    if (N >= 12) emu::launch(tff::k_gh_finish_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);     // (as the C ABI)
+    else emu::launch(tff::k_gh_finish, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
     return 0;
 }
 // FaugPapa through its own block kernel (gh_fp_kernel.h), then the generic one over what it handed back
@@ -226,7 +228,8 @@ extern "C" int emu_fp_pose(const double* corresp, const double* calm, long calm_
         const size_t lds = (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, N, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double);
         emu::launch(tff::k_gh_block<Model>, emu_grid(B), tff::GH_WG_THREADS, lds, m);
     }
-    emu::launch(tff::k_gh_finish, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
+    if (N >= 12) emu::launch(tff::k_gh_finish_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);     // (as the C ABI)
+    else emu::launch(tff::k_gh_finish, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
     return handed;
 }
 extern "C" int emu_gh_wg_pose(int model, const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,

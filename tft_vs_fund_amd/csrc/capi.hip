@@ -300,7 +300,10 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
         hipLaunchKernelGGL(kblock, dim3(grid), dim3(tff::GH_WG_THREADS), lds, c->stream, m);
         TFF_HIP(hipGetLastError());
     }
-    {
+    if (c->rows && rows_linear && N >= 12) {                                 // four triplets per wavefront (gh_rows_kernel.h); minimal samples: the one-triplet kernel's ladder
+        hipLaunchKernelGGL(tff::k_gh_finish_rows, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, a);
+        TFF_HIP(hipGetLastError());
+    } else {
         const size_t lds = tff::pose_lds_bytes(N, 0, false);
         hipLaunchKernelGGL(tff::k_gh_finish, dim3(tff::pose_grid(B)), dim3(64), lds, c->stream, a);
         TFF_HIP(hipGetLastError());

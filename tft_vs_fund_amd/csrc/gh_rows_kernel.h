@@ -4,6 +4,7 @@
 // Reference: TFT_methods/ResslTFTPoseEstimation.m:48-53 (the same lines open the Nordberg / FaugPapa / Pi / PiCol wrappers), linearTFT.m:33-91.
 #pragma once
 #include "tft_rows_kernel.h"
+#include "tft_rows_exact_kernel.h"
 #include "gh_wg_kernel.h"
 
 namespace tff {
@@ -44,6 +45,55 @@ __global__ void __launch_bounds__(64, 2) k_gh_linear_rows(const GhWgArgs a) {
             }
         }
         if (p == 0 && valid) { a.status[b] = status; if (a.iter) a.iter[b] = 0; }
+    }
+}
+
+// The last stage of the iterative trifocal methods (k_gh_finish, gh_wg_kernel.h: transform_TFT, R_t_from_TFT, optional Reconst from the optimised
+// tensor) with four triplets per wavefront: the pose tail of tft_rows_kernel.h on the fast tiers, and -- for the wavefronts in which some row
+// could not finish or certify its part -- once more on the exact tiers (tft_rows_exact_kernel.h's), storing only those rows.
+// Reference: TFT_methods/ResslTFTPoseEstimation.m:96-103 (the same lines close the other iterative wrappers).
+__global__ void __launch_bounds__(64, 2) k_gh_finish_rows(const GhWgArgs a) {
+    TFF_DYNAMIC_LDS(double, smem);
+    const int lane = lane_id();
+    const int p = lane & 15, row = lane >> 4;
+    RowLds* w = reinterpret_cast<RowLds*>(smem) + row;
+    RowRt* rt = reinterpret_cast<RowRt*>(w->ov);
+    LinearTftArgs la{};                                                      // what rows_pose_tail reads: outputs, flags
+    la.corresp = a.corresp; la.calm = a.calm; la.calm_stride = a.calm_stride; la.B = a.B; la.N = a.N; la.flags = a.flags;
+    la.Rt2 = a.Rt2; la.Rt3 = a.Rt3; la.T = a.T; la.reconst = a.reconst; la.iter = nullptr; la.status = a.status; la.dbg = nullptr;
+    for (long blk = blockIdx.x; blk * ROW_TRIPLETS < a.B; blk += gridDim.x) {
+        const int N = opaque_int(a.N);
+        RowJob j;
+        const long b_raw = blk * ROW_TRIPLETS + row;
+        j.valid = b_raw < a.B;
+        j.b = j.valid ? b_raw : a.B - 1;
+        j.bad_index = false; j.dbg = nullptr;
+        j.src.idx = nullptr; j.src.pts = a.corresp + j.b * 6 * (long)N; j.src.ns = 0; j.src.sampled = false;
+        wave_sync();
+        const int s0 = a.status[j.b];
+        const bool dead = s0 > 0;                                            // ST_TOO_FEW (or an unresolved retry): no outputs
+        if (dead) rows_store_nan(la, j, N);
+        w->calm[p] = a.calm[j.b * a.calm_stride + p];
+        if (p < 11) w->calm[16 + p] = a.calm[j.b * a.calm_stride + 16 + p];
+        w->t[p] = dead ? ((p == 0) ? 1.0 : 0.0) : a.topt[j.b * 27 + p];     // (a dead row works on a harmless tensor and stores nothing)
+        if (p < 11) w->t[16 + p] = dead ? 0.0 : a.topt[j.b * 27 + 16 + p];
+        if (p < 9) w->nrm[p] = dead ? ((p % 3 == 0) ? 1.0 : 0.0) : a.rec[j.b * GH_REC_DOUBLES + 51 + p];
+        wave_sync();
+        j.valid = j.valid && !dead;
+        rows_transform_tft_inverse(w->t, rt->T1, rt->mats, [w](int v) { return normal_matrix(w->nrm, v); });
+        bool ok = rows_rt_prepare<false>(w, rt, nullptr);
+        int status = rows_pose_tail<false, false>(la, w, rt, j, N, ok);
+        if (wave_any(status == ST_RETRY)) {                                  // a fast tier gave up in some row: the exact tiers, for those rows only
+            RowJob jx = j;
+            jx.valid = j.valid && status == ST_RETRY;
+            wave_sync();
+            rows_transform_tft_inverse(w->t, rt->T1, rt->mats, [w](int v) { return normal_matrix(w->nrm, v); });
+            ok = rows_rt_prepare<true>(w, rt, nullptr);
+            const int sx = rows_pose_tail<false, true>(la, w, rt, jx, N, ok);
+            status = (status == ST_RETRY) ? sx : status;
+        }
+        if (s0 < 0) status = -s0;
+        if (p == 0 && j.valid) a.status[j.b] = status;
     }
 }
 
