@@ -82,6 +82,9 @@ typedef struct tff_ctx tff_ctx;
 #define TFF_OPT_ROWS 7      /* LinearTFT / LinearF pose kernels and the linear stage of the iterative TFT methods: 1 (default) four triplets per wavefront,
                              * one per row of 16 lanes (csrc/tft_rows_kernel.h, f_rows_kernel.h, gh_rows_kernel.h); 0 one triplet per wavefront
                              * (csrc/tft_kernel.h, f_kernel.h) -- an A/B switch, results agree to rounding */
+#define TFF_OPT_DEBUG_FP_HANDOVER 8 /* test hook: 1 = FaugPapa's block kernel hands every third triplet back to the generic workgroup kernel, as it does when its
+                             * pseudo-inverse reports a failure (exercises that production fall-back; results must not depend on it beyond the
+                             * generic kernel's LAPACK-level noise) */
 #define TFF_DEBUG_STRIDE 128 /* doubles per triplet written by the *_debug_dev entry points */
 
 int tff_version(void);

@@ -197,3 +197,33 @@ def test_picol_against_the_extended_precision_fixture(gpu_ctx, golden_dir):
                      abs(int(out["iter"][b]) - int(it4[b, c])), int(it4[b, c])) for c in range(4) if it4[b, c] >= 0]
             d, dit, mit = min(cand)
             assert dit == 0 and d < 1e-9, (ci, b, d, dit, mit)
+
+
+def test_faugpapa_hand_over_to_the_generic_kernel(gpu_ctx):
+    """k_fp_block marks a triplet ST_RETRY when its pseudo-inverse reports a failure (non-converged eigenpair, lost orthogonality in a cluster,
+    weight block without the one-small-eigenvalue structure) and k_gh_block<FaugPapaModel> redoes it under FLAG_ONLY_RETRY.  None of that
+    happens on ordinary data, so a test hook makes the block kernel hand every third triplet back: those must come out exactly as the generic
+    kernel computes them when it runs for all (TFF_OPT_KERNEL = 2), the others exactly as the block kernel computes them, statuses 0."""
+    import torch
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    B, N = 300, 60
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=77)
+    d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
+    fp = gpu_ctx.pose_batch("FaugPapaTFTPoseEstimation", d, calm, reconst=False)
+    gpu_ctx.set_kernel_variant(2)
+    try:
+        gen = gpu_ctx.pose_batch("FaugPapaTFTPoseEstimation", d, calm, reconst=False)
+    finally:
+        gpu_ctx.set_kernel_variant(0)
+    gpu_ctx.set_debug_fp_handover(True)
+    try:
+        mix = gpu_ctx.pose_batch("FaugPapaTFTPoseEstimation", d, calm, reconst=False)
+    finally:
+        gpu_ctx.set_debug_fp_handover(False)
+    torch.cuda.synchronize()
+    assert int((mix["status"] != 0).sum()) == 0 and int((fp["status"] != 0).sum()) == 0 and int((gen["status"] != 0).sum()) == 0
+    third = torch.arange(B, device="cuda") % 3 == 0
+    for k in ("T", "R_t_2", "R_t_3", "iter"):
+        assert torch.equal(mix[k][third], gen[k][third]), k               # handed over: the generic kernel's result, bit for bit
+        assert torch.equal(mix[k][~third], fp[k][~third]), k              # kept: the block kernel's
+

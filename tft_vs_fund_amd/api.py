@@ -36,6 +36,7 @@ TFF_OPT_GH_EXACT = 4
 TFF_OPT_EXACT_BELOW = 5
 TFF_OPT_SPILL = 6
 TFF_OPT_ROWS = 7
+TFF_OPT_DEBUG_FP_HANDOVER = 8
 DEBUG_STRIDE = 128
 
 ST_OK, ST_TOO_FEW, ST_NONFINITE, ST_NO_POSE, ST_RANK, ST_NO_PARAM = 0, 1, 2, 3, 4, 5
@@ -188,6 +189,10 @@ class Context:
     def set_rows(self, on):
         """TFF_OPT_ROWS: True (default) = LinearTFT runs four triplets per wavefront (one per row of 16 lanes); False = one per wavefront."""
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_ROWS, int(bool(on))), "set_option")
+
+    def set_debug_fp_handover(self, on):
+        """TFF_OPT_DEBUG_FP_HANDOVER (test hook): FaugPapa's block kernel hands every third triplet back to the generic workgroup kernel."""
+        _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_DEBUG_FP_HANDOVER, int(bool(on))), "set_option")
 
     def set_gh_exact(self, on):
         """Gauss-Helmert methods: True = pinv(W) always through per-block eigen-decompositions (A/B; slower)."""

@@ -756,7 +756,8 @@ __global__ void __launch_bounds__(GH_WG_THREADS, FP_WG_PER_CU) k_fp_block(const 
         int gst = ST_OK;
         const int iters = gauss_helmert_fp<SP>(s, own, pts, N, xi, pp, &gst, a.dbg ? a.dbg + b * DBG_STRIDE : nullptr);
         phase_stamp((a.dbg && wave == own) ? a.dbg + b * DBG_STRIDE : nullptr, 35);
-        if (gst == ST_OK && s.flag[2] != 0.0) gst = ST_RETRY;                // an eigenpair of the pseudo-inverse did not converge (never observed)
+        if (gst == ST_OK && s.flag[2] != 0.0) gst = ST_RETRY;                // an eigenpair of the pseudo-inverse did not converge / lost its orthogonality (never observed)
+        if ((a.flags & FLAG_DBG_FP_HANDOVER) && gst == ST_OK && b % 3 == 0) gst = ST_RETRY;   // test hook: exercise the hand-over
         if (wave == own) {
             if (lane < 27) a.topt[b * 27 + lane] = s.p[lane];
             if (lane == 0) {

@@ -16,6 +16,7 @@ constexpr int FLAG_RECONST = 1;       // also produce Reconst (3-view triangulat
 constexpr int FLAG_JACOBI = 2;        // force the Jacobi eigen-solver for the Gram matrices
 constexpr int FLAG_STAGE_LDS = 4;     // correspondences are staged once in LDS (else re-read through L2)
 constexpr int FLAG_ONLY_RETRY = 8;    // fix-up pass: process only triplets whose status is ST_RETRY
+constexpr int FLAG_DBG_FP_HANDOVER = 64; // FaugPapa block kernel, test hook (TFF_OPT_DEBUG_FP_HANDOVER): hand every third triplet back to the generic kernel as if its pseudo-inverse had failed
 constexpr int FLAG_DBG_ADAPTIVE = 32; // rows kernel, debug entry points only: keep the adaptive cheirality votes (the default under debug is all four scores)
 constexpr int FLAG_GH_EXACT = 16;     // Gauss-Helmert: always take the eigen-decomposition path for pinv(W) (A/B against the Cholesky path)
 
