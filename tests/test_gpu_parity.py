@@ -642,7 +642,7 @@ def test_pi_methods_noise_free_and_wrappers(gpu_ctx, method, angle):
         getattr(api, method)(C[0].T[:, :6].copy(), CalM)
 
 
-@pytest.mark.parametrize("method,angle,B", [("PiPoseEstimation", None, 2000), ("PiColPoseEstimation", 180, 300)])
+@pytest.mark.parametrize("method,angle,B", [("PiPoseEstimation", None, 10000), ("PiColPoseEstimation", 180, 10000)])     # BASELINE's batch size
 def test_pi_methods_full_size_statistics(gpu_ctx, method, angle, B):
     """N = 200 batches: every triplet finishes, the iteration counts stay in the oracle's range, and the mean pose
     error is comparable with the linear method's (the refinement imposes the minimal parameterisation; on these scenes
