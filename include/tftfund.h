@@ -79,9 +79,12 @@ typedef struct tff_ctx tff_ctx;
                              * the fused single-wavefront kernel below the measured crossover: N < 80 for Ressl, N < 72 for Nordberg, N < 128 for Pi);
                              * 1 fused kernel always;
                              * 2 workgroup kernels always */
-#define TFF_OPT_ROWS 7      /* LinearTFT / LinearF pose kernels and the linear stage of the iterative TFT methods: 1 (default) four triplets per wavefront,
+#define TFF_OPT_ROWS 7      /* LinearTFT / LinearF pose kernels and the linear stage of the iterative TFT methods: 1 four triplets per wavefront,
                              * one per row of 16 lanes (csrc/tft_rows_kernel.h, f_rows_kernel.h, gh_rows_kernel.h); 0 one triplet per wavefront
-                             * (csrc/tft_kernel.h, f_kernel.h) -- an A/B switch, results agree to rounding */
+                             * (csrc/tft_kernel.h, f_kernel.h); 2 (default) by batch size: the row kernels (2.5x fewer instructions per triplet) once
+                             * the batch no longer fits the device's wavefront slots in one go (B >= 1024, or > 2048 when N > 256), the one-triplet
+                             * kernels (shorter latency) below.  The two routes agree to rounding (1e-14), so a triplet's last bits may depend on
+                             * the size of the batch it arrives in; set 0 or 1 where that matters */
 #define TFF_OPT_DEBUG_FP_HANDOVER 8 /* test hook: 1 = FaugPapa's block kernel hands every third triplet back to the generic workgroup kernel, as it does when its
                              * pseudo-inverse reports a failure (exercises that production fall-back; results must not depend on it beyond the
                              * generic kernel's LAPACK-level noise) */

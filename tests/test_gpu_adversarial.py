@@ -17,12 +17,14 @@ METHODS = ["LinearTFTPoseEstimation", "LinearFPoseEstimation", "OptimFPoseEstima
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("rows", [1, 0])                                        # four triplets per wavefront / one (TFF_OPT_ROWS; the default picks by batch size)
 @pytest.mark.parametrize("N", [7, 8, 9, 12, 64, 200])
-def test_degenerate_inputs_never_return_silent_garbage(N):
+def test_degenerate_inputs_never_return_silent_garbage(N, rows):
     import torch
     from tft_vs_fund_amd import api
     from tft_vs_fund_amd.scenes import generate_scene_batch
     ctx = api.Context(0)
+    ctx.set_rows(rows)
     C, CalM, _, _ = generate_scene_batch(16, N, noise=1.0, seed=N)
     cases = {}
     c = C.copy(); c[0] = 0.0; cases["all zeros"] = c

@@ -28,7 +28,9 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def gpu_ctx():
     from tft_vs_fund_amd import api
-    return api.Context(0)
+    ctx = api.Context(0)
+    ctx.set_rows(1)                                                          # (the linear stage of the large-batch route: tests/conftest.py)
+    return ctx
 
 
 def _dev(T, R2, R3, g, pre, b):

@@ -1,9 +1,10 @@
 """
-The four-triplets-per-wavefront kernels (csrc/tft_rows_kernel.h, f_rows_kernel.h, gh_rows_kernel.h; TFF_OPT_ROWS = 1, the default) on the MI355X
+The four-triplets-per-wavefront kernels (csrc/tft_rows_kernel.h, f_rows_kernel.h, gh_rows_kernel.h; TFF_OPT_ROWS = 1; the default, 2, takes them for
+batches of 1024 triplets and more) on the MI355X
 against the one-triplet-per-wavefront kernels (TFF_OPT_ROWS = 0) and the oracle: same arithmetic per matrix entry and correspondence, sums taken in
 a different order, so the two routes must agree to rounding on every batch shape -- full and ragged last wavefronts, one to many trips
 per data pass, well-posed and outlier-ridden data (adaptive cheirality votes: second sweep), sampled hypotheses (config 4).
-The oracle comparisons of tests/test_gpu_parity.py run through the rows kernel as well, since it is the default route.
+The oracle comparisons of tests/test_gpu_parity.py run through the rows kernels as well (tests/conftest.py forces TFF_OPT_ROWS = 1).
 """
 import numpy as np
 import pytest
@@ -154,3 +155,29 @@ def test_exact_rows_kernel_against_the_one_triplet_exact_kernel(gpu_ctx, method,
     eT = np.abs(r["T"] * sg - w["T"]).reshape(B, -1).max(axis=1)[ok]
     e3 = (np.abs(r["R_t_3"] - w["R_t_3"]).reshape(B, -1).max(axis=1) / np.abs(w["R_t_3"]).reshape(B, -1).max(axis=1).clip(1.0))[ok]
     assert np.quantile(eT, 0.999) < 1e-7 and (e3 > 1e-6).mean() < 3e-3, (np.quantile(eT, 0.999), (e3 > 1e-6).mean())
+
+
+@pytest.mark.parametrize("method", ["LinearTFTPoseEstimation", "LinearFPoseEstimation", "ResslTFTPoseEstimation"])
+def test_default_route_goes_by_batch_size(method):
+    """TFF_OPT_ROWS = 2 (the default of a new context): bit-identical to the one-triplet kernels on a batch that fits the device in one go, to the
+    row kernels on a large one (include/tftfund.h; the crossover is measured: tools/ab_rows_sweep.py)."""
+    import torch
+    from tft_vs_fund_amd import api
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    calm = None
+    for B, N, expect in [(300, 100, 0), (1023, 200, 0), (1024, 200, 1), (2048, 300, 0), (2049, 300, 1), (6000, 100, 1)]:
+        C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=B)
+        d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
+        auto = api.Context(0)
+        forced = api.Context(0)
+        forced.set_rows(expect)
+        other = api.Context(0)
+        other.set_rows(1 - expect)
+        a = auto.pose_batch(method, d, calm, reconst=False)
+        f = forced.pose_batch(method, d, calm, reconst=False)
+        o = other.pose_batch(method, d, calm, reconst=False)
+        for k in ("T", "R_t_2", "R_t_3", "iter", "status"):
+            assert torch.equal(a[k], f[k]), (B, N, k)
+        assert not torch.equal(a["T"], o["T"])                               # (the two routes differ in the last bits, so the check above says which one ran)
+        with pytest.raises(Exception):
+            auto.set_rows(3)

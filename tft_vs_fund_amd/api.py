@@ -187,8 +187,10 @@ class Context:
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_SPILL, int(bool(on))), "set_option")
 
     def set_rows(self, on):
-        """TFF_OPT_ROWS: True (default) = LinearTFT runs four triplets per wavefront (one per row of 16 lanes); False = one per wavefront."""
-        _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_ROWS, int(bool(on))), "set_option")
+        """TFF_OPT_ROWS: "auto" or 2 (default) = by batch size (four triplets per wavefront, one per row of 16 lanes, once the batch no longer fits
+        the device in one go; one per wavefront below); True / 1 = the row kernels always; False / 0 = never."""
+        v = 2 if on == "auto" else (int(on) if isinstance(on, int) and not isinstance(on, bool) else int(bool(on)))
+        _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_ROWS, v), "set_option")
 
     def set_debug_fp_handover(self, on):
         """TFF_OPT_DEBUG_FP_HANDOVER (test hook): FaugPapa's block kernel hands every third triplet back to the generic workgroup kernel."""

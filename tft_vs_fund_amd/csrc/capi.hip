@@ -62,11 +62,20 @@ struct tff_ctx {
     int kernel_variant = 0;                // TFF_OPT_KERNEL
     int gh_exact = 0;                      // TFF_OPT_GH_EXACT
     int spill_only_if_needed = 0;          // TFF_OPT_SPILL
-    int rows = 1;                          // TFF_OPT_ROWS
+    int rows = 2;                          // TFF_OPT_ROWS: 0 never, 1 always, 2 by batch size (rows_for)
     int dbg_fp_handover = 0;               // TFF_OPT_DEBUG_FP_HANDOVER
 };
 
 namespace {
+
+// Four triplets per wavefront or one?  The row kernels issue ~2.5x fewer instructions per triplet, but a wavefront of theirs lives ~1.3x (N = 200)
+// to 1.7x (N = 500) as long as a one-triplet wavefront, and a batch that fits the device's 2048 wavefront slots in one go pays that latency
+// for nothing.  Measured (tools/ab_rows_sweep.py, ms per batch, rows / one-triplet): N = 200: B = 256 0.075 / 0.059, 1024 0.077 / 0.079,
+// 3072 0.085 / 0.125; N = 500: B = 1024 0.125 / 0.103, 2048 0.138 / 0.118, 3072 0.140 / 0.178; LinearF alike.  TFF_OPT_ROWS = 0 / 1 force a route.
+bool rows_for(const tff_ctx* c, int64_t B, int32_t N) {
+    if (c->rows != 2) return c->rows != 0;
+    return B >= (N <= 256 ? 1024 : 2048 + 1);
+}
 
 int base_flags(const tff_ctx* c, bool reconst) {
     return (reconst ? tff::FLAG_RECONST : 0) | (c->gh_exact ? tff::FLAG_GH_EXACT : 0) | (c->dbg_fp_handover ? tff::FLAG_DBG_FP_HANDOVER : 0);
@@ -213,10 +222,11 @@ int launch_pose_rows(tff_ctx* c, KRows krows, KExact kexact, lds_fn exact_lds, i
 // LinearTFTPoseEstimation: one wavefront per triplet (fast tiers) + the exact kernel over what they could not finish.
 int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    if (c && c->rows && c->solver == 0 && N >= c->exact_below)
+    const bool rows = c && rows_for(c, B, N);
+    if (rows && c->solver == 0 && N >= c->exact_below)
         return launch_pose_rows(c, tff::k_linear_tft_pose_rows, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, corresp, calm, calm_stride,
                                 B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
-    if (c && c->rows)     // whole batches for the exact tiers (minimal samples, TFF_OPT_SOLVER = 1): four triplets per wavefront there too (tft_rows_exact_kernel.h)
+    if (rows)             // whole batches for the exact tiers (minimal samples, TFF_OPT_SOLVER = 1): four triplets per wavefront there too (tft_rows_exact_kernel.h)
         return launch_pose_rows(c, tff::k_linear_tft_pose_rows_exact, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, corresp, calm,
                                 calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     return launch_pose(c, tff::k_linear_tft_pose<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, 0, corresp, calm, calm_stride,
@@ -224,7 +234,7 @@ int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int
 }
 int launch_linear_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    if (c && c->rows)                                                         // four triplets per wavefront (f_rows_kernel.h): fast tiers, or -- whole batches for the exact tiers -- the exact ones
+    if (c && rows_for(c, B, N))                                               // four triplets per wavefront (f_rows_kernel.h): fast tiers, or -- whole batches for the exact tiers -- the exact ones
         return (c->solver == 0 && N >= c->exact_below)
             ? launch_pose_rows(c, tff::k_linear_f_pose_rows, tff::k_f_pose<true, 0>, tff::f_pose_lds_bytes, tff::STAGE_MAX_N_F, corresp, calm, calm_stride,
                                B, N, Rt2, Rt3, T, reconst, iter, status, dbg)
@@ -263,7 +273,7 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
         const bool all_exact = c->solver != 0 || N < c->exact_below;
         tff::GhWgArgs m = a;
         size_t lds;
-        if (!all_exact && c->rows && rows_linear) {                          // four triplets per wavefront (gh_rows_kernel.h)
+        if (!all_exact && rows_linear && rows_for(c, B, N)) {                          // four triplets per wavefront (gh_rows_kernel.h)
             hipLaunchKernelGGL(tff::k_gh_linear_rows, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, m);
             TFF_HIP(hipGetLastError());
         } else if (!all_exact) {
@@ -303,7 +313,7 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
         hipLaunchKernelGGL(kblock, dim3(grid), dim3(tff::GH_WG_THREADS), lds, c->stream, m);
         TFF_HIP(hipGetLastError());
     }
-    if (c->rows && rows_linear && N >= 12) {                                 // four triplets per wavefront (gh_rows_kernel.h); minimal samples: the one-triplet kernel's ladder
+    if (rows_linear && N >= 12 && rows_for(c, B, N)) {                                 // four triplets per wavefront (gh_rows_kernel.h); minimal samples: the one-triplet kernel's ladder
         hipLaunchKernelGGL(tff::k_gh_finish_rows, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, a);
         TFF_HIP(hipGetLastError());
     } else {
@@ -491,7 +501,7 @@ int tff_ctx_set_option(tff_ctx* c, int option, long value) {
         case TFF_OPT_STAGE_LDS: if (value < -1 || value > 1) return fail(TFF_E_INVALID, "stage_lds must be -1, 0 or 1"); c->stage = (int)value; return 0;
         case TFF_OPT_GH_EXACT: c->gh_exact = value != 0; return 0;
         case TFF_OPT_SPILL: c->spill_only_if_needed = value != 0; return 0;
-        case TFF_OPT_ROWS: c->rows = value != 0; return 0;
+        case TFF_OPT_ROWS: if (value < 0 || value > 2) return fail(TFF_E_INVALID, "rows must be 0, 1 or 2"); c->rows = (int)value; return 0;
         case TFF_OPT_DEBUG_FP_HANDOVER: c->dbg_fp_handover = value != 0; return 0;
         case TFF_OPT_KERNEL: if (value < 0 || value > 2) return fail(TFF_E_INVALID, "kernel must be 0, 1 or 2"); c->kernel_variant = (int)value; return 0;
         default: return fail(TFF_E_INVALID, "unknown option");
