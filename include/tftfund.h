@@ -88,6 +88,8 @@ typedef struct tff_ctx tff_ctx;
 #define TFF_OPT_DEBUG_FP_HANDOVER 8 /* test hook: 1 = FaugPapa's block kernel hands every third triplet back to the generic workgroup kernel, as it does when its
                              * pseudo-inverse reports a failure (exercises that production fall-back; results must not depend on it beyond the
                              * generic kernel's LAPACK-level noise) */
+#define TFF_OPT_DEBUG_ADAPTIVE 9 /* profiling hook: 1 = the *_debug_dev entry points of the linear methods keep the production vote logic (main candidates only,
+                             * scale sums during the votes) instead of evaluating all four cheirality scores for the debug record */
 #define TFF_DEBUG_STRIDE 128 /* doubles per triplet written by the *_debug_dev entry points */
 
 int tff_version(void);

@@ -539,6 +539,13 @@ def test_rows_kernel_matches_oracle(emu, B, N, sigma):
             assert rel_err_T(out["T"][b], T) < 1e-9
             assert rel_err(out["R_t_2"][b], R2) < 1e-9 and rel_err(out["R_t_3"][b], R3) < 1e-9
             assert rel_err(out["Reconst"][b], Rec) < 1e-9
+    # the t3 scale from the sums taken during the votes (production; debug[95] = 1: the picks are the main candidates) and from the separate
+    # pass (all four scores evaluated, main candidate (R,t) whatever the data say: the pick is the other rotation in about half of the triplets)
+    prod = run_linear_tft(emu, C, CalM, flags=FLAG_DBG_ADAPTIVE, entry="emu_linear_tft_pose_rows", debug=True)
+    assert np.all(prod["debug"][:, 95] == 1.0)
+    assert np.abs(prod["debug"][:, 68] / out["debug"][:, 68] - 1.0).max() < 1e-12
+    if B >= 5:
+        assert set(out["debug"][:, 95].tolist()) == {0.0, 1.0}
     wave = run_linear_tft(emu, C, CalM)
     # the four cheirality scores of both essential matrices, up to the candidate order (the signs svd(E) gives U(:,3), V(:,3) permute the list)
     so, sw = out["debug"][:, 60:68].reshape(B, 2, 4), wave["debug"][:, 60:68].reshape(B, 2, 4)

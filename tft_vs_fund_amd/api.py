@@ -37,6 +37,7 @@ TFF_OPT_EXACT_BELOW = 5
 TFF_OPT_SPILL = 6
 TFF_OPT_ROWS = 7
 TFF_OPT_DEBUG_FP_HANDOVER = 8
+TFF_OPT_DEBUG_ADAPTIVE = 9
 DEBUG_STRIDE = 128
 
 ST_OK, ST_TOO_FEW, ST_NONFINITE, ST_NO_POSE, ST_RANK, ST_NO_PARAM = 0, 1, 2, 3, 4, 5
@@ -191,6 +192,10 @@ class Context:
         the device in one go; one per wavefront below); True / 1 = the row kernels always; False / 0 = never."""
         v = 2 if on == "auto" else (int(on) if isinstance(on, int) and not isinstance(on, bool) else int(bool(on)))
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_ROWS, v), "set_option")
+
+    def set_debug_adaptive(self, on):
+        """TFF_OPT_DEBUG_ADAPTIVE (profiling hook): debug entry points keep the production cheirality-vote logic."""
+        _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_DEBUG_ADAPTIVE, int(bool(on))), "set_option")
 
     def set_debug_fp_handover(self, on):
         """TFF_OPT_DEBUG_FP_HANDOVER (test hook): FaugPapa's block kernel hands every third triplet back to the generic workgroup kernel."""

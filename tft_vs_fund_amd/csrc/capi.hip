@@ -64,6 +64,7 @@ struct tff_ctx {
     int spill_only_if_needed = 0;          // TFF_OPT_SPILL
     int rows = 2;                          // TFF_OPT_ROWS: 0 never, 1 always, 2 by batch size (rows_for)
     int dbg_fp_handover = 0;               // TFF_OPT_DEBUG_FP_HANDOVER
+    int dbg_adaptive = 0;                  // TFF_OPT_DEBUG_ADAPTIVE
 };
 
 namespace {
@@ -78,7 +79,8 @@ bool rows_for(const tff_ctx* c, int64_t B, int32_t N) {
 }
 
 int base_flags(const tff_ctx* c, bool reconst) {
-    return (reconst ? tff::FLAG_RECONST : 0) | (c->gh_exact ? tff::FLAG_GH_EXACT : 0) | (c->dbg_fp_handover ? tff::FLAG_DBG_FP_HANDOVER : 0);
+    return (reconst ? tff::FLAG_RECONST : 0) | (c->gh_exact ? tff::FLAG_GH_EXACT : 0) | (c->dbg_fp_handover ? tff::FLAG_DBG_FP_HANDOVER : 0) |
+           (c->dbg_adaptive ? tff::FLAG_DBG_ADAPTIVE : 0);
 }
 int staged_flags(const tff_ctx* c, int N, int flags, bool jacobi, int max_n = tff::STAGE_MAX_N_TFT) {
     if (c->stage < 0) return tff::pose_auto_flags(N, flags, jacobi, max_n);
@@ -503,6 +505,7 @@ int tff_ctx_set_option(tff_ctx* c, int option, long value) {
         case TFF_OPT_SPILL: c->spill_only_if_needed = value != 0; return 0;
         case TFF_OPT_ROWS: if (value < 0 || value > 2) return fail(TFF_E_INVALID, "rows must be 0, 1 or 2"); c->rows = (int)value; return 0;
         case TFF_OPT_DEBUG_FP_HANDOVER: c->dbg_fp_handover = value != 0; return 0;
+        case TFF_OPT_DEBUG_ADAPTIVE: c->dbg_adaptive = value != 0; return 0;
         case TFF_OPT_KERNEL: if (value < 0 || value > 2) return fail(TFF_E_INVALID, "kernel must be 0, 1 or 2"); c->kernel_variant = (int)value; return 0;
         default: return fail(TFF_E_INVALID, "unknown option");
     }

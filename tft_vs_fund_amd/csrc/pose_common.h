@@ -571,7 +571,12 @@ __device__ __attribute__((noinline)) int tri_vote_fast(PoseLds* w, const double*
 // instructions of the second candidate.  Same arithmetic per candidate as tri_vote_fast.  Returns tri_vote_fast's value for candidate 0 in
 // the low and for candidate 1 in the high 16 bits (|score| <= 2 N <= 2^14 is the caller's business: it falls back to two single passes beyond).
 struct VoteCam { double PB[12], R3[4]; };
-__device__ __forceinline__ void vote_one(const double (&SA)[6], const VoteCam& cam, const double x2, const double y2, int& score, bool& all_certain) {
+// what vote_one knows about the 4 x 4 system when it is done: the Cholesky factor of S + delta I short of its last pivot (d4, unfloored) and the
+// inhomogeneous point z -- exactly the state of spd_min_eigvec<4> before its first iteration (dlt_from_vote goes on from there)
+struct VoteFactor { double L[4][3], inv[3], d4, z[3], pfloor; };
+template <bool KEEP = false>
+__device__ __forceinline__ void vote_one(const double (&SA)[6], const VoteCam& cam, const double x2, const double y2, int& score, bool& all_certain,
+                                         VoteFactor* keep = nullptr) {
     double b0[4], b1[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) { b0[c] = y2 * cam.PB[8 + c] - cam.PB[4 + c]; b1[c] = cam.PB[c] - x2 * cam.PB[8 + c]; }
@@ -624,6 +629,34 @@ __device__ __forceinline__ void vote_one(const double (&SA)[6], const VoteCam& c
     const bool certain = Gp > 0.0 && dmin2 * Gp * Gp > rhs * rhs * zz;      // false for NaN / inf
     all_certain = all_certain && certain;
     score += (int)sgn(d1) + (int)sgn(d2);
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) keep->L[r][c] = (c < r) ? L[r][c] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { keep->inv[c] = inv[c]; keep->z[c] = z[c]; }
+        keep->d4 = d4;
+        keep->pfloor = pfloor;
+    }
+}
+// The homogeneous two-view DLT point (triangulation3D.m:61-62) of the system vote_one has just factored: what dlt_point's fast tier
+// (spd_min_eigvec<4>) computes from scratch -- same factor, same start, same loop.  Returns false when the iteration hit its cap.
+__device__ __forceinline__ bool dlt_from_vote(const VoteFactor& f, double (&X)[4]) {
+    double L[4][4], inv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) L[r][c] = (c < r) ? f.L[r][c] : 0.0;    // (the loop reads the strict lower triangle and inv[])
+    inv[0] = f.inv[0]; inv[1] = f.inv[1]; inv[2] = f.inv[2];
+    inv[3] = rsqrt_pos(fmax(f.d4, f.pfloor));
+    const double nn0 = 1.0 + (f.z[0] * f.z[0] + f.z[1] * f.z[1] + f.z[2] * f.z[2]);
+    const double r0 = rsqrt(nn0);
+    const bool fin = nn0 <= 1e300;
+    X[0] = fin ? f.z[0] * r0 : 0.5; X[1] = fin ? f.z[1] * r0 : 0.5; X[2] = fin ? f.z[2] * r0 : 0.5; X[3] = fin ? r0 : 0.5;
+    bool conv;
+    chol_invit<4>(L, inv, X, 40, &conv);
+    return conv;
 }
 // CAM1_IN_REGISTERS: the second camera in vector registers (194 registers: for kernels that run two wavefronts per SIMD anyway) or re-read from
 // LDS per trip (132: for the fundamental-matrix kernels, three wavefronts per SIMD at <= 168; 1 % slower inside the trifocal kernel).

@@ -68,6 +68,50 @@ __device__ __forceinline__ double det4(const double (&m)[4][4]) {
     return s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
 }
 
+// Inverse iteration x <- (L L')^-1 x, normalised, from the unit start x, until the iterate stops moving (the loop of spd_min_eigvec, for
+// callers that hold the Cholesky factor already: pose_common.h::vote_one's).  inv[i] = 1 / L[i][i].  Returns the iterations used.
+template <int n>
+__device__ __forceinline__ int chol_invit(const double (&L)[n][n], const double (&inv)[n], double (&x)[n], const int maxit, bool* converged) {
+    bool conv = false;
+    double rprev2 = 1.0;
+    int it = 0;
+#pragma clang loop unroll(disable)
+    for (; it < maxit;) {
+        double y[n];
+        // forward L y = x
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double s = x[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+            y[i] = s * inv[i];
+        }
+        // backward L' z = y (in place)
+#pragma unroll
+        for (int i = n - 1; i >= 0; --i) {
+            double s = y[i];
+#pragma unroll
+            for (int k = i + 1; k < n; ++k) s -= L[k][i] * y[k];
+            y[i] = s * inv[i];
+        }
+        double nn = 0.0, dot = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) { nn += y[i] * y[i]; dot += y[i] * x[i]; }
+        const double rn = rsqrt(nn);
+        const double sg = (dot < 0.0) ? -rn : rn;
+        double r2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) { const double yi = y[i] * sg; const double d = yi - x[i]; r2 += d * d; x[i] = yi; }
+        ++it;
+        // r2 = |step|^2.  Error of the new iterate ~ rho*|step|/(1-rho), rho ~ |step|/|previous step|.
+        if (!(r2 > 1e-28)) { conv = (r2 == r2); break; }                 // also leaves on NaN
+        if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) { conv = true; break; }
+        rprev2 = r2;
+    }
+    if (converged) *converged = conv;
+    return it;
+}
+
 // --------------------------------------------------------------------------
 // Eigenvector of the smallest eigenvalue of a symmetric positive
 // semi-definite n x n matrix S (n = 3, 4): Cholesky of S + delta*I followed by
@@ -82,7 +126,6 @@ __device__ __forceinline__ double det4(const double (&m)[4][4]) {
 // smallest eigenvalues) -- the callers with an exact fall-back (hestenes_min_rsv on the matrix itself) test it.
 template <int n>
 __device__ __forceinline__ int spd_min_eigvec(const double (&S)[n][n], double (&x)[n], int maxit = 40, bool* converged = nullptr) {
-    bool conv = false;
     double tr = 0.0;
 #pragma unroll
     for (int i = 0; i < n; ++i) tr += S[i][i];
@@ -131,43 +174,7 @@ __device__ __forceinline__ int spd_min_eigvec(const double (&S)[n][n], double (&
         for (int i = 0; i < n - 1; ++i) x[i] = fin ? z[i] * r0 : xu;
         x[n - 1] = fin ? r0 : xu;
     }
-    double rprev2 = 1.0;
-    int it = 0;
-#pragma clang loop unroll(disable)
-    for (; it < maxit;) {
-        double y[n];
-        // forward L y = x
-#pragma unroll
-        for (int i = 0; i < n; ++i) {
-            double s = x[i];
-#pragma unroll
-            for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
-            y[i] = s * inv[i];
-        }
-        // backward L' z = y (in place)
-#pragma unroll
-        for (int i = n - 1; i >= 0; --i) {
-            double s = y[i];
-#pragma unroll
-            for (int k = i + 1; k < n; ++k) s -= L[k][i] * y[k];
-            y[i] = s * inv[i];
-        }
-        double nn = 0.0, dot = 0.0;
-#pragma unroll
-        for (int i = 0; i < n; ++i) { nn += y[i] * y[i]; dot += y[i] * x[i]; }
-        const double rn = rsqrt(nn);
-        const double sg = (dot < 0.0) ? -rn : rn;
-        double r2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < n; ++i) { const double yi = y[i] * sg; const double d = yi - x[i]; r2 += d * d; x[i] = yi; }
-        ++it;
-        // r2 = |step|^2.  Error of the new iterate ~ rho*|step|/(1-rho), rho ~ |step|/|previous step|.
-        if (!(r2 > 1e-28)) { conv = (r2 == r2); break; }                 // also leaves on NaN
-        if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) { conv = true; break; }
-        rprev2 = r2;
-    }
-    if (converged) *converged = conv;
-    return it;
+    return chol_invit<n>(L, inv, x, maxit, converged);
 }
 
 // --------------------------------------------------------------------------

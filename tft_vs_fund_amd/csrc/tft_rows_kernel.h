@@ -118,11 +118,9 @@ __device__ __forceinline__ void rows_distances_moments(const RowSrc& s, const in
 #pragma unroll
     for (int k = 0; k < 48; ++k) acc[k] = 0.0;
     double dA = 0.0, dB = 0.0;
-    Pt6 pnext = rows_load(s, (slot < N) ? slot : 0);
-#pragma unroll 1
-    for (int i = slot; i < N; i += ROWL / 2) {
-        const Pt6 q = pnext;
-        if (i + ROWL / 2 < N) pnext = rows_load(s, i + ROWL / 2);
+    // (the loads of trips t + 1 and t + 2 are in flight while trip t is consumed: a trip issues ~80 fp64 instructions, an L2 / MALL round trip
+    // lasts five times that, and the other wavefront of the SIMD is in the same pass more often than not)
+    auto body = [&](const Pt6& q) {
         const double x1 = q.v[0] - c[0], y1 = q.v[1] - c[1];
         const double x2 = q.v[2] - c[2], y2 = q.v[3] - c[3];
         const double x3 = q.v[4] - c[4], y3 = q.v[5] - c[5];
@@ -141,6 +139,20 @@ __device__ __forceinline__ void rows_distances_moments(const RowSrc& s, const in
                 acc[16 + 4 * b + cc] += pb * wv;
                 acc[32 + 4 * b + cc] += pc * wv;
             }
+    };
+    constexpr int STEP = ROWL / 2;
+    Pt6 pe = rows_load(s, (slot < N) ? slot : 0);
+    Pt6 po = rows_load(s, (slot + STEP < N) ? slot + STEP : 0);
+#pragma unroll 1
+    for (int i = slot; i < N; i += 2 * STEP) {
+        const Pt6 q = pe;
+        if (i + 2 * STEP < N) pe = rows_load(s, i + 2 * STEP);
+        body(q);
+        if (i + STEP < N) {
+            const Pt6 r = po;
+            if (i + 3 * STEP < N) po = rows_load(s, i + 3 * STEP);
+            body(r);
+        }
     }
     // mean distances -> scales and offsets (every lane of the row)
     const double d1 = row_sum16(odd ? 0.0 : dA), d3 = row_sum16(odd ? dA : 0.0), d2 = 0.5 * row_sum16(dB);
@@ -532,8 +544,15 @@ __device__ __forceinline__ void rows_recover_prepare(RowLds* w, RowRt* rt) {
 // broadcast reads that cost no VALU slot).
 // Returns false (per row) when a needed vote could not be certified.  sc[call][0] = sR, sc[call][1] = sRp; a score that was not needed is
 // reported as 0 (it is below 2 N in magnitude and its partner is +-2 N: same pick).
+// The sums of the t3 scale (R_t_from_TFT.m:68-74) ride along (RowScale, SPEC): they need the two-view point of (P1, P2) for the CHOSEN second
+// camera and the chosen third camera, neither known before the votes are in -- but the main candidates are the choice on every triplet whose votes
+// are unanimous, the point is the null vector of the very system vote_one has just factored (dlt_from_vote: no second build, no second
+// factorisation), and a candidate's sign variant (R, -t) mirrors everything exactly: X -> diag(1,1,1,-1) X, so num -> s2 s3 num, den -> den.
+// rows_pose_tail takes the speculative sums when the picks' rotations are the main candidates' and makes the separate pass otherwise.
+struct RowScale { double num, den; bool conv; bool main1[2]; };
+template <bool SPEC = false>
 __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const RowRt* rt, const bool all4, int (&sc)[2][2], int* sweeps_out = nullptr,
-                                           bool* cert_out = nullptr) {
+                                           bool* cert_out = nullptr, RowScale* scale = nullptr) {
     const int p = rows_p();
     double PA[12];
 #pragma unroll
@@ -545,6 +564,8 @@ __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const R
     bool evalA = true, evalB[2] = {true, true};                              // wave-uniform: what the running sweep evaluates
     bool fullB[2] = {true, true};                                            // wave-uniform: B covers every trip
     int sweeps = 0;
+    double snum = 0.0, sden = 0.0;
+    bool sconv = true;
 #pragma unroll 1
     for (int sweep = 0; sweep < 2; ++sweep) {
         ++sweeps;
@@ -563,9 +584,12 @@ __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const R
             for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
                 for (int c = 0; c <= rr; ++c) SA[rr * (rr + 1) / 2 + c] = a0[rr] * a0[c] + a1[rr] * a1[c];
+            const bool first = sweep == 0 && i0 == 0;
 #pragma unroll
-            for (int call = 0; call < 2; ++call) {
+            for (int cc = 0; cc < 2; ++cc) {
+                const int call = 1 - cc;                                     // view 3 first: the scale sums of view 2's main candidate need view 3's
                 const double x2 = (call == 0) ? q.v[2] : q.v[4], y2 = (call == 0) ? q.v[3] : q.v[5];
+                VoteFactor fA, fB;
                 if (evalA) {
                     VoteCam cam;
                     const int off = opaque_lane_int(offA[call]);
@@ -577,7 +601,8 @@ __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const R
                     for (int c = 0; c < 4; ++c) cam.R3[c] = pr[8 + c];
                     int term = 0;
                     bool cert = true;
-                    vote_one(SA, cam, x2, y2, term, cert);
+                    if (SPEC && call == 0) vote_one<true>(SA, cam, x2, y2, term, cert, &fA);
+                    else vote_one(SA, cam, x2, y2, term, cert);
                     scA[call] += have ? term : 0;
                     certA[call] = certA[call] && (cert || !have);
                 }
@@ -592,28 +617,44 @@ __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const R
                     for (int c = 0; c < 4; ++c) cam.R3[c] = pr[8 + c];
                     int term = 0;
                     bool cert = true;
-                    vote_one(SA, cam, x2, y2, term, cert);
+                    if (SPEC && call == 0 && first) vote_one<true>(SA, cam, x2, y2, term, cert, &fB);
+                    else vote_one(SA, cam, x2, y2, term, cert);
                     scB[call] += have ? term : 0;
                     certB[call] = certB[call] && (cert || !have);
                 }
-            }
-            if (sweep == 0 && i0 == 0) {                                     // after the first trip: which candidates are already out of the race?
-#pragma unroll
-                for (int call = 0; call < 2; ++call) {
+                if (first) {                                                 // after the first trip: which candidates are already out of the race?
                     // the accumulators hold the vote of this lane's first correspondence
                     // (every ballot is taken by the whole wavefront: no short-circuit between them)
-                    const bool a0 = row_any(have && certA[call] && scA[call] != 2), a1 = row_any(have && certA[call] && scA[call] != -2);
+                    const bool v0 = row_any(have && certA[call] && scA[call] != 2), v1 = row_any(have && certA[call] && scA[call] != -2);
                     const bool b0 = row_any(have && certB[call] && scB[call] != 2), b1 = row_any(have && certB[call] && scB[call] != -2);
-                    const bool mixA = a0 && a1, mixB = b0 && b1;
+                    const bool mixA = v0 && v1, mixB = b0 && b1;
                     const bool single = !all4 && (mixA != mixB);
                     main1[call] = single && mixA;                            // (R,t) is out: (Rp,t) is the row's main candidate
                     if (main1[call]) {
                         const int ts = scA[call]; scA[call] = scB[call]; scB[call] = ts;
                         const bool tc = certA[call]; certA[call] = certB[call]; certB[call] = tc;
                         offA[call] = 12 + 24 * call; offB[call] = 24 * call;
+                        if (SPEC && call == 0) fA = fB;
                     }
                     evalB[call] = wave_any(!single);                         // some row of the wavefront needs both candidates of this pair
                     fullB[call] = evalB[call];
+                }
+                if (SPEC && call == 0 && evalA) {                            // scale sums with the main candidates (R_t_from_TFT.m:70-73)
+                    double X[4];
+                    const bool conv = dlt_from_vote(fA, X);
+                    sconv = sconv && (conv || !have);
+                    const double iw = 1.0 / X[3];
+                    const double X0 = X[0] * iw, X1 = X[1] * iw, X2 = X[2] * iw;
+                    const double* ax = rt->P[0] + opaque_lane_int(offA[1]);  // K3 [R3 | t3] of view 3's main candidate
+                    double X3[3], u3[3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) { X3[r] = ax[4 * r] * X0 + ax[4 * r + 1] * X1 + ax[4 * r + 2] * X2; u3[r] = ax[4 * r + 3]; }
+                    const double p3[3] = {q.v[4], q.v[5], 1.0};
+                    double c1[3], c2[3];
+                    cross3(p3, X3, c1);
+                    cross3(p3, u3, c2);
+                    snum += have ? c1[0] * c2[0] + c1[1] * c2[1] + c1[2] * c2[2] : 0.0;
+                    sden += have ? c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2] : 0.0;
                 }
             }
         }
@@ -644,6 +685,13 @@ __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const R
         }
         sc[call][0] = main1[call] ? tB : tA;
         sc[call][1] = main1[call] ? tA : tB;
+    }
+    if constexpr (SPEC) {
+        scale->num = row_sum16(snum);
+        scale->den = row_sum16(sden);
+        scale->conv = !row_any(!sconv);
+        scale->main1[0] = main1[0];
+        scale->main1[1] = main1[1];
     }
     if (sweeps_out) *sweeps_out = sweeps + (fullB[0] ? 16 : 0) + (fullB[1] ? 32 : 0);   // (debug: sweeps made, which pairs were evaluated in full)
     return ok;
@@ -778,6 +826,10 @@ __device__ __forceinline__ int rows_pose_tail(const LinearTftArgs& a, RowLds* w,
     double* dbg = j.dbg;
     const long b = j.b;
     int status = ST_OK;
+    RowScale spec;
+    spec.num = 0.0; spec.den = 1.0; spec.conv = true; spec.main1[0] = spec.main1[1] = false;
+    bool spec_valid = !EXACT;                                                // per row: the picks' rotations are the ones the scale sums were taken with
+    double spec_sign = 1.0;
     {                                                                        // recover_R_t, see pose_common.h::recover_vote
         int sc[2][2];
         int sweeps = 0;
@@ -792,7 +844,7 @@ __device__ __forceinline__ int rows_pose_tail(const LinearTftArgs& a, RowLds* w,
                 if (need) { if (k == 0) sc[0][0] = ex; else if (k == 1) sc[0][1] = ex; else if (k == 2) sc[1][0] = ex; else sc[1][1] = ex; }
             }
         } else {
-            ok = rows_votes(j.src, N, rt, dbg != nullptr && !(a.flags & FLAG_DBG_ADAPTIVE), sc, &sweeps) && ok;   // an uncertified sign: the exact kernel's business
+            ok = rows_votes<true>(j.src, N, rt, dbg != nullptr && !(a.flags & FLAG_DBG_ADAPTIVE), sc, &sweeps, nullptr, &spec) && ok;   // an uncertified sign: the exact kernel's business
         }
         if (dbg && p == 0) dbg[94] = (double)sweeps;
 #pragma unroll
@@ -811,6 +863,8 @@ __device__ __forceinline__ int rows_pose_tail(const LinearTftArgs& a, RowLds* w,
                 const double tsign = (pick == 1 || pick == 2) ? -1.0 : 1.0;
                 rt->Rt[call][p] = (c < 3) ? R[3 * r + c] : tsign * rt->cand[call][18 + r];
             }
+            spec_valid = spec_valid && pick >= 0 && ((pick >= 2) == spec.main1[call]);
+            spec_sign = (pick == 1 || pick == 2) ? -spec_sign : spec_sign;
         }
         wave_sync();
     }
@@ -818,8 +872,16 @@ __device__ __forceinline__ int rows_pose_tail(const LinearTftArgs& a, RowLds* w,
     {                                                                        // t3 scale, R_t_from_TFT.m:68-74
         if (p < 2) compose_camera_from_pose(load_K(w->calm, p + 1), rt->Rt[p], rt->Pfin[p + 1]);   // Pfin[1] = K2 [R2|t2]; Pfin[2] = [K3*R3 | K3*t3]
         wave_sync();
-        double num, den;
-        const bool conv = rows_tri_pass<TRI_SCALE, EXACT>(j.src, N, rt->Pfin[0], rt->Pfin[1], rt->Pfin[2], nullptr, num, den);
+        // the sums taken during the votes (rows_votes) when they were taken with the chosen rotations, the separate pass otherwise
+        // (wave-uniform branch; a row keeps its own speculative values, so its result does not depend on its neighbours)
+        double num = spec_sign * spec.num, den = spec.den;
+        bool conv = spec.conv;
+        if (dbg && p == 0) dbg[95] = spec_valid ? 1.0 : 0.0;
+        if (wave_any(!spec_valid)) {
+            double n2, d2;
+            const bool c2 = rows_tri_pass<TRI_SCALE, EXACT>(j.src, N, rt->Pfin[0], rt->Pfin[1], rt->Pfin[2], nullptr, n2, d2);
+            if (!spec_valid) { num = n2; den = d2; conv = c2; }
+        }
         ok = ok && conv;
         const double lam = -num / den;                                       // :72-73
         if (dbg && p == 0) dbg[68] = lam;

@@ -7,8 +7,11 @@ from tft_vs_fund_amd.scenes import generate_scene_batch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 names = ["stage+calm->normalise", "moments", "gram27", "eig27", "epipoles", "Gp build", "eig15+t", "P/misc",
-         "transform x2+epi2+E", "svd3+cands", "votes(4 tri/pt)", "t3 scale(1 tri/pt)", "reconst/finish"]
+         "transform x2+epi2+E", "svd3+cands", "votes (+ scale sums)", "t3 scale pass", "reconst/finish"]
 ctx = api.Context(0)
+ctx.set_rows(1)
+if os.environ.get("TFF_ADAPTIVE", "1") != "0":
+    ctx.set_debug_adaptive(True)           # production vote logic (TFF_ADAPTIVE=0: all four candidates, what the debug record otherwise holds)
 C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=1)
 d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
 for rec in (False, True):
