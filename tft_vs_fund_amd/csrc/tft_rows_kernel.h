@@ -78,8 +78,9 @@ __device__ __forceinline__ void rows_stamp(double* dbg, const int slot) {
 
 // ---- the data passes ------------------------------------------------------------------------------------------------------
 // The correspondences cannot be staged (4 x 48 N bytes per wavefront), so every pass over them is a pass over L2 / MALL, and with the
-// lane-sparse middle four times cheaper those passes are what the kernel waits for.  There are four of them (the one-triplet kernel makes
-// eight over its LDS copy): centroids | mean distances + all 96 moment sums | cheirality votes of both essential matrices | t3 scale.
+// lane-sparse middle four times cheaper those passes are what the kernel waits for.  There are three of them (the one-triplet kernel makes
+// eight over its LDS copy): centroids | mean distances + all 96 moment sums | cheirality votes of both essential matrices, with the t3-scale
+// sums of the main candidates riding along (a separate t3-scale pass only for a row whose pick is not a main candidate).
 
 // Pass 1, Normalize2Ddata.m:33: points0 = mean(points,2) for the three views; every lane of the row ends with c[0..5].
 // Nothing but loads and six additions per correspondence: four trips' loads are issued before the first is consumed.

@@ -13,8 +13,8 @@ pmc = {
     "_comment": "k_linear_tft_pose_rows per launch (B=%d, N=%d), rocprofv3 --kernel-trace --stats and separate --pmc passes of `python3 bench.py --no-cpu-baseline "
                 "--no-secondary --steps 20 --warmup 3` (profiles/r4_headline_summary.json, tools/gpu_profile_r4.sh; r4_headline1_*: the same with --streams 1). "
                 "FETCH_SIZE is in KiB and, for 16-B-per-lane streaming loads on gfx950, reports half the bytes (MI355X_MICROARCH.md, HBM section): "
-                "read = FETCH_SIZE KiB * 1024 * 2; write = WRITE_SIZE KiB * 1024.  The kernel makes four passes over the correspondences (they are not "
-                "staged in LDS): the bytes counted at the L2 boundary are ~3.5x the algorithmic ones, most of them MALL hits (the 96 MB batch fits the "
+                "read = FETCH_SIZE KiB * 1024 * 2; write = WRITE_SIZE KiB * 1024.  The kernel makes three passes over the correspondences (they are not "
+                "staged in LDS): the bytes counted at the L2 boundary are ~2.7x the algorithmic ones, most of them MALL hits (the 96 MB batch fits the "
                 "256 MB infinity cache)." % (B, N),
     "kernel": "k_linear_tft_pose_rows",
     "fetch_size_kib": c["FETCH_SIZE"], "write_size_kib": c["WRITE_SIZE"],

@@ -7,6 +7,8 @@ import numpy as np
 from tft_vs_fund_amd import api
 from tft_vs_fund_amd.scenes import generate_scene_batch
 fast, exact = api.Context(0), api.Context(0, solver="jacobi")
+fast.set_rows(1)                         # the row kernels whatever the batch size (the default goes by batch size)
+exact.set_rows(0)                        # the one-triplet exact kernel for all
 B = int(os.environ.get("SOAK_B", "400"))
 def dev(a, b):
     T = np.minimum(np.abs(a["T"] - b["T"]).reshape(B, -1).max(axis=1), np.abs(a["T"] + b["T"]).reshape(B, -1).max(axis=1)) / np.abs(b["T"]).reshape(B, -1).max(axis=1)

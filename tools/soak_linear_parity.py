@@ -10,6 +10,7 @@ from tft_vs_fund_amd import api
 from tft_vs_fund_amd.scenes import generate_scene_batch
 from helpers import pose_err, pose_err_any_convention
 ctx = api.Context(0, solver=os.environ.get("SOAK_SOLVER", "invit"))
+ctx.set_rows(int(os.environ.get("TFF_ROWS", "1")))   # the soak batches are small: force the four-triplets-per-wavefront kernels (the default goes by batch size); 0: one-triplet kernels
 if "SOAK_EXACT_BELOW" in os.environ:
     ctx.set_exact_below(int(os.environ["SOAK_EXACT_BELOW"]))
 worst = {}
