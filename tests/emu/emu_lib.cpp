@@ -144,6 +144,27 @@ extern "C" int emu_linear_f_pose(const double* corresp, const double* calm, long
     return emu_pose(tff::k_f_pose<false, 0>, tff::k_f_pose<true, 0>, tff::f_pose_lds_bytes, true, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T,
                     reconst, iter, status, dbg);
 }
+// OptimFPoseEstimation as the library runs large batches (capi.hip::launch_optim_f): linear stage and pose tail four triplets per wavefront,
+// Gauss-Helmert refinement one wavefront per triplet, exact kernel over what they handed on
+extern "C" int emu_optim_f_pose_staged(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+                                       double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
+    (void)dbg;
+    std::vector<double> rec((size_t)B * tff::OPTIMF_REC_DOUBLES, 0.0);
+    tff::OptimFStageArgs sa{};
+    sa.la = tff::LinearTftArgs{corresp, calm, calm_stride, B, N, flags & ~tff::FLAG_JACOBI, Rt2, Rt3, T, reconst, iter, status, nullptr, nullptr, nullptr, nullptr};
+    if (reconst) sa.la.flags |= tff::FLAG_RECONST;
+    sa.rec = rec.data();
+    emu::launch(tff::k_optimf_linear_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), sa);
+    emu::launch(tff::k_optimf_refine<tff::OPTIMF_REFINE_WAVES>, emu_grid(B), 64, tff::optimf_refine_lds_bytes(N), sa);
+    emu::launch(tff::k_optimf_finish_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), sa);
+    bool any = false;
+    for (long b = 0; b < B; ++b) any = any || status[b] == tff::ST_RETRY;
+    if (!any) return 0;
+    tff::LinearTftArgs a = sa.la;
+    a.flags |= tff::FLAG_ONLY_RETRY;
+    emu::launch(tff::k_f_pose<true, 1>, emu_grid(B), 64, tff::optimf_lds_bytes(N, a.flags, true), a);
+    return 1;
+}
 extern "C" int emu_optim_f_pose(const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
                                 double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
     return emu_pose(tff::k_f_pose<false, 1>, tff::k_f_pose<true, 1>, tff::optimf_lds_bytes, false, corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T,

@@ -98,14 +98,19 @@ def test_linear_f_needs_8_points(emu):
     assert out["status"][0] == 1 and np.all(np.isnan(out["T"][0]))
 
 
-def test_optim_f_kernel_matches_golden(emu, golden_dir):
+@pytest.mark.parametrize("entry", ["emu_optim_f_pose", "emu_optim_f_pose_staged"])
+def test_optim_f_kernel_matches_golden(emu, golden_dir, entry):
     """OptimFPoseEstimation kernel (linearF start + per-pair Gauss-Helmert with scalar weight blocks): the
-    epipolar model is well conditioned, so iteration counts and results match the dense oracle to rounding."""
+    epipolar model is well conditioned, so iteration counts and results match the dense oracle to rounding.
+    emu_optim_f_pose: the fused one-triplet kernel (small batches); emu_optim_f_pose_staged: the three stages of csrc/optimf_rows_kernel.h
+    (linear stage and pose tail four triplets per wavefront, the refinement with all 54 sums of an iteration in one sweep)."""
     import os
     g = np.load(os.path.join(golden_dir, "optimf.npz"))
     for pre, flags, nb in (("c0_", 0, 2), ("c3_", 0, 1), ("c1_", FLAG_JACOBI, 1)):
+        if flags and entry.endswith("staged"):
+            continue
         C, CalM = g[pre + "Corresp"][:nb], g[pre + "CalM"]
-        out = run_linear_tft(emu, C, CalM, flags, entry="emu_optim_f_pose")
+        out = run_linear_tft(emu, C, CalM, flags, entry=entry)
         assert np.all(out["status"] == 0)
         for b in range(nb):
             assert int(out["iter"][b]) == int(g[pre + "optimf_iter"][b])
@@ -113,12 +118,28 @@ def test_optim_f_kernel_matches_golden(emu, golden_dir):
             assert rel_err(out["R_t_2"][b], g[pre + "optimf_Rt2"][b]) < 1e-8 and rel_err(out["R_t_3"][b], g[pre + "optimf_Rt3"][b]) < 1e-8
             assert rel_err(out["Reconst"][b], g[pre + "optimf_Rec"][b]) < 1e-8
     e = np.load(os.path.join(golden_dir, "epfl.npz"))
-    out = run_linear_tft(emu, np.ascontiguousarray(e["t3_sample"].T)[None], e["t3_CalM"], entry="emu_optim_f_pose")
+    out = run_linear_tft(emu, np.ascontiguousarray(e["t3_sample"].T)[None], e["t3_CalM"], entry=entry)
     assert out["status"][0] == 0 and int(out["iter"][0]) == int(g["t3_optimf_iter"])
     assert rel_err_T(out["T"][0], g["t3_optimf_T"]) < 1e-8 and rel_err(out["R_t_3"][0], g["t3_optimf_Rt3"]) < 1e-8
     C, CalM, _, _ = generate_scene_batch(1, 7, noise=1.0, seed=1)
-    out = run_linear_tft(emu, C, CalM, entry="emu_optim_f_pose")
+    out = run_linear_tft(emu, C, CalM, entry=entry)
     assert out["status"][0] == 1 and np.all(np.isnan(out["T"][0]))          # optimF.m:36-38
+
+
+def test_optim_f_staged_matches_fused_and_oracle(emu):
+    """Seven triplets (a ragged last wavefront in the two row-layout stages), N = 40: the staged route against the fused kernel and the oracle --
+    same iteration counts, results within the Gauss-Helmert loop's amplification of the start's rounding."""
+    B, N = 7, 40
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=21)
+    st = run_linear_tft(emu, C, CalM, entry="emu_optim_f_pose_staged", debug=False)
+    fu = run_linear_tft(emu, C, CalM, entry="emu_optim_f_pose", debug=False)
+    assert np.all(st["status"] == 0) and np.array_equal(st["iter"], fu["iter"]) and np.all(st["iter"] >= 2)
+    assert np.abs(st["R_t_2"] - fu["R_t_2"]).max() < 1e-8 and np.abs(st["R_t_3"] - fu["R_t_3"]).max() < 1e-8
+    for b in (0, B - 1):
+        R2, R3, Rec, T, it = O.OptimFPoseEstimation(C[b].T.copy(), CalM)
+        assert int(it) == int(st["iter"][b])
+        assert rel_err_T(st["T"][b], T) < 1e-8 and rel_err(st["R_t_2"][b], R2) < 1e-8 and rel_err(st["R_t_3"][b], R3) < 1e-8
+        assert rel_err(st["Reconst"][b], Rec) < 1e-8
 
 
 @pytest.mark.parametrize("refine", [0, 1])

@@ -50,11 +50,12 @@ def test_rows_and_wave_routes_agree(gpu_ctx, method, B, N, sigma):
         assert rel_err(r["Reconst"][b], Rec) < TOL
 
 
-@pytest.mark.parametrize("method", ["ResslTFTPoseEstimation", "NordbergTFTPoseEstimation", "FaugPapaTFTPoseEstimation", "PiPoseEstimation"])
+@pytest.mark.parametrize("method", ["ResslTFTPoseEstimation", "NordbergTFTPoseEstimation", "FaugPapaTFTPoseEstimation", "PiPoseEstimation", "OptimFPoseEstimation"])
 def test_iterative_methods_do_not_depend_on_the_layout_of_their_linear_stage(gpu_ctx, method):
     """k_gh_linear_rows (four triplets per wavefront) against k_gh_linear<false>: the start of the Gauss-Helmert iteration agrees to rounding,
     so do the results -- same iteration counts, 1e-7 (the iteration amplifies the start's last bits; the 50-digit gates of
-    tests/test_gpu_gh_noise.py run on the rows route, the default)."""
+    tests/test_gpu_gh_noise.py run on the rows route, the default).  OptimF: the three stages of csrc/optimf_rows_kernel.h against the fused
+    one-triplet kernel k_f_pose<false, 1>."""
     import torch
     from tft_vs_fund_amd.scenes import generate_scene_batch
     B, N = 1001, 200
@@ -157,7 +158,7 @@ def test_exact_rows_kernel_against_the_one_triplet_exact_kernel(gpu_ctx, method,
     assert np.quantile(eT, 0.999) < 1e-7 and (e3 > 1e-6).mean() < 3e-3, (np.quantile(eT, 0.999), (e3 > 1e-6).mean())
 
 
-@pytest.mark.parametrize("method", ["LinearTFTPoseEstimation", "LinearFPoseEstimation", "ResslTFTPoseEstimation"])
+@pytest.mark.parametrize("method", ["LinearTFTPoseEstimation", "LinearFPoseEstimation", "ResslTFTPoseEstimation", "OptimFPoseEstimation"])
 def test_default_route_goes_by_batch_size(method):
     """TFF_OPT_ROWS = 2 (the default of a new context): bit-identical to the one-triplet kernels on a batch that fits the device in one go, to the
     row kernels on a large one (include/tftfund.h; the crossover is measured: tools/ab_rows_sweep.py)."""

@@ -138,7 +138,7 @@ typedef size_t (*lds_fn)(int N, int flags, bool jacobi);
 
 template <class KMain, class KJac>
 int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_n, int occupancy_cap, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
-                int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+                int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg, bool main_done = false) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     TFF_LOCK(c);
     if (B == 0) return 0;
@@ -155,8 +155,9 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_
         a.flags |= tff::FLAG_STAGE_LDS;
         stage_max_n = 0;
     }
-    const bool all_exact = c->solver != 0 || N < c->exact_below;
-    if (!all_exact) {
+    const bool all_exact = !main_done && (c->solver != 0 || N < c->exact_below);
+    if (main_done) a.flags |= tff::FLAG_ONLY_RETRY;                          // (the caller has run the fast stages: launch_optim_f)
+    if (!all_exact && !main_done) {
         tff::LinearTftArgs m = a;
         m.flags = stage_max_n ? staged_flags(c, N, a.flags, false, stage_max_n) : a.flags;
         unsigned grid = tff::pose_grid(B);
@@ -245,8 +246,41 @@ int launch_linear_f(tff_ctx* c, const double* corresp, const double* calm, int64
     return launch_pose(c, tff::k_f_pose<false, 0>, tff::k_f_pose<true, 0>, tff::f_pose_lds_bytes, tff::STAGE_MAX_N_F, 0, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
                        reconst, iter, status, dbg);
 }
+// OptimFPoseEstimation.  Large batches: three stages (optimf_rows_kernel.h) -- linear stage and pose tail four triplets per wavefront, the
+// Gauss-Helmert refinement one wavefront per triplet -- then the exact kernel over what they could not finish.  Small batches, minimal
+// samples, TFF_OPT_SOLVER = 1, debug records: the fused one-triplet kernel.
 int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                    double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+    if (c && B > 0 && rows_for(c, B, N) && c->solver == 0 && N >= c->exact_below && N >= 8 && !dbg && !c->sample_idx && c->kernel_variant != 1) {
+        if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
+        TFF_LOCK(c);
+        if (!Rt2 || !Rt3 || !T) return fail(TFF_E_INVALID, "null output pointer");
+        TFF_HIP(hipSetDevice(c->device));
+        if (!status) {
+            if (int r = c->scratch_status.reserve((size_t)B * sizeof(int32_t))) return r;
+            status = (int32_t*)c->scratch_status.p;
+        }
+        if (int r = c->gh_rec.reserve((size_t)B * tff::OPTIMF_REC_DOUBLES * sizeof(double))) return r;
+        tff::OptimFStageArgs sa{};
+        sa.la = tff::LinearTftArgs{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr),
+                                   Rt2, Rt3, T, reconst, iter, status, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+        sa.rec = (double*)c->gh_rec.p;
+        hipLaunchKernelGGL(tff::k_optimf_linear_rows, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, sa);
+        TFF_HIP(hipGetLastError());
+        {
+            tff::OptimFStageArgs m = sa;
+            unsigned grid = tff::pose_grid(B);
+            size_t lds;
+            if (int r = plan_spill(c, tff::optimf_refine_lds_bytes(N), tff::optimf_refine_lds_bytes(0), &grid, &m.spill, &m.spill_stride, &lds, 4 * tff::OPTIMF_REFINE_WAVES)) return r;
+            if (int r = ensure_lds(tff::k_optimf_refine<tff::OPTIMF_REFINE_WAVES>, lds)) return r;
+            hipLaunchKernelGGL(tff::k_optimf_refine<tff::OPTIMF_REFINE_WAVES>, dim3(grid), dim3(64), lds, c->stream, m);
+            TFF_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(tff::k_optimf_finish_rows, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, sa);
+        TFF_HIP(hipGetLastError());
+        return launch_pose(c, tff::k_f_pose<false, 1>, tff::k_f_pose<true, 1>, tff::optimf_lds_bytes, 0, 12, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
+                           reconst, iter, status, dbg, true);
+    }
     return launch_pose(c, tff::k_f_pose<false, 1>, tff::k_f_pose<true, 1>, tff::optimf_lds_bytes, 0, 12, corresp, calm, calm_stride, B, N, Rt2, Rt3, T,
                        reconst, iter, status, dbg);
 }

@@ -87,7 +87,7 @@ struct OptimFLds {
     double M[11 * 12];     // augmented KKT matrix
 };
 constexpr int OPTIMF_FIXED_DOUBLES = (int)(sizeof(OptimFLds) / sizeof(double));
-__host__ __device__ inline int optimf_lds_doubles(int N) { return OPTIMF_FIXED_DOUBLES + 8 * N + 2; }   // + xi (4N) + v (4N)
+__host__ __device__ inline int optimf_lds_doubles(int N) { return OPTIMF_FIXED_DOUBLES + 4 * N + 2; }   // + xi (4N)
 
 // per correspondence: f = x2' F x1, a (1x9), B (1x4)   (optimF.m:101-107); o = [x1 y1 x2 y2], Fl = F(:) column-major
 __device__ __forceinline__ void epi_block(const double (&Fl)[9], const double (&o)[4], double& f, double (&a)[9], double (&B)[4]) {
@@ -109,15 +109,31 @@ __device__ __forceinline__ void obs4(const double* pts, int i, const double* nrm
 }
 
 // Gauss_Helmert.m:38-83 specialised to optimF's callback.  g.p holds F(:), xi the initial estimates.  Returns iterations.
-__device__ inline int gauss_helmert_f_wave(PoseLds* w, OptimFLds* g, double* xi, double* vbuf, const double* pts, int N, int v2, int* st) {
+// Three passes over the correspondences per iteration (round 4; five before): the two accumulation sweeps and the pass for v.  The latter
+// also writes xi = x + v in place -- nothing reads xi again when one of the stopping tests fires (only ti = p is kept then, :82) -- and takes
+// the maximum of W = B B' at the NEXT iterate (F + dt, x + v) that pinv's tolerance needs (:52,57), so neither the update pass (:80) nor the
+// maximum pass of the next iteration exist, nor the buffer for v.
+// ONE_SWEEP (kernels compiled for 256 registers): all 54 sums in one pass, 64 accumulators, instead of two passes with 32 each.
+template <bool ONE_SWEEP = false>
+__device__ inline int gauss_helmert_f_wave(PoseLds* w, OptimFLds* g, double* xi, const double* pts, int N, int v2, int* st) {
     const int lane = lane_id();
     constexpr int u = 9, n = 11, ld = 12;
-    double objFunc = 0.0;
-    for (int i = lane; i < N; i += WAVE) {
-        double x[4];
-        obs4(pts, i, w->nrm, v2, x);
+    double objFunc = 0.0, smax = 0.0;
+    {
+        double Fl[9];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const double d = xi[4 * i + k] - x[k]; objFunc += d * d; }
+        for (int k = 0; k < 9; ++k) Fl[k] = wave_uniform(g->p[k]);
+        for (int i = lane; i < N; i += WAVE) {
+            double x[4];
+            obs4(pts, i, w->nrm, v2, x);
+            double o[4] = {xi[4 * i], xi[4 * i + 1], xi[4 * i + 2], xi[4 * i + 3]}, f, a[9], B[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const double d = o[k] - x[k]; objFunc += d * d; }
+            epi_block(Fl, o, f, a, B);
+            const double wv = B[0] * B[0] + B[1] * B[1] + B[2] * B[2] + B[3] * B[3] + 1e-12;
+            smax = (wv > smax) ? wv : smax;
+            if (!(wv <= 1.79e308)) smax = wv;                                // NaN/Inf propagates
+        }
     }
     objFunc = wave_sum(objFunc);
     int it = 0;
@@ -127,18 +143,36 @@ __device__ inline int gauss_helmert_f_wave(PoseLds* w, OptimFLds* g, double* xi,
 #pragma unroll
         for (int k = 0; k < 9; ++k) Fl[k] = wave_uniform(g->p[k]);
         // W = B B' (+1e-12), its maximum -> pinv tolerance   (Gauss_Helmert.m:52,57)
-        double smax = 0.0;
-        for (int i = lane; i < N; i += WAVE) {
-            double o[4] = {xi[4 * i], xi[4 * i + 1], xi[4 * i + 2], xi[4 * i + 3]}, f, a[9], B[4];
-            epi_block(Fl, o, f, a, B);
-            const double wv = B[0] * B[0] + B[1] * B[1] + B[2] * B[2] + B[3] * B[3] + 1e-12;
-            smax = (wv > smax) ? wv : smax;
-            if (!(wv <= 1.79e308)) smax = wv;                                // NaN/Inf propagates
-        }
         smax = wave_max(smax);
         if (!(smax <= 1.79e308)) { *st = ST_NONFINITE; break; }              // :53-55
         const double tolW = (double)N * eps_of(smax);
         // sums: H[0..44] = lower triangle of sum W a a', H[45..53] = sum W w a
+        if constexpr (ONE_SWEEP) {
+            double acc[64];
+#pragma unroll
+            for (int k = 0; k < 64; ++k) acc[k] = 0.0;
+            for (int i = lane; i < N; i += WAVE) {
+                double o[4] = {xi[4 * i], xi[4 * i + 1], xi[4 * i + 2], xi[4 * i + 3]}, f, a[9], B[4], x[4];
+                epi_block(Fl, o, f, a, B);
+                const double wv = B[0] * B[0] + B[1] * B[1] + B[2] * B[2] + B[3] * B[3] + 1e-12;
+                const double Wp = ((wv > tolW) ? 1.0 / wv : 0.0) + 1e-12;    // :57
+                obs4(pts, i, w->nrm, v2, x);
+                const double wr = -f - (B[0] * (x[0] - o[0]) + B[1] * (x[1] - o[1]) + B[2] * (x[2] - o[2]) + B[3] * (x[3] - o[3]));   // :58
+                double wa[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) wa[k] = Wp * a[k];
+                int e = 0;
+#pragma unroll
+                for (int r = 0; r < 9; ++r)
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) { acc[e] += wa[r] * a[c]; ++e; }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[45 + k] += wa[k] * wr;
+            }
+            const double tot = wave_reduce_scatter64(acc);
+            const int idx = reduce64_index(lane);
+            if (idx < 54) g->H[idx] = tot;
+        } else {
 #pragma unroll 1
         for (int sweep = 0; sweep < 2; ++sweep) {
             double acc[32];
@@ -174,6 +208,7 @@ __device__ inline int gauss_helmert_f_wave(PoseLds* w, OptimFLds* g, double* xi,
             const int idx = reduce32_index(lane);
             if ((lane & 1) == 0 && (sweep == 0 || idx < 22)) g->H[32 * sweep + idx] = tot;
         }
+        }
         wave_sync();
         // KKT matrix: [N + 1e-12 I, C'; C, 1e-12 I], b = [A'Ww; -g]   (:59-62), constraints optimF.m:90-95
         for (int e = lane; e < n * ld; e += WAVE) g->M[e] = 0.0;
@@ -207,11 +242,11 @@ __device__ inline int gauss_helmert_f_wave(PoseLds* w, OptimFLds* g, double* xi,
         if (!(fabs(wave_sum(chk)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
         if (!wave_solve_gj<n>(g->M, g->dt)) { *st = ST_RANK; break; }        // :67
         wave_sync();
-        double dt[9];
+        double dt[9], Fn[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) dt[k] = wave_uniform(g->dt[k]);
-        // v = -B' W (A dt - w)   (:69)
-        double obj = 0.0, diff = 0.0, ndt2 = 0.0;
+        for (int k = 0; k < 9; ++k) { dt[k] = wave_uniform(g->dt[k]); Fn[k] = Fl[k] + dt[k]; }   // Fn: ti + dt (:80), should the step be accepted
+        // v = -B' W (A dt - w)   (:69); xi = x + v (:80); max W at the next iterate
+        double obj = 0.0, diff = 0.0, ndt2 = 0.0, snext = 0.0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) ndt2 += dt[k] * dt[k];
         for (int i = lane; i < N; i += WAVE) {
@@ -225,27 +260,29 @@ __device__ inline int gauss_helmert_f_wave(PoseLds* w, OptimFLds* g, double* xi,
 #pragma unroll
             for (int k = 0; k < 9; ++k) adt += a[k] * dt[k];
             const double r = Wp * (adt - wr);
+            double on[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const double v = -B[k] * r;
-                vbuf[4 * i + k] = v;
                 obj += v * v;
                 const double d = o[k] - x[k] - v;
                 diff += d * d;
+                on[k] = x[k] + v;
+                xi[4 * i + k] = on[k];
             }
+            const double Bn0 = Fn[2] + Fn[0] * on[2] + Fn[1] * on[3], Bn1 = Fn[5] + Fn[3] * on[2] + Fn[4] * on[3];   // epi_block's B at (Fn, on)
+            const double Bn2 = Fn[6] + Fn[0] * on[0] + Fn[3] * on[1], Bn3 = Fn[7] + Fn[1] * on[0] + Fn[4] * on[1];
+            const double wn = Bn0 * Bn0 + Bn1 * Bn1 + Bn2 * Bn2 + Bn3 * Bn3 + 1e-12;
+            snext = (wn > snext) ? wn : snext;
+            if (!(wn <= 1.79e308)) snext = wn;
         }
         obj = wave_sum(obj);
         diff = wave_sum(diff);
         if (sqrt(ndt2) < 1e-6 && sqrt(diff) < 1e-6) break;                   // :71-73
         if (obj > objFunc) break;                                            // :75-76
         objFunc = obj;
-        for (int i = lane; i < N; i += WAVE) {                               // xi = x + v; ti += dt   (:80)
-            double x[4];
-            obs4(pts, i, w->nrm, v2, x);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) xi[4 * i + k] = x[k] + vbuf[4 * i + k];
-        }
-        if (lane < 9) g->p[lane] += g->dt[lane];
+        smax = snext;
+        if (lane < 9) g->p[lane] += g->dt[lane];                             // ti += dt   (:80)
         wave_sync();
     }
     return (it > 400) ? 400 : it;
@@ -362,7 +399,7 @@ __device__ inline bool linear_f_wave(PoseLds* w, JacobiLdsF* jw, const double* p
 // optimF.m:52-69 for both pairs: initial x_est by two-view triangulation with P1 = [I|0], P2 = [crossM(epi21) F, epi21],
 // then Gauss-Helmert on F(:).  w->Fm holds the unit-norm linear F (x-frame) on entry, the refined one on exit.  Returns it1 + it2.
 // *ok (EXACT = false): cleared when a fast tier (null vector, DLT point) could not finish.
-template <bool EXACT = true>
+template <bool EXACT = true, bool ONE_SWEEP = false>
 __device__ inline int optim_f_refine(PoseLds* w, OptimFLds* og, double* oxi, const double* pts, int N, int* gst, bool* ok = nullptr) {
     const int lane = lane_id();
     int iters = 0;
@@ -389,7 +426,7 @@ __device__ inline int optim_f_refine(PoseLds* w, OptimFLds* og, double* oxi, con
         fine = tri_pass<EXACT>(w, pts, N, TRI_REPROJECT2, pair + 1, w->P[0], w->P[0], oxi, w->nrm) && fine;   // x_est   (:56-60)
         if (!EXACT && wave_any(!fine)) { if (ok) *ok = false; return iters; }                                  // the exact kernel redoes the triplet
         wave_sync();
-        iters += gauss_helmert_f_wave(w, og, oxi, oxi + 4 * N + 2, pts, N, pair + 1, gst);   // :66
+        iters += gauss_helmert_f_wave<ONE_SWEEP>(w, og, oxi, pts, N, pair + 1, gst);   // :66
         wave_sync();
         if (lane < 9) w->Fm[9 * pair + 3 * (lane % 3) + lane / 3] = og->p[lane];   // F = reshape(p_opt,3,3)   (:69)
         wave_sync();
@@ -406,8 +443,8 @@ __global__ void __launch_bounds__(64, (METHOD == 1 && !JAC) ? 3 : 2) k_f_pose(co
     JacobiLdsF* jw = JAC ? reinterpret_cast<JacobiLdsF*>(smem + base) : nullptr;
     double* extra = smem + base + (JAC ? ((JACOBI_F_LDS_DOUBLES + 1) & ~1) : 0);
     OptimFLds* og = (METHOD == 1) ? reinterpret_cast<OptimFLds*>(extra) : nullptr;
-    double* oxi = a.spill ? a.spill + blockIdx.x * a.spill_stride : extra + ((OPTIMF_FIXED_DOUBLES + 1) & ~1);   // METHOD 1: xi (4N), then v (4N); large N: global
-    double* lds_pts = (METHOD == 1) ? oxi + 8 * a.N + 2 : extra;             // staged correspondences (METHOD 0, or sampled)
+    double* oxi = a.spill ? a.spill + blockIdx.x * a.spill_stride : extra + ((OPTIMF_FIXED_DOUBLES + 1) & ~1);   // METHOD 1: xi (4N); large N: global
+    double* lds_pts = (METHOD == 1) ? oxi + 4 * a.N + 2 : extra;             // staged correspondences (METHOD 0, or sampled)
     const int lane = lane_id();
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
         if ((a.flags & FLAG_ONLY_RETRY) && a.status[b] != ST_RETRY) continue;      // wave-uniform

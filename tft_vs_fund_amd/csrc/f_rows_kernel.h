@@ -85,6 +85,9 @@ __device__ __forceinline__ void rows_distances_moments_f(const RowSrc& s, const 
 
 // linearF.m:48-62 for both view pairs from the moment sums, then LinearFPoseEstimation.m:55-56 and E = K' F K (recover_R_t) -> rt->Ein.
 // Fm: 18 doubles of the row's LDS (F21, F31 row-major).  Returns false (per row) when a fast tier could not finish.
+// X_FRAME (OptimFPoseEstimation, optimf_rows_kernel.h): stop after linearF itself and leave F / |F|_F (optimF.m:49-50) in Fm, in the frame of the
+// normalised points; rt is not used.
+template <bool X_FRAME = false>
 __device__ __forceinline__ bool rows_linear_f_middle(RowLds* w, RowRt* rt, double* Fm, const double* nrm2, double* dbg) {
     const int p = opaque_lane_int(rows_p());
     bool ok = true;
@@ -124,12 +127,25 @@ __device__ __forceinline__ bool rows_linear_f_middle(RowLds* w, RowRt* rt, doubl
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) F.m[r][c] -= fv[r] * v3[c];
-        F = mat3_mul(mat3_mul(mat3_T(normal_matrix(w->nrm, v2)), F), normal_matrix(w->nrm, 0));      // LinearFPoseEstimation.m:55-56: back to pixels
-        const Mat3 E = mat3_mul(mat3_mul(mat3_T(load_K(w->calm, v2)), F), load_K(w->calm, 0));       // recover_R_t: E = K2' F K1
+        if constexpr (X_FRAME) {
+            double nn = 0.0;
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) rt->Ein[9 * p + 3 * r + c] = E.m[r][c];
+                for (int c = 0; c < 3; ++c) nn += F.m[r][c] * F.m[r][c];
+            const double sc = rsqrt(nn);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Fm[9 * p + 3 * r + c] = F.m[r][c] * sc;
+        } else {
+            F = mat3_mul(mat3_mul(mat3_T(normal_matrix(w->nrm, v2)), F), normal_matrix(w->nrm, 0));      // LinearFPoseEstimation.m:55-56: back to pixels
+            const Mat3 E = mat3_mul(mat3_mul(mat3_T(load_K(w->calm, v2)), F), load_K(w->calm, 0));       // recover_R_t: E = K2' F K1
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rt->Ein[9 * p + 3 * r + c] = E.m[r][c];
+        }
     }
     const bool bad = row_any(!nok);
     wave_sync();

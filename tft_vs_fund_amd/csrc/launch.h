@@ -11,6 +11,7 @@
 #include "pi_kernel.h"
 #include "gh_wg_kernel.h"
 #include "gh_rows_kernel.h"
+#include "optimf_rows_kernel.h"
 #include "gh_fp_kernel.h"
 #include "pi_wg_kernel.h"
 #include "ba_kernel.h"
@@ -57,11 +58,11 @@ inline size_t pi_lds_bytes(int N, int /*flags*/, bool jacobi) {
     d += (size_t)pi_lds_doubles(Model::E, Model::C, N, Model::PINV_KKT);
     return d * sizeof(double);
 }
-// OptimFPoseEstimation: xi and v (4N each) + the 11 x 11 KKT workspace
+// OptimFPoseEstimation: xi (4N) + the 11 x 11 KKT workspace
 inline size_t optimf_lds_bytes(int N, int flags, bool jacobi) {
     size_t d = (size_t)((POSE_LDS_DOUBLES + 1) & ~1);
     if (jacobi) d += (size_t)((JACOBI_F_LDS_DOUBLES + 1) & ~1);
-    d += (size_t)((OPTIMF_FIXED_DOUBLES + 1) & ~1) + 8 * (size_t)N + 2;
+    d += (size_t)((OPTIMF_FIXED_DOUBLES + 1) & ~1) + 4 * (size_t)N + 2;
     if (flags & FLAG_STAGE_LDS) d += 6 * (size_t)N;
     return d * sizeof(double);
 }

@@ -149,6 +149,23 @@ __device__ __forceinline__ double wave_reduce_scatter(double (&v)[K]) {
     v[0] += dpp_mov<0xB1>(v[0]);
     return v[0];
 }
+// 64 values: one more halving step at either end, every lane ends with the full sum of ONE value (index reduce64_index(lane))
+__device__ __forceinline__ double wave_reduce_scatter64(double (&v)[64]) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = halve_sum<32>(v[i], v[i + 32]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = halve_sum<16>(v[i], v[i + 16]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = halve_sum<8>(v[i], v[i + 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = halve_sum<4>(v[i], v[i + 4]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) v[i] = halve_sum<2>(v[i], v[i + 2]);
+    return halve_sum<1>(v[0], v[1]);
+}
+__device__ __forceinline__ int reduce64_index(int lane) {
+    return ((lane >> 5) & 1) * 32 + ((lane >> 4) & 1) * 16 + ((lane >> 3) & 1) * 8 + ((lane >> 2) & 1) * 4 + ((lane >> 1) & 1) * 2 + (lane & 1);
+}
 // value index owned by `lane` after wave_reduce_scatter<32>
 __device__ __forceinline__ int reduce32_index(int lane) {
     return ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
