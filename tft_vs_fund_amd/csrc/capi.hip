@@ -271,9 +271,18 @@ int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_
             tff::OptimFStageArgs m = sa;
             unsigned grid = tff::pose_grid(B);
             size_t lds;
-            if (int r = plan_spill(c, tff::optimf_refine_lds_bytes(N), tff::optimf_refine_lds_bytes(0), &grid, &m.spill, &m.spill_stride, &lds, 4 * tff::OPTIMF_REFINE_WAVES)) return r;
-            if (int r = ensure_lds(tff::k_optimf_refine<tff::OPTIMF_REFINE_WAVES>, lds)) return r;
-            hipLaunchKernelGGL(tff::k_optimf_refine<tff::OPTIMF_REFINE_WAVES>, dim3(grid), dim3(64), lds, c->stream, m);
+            // the normalised observations go to LDS with xi while eight wavefronts still fit a CU (N <= ~220); beyond, the passes read the correspondences
+            // through L2 as the fused kernel does, and xi follows plan_spill's occupancy rule
+            const bool stage_x = tff::optimf_refine_lds_bytes(N, true) + 512 <= LDS_LIMIT / (4 * tff::OPTIMF_REFINE_WAVES);
+            if (stage_x) {
+                lds = tff::optimf_refine_lds_bytes(N, true);
+                if (int r = ensure_lds(tff::k_optimf_refine<tff::OPTIMF_REFINE_WAVES, true>, lds)) return r;
+                hipLaunchKernelGGL((tff::k_optimf_refine<tff::OPTIMF_REFINE_WAVES, true>), dim3(grid), dim3(64), lds, c->stream, m);
+            } else {
+                if (int r = plan_spill(c, tff::optimf_refine_lds_bytes(N, false), tff::optimf_refine_lds_bytes(0, false), &grid, &m.spill, &m.spill_stride, &lds, 4 * tff::OPTIMF_REFINE_WAVES)) return r;
+                if (int r = ensure_lds(tff::k_optimf_refine<tff::OPTIMF_REFINE_WAVES, false>, lds)) return r;
+                hipLaunchKernelGGL((tff::k_optimf_refine<tff::OPTIMF_REFINE_WAVES, false>), dim3(grid), dim3(64), lds, c->stream, m);
+            }
             TFF_HIP(hipGetLastError());
         }
         hipLaunchKernelGGL(tff::k_optimf_finish_rows, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, sa);

@@ -108,14 +108,15 @@ __device__ __forceinline__ void obs4(const double* pts, int i, const double* nrm
     x[0] = p.v[0]; x[1] = p.v[1]; x[2] = p.v[2 * v2]; x[3] = p.v[2 * v2 + 1];
 }
 
-// Gauss_Helmert.m:38-83 specialised to optimF's callback.  g.p holds F(:), xi the initial estimates.  Returns iterations.
+// Gauss_Helmert.m:38-83 specialised to optimF's callback.  g.p holds F(:), xi the initial estimates, nrm the map from pts to the
+// normalised observations.  Returns iterations.
 // Three passes over the correspondences per iteration (round 4; five before): the two accumulation sweeps and the pass for v.  The latter
 // also writes xi = x + v in place -- nothing reads xi again when one of the stopping tests fires (only ti = p is kept then, :82) -- and takes
 // the maximum of W = B B' at the NEXT iterate (F + dt, x + v) that pinv's tolerance needs (:52,57), so neither the update pass (:80) nor the
 // maximum pass of the next iteration exist, nor the buffer for v.
 // ONE_SWEEP (kernels compiled for 256 registers): all 54 sums in one pass, 64 accumulators, instead of two passes with 32 each.
 template <bool ONE_SWEEP = false>
-__device__ inline int gauss_helmert_f_wave(PoseLds* w, OptimFLds* g, double* xi, const double* pts, int N, int v2, int* st) {
+__device__ inline int gauss_helmert_f_wave(const double* nrm, OptimFLds* g, double* xi, const double* pts, int N, int v2, int* st) {
     const int lane = lane_id();
     constexpr int u = 9, n = 11, ld = 12;
     double objFunc = 0.0, smax = 0.0;
@@ -125,7 +126,7 @@ __device__ inline int gauss_helmert_f_wave(PoseLds* w, OptimFLds* g, double* xi,
         for (int k = 0; k < 9; ++k) Fl[k] = wave_uniform(g->p[k]);
         for (int i = lane; i < N; i += WAVE) {
             double x[4];
-            obs4(pts, i, w->nrm, v2, x);
+            obs4(pts, i, nrm, v2, x);
             double o[4] = {xi[4 * i], xi[4 * i + 1], xi[4 * i + 2], xi[4 * i + 3]}, f, a[9], B[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const double d = o[k] - x[k]; objFunc += d * d; }
@@ -156,7 +157,7 @@ __device__ inline int gauss_helmert_f_wave(PoseLds* w, OptimFLds* g, double* xi,
                 epi_block(Fl, o, f, a, B);
                 const double wv = B[0] * B[0] + B[1] * B[1] + B[2] * B[2] + B[3] * B[3] + 1e-12;
                 const double Wp = ((wv > tolW) ? 1.0 / wv : 0.0) + 1e-12;    // :57
-                obs4(pts, i, w->nrm, v2, x);
+                obs4(pts, i, nrm, v2, x);
                 const double wr = -f - (B[0] * (x[0] - o[0]) + B[1] * (x[1] - o[1]) + B[2] * (x[2] - o[2]) + B[3] * (x[3] - o[3]));   // :58
                 double wa[9];
 #pragma unroll
@@ -183,7 +184,7 @@ __device__ inline int gauss_helmert_f_wave(PoseLds* w, OptimFLds* g, double* xi,
                 epi_block(Fl, o, f, a, B);
                 const double wv = B[0] * B[0] + B[1] * B[1] + B[2] * B[2] + B[3] * B[3] + 1e-12;
                 const double Wp = ((wv > tolW) ? 1.0 / wv : 0.0) + 1e-12;    // :57
-                obs4(pts, i, w->nrm, v2, x);
+                obs4(pts, i, nrm, v2, x);
                 const double wr = -f - (B[0] * (x[0] - o[0]) + B[1] * (x[1] - o[1]) + B[2] * (x[2] - o[2]) + B[3] * (x[3] - o[3]));   // :58
                 double wa[9];
 #pragma unroll
@@ -254,7 +255,7 @@ __device__ inline int gauss_helmert_f_wave(PoseLds* w, OptimFLds* g, double* xi,
             epi_block(Fl, o, f, a, B);
             const double wv = B[0] * B[0] + B[1] * B[1] + B[2] * B[2] + B[3] * B[3] + 1e-12;
             const double Wp = ((wv > tolW) ? 1.0 / wv : 0.0) + 1e-12;
-            obs4(pts, i, w->nrm, v2, x);
+            obs4(pts, i, nrm, v2, x);
             const double wr = -f - (B[0] * (x[0] - o[0]) + B[1] * (x[1] - o[1]) + B[2] * (x[2] - o[2]) + B[3] * (x[3] - o[3]));
             double adt = 0.0;
 #pragma unroll
@@ -426,7 +427,7 @@ __device__ inline int optim_f_refine(PoseLds* w, OptimFLds* og, double* oxi, con
         fine = tri_pass<EXACT>(w, pts, N, TRI_REPROJECT2, pair + 1, w->P[0], w->P[0], oxi, w->nrm) && fine;   // x_est   (:56-60)
         if (!EXACT && wave_any(!fine)) { if (ok) *ok = false; return iters; }                                  // the exact kernel redoes the triplet
         wave_sync();
-        iters += gauss_helmert_f_wave<ONE_SWEEP>(w, og, oxi, pts, N, pair + 1, gst);   // :66
+        iters += gauss_helmert_f_wave<ONE_SWEEP>(w->nrm, og, oxi, pts, N, pair + 1, gst);   // :66
         wave_sync();
         if (lane < 9) w->Fm[9 * pair + 3 * (lane % 3) + lane / 3] = og->p[lane];   // F = reshape(p_opt,3,3)   (:69)
         wave_sync();

@@ -61,32 +61,98 @@ __global__ void __launch_bounds__(64, 2) k_optimf_linear_rows(const OptimFStageA
     }
 }
 
-// LDS of k_optimf_refine: PoseLds (normalisations, F, the two cameras of the initial triangulation) | OptimFLds | xi (4 N + 2, unless spilled)
-__host__ __device__ inline size_t optimf_refine_lds_bytes(int N) {
-    return (size_t)(((POSE_LDS_DOUBLES + 1) & ~1) + ((OPTIMF_FIXED_DOUBLES + 1) & ~1) + 4 * N + 2) * sizeof(double);
+// k_optimf_refine keeps what the iteration touches in every pass in LDS: xi (4 N) and -- STAGE_X -- the NORMALISED observations (6 N, the
+// correspondences mapped once: every pass of the fused kernel re-read them from L2 and mapped them again, a dependent global load per trip that
+// two wavefronts per SIMD cannot hide).  18 KB at N = 200: eight wavefronts per CU, as the 256-register build allows.
+struct OptimFRefineLds {
+    double nrm[10];        // map from the points the passes read to the normalised frame (STAGE_X: the identity)
+    double Fm[18];         // F21, F31 (row-major, normalised frame)
+    double PA[12], PB[12]; // cameras of the initial triangulation   (optimF.m:54-55)
+};
+constexpr int OPTIMF_REFINE_FIXED_DOUBLES = (int)(sizeof(OptimFRefineLds) / sizeof(double)) + ((OPTIMF_FIXED_DOUBLES + 1) & ~1);
+__host__ __device__ inline size_t optimf_refine_lds_bytes(int N, bool stage_x) {
+    return (size_t)(OPTIMF_REFINE_FIXED_DOUBLES + 4 * N + 2 + (stage_x ? 6 * N : 0)) * sizeof(double);
 }
 
-template <int WAVES_PER_SIMD>
+template <int WAVES_PER_SIMD, bool STAGE_X>
 __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_optimf_refine(const OptimFStageArgs sa) {
     TFF_DYNAMIC_LDS(double, smem);
     const LinearTftArgs& a = sa.la;
-    PoseLds* w = reinterpret_cast<PoseLds*>(smem);
-    constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
-    OptimFLds* og = reinterpret_cast<OptimFLds*>(smem + base);
-    double* oxi = sa.spill ? sa.spill + blockIdx.x * sa.spill_stride : smem + base + ((OPTIMF_FIXED_DOUBLES + 1) & ~1);
+    OptimFRefineLds* w = reinterpret_cast<OptimFRefineLds*>(smem);
+    OptimFLds* og = reinterpret_cast<OptimFLds*>(smem + sizeof(OptimFRefineLds) / sizeof(double));
+    double* var = smem + OPTIMF_REFINE_FIXED_DOUBLES;
+    double* xn = var;                                                        // STAGE_X: 6 N
+    double* oxi = sa.spill ? sa.spill + blockIdx.x * sa.spill_stride : var + (STAGE_X ? 6 * a.N : 0);
     const int lane = lane_id();
     for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
         if (a.status[b] != ST_OK) continue;                                  // wave-uniform: too few points, or left to the exact kernel
         const int N = opaque_int(a.N);
-        const double* pts = a.corresp + b * 6 * (long)N;
+        const double* src = a.corresp + b * 6 * (long)N;
         wave_sync();
         double* r = sa.rec + b * OPTIMF_REC_DOUBLES;
         if (lane < 18) w->Fm[lane] = r[lane];
         if (lane < 9) w->nrm[lane] = r[18 + lane];
         wave_sync();
-        int gst = ST_OK;
+        const double* pts = src;
+        if constexpr (STAGE_X) {
+            for (int i = lane; i < N; i += WAVE) {
+                const Pt6 q = premap(load_pt(src, i), w->nrm);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) xn[6 * i + k] = q.v[k];
+            }
+            wave_sync();
+            if (lane < 9) w->nrm[lane] = (lane % 3 == 0) ? 1.0 : 0.0;        // the passes below read normalised points
+            wave_sync();
+            pts = xn;
+        }
+        int gst = ST_OK, iters = 0;
         bool fine = true;
-        const int iters = optim_f_refine<false, WAVES_PER_SIMD == 2>(w, og, oxi, pts, N, &gst, &fine);   // [F21,it1] = optimF(...), [F31,it2] = optimF(...)   (:48-49)
+#pragma unroll 1
+        for (int pair = 0; pair < 2; ++pair) {                               // [F21,it1] = optimF(...), [F31,it2] = optimF(...)   (OptimFPoseEstimation.m:48-49)
+            if (lane == 0) {                                                 // f_kernel.h::optim_f_refine
+                Mat3 F, Ft;
+                for (int rr = 0; rr < 3; ++rr) for (int c = 0; c < 3; ++c) F.m[rr][c] = w->Fm[9 * pair + 3 * rr + c];
+                Ft = mat3_T(F);
+                double e[3];
+                fine = null3<false>(Ft, e) && fine;                          // epi21 = U(:,3): left null vector   (optimF.m:53)
+                for (int rr = 0; rr < 3; ++rr) for (int c = 0; c < 4; ++c) w->PA[4 * rr + c] = (rr == c) ? 1.0 : 0.0;   // P1 = [I|0]   (:54)
+                for (int c = 0; c < 3; ++c) {                                // P2 = [crossM(epi21)*F, epi21]   (:55)
+                    w->PB[c] = -e[2] * F.m[1][c] + e[1] * F.m[2][c];
+                    w->PB[4 + c] = e[2] * F.m[0][c] - e[0] * F.m[2][c];
+                    w->PB[8 + c] = -e[1] * F.m[0][c] + e[0] * F.m[1][c];
+                }
+                w->PB[3] = e[0]; w->PB[7] = e[1]; w->PB[11] = e[2];
+            }
+            if (lane < 9) og->p[lane] = w->Fm[9 * pair + 3 * (lane % 3) + lane / 3];   // p = F(:) column-major   (:61)
+            wave_sync();
+            {                                                                // x_est: the two reprojections of the two-view DLT point   (:56-60)
+                double PA[12], PB[12];
+                load_uniform12(w->PA, PA);
+                load_uniform12(w->PB, PB);
+                for (int i = lane; i < N; i += WAVE) {
+                    const Pt6 q = premap(load_pt(pts, i), w->nrm);
+                    double X[4];
+                    const bool conv = dlt_point<false, false>(PA, PB, PB, w->PA, w->PB, w->PB, false, q.v[0], q.v[1], pair ? q.v[4] : q.v[2],
+                                                              pair ? q.v[5] : q.v[3], 0.0, 0.0, X);
+                    fine = fine && conv;
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        const double (&P)[12] = (v == 0) ? PA : PB;
+                        const double pa = P[0] * X[0] + P[1] * X[1] + P[2] * X[2] + P[3] * X[3];
+                        const double pb = P[4] * X[0] + P[5] * X[1] + P[6] * X[2] + P[7] * X[3];
+                        const double pc = P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11] * X[3];
+                        oxi[4 * (long)i + 2 * v] = pa / pc;
+                        oxi[4 * (long)i + 2 * v + 1] = pb / pc;
+                    }
+                }
+            }
+            if (wave_any(!fine)) break;                                      // a fast tier gave up: the exact kernel redoes the triplet
+            wave_sync();
+            iters += gauss_helmert_f_wave<WAVES_PER_SIMD == 2>(w->nrm, og, oxi, pts, N, pair + 1, &gst);   // :66
+            wave_sync();
+            if (lane < 9) w->Fm[9 * pair + 3 * (lane % 3) + lane / 3] = og->p[lane];   // F = reshape(p_opt,3,3)   (:69)
+            wave_sync();
+        }
         fine = !wave_any(!fine);
         if (fine && lane < 18) r[lane] = w->Fm[lane];
         if (lane == 0) {

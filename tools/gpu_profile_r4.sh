@@ -32,7 +32,7 @@ for T in ${@:-headline headline1 ressl nordberg faugpapa pi picol linearf optimf
     pi)         run_one pi "python3 $R/tools/bench_one.py PiPoseEstimation 8" "k_pi_block" 10000 $ALG 2;;
     picol)      run_one picol "python3 $R/tools/bench_one.py PiColPoseEstimation 6" "k_pi_block" 10000 $ALG 4;;
     linearf)    run_one linearf "python3 $R/tools/bench_one.py LinearFPoseEstimation 20" "k_linear_f_pose_rows" 10000 $ALG 2;;
-    optimf)     run_one optimf "python3 $R/tools/bench_one.py OptimFPoseEstimation 10" "k_f_pose<false, 1>" 10000 $ALG 3;;
+    optimf)     run_one optimf "python3 $R/tools/bench_one.py OptimFPoseEstimation 10" "k_optimf_refine" 10000 $ALG 2;;
     config4tft) run_one config4tft "python3 $R/tools/config4_split.py 1000000" "k_linear_tft_pose_rows_exact" 1000000 $((1000000 * 440)) 2;;
     config4f)   run_one config4f "python3 $R/tools/config4_split.py 1000000" "k_linear_f_pose_rows_exact" 1000000 $((1000000 * 444)) 2;;
   esac
