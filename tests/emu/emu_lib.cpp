@@ -227,6 +227,12 @@ static int emu_gh_wg_impl(const double* corresp, const double* calm, long calm_s
     m.flags |= tff::FLAG_ONLY_RETRY;
     emu::launch(tff::k_gh_linear<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
     const size_t lds = (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, N, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double);
+    std::vector<double> pre;
+    if (tff::gh_has_preinit<Model>::value && !(flags & 4096)) {              // (as the C ABI; flag 4096, a test switch: the block kernel computes it itself)
+        pre.assign((size_t)B * 64, 0.0);
+        a.init_rec = pre.data();
+        emu::launch(tff::k_nordberg_init, (unsigned)((B + 63) / 64), 64, 0, a);
+    }
     emu::launch(tff::k_gh_block<Model>, emu_grid(B), tff::GH_WG_THREADS, lds, a);
     if (N >= 12) emu::launch(tff::k_gh_finish_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);     // (as the C ABI)
     else emu::launch(tff::k_gh_finish, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);

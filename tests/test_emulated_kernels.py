@@ -403,6 +403,14 @@ def test_emulated_workgroup_kernels_reproduce_the_50_digit_iteration(emu, model,
         emu.emu_gh_wg_pose(ctypes.c_int(0 if model == "ressl" else 1), _p(C), _p(calm), ctypes.c_long(0), ctypes.c_long(B), ctypes.c_int(N),
                            ctypes.c_int(0), _p(Rt2), _p(Rt3), _p(T), None, _p(it), _p(st))
     assert np.all(st == 0)
+    if model == "nordberg":
+        # the serial part of the initial parameters ran in k_nordberg_init, one triplet per lane (as the C ABI); flag 4096: on lane 0 of the block
+        # kernel's owner wavefront, as the fused kernel does -- same function, same results
+        T0 = np.zeros_like(T); R20 = np.zeros_like(Rt2); R30 = np.zeros_like(Rt3); it0 = np.zeros_like(it); st0 = np.zeros_like(st)
+        emu.emu_gh_wg_pose(ctypes.c_int(1), _p(C), _p(calm), ctypes.c_long(0), ctypes.c_long(B), ctypes.c_int(N), ctypes.c_int(4096),
+                           _p(R20), _p(R30), _p(T0), None, _p(it0), _p(st0))
+        assert np.array_equal(it0, it) and np.array_equal(st0, st)
+        assert np.abs(T0 - T).max() < 1e-12 and np.abs(R30 - Rt3).max() < 1e-12 * max(1.0, np.abs(Rt3).max())
     Tt = T.reshape(B, 3, 3, 3).transpose(0, 3, 2, 1); R2 = Rt2.reshape(B, 4, 3).transpose(0, 2, 1); R3 = Rt3.reshape(B, 4, 3).transpose(0, 2, 1)
     for b in range(B):
         if pre + "mp4_T" in g.files:

@@ -55,7 +55,7 @@ struct tff_ctx {
     int solver = 0;
     int exact_below = tff::EXACT_BELOW_N;   // TFF_OPT_EXACT_BELOW
     int stage = -1;
-    DevBuf in, calm, out, idx, scratch_status, gh_rec, gh_topt, spill;
+    DevBuf in, calm, out, idx, scratch_status, gh_rec, gh_topt, gh_init, spill;
     const int32_t* sample_idx = nullptr;   // set around a *_sampled_dev call
     int32_t sample_ns = 0;                 //   size of the scene the indices refer to
     double* init_p = nullptr; double* init_x = nullptr;   // set around tff_pi_pose_batch_debug_dev
@@ -300,7 +300,7 @@ int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_
 template <class KBlock, class LdsFn>
 int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg, bool fp_first = false,
-              bool rows_linear = true) {
+              bool rows_linear = true, bool nordberg_pre = false) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     TFF_LOCK(c);
     if (B == 0) return 0;
@@ -332,6 +332,12 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
         lds = tff::pose_lds_bytes(N, m.flags, true);
         if (int r = ensure_lds(tff::k_gh_linear<true>, lds)) return r;
         hipLaunchKernelGGL(tff::k_gh_linear<true>, dim3(all_exact ? tff::pose_grid(B) : (unsigned)(B < FIXUP_GRID ? B : FIXUP_GRID)), dim3(64), lds, c->stream, m);
+        TFF_HIP(hipGetLastError());
+    }
+    if (nordberg_pre) {   // the serial part of Nordberg's initial parameters, one triplet per lane (gh_wg_kernel.h::k_nordberg_init)
+        if (int r = c->gh_init.reserve((size_t)B * tff::NordbergModel::PRE_DOUBLES * sizeof(double))) return r;
+        a.init_rec = (double*)c->gh_init.p;
+        hipLaunchKernelGGL(tff::k_nordberg_init, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, c->stream, a);
         TFF_HIP(hipGetLastError());
     }
     if (fp_first) {   // FaugPapa's own block kernel (gh_fp_kernel.h); the generic one below then redoes what it handed back (ST_RETRY: almost always nothing)
@@ -387,7 +393,8 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
     // slices at three (3.89 vs 3.87 ms per 10 k x 200) -- without the state's HBM round trips (what is left of its 52x algorithmic traffic is scratch:
     // the 168-register build spills 368 registers, and is still faster than the 256-register one, 3.69 vs 3.90 ms)
     const int occupancy_cap = std::is_same<Model, tff::NordbergModel>::value ? 2 : Model::WG_PER_CU;
-    return launch_wg(c, tff::k_gh_block<Model>, wg_lds, occupancy_cap, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg, fp_first);
+    return launch_wg(c, tff::k_gh_block<Model>, wg_lds, occupancy_cap, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg, fp_first, true,
+                     std::is_same<Model, tff::NordbergModel>::value);
 }
 template <class Model>
 int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
@@ -497,7 +504,7 @@ void tff_ctx_destroy(tff_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->own) { (void)hipStreamSynchronize(c->own); (void)hipStreamDestroy(c->own); }
     if (c->handover) (void)hipEventDestroy(c->handover);
-    c->in.release(); c->calm.release(); c->out.release(); c->idx.release(); c->scratch_status.release(); c->gh_rec.release(); c->gh_topt.release(); c->spill.release();
+    c->in.release(); c->calm.release(); c->out.release(); c->idx.release(); c->scratch_status.release(); c->gh_rec.release(); c->gh_topt.release(); c->gh_init.release(); c->spill.release();
     delete c;
 }
 

@@ -492,60 +492,78 @@ struct NordbergModel {
         out3[0] = v[0] * o; out3[1] = v[1] * o; out3[2] = v[2] * o;
     }
 
+    // The serial part of the initial parameters (:56-78): projective fix-up of P2, P3, r = A\a, s = B\b, the three orthogonalised frames and
+    // their axis-angle vectors.  One LANE's work -- 58 k cycles of svd3 / jacobi3 / null3 / atan2, an eighth of the block kernel's time when the
+    // owner wavefront's lane 0 runs it while 255 threads wait.  k_nordberg_init (gh_wg_kernel.h) runs it for 64 triplets per wavefront, one per
+    // lane, ahead of the block kernel, which then only loads the result (`pre`).  P2 / P3: row-major 3 x 4, updated in place when deficient.
+    static constexpr bool PREINIT = true;
+    static constexpr int PRE_DOUBLES = 64;                                   // P2 12 | P3 12 | U, V, W 27 | axis-angles 9 | deficient 1 | pad
+    const double* pre = nullptr;
+    __device__ static inline void init_serial(double* P2, double* P3, double* rot, double* p9, int* deficient_out) {
+        Mat3 A, B;
+        double a[3], b[3];
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) { A.m[r][c] = P2[4 * r + c]; B.m[r][c] = P3[4 * r + c]; } a[r] = P2[4 * r + 3]; b[r] = P3[4 * r + 3]; }
+        // H = eye(4); H(4,1:3) = null(P3(:,1:3))' if rank(P3(:,1:3)) < 3, else the same with P2   (:56-62).
+        // rank(X) < 3 <=> sigma_3 <= 3 eps(sigma_1), with sigma_3 = |det X| / (sigma_1 sigma_2) (the squared-matrix
+        // Jacobi of svd3 cannot resolve a singular value that small).  P*H = [P(:,1:3) + P(:,4) n', P(:,4)]; P1*H = P1.
+        int deficient = 0;
+        {
+            Mat3 Us, Vs;
+            double svB[3], svA[3];
+            svd3(B, Us, Vs, svB);
+            const bool defB = !(fabs(mat3_det(B)) > 3.0 * eps_of(svB[0]) * svB[0] * svB[1]);
+            svd3(A, Us, Vs, svA);
+            const bool defA = !(fabs(mat3_det(A)) > 3.0 * eps_of(svA[0]) * svA[0] * svA[1]);
+            if (defB || defA) {
+                double nv[3];
+                null3(defB ? B : A, nv);
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) { A.m[r][c] += a[r] * nv[c]; B.m[r][c] += b[r] * nv[c]; }
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) { P2[4 * r + c] = A.m[r][c]; P3[4 * r + c] = B.m[r][c]; }
+                // a null space of dimension > 1 makes H(4,1:3) = null(.)' a MATLAB error: reported
+                const double s2 = defB ? svB[1] : svA[1], s1 = defB ? svB[0] : svA[0];
+                deficient = !(s2 > 3.0 * eps_of(s1) * s1) ? 1 : 0;
+            }
+        }
+        double r3[3], s3[3];
+        matvec(mat3_inv(A), a, r3);                                          // r = A\a   (:65)
+        matvec(mat3_inv(B), b, s3);                                          // s = B\b   (:66)
+        Mat3 Xr, Xa, Xb, M0;
+        double t1[3], t2[3], t3[3];
+        crossm(r3, Xr); crossm(a, Xa); crossm(b, Xb);
+        // U = [r, crossM(r)^2 s, crossM(r) s]   (:68)
+        matvec(Xr, s3, t1); matvec(Xr, t1, t2);
+        for (int i = 0; i < 3; ++i) { M0.m[i][0] = r3[i]; M0.m[i][1] = t2[i]; M0.m[i][2] = t1[i]; }
+        const Mat3 Um = orthogonalise(M0);
+        // V = [a, crossM(a) A s, crossM(a)^2 A s]   (:69)
+        matvec(A, s3, t3); matvec(Xa, t3, t1); matvec(Xa, t1, t2);
+        for (int i = 0; i < 3; ++i) { M0.m[i][0] = a[i]; M0.m[i][1] = t1[i]; M0.m[i][2] = t2[i]; }
+        const Mat3 Vm = orthogonalise(M0);
+        // W = [b, crossM(b) B r, crossM(b)^2 B r]   (:70)
+        matvec(B, r3, t3); matvec(Xb, t3, t1); matvec(Xb, t1, t2);
+        for (int i = 0; i < 3; ++i) { M0.m[i][0] = b[i]; M0.m[i][1] = t1[i]; M0.m[i][2] = t2[i]; }
+        const Mat3 Wm = orthogonalise(M0);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { rot[3 * i + j] = Um.m[i][j]; rot[9 + 3 * i + j] = Vm.m[i][j]; rot[18 + 3 * i + j] = Wm.m[i][j]; }
+        axis_angle(Um, p9 + 0);                                              // :73-78, :94
+        axis_angle(Vm, p9 + 3);
+        axis_angle(Wm, p9 + 6);
+        *deficient_out = deficient;
+    }
+
     __device__ inline void init(PoseLds* w, GhWork& g) {
         const int lane = lane_id();
         gh_linear_cameras(w);
         double* rot = g.V;                                                   // scratch: U, V, W row-major (27)
         bad = 0;
-        if (lane == 0) {
-            Mat3 A, B;
-            double a[3], b[3];
-            for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) { A.m[r][c] = w->P[0][4 * r + c]; B.m[r][c] = w->P[1][4 * r + c]; } a[r] = w->P[0][4 * r + 3]; b[r] = w->P[1][4 * r + 3]; }
-            // H = eye(4); H(4,1:3) = null(P3(:,1:3))' if rank(P3(:,1:3)) < 3, else the same with P2   (:56-62).
-            // rank(X) < 3 <=> sigma_3 <= 3 eps(sigma_1), with sigma_3 = |det X| / (sigma_1 sigma_2) (the squared-matrix
-            // Jacobi of svd3 cannot resolve a singular value that small).  P*H = [P(:,1:3) + P(:,4) n', P(:,4)]; P1*H = P1.
+        if (pre) {                                                           // k_nordberg_init has run
+            if (lane < 12) { w->P[0][lane] = pre[lane]; w->P[1][lane] = pre[12 + lane]; }
+            if (lane < 27) rot[lane] = pre[24 + lane];
+            if (lane < 9) g.p[lane] = pre[51 + lane];
+            if (lane == 0) rot[27] = pre[60];
+        } else if (lane == 0) {
             int deficient = 0;
-            {
-                Mat3 Us, Vs;
-                double svB[3], svA[3];
-                svd3(B, Us, Vs, svB);
-                const bool defB = !(fabs(mat3_det(B)) > 3.0 * eps_of(svB[0]) * svB[0] * svB[1]);
-                svd3(A, Us, Vs, svA);
-                const bool defA = !(fabs(mat3_det(A)) > 3.0 * eps_of(svA[0]) * svA[0] * svA[1]);
-                if (defB || defA) {
-                    double nv[3];
-                    null3(defB ? B : A, nv);
-                    for (int r = 0; r < 3; ++r)
-                        for (int c = 0; c < 3; ++c) { A.m[r][c] += a[r] * nv[c]; B.m[r][c] += b[r] * nv[c]; }
-                    for (int r = 0; r < 3; ++r)
-                        for (int c = 0; c < 3; ++c) { w->P[0][4 * r + c] = A.m[r][c]; w->P[1][4 * r + c] = B.m[r][c]; }
-                    // a null space of dimension > 1 makes H(4,1:3) = null(.)' a MATLAB error: reported
-                    const double s2 = defB ? svB[1] : svA[1], s1 = defB ? svB[0] : svA[0];
-                    deficient = !(s2 > 3.0 * eps_of(s1) * s1) ? 1 : 0;
-                }
-            }
-            double r3[3], s3[3];
-            matvec(mat3_inv(A), a, r3);                                      // r = A\a   (:65)
-            matvec(mat3_inv(B), b, s3);                                      // s = B\b   (:66)
-            Mat3 Xr, Xa, Xb, M0;
-            double t1[3], t2[3], t3[3];
-            crossm(r3, Xr); crossm(a, Xa); crossm(b, Xb);
-            // U = [r, crossM(r)^2 s, crossM(r) s]   (:68)
-            matvec(Xr, s3, t1); matvec(Xr, t1, t2);
-            for (int i = 0; i < 3; ++i) { M0.m[i][0] = r3[i]; M0.m[i][1] = t2[i]; M0.m[i][2] = t1[i]; }
-            const Mat3 Um = orthogonalise(M0);
-            // V = [a, crossM(a) A s, crossM(a)^2 A s]   (:69)
-            matvec(A, s3, t3); matvec(Xa, t3, t1); matvec(Xa, t1, t2);
-            for (int i = 0; i < 3; ++i) { M0.m[i][0] = a[i]; M0.m[i][1] = t1[i]; M0.m[i][2] = t2[i]; }
-            const Mat3 Vm = orthogonalise(M0);
-            // W = [b, crossM(b) B r, crossM(b)^2 B r]   (:70)
-            matvec(B, r3, t3); matvec(Xb, t3, t1); matvec(Xb, t1, t2);
-            for (int i = 0; i < 3; ++i) { M0.m[i][0] = b[i]; M0.m[i][1] = t1[i]; M0.m[i][2] = t2[i]; }
-            const Mat3 Wm = orthogonalise(M0);
-            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { rot[3 * i + j] = Um.m[i][j]; rot[9 + 3 * i + j] = Vm.m[i][j]; rot[18 + 3 * i + j] = Wm.m[i][j]; }
-            axis_angle(Um, g.p + 0);                                         // :73-78, :94
-            axis_angle(Vm, g.p + 3);
-            axis_angle(Wm, g.p + 6);
+            init_serial(w->P[0], w->P[1], rot, g.p, &deficient);
             rot[27] = (double)deficient;
         }
         wave_sync();

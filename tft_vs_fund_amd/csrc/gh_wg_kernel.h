@@ -84,6 +84,7 @@ struct GhWgArgs {
     double* topt;            // B x 27 (k_gh_block out, k_gh_finish in): optimised tensor in the normalised frame
     double* Rt2; double* Rt3; double* T; double* reconst; int* iter; int* status; double* dbg;
     double* spill; long spill_stride;   // see LinearTftArgs
+    double* init_rec;        // B x Model::PRE_DOUBLES (k_nordberg_init out, k_gh_block<NordbergModel> in) or null
 };
 
 template <bool JAC>
@@ -117,6 +118,36 @@ __global__ void __launch_bounds__(64, 2) k_gh_linear(const GhWgArgs a) {
         }
         if (lane == 0) { a.status[b] = status; if (a.iter) a.iter[b] = 0; }
     }
+}
+
+// Models whose initial parameters have a serial part that runs ahead of the block kernel, one triplet per LANE (NordbergModel::init_serial)
+template <class M, class = void> struct gh_has_preinit { static constexpr bool value = false; };
+template <class M> struct gh_has_preinit<M, decltype((void)M::PREINIT)> { static constexpr bool value = M::PREINIT; };
+
+// NordbergTFTPoseEstimation.m:56-78 for 64 triplets per wavefront, one per lane: cameras of the linear solution (record of k_gh_linear) ->
+// P2, P3 after the projective fix-up | U, V, W | their axis-angle vectors | deficient flag.  The block kernel's owner wavefront used to run
+// this on its lane 0 (58 k cycles per triplet, 255 threads waiting: an eighth of the method's time).
+__global__ void __launch_bounds__(64) k_nordberg_init(const GhWgArgs a) {
+    const long b = (long)blockIdx.x * WAVE + lane_id();
+    if (b >= a.B || a.status[b] != ST_OK) return;
+    const double* r = a.rec + b * GH_REC_DOUBLES;
+    double P2[12], P3[12], rot[27], p9[9];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {                                           // gh_linear_cameras: P2 = [reshape(a(1:9),3,3) e21], P3 = [reshape(a(10:18),3,3) e31]
+        const int rr = e >> 2, c = e & 3;
+        P2[e] = (c < 3) ? r[27 + 3 * c + rr] : r[45 + rr];
+        P3[e] = (c < 3) ? r[27 + 9 + 3 * c + rr] : r[45 + 3 + rr];
+    }
+    int deficient = 0;
+    NordbergModel::init_serial(P2, P3, rot, p9, &deficient);
+    double* o = a.init_rec + b * NordbergModel::PRE_DOUBLES;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) { o[e] = P2[e]; o[12 + e] = P3[e]; }
+#pragma unroll
+    for (int e = 0; e < 27; ++e) o[24 + e] = rot[e];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) o[51 + e] = p9[e];
+    o[60] = (double)deficient;
 }
 
 // ---- block-level helpers (256 threads) -------------------------------------------------------------------------------
@@ -566,6 +597,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::WG_PER_CU) k_gh_block(co
         if (tid < 9) w->nrm[tid] = r[51 + tid];
         __syncthreads();
         Model model;
+        if constexpr (gh_has_preinit<Model>::value) model.pre = a.init_rec ? a.init_rec + b * Model::PRE_DOUBLES : nullptr;
         double* sdbg = (a.dbg && wave == own) ? a.dbg + b * DBG_STRIDE : nullptr;
         phase_stamp(sdbg, 36);
         if (wave == own) {                                                   // initial parameters; cameras P1, P2, P3 of the linear solution
