@@ -75,10 +75,10 @@ typedef struct tff_ctx tff_ctx;
                              * reproduce a 50-digit evaluation of the reference's iteration to 1e-11 for Ressl, Nordberg and Pi) */
 #define TFF_OPT_SPILL 6     /* per-correspondence state of the iterative methods: 0 (default) it leaves the LDS for the context's global slices whenever that lets
                              * more workgroups share a CU (measured faster, at the price of HBM traffic); 1 = only when the LDS cannot hold it (large N) */
-#define TFF_OPT_KERNEL 3    /* Kernel variants of the iterative TFT methods: 0 automatic (default: a 4-wavefront workgroup per triplet for the iteration,
-                             * the fused single-wavefront kernel below the measured crossover: N < 80 for Ressl, N < 72 for Nordberg, N < 128 for Pi);
-                             * 1 fused kernel always;
-                             * 2 workgroup kernels always */
+#define TFF_OPT_KERNEL 3    /* Kernel variants of the iterative TFT methods: 0 automatic (default: a workgroup per triplet for the iteration -- two wavefronts
+                             * for Ressl / Nordberg / Pi / PiCol, four for FaugPapa -- at every N since round 4);
+                             * 1 the fused single-wavefront kernels (one wavefront per triplet from start to end);
+                             * 2 workgroup kernels always (the same as 0 now) */
 #define TFF_OPT_ROWS 7      /* LinearTFT / LinearF pose kernels and the linear stage of the iterative TFT methods: 1 four triplets per wavefront,
                              * one per row of 16 lanes (csrc/tft_rows_kernel.h, f_rows_kernel.h, gh_rows_kernel.h); 0 one triplet per wavefront
                              * (csrc/tft_kernel.h, f_kernel.h); 2 (default) by batch size: the row kernels (2.5x fewer instructions per triplet) once

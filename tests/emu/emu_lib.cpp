@@ -192,7 +192,7 @@ extern "C" int emu_pi_pose_debug(int collinear, const double* corresp, const dou
 }
 // Gauss-Helmert methods through the three-launch workgroup path (gh_wg_kernel.h): model 0 Ressl, 1 Nordberg, 2 FaugPapa
 template <class KBlock>
-static int emu_wg_run(KBlock kblock, size_t lds_block, const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
+static int emu_wg_run(KBlock kblock, int block_threads, size_t lds_block, const double* corresp, const double* calm, long calm_stride, long B, int N, int flags,
                       double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status) {
     std::vector<double> rec((size_t)B * tff::GH_REC_DOUBLES), topt((size_t)B * 27);
     tff::GhWgArgs a{corresp, calm, calm_stride, B, N, (flags & ~tff::FLAG_JACOBI) | (reconst ? tff::FLAG_RECONST : 0), rec.data(), topt.data(),
@@ -201,7 +201,7 @@ static int emu_wg_run(KBlock kblock, size_t lds_block, const double* corresp, co
     tff::GhWgArgs m = a;
     m.flags |= tff::FLAG_ONLY_RETRY;
     emu::launch(tff::k_gh_linear<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
-    emu::launch(kblock, emu_grid(B), tff::GH_WG_THREADS, lds_block, a);
+    emu::launch(kblock, emu_grid(B), block_threads, lds_block, a);
     if (N >= 12) emu::launch(tff::k_gh_finish_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);     // (as the C ABI)
     else emu::launch(tff::k_gh_finish, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
     return 0;
@@ -211,9 +211,9 @@ extern "C" int emu_pi_wg_pose(int collinear, const double* corresp, const double
                               double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status) {
     const size_t pre = (size_t)((tff::POSE_LDS_DOUBLES + 1) & ~1);
     if (collinear)
-        return emu_wg_run(tff::k_pi_block<tff::PiColModel>, (pre + tff::pi_wg_lds_doubles(tff::PiColModel::E, tff::PiColModel::C, N)) * sizeof(double),
+        return emu_wg_run(tff::k_pi_block<tff::PiColModel>, tff::pi_wg_waves<tff::PiColModel>::value * tff::WAVE, (pre + tff::pi_wg_lds_doubles(tff::PiColModel::E, tff::PiColModel::C, N)) * sizeof(double),
                           corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status);
-    return emu_wg_run(tff::k_pi_block<tff::PiModel>, (pre + tff::pi_wg_lds_doubles(tff::PiModel::E, tff::PiModel::C, N)) * sizeof(double),
+    return emu_wg_run(tff::k_pi_block<tff::PiModel>, tff::pi_wg_waves<tff::PiModel>::value * tff::WAVE, (pre + tff::pi_wg_lds_doubles(tff::PiModel::E, tff::PiModel::C, N)) * sizeof(double),
                       corresp, calm, calm_stride, B, N, flags, Rt2, Rt3, T, reconst, iter, status);
 }
 template <class Model>
@@ -233,7 +233,7 @@ static int emu_gh_wg_impl(const double* corresp, const double* calm, long calm_s
         a.init_rec = pre.data();
         emu::launch(tff::k_nordberg_init, (unsigned)((B + 63) / 64), 64, 0, a);
     }
-    emu::launch(tff::k_gh_block<Model>, emu_grid(B), tff::GH_WG_THREADS, lds, a);
+    emu::launch(tff::k_gh_block<Model>, emu_grid(B), tff::gh_wg_waves<Model>::value * tff::WAVE, lds, a);
     if (N >= 12) emu::launch(tff::k_gh_finish_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);     // (as the C ABI)
     else emu::launch(tff::k_gh_finish, emu_grid(B), 64, tff::pose_lds_bytes(N, 0, false), a);
     return 0;

@@ -300,7 +300,7 @@ int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_
 template <class KBlock, class LdsFn>
 int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg, bool fp_first = false,
-              bool rows_linear = true, bool nordberg_pre = false) {
+              bool rows_linear = true, bool nordberg_pre = false, int block_threads = tff::GH_WG_THREADS) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     TFF_LOCK(c);
     if (B == 0) return 0;
@@ -361,7 +361,7 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
         size_t lds;
         if (int r = plan_spill(c, wg_lds(N), wg_lds(0), &grid, &m.spill, &m.spill_stride, &lds, occupancy_cap)) return r;
         if (int r = ensure_lds(kblock, lds)) return r;
-        hipLaunchKernelGGL(kblock, dim3(grid), dim3(tff::GH_WG_THREADS), lds, c->stream, m);
+        hipLaunchKernelGGL(kblock, dim3(grid), dim3(block_threads), lds, c->stream, m);
         TFF_HIP(hipGetLastError());
     }
     if (rows_linear && N >= 12 && rows_for(c, B, N)) {                                 // four triplets per wavefront (gh_rows_kernel.h); minimal samples: the one-triplet kernel's ladder
@@ -379,11 +379,11 @@ template <class Model, class KFused, class KFusedJac>
 int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     // Both kernels evaluate the weights in the factored form that reproduces the 50-digit iteration (tests/test_gpu_gh_noise.py runs
-    // each of them on every fixture).  Small N: the fused single-wavefront kernel wins while a workgroup of 256 threads idles on a few
-    // correspondences -- measured (tools/time_methods.py, 10 k triplets): Ressl 2.41 vs 2.69 ms at N = 12, 2.91 vs 2.75 ms at N = 100;
-    // Nordberg 3.22 vs 3.47 ms at N = 12, 4.15 vs 3.50 ms at N = 100; FaugPapa's eigen-decomposition wants the workgroup.
-    const int crossover = std::is_same<Model, tff::ResslModel>::value ? 80 : (std::is_same<Model, tff::NordbergModel>::value ? 72 : 0);
-    const bool small = N < crossover && c->kernel_variant == 0 && c->solver == 0 && !dbg;
+    // each of them on every fixture).  Until round 4 the fused single-wavefront kernel won below N = 80 (Ressl) / 72 (Nordberg): a workgroup of 256
+    // threads idled on a few correspondences.  With TWO wavefronts per workgroup and four workgroups per CU (gh_wg_kernel.h::gh_wg_waves) the
+    // workgroup path wins at every N -- tools/ab_wg_fused.py, 10 k triplets, workgroup / fused: Ressl 1.62 / 2.33 ms at N = 12, 1.58 / 2.34 at 60,
+    // 1.77 / 2.85 at 100; Nordberg 2.00 / 2.96, 1.94 / 2.92, 2.10 / 3.74 -- so the fused kernels remain as TFF_OPT_KERNEL = 1 only.
+    const bool small = false;
     if (c->kernel_variant == 1 || small)                                     // TFF_OPT_SOLVER = 1 is honoured by launch_wg's linear stage
         return launch_pose(c, kfused, kfused_jac, tff::gh_lds_bytes<Model>, 0, std::is_same<Model, tff::ResslModel>::value ? 8 : 4, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::gh_wg_lds_doubles(Model::U, Model::C, n, Model::REDUNDANT_CONSTRAINTS)) * sizeof(double); };
@@ -392,16 +392,19 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
     // occupancy policy of the per-correspondence state (plan_spill): Nordberg runs as fast with it in LDS at two workgroups per CU as with it in global
     // slices at three (3.89 vs 3.87 ms per 10 k x 200) -- without the state's HBM round trips (what is left of its 52x algorithmic traffic is scratch:
     // the 168-register build spills 368 registers, and is still faster than the 256-register one, 3.69 vs 3.90 ms)
-    const int occupancy_cap = std::is_same<Model, tff::NordbergModel>::value ? 2 : Model::WG_PER_CU;
+    // (round 4: Ressl and Nordberg run two wavefronts per workgroup, four workgroups per CU at 256 registers -- gh_wg_kernel.h::gh_wg_waves)
+    const int occupancy_cap = tff::gh_wg_per_cu<Model>::value;
     return launch_wg(c, tff::k_gh_block<Model>, wg_lds, occupancy_cap, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg, fp_first, true,
-                     std::is_same<Model, tff::NordbergModel>::value);
+                     std::is_same<Model, tff::NordbergModel>::value, tff::gh_wg_waves<Model>::value * tff::WAVE);
 }
 template <class Model>
 int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                     double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     // Pi: both kernels carry the factored weights; the fused one wins below N ~ 130 (2.49 vs 3.6 ms at N = 12 .. 64, 3.04 vs 3.54 ms at
     // N = 100, 3.73 vs 3.70 ms at N = 140; tools/time_methods.py)
-    const bool small = !Model::PINV_KKT && N < 128 && c->kernel_variant == 0;
+    // (round 4: the two-wavefront workgroups of pi_wg_kernel.h win at every N -- Pi 2.12 / 2.42 ms at N = 12, 2.09 / 2.35 at 60, 2.28 / 3.04 at 100,
+    // workgroup / fused, tools/ab_wg_fused.py; before, the fused kernel won below N = 128)
+    const bool small = false;
     if (c->kernel_variant == 1 || c->solver != 0 || c->init_p || small)      // the debug outputs (init_p, init_x) come from the fused kernel
         return launch_pose(c, tff::k_pi_tft_pose<Model, false>, tff::k_pi_tft_pose<Model, true>, tff::pi_lds_bytes<Model>, 0, 4,
                            corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
@@ -409,8 +412,8 @@ int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64
     // PiCol keeps the one-triplet-per-wavefront linear stage: its scenes that take seven Gauss-Helmert iterations amplify a last-bit difference
     // of the start a million times (tools/diag_gh_noise_picol.py: 3.3e-10 from the 50-digit iteration with this start, 2.5e-9 with the rows
     // kernel's on the same N = 60 scene -- both draws of the same rounding noise, one of them over the 1e-9 gate of tests/test_gpu_gh_noise.py)
-    return launch_wg(c, tff::k_pi_block<Model>, wg_lds, Model::PINV_KKT ? 4 : 2, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg,
-                     false, !Model::PINV_KKT);
+    return launch_wg(c, tff::k_pi_block<Model>, wg_lds, 4, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg,
+                     false, !Model::PINV_KKT, false, tff::pi_wg_waves<Model>::value * tff::WAVE);
 }
 int launch_ressl_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {

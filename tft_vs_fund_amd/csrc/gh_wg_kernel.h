@@ -151,23 +151,33 @@ __global__ void __launch_bounds__(64) k_nordberg_init(const GhWgArgs a) {
 }
 
 // ---- block-level helpers (256 threads) -------------------------------------------------------------------------------
-__device__ __forceinline__ double block_sum(double v, double* red) {
+// (WV: wavefronts of the workgroup -- four everywhere but in k_pi_block<PiColModel>, which runs two per triplet so that four workgroups per CU
+// leave each thread 256 registers)
+template <int WV>
+__device__ __forceinline__ double block_sum_w(double v, double* red) {
+    static_assert(WV == 4 || WV == 2, "two or four wavefronts");
     v = wave_sum(v);
     if (lane_id() == 0) red[wave_in_block()] = v;
     __syncthreads();
-    const double r = (red[0] + red[1]) + (red[2] + red[3]);
+    const double r = (WV == 4) ? (red[0] + red[1]) + (red[2] + red[3]) : red[0] + red[1];
     __syncthreads();
     return r;
 }
-__device__ __forceinline__ double block_max(double v, double* red) {
+template <int WV>
+__device__ __forceinline__ double block_max_w(double v, double* red) {
     v = wave_max(v);
     if (lane_id() == 0) red[wave_in_block()] = v;
     __syncthreads();
-    const double a = (red[0] > red[1]) ? red[0] : red[1], b = (red[2] > red[3]) ? red[2] : red[3];
+    const double a = (red[0] > red[1]) ? red[0] : red[1];
+    double r = a;
+    if constexpr (WV == 4) { const double b = (red[2] > red[3]) ? red[2] : red[3]; r = (a > b) ? a : b; }
     __syncthreads();
-    return (a > b) ? a : b;
+    return r;
 }
-__device__ __forceinline__ bool block_any(bool p, double* red) { return block_sum(p ? 1.0 : 0.0, red) != 0.0; }
+template <int WV> __device__ __forceinline__ bool block_any_w(bool p, double* red) { return block_sum_w<WV>(p ? 1.0 : 0.0, red) != 0.0; }
+__device__ __forceinline__ double block_sum(double v, double* red) { return block_sum_w<GH_WG_WAVES>(v, red); }
+__device__ __forceinline__ double block_max(double v, double* red) { return block_max_w<GH_WG_WAVES>(v, red); }
+__device__ __forceinline__ bool block_any(bool p, double* red) { return block_any_w<GH_WG_WAVES>(p, red); }
 
 // The wavefront of the workgroup that runs the wave-serial steps (parameter Jacobian, KKT solve, pseudo-inverse).  The workgroups that
 // share a CU should run theirs on DIFFERENT SIMDs.  `blockIdx & 3` does not achieve that: consecutive workgroups go round-robin over the
@@ -175,17 +185,19 @@ __device__ __forceinline__ bool block_any(bool p, double* red) { return block_su
 // dealt to the SIMDs in order) the same SIMD -- four serial waves time-slicing one SIMD while three idle, measured as ~30 cycles per
 // instruction in those steps.  The hardware knows better: the workgroup's slot number on its CU picks the SIMD, the wave that actually
 // runs there takes the job.  red: 4 doubles of scratch at red[12 ..].
-__device__ inline int pick_serial_wave(double* red) {
+template <int WV>
+__device__ inline int pick_serial_wave_w(double* red) {
     if (lane_id() == 0) red[12 + wave_in_block()] = (double)hw_simd_id();
     __syncthreads();
-    const int target = hw_workgroup_slot() & (GH_WG_WAVES - 1);
+    const int target = hw_workgroup_slot() & 3;                              // the SIMD this workgroup's serial steps should run on
     int own = -1;
 #pragma unroll
-    for (int w = GH_WG_WAVES - 1; w >= 0; --w) own = ((int)red[12 + w] == target) ? w : own;
-    own = (own < 0) ? target : own;                                          // no wave of this workgroup on that SIMD
+    for (int w = WV - 1; w >= 0; --w) own = ((int)red[12 + w] == target) ? w : own;
+    own = (own < 0) ? (target & (WV - 1)) : own;                             // no wave of this workgroup on that SIMD
     __syncthreads();
     return wave_uniform_i(own);
 }
+__device__ inline int pick_serial_wave(double* red) { return pick_serial_wave_w<GH_WG_WAVES>(red); }
 
 // x = pinv(M) b through the eigen-decomposition (wave_pinv_solve_sym) on the wavefront `own` of the workgroup; the others wait.
 // (A workgroup-parallel cyclic Jacobi was measured here first: 11 sweeps x 39 rounds x 2 barriers on the 39 x 39 matrix, 1.5 ms per
@@ -235,13 +247,14 @@ __device__ inline void gh_sweep_part(const GhWork& g, double* Hp, int N, const d
 }
 
 // x_est: reprojection of the projective triangulation with P1 (Pfin[0]), P2 (P[0]), P3 (P[1])   (ResslTFT...m:72-75)
+template <int WV = GH_WG_WAVES>
 __device__ inline void gh_block_reproject(PoseLds* w, const double* pts, int N, double* xi) {
     double PA[12], PB[12], PC[12];
     load_uniform12(w->Pfin[0], PA);
     load_uniform12(w->P[0], PB);
     load_uniform12(w->P[1], PC);
 #pragma unroll 1
-    for (int i = thread_in_block(); i < N; i += GH_WG_THREADS) {
+    for (int i = thread_in_block(); i < N; i += WV * WAVE) {
         const Pt6 p = premap(load_pt(pts, i), w->nrm);
         double X[4];
         dlt_point<true>(PA, PB, PC, w->Pfin[0], w->P[0], w->P[1], true, p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], p.v[5], X);
@@ -258,20 +271,21 @@ __device__ inline void gh_block_reproject(PoseLds* w, const double* pts, int N, 
 }
 
 // Gauss_Helmert.m:38-83, one workgroup per problem.  `own`: the wavefront that runs the wave-serial steps.
-template <class Model>
+template <class Model, int WV>
 __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Model& model, int own, const double* pts, int N,
                                           int* st, bool exact_pinv, double* dbg) {
     const int tid = thread_in_block(), lane = lane_id(), wave = wave_in_block();
+    constexpr int THREADS = WV * WAVE;
     constexpr int u = Model::U, c = Model::C, n = u + c, ld = n + 1;
     const bool owner = wave == own;
     double* sdbg = owner ? dbg : nullptr;                                    // phase stamps of the first iteration (debug entry point)
     double objFunc = 0.0;                                                    // v0' v0, v0 = x0 - x   (:45-46)
-    for (int i = tid; i < N; i += GH_WG_THREADS) {
+    for (int i = tid; i < N; i += THREADS) {
         const Pt6 x = premap(load_pt(pts, i), w->nrm);
 #pragma unroll
         for (int k = 0; k < 6; ++k) { const double d = g.xi[GH_XI * i + k] - x.v[k]; objFunc += d * d; }
     }
-    objFunc = block_sum(objFunc, red);
+    objFunc = block_sum_w<WV>(objFunc, red);
     int it = 0;
 #pragma unroll 1
     for (it = 1; it <= GH_IT_MAX; ++it) {
@@ -284,7 +298,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         // ---- W = B B' (:52): finite check, bound on the largest eigenvalue; see gh_kernel.h for the two pinv paths ----
         double f2max = 0.0;                                                  // max_i |W_i|_F^2
         bool finite = true;
-        for (int i = tid; i < N; i += GH_WG_THREADS) {
+        for (int i = tid; i < N; i += THREADS) {
             double o[6], f[4], B[4][6], W[4][4];
 #pragma unroll
             for (int k = 0; k < 6; ++k) o[k] = g.xi[GH_XI * i + k];
@@ -299,8 +313,8 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
             finite = finite && (fabs(chk) <= 1.79e308);
             f2max = (fro2 > f2max) ? fro2 : f2max;
         }
-        f2max = block_max(f2max, red);
-        if (block_any(!finite, red) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
+        f2max = block_max_w<WV>(f2max, red);
+        if (block_any_w<WV>(!finite, red) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
         // blocks in the deflated form (gh_kernel.h, pinv_block_deflated); pinv's tolerance is needed only when it can truncate
         const bool may_truncate = !(4.0 * (double)N * eps_of(sqrt(f2max)) < 0.9e-12);
         if (it == 1) phase_stamp(sdbg, 42);
@@ -315,7 +329,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
                 // pinv's tolerance 4N eps(max_i lambda_max(W_i)) needs only the binade of that maximum: when cheap bounds agree on it,
                 // the eigenvalue pass that would find the maximum is skipped
                 double umax = 0.0, lmax = 0.0;                               // upper / lower bound on max_i lambda_max(W_i)
-                for (int i = tid; i < N; i += GH_WG_THREADS) {
+                for (int i = tid; i < N; i += THREADS) {
                     double o[6], f[4], B[4][6], W[4][4];
 #pragma unroll
                     for (int k = 0; k < 6; ++k) o[k] = g.xi[GH_XI * i + k];
@@ -326,12 +340,12 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
                     umax = (up > umax) ? up : umax;
                     lmax = (lo > lmax) ? lo : lmax;
                 }
-                umax = block_max(umax, red);
-                lmax = block_max(lmax, red);
+                umax = block_max_w<WV>(umax, red);
+                lmax = block_max_w<WV>(lmax, red);
                 double smax = umax;
                 if (eps_of(lmax) != eps_of(umax)) {
                     smax = 0.0;
-                    for (int i = tid; i < N; i += GH_WG_THREADS) {
+                    for (int i = tid; i < N; i += THREADS) {
                         double o[6], f[4], B[4][6], W[4][4], V[4][4];
 #pragma unroll
                         for (int k = 0; k < 6; ++k) o[k] = g.xi[GH_XI * i + k];
@@ -341,7 +355,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
 #pragma unroll
                         for (int a = 0; a < 4; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
                     }
-                    smax = block_max(smax, red);
+                    smax = block_max_w<WV>(smax, red);
                 }
                 tolW = 4.0 * (double)N * eps_of(smax);
                 have_tol = true;
@@ -351,11 +365,11 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
                 constexpr int SLOT = (Model::U * (Model::U + 1) / 2 + Model::U + 1) & ~1;
                 double* slot = nullptr;
                 if (want_factored) {                                         // per-wavefront partial sums of the strong-direction terms
-                    slot = (wave < 3) ? g.G + wave * SLOT : g.S;             // Ghat's slot is not yet in use; 3 SLOT <= 729
+                    slot = (wave < WV - 1) ? g.G + wave * SLOT : g.S;        // Ghat's slot is not yet in use; 3 SLOT <= 729
                     for (int e = lane; e < SLOT; e += WAVE) slot[e] = 0.0;
                 }
 #pragma unroll 1
-                for (int base = 0; base < N; base += GH_WG_THREADS) {        // block-uniform trip count (the butterflies need whole wavefronts)
+                for (int base = 0; base < N; base += THREADS) {        // block-uniform trip count (the butterflies need whole wavefronts)
                     const int i = base + tid;
                     double bv[Model::U], tv = 0.0;
 #pragma unroll
@@ -394,14 +408,14 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
                 if (want_factored) {
                     __syncthreads();
                     constexpr int total = Model::U * (Model::U + 1) / 2 + Model::U;
-                    if (tid < total) g.S[tid] = (g.G[tid] + g.G[SLOT + tid]) + (g.G[2 * SLOT + tid] + g.S[tid]);
-                    if (tid + GH_WG_THREADS < total) g.S[tid + GH_WG_THREADS] = (g.G[tid + GH_WG_THREADS] + g.G[SLOT + tid + GH_WG_THREADS]) + (g.G[2 * SLOT + tid + GH_WG_THREADS] + g.S[tid + GH_WG_THREADS]);
+                    for (int e = tid; e < total; e += THREADS)
+                        g.S[e] = (WV == 4) ? (g.G[e] + g.G[SLOT + e]) + (g.G[2 * SLOT + e] + g.S[e]) : g.G[e] + g.S[e];
                 }
-                if (!block_any(bad, red)) { factored = want_factored; break; }
+                if (!block_any_w<WV>(bad, red)) { factored = want_factored; break; }
                 jacobi = true;                                               // a block without the structure: eigen-decompositions for all
                 continue;
             }
-            for (int i = tid; i < N; i += GH_WG_THREADS) {
+            for (int i = tid; i < N; i += THREADS) {
                 double o[6], f[4], B[4][6], W[4][4], V[4][4];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) o[k] = g.xi[GH_XI * i + k];
@@ -428,13 +442,18 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         //      (4 per lane at N = 200) and ends in one reduce-scatter: a quarter of the reductions of the per-wavefront-partial layout
         //      and no combine step ----
         __syncthreads();                                                     // xi, W+ of every correspondence are in place
-        if (wave == 0) { gh_sweep_part<0>(g, g.H, N, T, w, pts); gh_sweep_part<4>(g, g.H, N, T, w, pts); gh_sweep_part<8>(g, g.H, N, T, w, pts); }
-        else if (wave == 1) { gh_sweep_part<1>(g, g.H, N, T, w, pts); gh_sweep_part<5>(g, g.H, N, T, w, pts); gh_sweep_part<7>(g, g.H, N, T, w, pts); }
-        else if (wave == 2) { gh_sweep_part<2>(g, g.H, N, T, w, pts); gh_sweep_part<6>(g, g.H, N, T, w, pts); }
-        else { gh_sweep_part<3>(g, g.H, N, T, w, pts); gh_sweep_part<9>(g, g.H, N, T, w, pts); }   // 9: the right-hand side, recomputes w
+        if constexpr (WV == 4) {
+            if (wave == 0) { gh_sweep_part<0>(g, g.H, N, T, w, pts); gh_sweep_part<4>(g, g.H, N, T, w, pts); gh_sweep_part<8>(g, g.H, N, T, w, pts); }
+            else if (wave == 1) { gh_sweep_part<1>(g, g.H, N, T, w, pts); gh_sweep_part<5>(g, g.H, N, T, w, pts); gh_sweep_part<7>(g, g.H, N, T, w, pts); }
+            else if (wave == 2) { gh_sweep_part<2>(g, g.H, N, T, w, pts); gh_sweep_part<6>(g, g.H, N, T, w, pts); }
+            else { gh_sweep_part<3>(g, g.H, N, T, w, pts); gh_sweep_part<9>(g, g.H, N, T, w, pts); }   // 9: the right-hand side, recomputes w
+        } else {                                                             // two wavefronts: five sweeps each
+            if (wave == 0) { gh_sweep_part<0>(g, g.H, N, T, w, pts); gh_sweep_part<4>(g, g.H, N, T, w, pts); gh_sweep_part<8>(g, g.H, N, T, w, pts); gh_sweep_part<2>(g, g.H, N, T, w, pts); gh_sweep_part<6>(g, g.H, N, T, w, pts); }
+            else { gh_sweep_part<1>(g, g.H, N, T, w, pts); gh_sweep_part<5>(g, g.H, N, T, w, pts); gh_sweep_part<7>(g, g.H, N, T, w, pts); gh_sweep_part<3>(g, g.H, N, T, w, pts); gh_sweep_part<9>(g, g.H, N, T, w, pts); }
+        }
         __syncthreads();
         if (it == 1) phase_stamp(sdbg, 44);
-        for (int e = tid; e < 729; e += GH_WG_THREADS) {                     // Ghat[(q,i1),(q',i1')] = H[6 tri(q,q') + hht(i1,i1')]
+        for (int e = tid; e < 729; e += THREADS) {                     // Ghat[(q,i1),(q',i1')] = H[6 tri(q,q') + hht(i1,i1')]
             const int r = e / 27, cc = e % 27;
             const int q = r % 9, i1 = r / 9, qq = cc % 9, i1p = cc / 9;
             const int hi = (q > qq) ? q : qq, lo = (q > qq) ? qq : q;
@@ -442,7 +461,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         }
         __syncthreads();
         if (Model::IDENTITY_D) {                                             // A = Ap: A'WA = Ghat, A'Ww = ghat
-            for (int e = tid; e < 729 + 27; e += GH_WG_THREADS) {
+            for (int e = tid; e < 729 + 27; e += THREADS) {
                 if (e < 729) g.M[(e / 27) * ld + e % 27] = g.G[e] + ((e / 27 == e % 27) ? 1e-12 : 0.0);
                 else g.M[(e - 729) * ld + n] = g.H[270 + e - 729];
             }
@@ -450,14 +469,14 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
             // (Summing over the <= 9 non-zeros per column of Ressl's D instead -- 5 k multiply-adds for the two products, not 25 k -- was
             // measured SLOWER, 14.2 k -> 23.8 k cycles: the index arithmetic and the irregular LDS addresses cost more than the dense,
             // perfectly regular loops save.)
-            for (int e = tid; e < 27 * u; e += GH_WG_THREADS) {              // Y = Ghat D
+            for (int e = tid; e < 27 * u; e += THREADS) {              // Y = Ghat D
                 const int r = e / u, pcol = e % u;
                 double acc = 0.0;
                 for (int k = 0; k < 27; ++k) acc += g.G[r * 27 + k] * g.D[k * u + pcol];
                 g.Y[e] = acc;
             }
             __syncthreads();
-            for (int e = tid; e < u * u + u; e += GH_WG_THREADS) {           // M = [D'Y + 1e-12 I ...], b = [D' ghat; -g]
+            for (int e = tid; e < u * u + u; e += THREADS) {           // M = [D'Y + 1e-12 I ...], b = [D' ghat; -g]
                 const int pr = e / u, pc = e % u;
                 double acc = 0.0;
                 if (e < u * u) {
@@ -474,8 +493,8 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         if (tid < c) g.M[(u + tid) * ld + u + tid] = 1e-12;
         __syncthreads();
         double chkM = 0.0;
-        for (int e = tid; e < n * ld; e += GH_WG_THREADS) chkM += g.M[e];
-        if (!(fabs(block_sum(chkM, red)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
+        for (int e = tid; e < n * ld; e += THREADS) chkM += g.M[e];
+        if (!(fabs(block_sum_w<WV>(chkM, red)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
         if (it == 1) phase_stamp(sdbg, 45);
         // aux = pinv(M + 1e-12 I) * b   (:67): truncated pseudo-inverse by the workgroup, or Gauss-Jordan on the owner wavefront
         if (Model::REDUNDANT_CONSTRAINTS) block_pinv_solve_sym<n>(g.M, g.V, g.dt, g.V + n * n, own);
@@ -509,7 +528,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         if (it == 1) phase_stamp(sdbg, 46);
         // ---- v = -B' W+ (A dt - w)   (:69) ----
         double obj = 0.0, diff = 0.0;
-        for (int i = tid; i < N; i += GH_WG_THREADS) {
+        for (int i = tid; i < N; i += THREADS) {
             double o[6], f[4], B[4][6], Ad[4];
 #pragma unroll
             for (int k = 0; k < 6; ++k) o[k] = g.xi[GH_XI * i + k];
@@ -551,15 +570,15 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
                 diff += d * d;
             }
         }
-        obj = block_sum(obj, red);
-        diff = block_sum(diff, red);
+        obj = block_sum_w<WV>(obj, red);
+        diff = block_sum_w<WV>(diff, red);
         if (it == 1) phase_stamp(sdbg, 47);
         double ndt2 = 0.0;
         for (int k = 0; k < u; ++k) ndt2 += g.dt[k] * g.dt[k];               // same order on every thread
         if (sqrt(ndt2) < GH_TOL && sqrt(diff) < GH_TOL) break;               // :71-73 (dy is empty)
         if (obj > objFunc) break;                                            // :75-76, factor = 1
         objFunc = obj;                                                       // :78
-        for (int i = tid; i < N; i += GH_WG_THREADS) {                       // xi = x + v; ti = ti + dt   (:80)
+        for (int i = tid; i < N; i += THREADS) {                       // xi = x + v; ti = ti + dt   (:80)
             const Pt6 x = premap(load_pt(pts, i), w->nrm);
 #pragma unroll
             for (int k = 0; k < 6; ++k) g.xi[GH_XI * i + k] = x.v[k] + g.pp[GH_PP * i + k];
@@ -571,8 +590,14 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
     return (it > GH_IT_MAX) ? GH_IT_MAX : it;                                // :82
 }
 
+// Wavefronts per workgroup (round 4): TWO for the models whose KKT system is solved by pivoted elimination on one wavefront (Ressl, Nordberg) --
+// four workgroups per CU at 256 registers per thread instead of two (Ressl) or three with 200 registers spilled (Nordberg): what overlaps the
+// wave-serial steps is the number of workgroups per CU (pi_wg_kernel.h).  Four for FaugPapa's generic kernel (the fall-back of gh_fp_kernel.h).
+template <class Model> struct gh_wg_waves { static constexpr int value = Model::REDUNDANT_CONSTRAINTS ? 4 : 2; };
+template <class Model> struct gh_wg_per_cu { static constexpr int value = Model::REDUNDANT_CONSTRAINTS ? Model::WG_PER_CU : 4; };
 template <class Model>
-__global__ void __launch_bounds__(GH_WG_THREADS, Model::WG_PER_CU) k_gh_block(const GhWgArgs a) {
+__global__ void __launch_bounds__(gh_wg_waves<Model>::value * WAVE, gh_wg_per_cu<Model>::value * gh_wg_waves<Model>::value / 4) k_gh_block(const GhWgArgs a) {   // (second argument: wavefronts per SIMD)
+    constexpr int WV = gh_wg_waves<Model>::value;
     static_assert(!Model::REDUNDANT_CONSTRAINTS || (Model::IDENTITY_D && 2 * 27 * Model::U + 298 >= (Model::U + Model::C) * (Model::U + Model::C + 2)),
                   "pseudo-inverse workspace must fit D | H | Y");
     TFF_DYNAMIC_LDS(double, smem);
@@ -589,7 +614,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::WG_PER_CU) k_gh_block(co
         double* red;
         GhWork g = gh_wg_carve(ghbase, w, Model::U, Model::C, a.spill ? 0 : N, Model::REDUNDANT_CONSTRAINTS, &red);
         if (a.spill) { g.xi = a.spill + blockIdx.x * a.spill_stride; g.pp = g.xi + GH_XI * (long)N; }
-        const int own = pick_serial_wave(red);
+        const int own = pick_serial_wave_w<WV>(red);
         const double* r = a.rec + b * GH_REC_DOUBLES;
         if (tid < 27) w->t[tid] = r[tid];
         if (tid < 18) w->pa[tid] = r[27 + tid];
@@ -607,11 +632,11 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::WG_PER_CU) k_gh_block(co
         __syncthreads();
         if (wave != own) model.adopt(red + 10);
         phase_stamp(sdbg, 37);
-        gh_block_reproject(w, pts, N, g.xi);
+        gh_block_reproject<WV>(w, pts, N, g.xi);
         __syncthreads();
         phase_stamp(sdbg, 38);
         int gst = ST_OK;
-        const int iters = gauss_helmert_block<Model>(w, g, red, model, own, pts, N, &gst, (a.flags & FLAG_GH_EXACT) != 0,
+        const int iters = gauss_helmert_block<Model, WV>(w, g, red, model, own, pts, N, &gst, (a.flags & FLAG_GH_EXACT) != 0,
                                                        a.dbg ? a.dbg + b * DBG_STRIDE : nullptr);
         phase_stamp(sdbg, 39);
         if (wave == own) {

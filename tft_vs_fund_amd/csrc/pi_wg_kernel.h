@@ -90,11 +90,12 @@ __device__ __forceinline__ bool pinv_block_deflated2(const double (&B)[E][6], co
 
 // pinv's tolerance E N eps(max_i lambda_max(W_i)) for the block-diagonal weight matrix (Gauss_Helmert.m:57).  Only the binade of the
 // maximum enters: the eigenvalue pass is skipped when cheap upper / lower bounds agree on it.  Block-wide (contains barriers).
-template <class Model>
+template <class Model, int WV>
 __device__ inline double pi_block_tolerance(const PiWork& g, const double (&pi)[27], const int N, const int tid, double* red) {
+    constexpr int THREADS = WV * WAVE;
     constexpr int E = Model::E;
     double umax = 0.0, lmax = 0.0;                                           // upper / lower bound on max_i lambda_max(W_i)
-    for (int i = tid; i < N; i += GH_WG_THREADS) {
+    for (int i = tid; i < N; i += THREADS) {
         double o[6], W[E][E];
 #pragma unroll
         for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
@@ -106,12 +107,12 @@ __device__ inline double pi_block_tolerance(const PiWork& g, const double (&pi)[
         umax = (up > umax) ? up : umax;
         lmax = (lo > lmax) ? lo : lmax;
     }
-    umax = block_max(umax, red);
-    lmax = block_max(lmax, red);
+    umax = block_max_w<WV>(umax, red);
+    lmax = block_max_w<WV>(lmax, red);
     double smax = umax;
     if (eps_of(lmax) != eps_of(umax)) {
         smax = 0.0;
-        for (int i = tid; i < N; i += GH_WG_THREADS) {
+        for (int i = tid; i < N; i += THREADS) {
             double o[6], W[E][E], V[E][E];
 #pragma unroll
             for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
@@ -122,23 +123,24 @@ __device__ inline double pi_block_tolerance(const PiWork& g, const double (&pi)[
 #pragma unroll
             for (int a = 0; a < E; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
         }
-        smax = block_max(smax, red);
+        smax = block_max_w<WV>(smax, red);
     }
     return (double)E * (double)N * eps_of(smax);
 }
 
-template <class Model>
+template <class Model, int WV>
 __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red, int own, const double* pts, int N, int* st, bool exact_pinv) {
+    constexpr int THREADS = WV * WAVE;
     constexpr int E = Model::E, C = Model::C, u = 27, n = u + C, ld = n + 1, PP = pi_pp(E), NW = E * (E + 1) / 2;
     const int tid = thread_in_block(), lane = lane_id(), wave = wave_in_block();
     const bool owner = wave == own;
     double objFunc = 0.0;                                                    // v0' v0, v0 = x0 - x   (:45-46)
-    for (int i = tid; i < N; i += GH_WG_THREADS) {
+    for (int i = tid; i < N; i += THREADS) {
         const Pt6 x = premap(load_pt(pts, i), w->nrm);
 #pragma unroll
         for (int k = 0; k < 6; ++k) { const double d = g.xi[6 * i + k] - x.v[k]; objFunc += d * d; }
     }
-    objFunc = block_sum(objFunc, red);
+    objFunc = block_sum_w<WV>(objFunc, red);
     int it = 0;
 #pragma unroll 1
     for (it = 1; it <= GH_IT_MAX; ++it) {
@@ -146,7 +148,7 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
         load_uniform27(g.p, pi);
         double f2max = 0.0;                                                  // max_i |W_i|_F^2
         bool finite = true;
-        for (int i = tid; i < N; i += GH_WG_THREADS) {
+        for (int i = tid; i < N; i += THREADS) {
             double o[6], W[E][E];
 #pragma unroll
             for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
@@ -162,8 +164,8 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
             finite = finite && (fabs(chk) <= 1.79e308);
             f2max = (fro2 > f2max) ? fro2 : f2max;
         }
-        f2max = block_max(f2max, red);
-        if (block_any(!finite, red) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
+        f2max = block_max_w<WV>(f2max, red);
+        if (block_any_w<WV>(!finite, red) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
         // ---- Pi (4 x 4 blocks, non-singular KKT): weights at the accuracy of the formulas, as in gh_wg_kernel.h -- the block
         //      pseudo-inverse deflated by its one small eigenvalue (pinv_block_deflated<true>: regular part only in pp), the strong
         //      direction kept apart as (n, cs, n'w) and its contributions cs a a', cs a n'w formed from a = A_i' n FIRST (a is the
@@ -173,13 +175,13 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
         constexpr int SN = pi_sn(E);
         {
             if (!exact_pinv && g.sn != nullptr) {
-                const double tolW = pi_block_tolerance<Model>(g, pi, N, tid, red);
+                const double tolW = pi_block_tolerance<Model, WV>(g, pi, N, tid, red);
                 constexpr int SLOT = 406;
-                double* slot = (wave < 3) ? g.V + wave * SLOT : g.H;
+                double* slot = (wave < WV - 1) ? g.V + wave * SLOT : g.H;
                 for (int e = lane; e < SLOT; e += WAVE) slot[e] = 0.0;
                 bool bad = false;
 #pragma unroll 1
-                for (int base = 0; base < N; base += GH_WG_THREADS) {        // block-uniform trip count (the butterflies need whole wavefronts)
+                for (int base = 0; base < N; base += THREADS) {        // block-uniform trip count (the butterflies need whole wavefronts)
                     const int i = base + tid;
                     double bv[27], tv = 0.0, bv2[27], tv2 = 0.0;
 #pragma unroll
@@ -241,15 +243,15 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
                     if constexpr (E == 5) strong_accumulate<27>(bv2, tv2, slot);   // kept apart from the first: adding the products before the butterflies saves 4 % and moves the worst fixture scene from 7e-10 to 1.7e-9
                 }
                 __syncthreads();
-                for (int e = tid; e < 405; e += GH_WG_THREADS) g.V[e] = (g.V[e] + g.V[SLOT + e]) + (g.V[2 * SLOT + e] + g.H[e]);
-                factored = !block_any(bad, red);                             // a block without the structure: the unfactored paths below for all
+                for (int e = tid; e < 405; e += THREADS) g.V[e] = (WV == 4) ? (g.V[e] + g.V[SLOT + e]) + (g.V[2 * SLOT + e] + g.H[e]) : g.V[e] + g.H[e];
+                factored = !block_any_w<WV>(bad, red);                             // a block without the structure: the unfactored paths below for all
             }
         }
         bool fast = !exact_pinv && (double)E * (double)N * eps_of(sqrt(f2max)) < 0.9e-12;
         if (factored) {
         } else if (fast) {
             bool bad = false;
-            for (int i = tid; i < N; i += GH_WG_THREADS) {
+            for (int i = tid; i < N; i += THREADS) {
                 double o[6], W[E][E], Wp[NW];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
@@ -261,11 +263,11 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
                 for (int a = 0; a < E; ++a) Wp[a * (a + 1) / 2 + a] += 1e-12;
                 pi_store_point<E>(g, w, pts, i, o, pt, Wp);
             }
-            if (block_any(bad, red)) fast = false;
+            if (block_any_w<WV>(bad, red)) fast = false;
         }
         if (!fast && !factored) {
-            const double tolW = pi_block_tolerance<Model>(g, pi, N, tid, red);
-            for (int i = tid; i < N; i += GH_WG_THREADS) {
+            const double tolW = pi_block_tolerance<Model, WV>(g, pi, N, tid, red);
+            for (int i = tid; i < N; i += THREADS) {
                 double o[6], W[E][E], V[E][E];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
@@ -298,14 +300,19 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
         // ---- A'WA and A'Ww: the sixteen sweeps are dealt to the four wavefronts (wave w: sweeps w, w + 4, w + 8, w + 12), each over ALL
         //      correspondences and straight into H -- a quarter of the reductions of a per-wavefront-partial layout, no combine step ----
         __syncthreads();                                                     // every correspondence's xi, W+ are in place
-        if (wave == 0) pi_sweeps_strided<Model, 0>(g, pi, N, lane, WAVE, g.H);
-        else if (wave == 1) pi_sweeps_strided<Model, 1>(g, pi, N, lane, WAVE, g.H);
-        else if (wave == 2) pi_sweeps_strided<Model, 2>(g, pi, N, lane, WAVE, g.H);
-        else pi_sweeps_strided<Model, 3>(g, pi, N, lane, WAVE, g.H);
+        if constexpr (WV == 4) {
+            if (wave == 0) pi_sweeps_strided<Model, 0>(g, pi, N, lane, WAVE, g.H);
+            else if (wave == 1) pi_sweeps_strided<Model, 1>(g, pi, N, lane, WAVE, g.H);
+            else if (wave == 2) pi_sweeps_strided<Model, 2>(g, pi, N, lane, WAVE, g.H);
+            else pi_sweeps_strided<Model, 3>(g, pi, N, lane, WAVE, g.H);
+        } else {                                                             // two wavefronts: eight sweeps each
+            if (wave == 0) { pi_sweeps_strided<Model, 0>(g, pi, N, lane, WAVE, g.H); pi_sweeps_strided<Model, 2>(g, pi, N, lane, WAVE, g.H); }
+            else { pi_sweeps_strided<Model, 1>(g, pi, N, lane, WAVE, g.H); pi_sweeps_strided<Model, 3>(g, pi, N, lane, WAVE, g.H); }
+        }
         __syncthreads();
-        for (int e = tid; e < n * ld; e += GH_WG_THREADS) g.M[e] = 0.0;
+        for (int e = tid; e < n * ld; e += THREADS) g.M[e] = 0.0;
         __syncthreads();
-        for (int e = tid; e < 729 + 27; e += GH_WG_THREADS) {
+        for (int e = tid; e < 729 + 27; e += THREADS) {
             if (e < 729) {
                 const int r = e / 27, cc = e % 27;
                 const int b = r / 3, k = r % 3, bp = cc / 3, kk = cc % 3;
@@ -333,8 +340,8 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
         }
         __syncthreads();
         double chkM = 0.0;
-        for (int e = tid; e < n * ld; e += GH_WG_THREADS) chkM += g.M[e];
-        if (!(fabs(block_sum(chkM, red)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
+        for (int e = tid; e < n * ld; e += THREADS) chkM += g.M[e];
+        if (!(fabs(block_sum_w<WV>(chkM, red)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
         // aux = pinv(M + 1e-12 I) b   (:67)
         bool need_pinv = Model::PINV_KKT;
         if (!Model::PINV_KKT) {
@@ -348,7 +355,7 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
         load_uniform27(g.dt, dt);
         // ---- v = -B' W+ (A dt - w)   (:69) ----
         double obj = 0.0, diff = 0.0;
-        for (int i = tid; i < N; i += GH_WG_THREADS) {
+        for (int i = tid; i < N; i += THREADS) {
             double o[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
@@ -406,15 +413,15 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
 #pragma unroll
             for (int k = 0; k < 6; ++k) pw[k] = vv[k];
         }
-        obj = block_sum(obj, red);
-        diff = block_sum(diff, red);
+        obj = block_sum_w<WV>(obj, red);
+        diff = block_sum_w<WV>(diff, red);
         double ndt2 = 0.0;
 #pragma unroll
         for (int k = 0; k < 27; ++k) ndt2 += dt[k] * dt[k];
         if (sqrt(ndt2) < GH_TOL && sqrt(diff) < GH_TOL) break;               // :71-73
         if (obj > objFunc) break;                                            // :75-76
         objFunc = obj;
-        for (int i = tid; i < N; i += GH_WG_THREADS) {                       // xi = x + v; ti = ti + dt   (:80)
+        for (int i = tid; i < N; i += THREADS) {                       // xi = x + v; ti = ti + dt   (:80)
             const Pt6 x = premap(load_pt(pts, i), w->nrm);
 #pragma unroll
             for (int k = 0; k < 6; ++k) g.xi[6 * i + k] = x.v[k] + g.pp[(long)PP * i + k];
@@ -426,8 +433,15 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
     return (it > GH_IT_MAX) ? GH_IT_MAX : it;
 }
 
+// TWO wavefronts per workgroup (round 4; four before), four workgroups per CU, 256 registers per thread.  The wave-serial steps (the 36 x 36
+// pivoted elimination of Pi, the truncated pseudo-inverse of PiCol's 38 x 38 KKT matrix) are what these kernels wait for, and what overlaps them is
+// the number of WORKGROUPS per CU: with four wavefronts each that was two at 256 registers (Pi) or four at 128 registers with 767 of them spilled
+// (PiCol: 1.3 KB of scratch per lane, 105x the algorithmic bytes).  Two wavefronts per workgroup give both four workgroups and 256 registers:
+// Pi 3.65 -> 3.19 ms, PiCol 6.19 -> 5.46 ms per 10 000 x 200.  The per-correspondence state goes to global slices (plan_spill) as before.
+template <class Model> struct pi_wg_waves { static constexpr int value = 2; };
 template <class Model>
-__global__ void __launch_bounds__(GH_WG_THREADS, Model::PINV_KKT ? 4 : 2) k_pi_block(const GhWgArgs a) {
+__global__ void __launch_bounds__(pi_wg_waves<Model>::value * WAVE, 2) k_pi_block(const GhWgArgs a) {   // (second argument: wavefronts per SIMD)
+    constexpr int WV = pi_wg_waves<Model>::value;
     TFF_DYNAMIC_LDS(double, smem);
     PoseLds* w = reinterpret_cast<PoseLds*>(smem);
     constexpr int base = (POSE_LDS_DOUBLES + 1) & ~1;
@@ -442,7 +456,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::PINV_KKT ? 4 : 2) k_pi_b
         g.sn = g.pp + (long)pi_pp(Model::E) * (a.spill ? 0 : N);
         double* red = g.sn + (long)pi_sn(Model::E) * (a.spill ? 0 : N);
         if (a.spill) { g.xi = a.spill + blockIdx.x * a.spill_stride; g.pp = g.xi + 6 * (long)N; g.sn = g.pp + (long)pi_pp(Model::E) * N; }
-        const int own = pick_serial_wave(red);
+        const int own = pick_serial_wave_w<WV>(red);
         const double* r = a.rec + b * GH_REC_DOUBLES;
         if (tid < 27) w->t[tid] = r[tid];
         if (tid < 18) w->pa[tid] = r[27 + tid];
@@ -456,10 +470,10 @@ __global__ void __launch_bounds__(GH_WG_THREADS, Model::PINV_KKT ? 4 : 2) k_pi_b
             if (tid == 0) a.status[b] = ist;
             continue;
         }
-        gh_block_reproject(w, pts, N, g.xi);                                 // x_est   (PiPoseEstimation.m:80-83)
+        gh_block_reproject<WV>(w, pts, N, g.xi);                             // x_est   (PiPoseEstimation.m:80-83)
         __syncthreads();
         int gst = ST_OK;
-        const int iters = gauss_helmert_pi_block<Model>(w, g, red, own, pts, N, &gst, (a.flags & FLAG_GH_EXACT) != 0);
+        const int iters = gauss_helmert_pi_block<Model, WV>(w, g, red, own, pts, N, &gst, (a.flags & FLAG_GH_EXACT) != 0);
         if (wave == own) {
             if (lane == 0) Model::cameras(g.p, w);                           // :94-100
             wave_sync();
