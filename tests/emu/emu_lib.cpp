@@ -248,7 +248,7 @@ extern "C" int emu_fp_pose(const double* corresp, const double* calm, long calm_
     tff::GhWgArgs m = a;
     m.flags |= tff::FLAG_ONLY_RETRY;
     emu::launch(tff::k_gh_linear<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
-    emu::launch(tff::k_fp_block<true>, emu_grid(B), tff::GH_WG_THREADS, tff::fp_lds_bytes(N), a);
+    emu::launch(tff::k_fp_block<true>, emu_grid(B), tff::FP_THREADS, tff::fp_lds_bytes(N), a);
     int handed = 0;
     for (long b = 0; b < B; ++b) handed += status[b] == tff::ST_RETRY;
     if (handed) {

@@ -347,10 +347,10 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
         if (int r = plan_spill(c, tff::fp_lds_bytes(N), tff::fp_lds_bytes(0), &grid, &m.spill, &m.spill_stride, &lds, tff::FP_WG_PER_CU)) return r;
         if (m.spill) {
             if (int r = ensure_lds(tff::k_fp_block<false>, lds)) return r;
-            hipLaunchKernelGGL(tff::k_fp_block<false>, dim3(grid), dim3(tff::GH_WG_THREADS), lds, c->stream, m);
+            hipLaunchKernelGGL(tff::k_fp_block<false>, dim3(grid), dim3(tff::FP_THREADS), lds, c->stream, m);
         } else {
             if (int r = ensure_lds(tff::k_fp_block<true>, lds)) return r;
-            hipLaunchKernelGGL(tff::k_fp_block<true>, dim3(grid), dim3(tff::GH_WG_THREADS), lds, c->stream, m);
+            hipLaunchKernelGGL(tff::k_fp_block<true>, dim3(grid), dim3(tff::FP_THREADS), lds, c->stream, m);
         }
         TFF_HIP(hipGetLastError());
     }

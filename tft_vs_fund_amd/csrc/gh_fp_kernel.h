@@ -36,7 +36,12 @@
 
 namespace tff {
 
-constexpr int FP_WG_PER_CU = 3;
+// Two wavefronts per workgroup, four workgroups per CU (what the 39 KB of matrices allow), 256 registers per thread (round 4; before: four
+// wavefronts, three workgroups, 168 registers).  The owner-only steps are 68 % of an iteration's wall time: the number of workgroups per CU is
+// what overlaps them (pi_wg_kernel.h, gh_wg_kernel.h::gh_wg_waves).
+constexpr int FP_WAVES = 2;
+constexpr int FP_THREADS = FP_WAVES * WAVE;
+constexpr int FP_WG_PER_CU = 4;
 constexpr bool FP_TRID_IN_REGISTERS = true;    // the pseudo-inverse's reduction in registers (two workgroups per CU leave 256 per thread)
 constexpr int FP_NS_MAX = 12;                // strong directions eliminated ahead of the pseudo-inverse (the normal space has dimension 9)
 constexpr int FP_C0 = 8;                     // columns FP_C0 .. 26 of Q get the rotated (accurate) strong sums when ns >= FP_C0
@@ -70,8 +75,8 @@ __device__ __forceinline__ double block_sum2(double v, double* w2, double* red) 
     const double u = wave_sum(*w2);
     if (lane_id() == 0) { red[wave_in_block()] = v; red[4 + wave_in_block()] = u; }
     __syncthreads();
-    const double r = (red[0] + red[1]) + (red[2] + red[3]);
-    *w2 = (red[4] + red[5]) + (red[6] + red[7]);
+    const double r = (FP_WAVES == 4) ? (red[0] + red[1]) + (red[2] + red[3]) : red[0] + red[1];
+    *w2 = (FP_WAVES == 4) ? (red[4] + red[5]) + (red[6] + red[7]) : red[4] + red[5];
     __syncthreads();
     return r;
 }
@@ -339,7 +344,7 @@ __device__ inline void fp_rotated_sums(const FpLds& s, const SP xi, const SP pp,
     for (int e = lane; e < ((total + 1) & ~1); e += WAVE) slot[e] = 0.0;
     wave_sync();
 #pragma unroll 1
-    for (int base = 0; base < N; base += GH_WG_THREADS) {
+    for (int base = 0; base < N; base += FP_THREADS) {
         if (base + wave * WAVE >= N) break;                                  // wave-uniform: no correspondence of this chunk on this wavefront
         const int i = base + tid;
         const bool have = i < N;
@@ -369,14 +374,14 @@ template <class SP>
 __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pts, const int N, const SP xi, const SP pp, int* st, double* dbg) {
     const int tid = thread_in_block(), lane = lane_id(), wave = wave_in_block();
     const bool owner = wave == own;
-    const int waves = (N < GH_WG_THREADS) ? (N + WAVE - 1) / WAVE : GH_WG_WAVES;   // wavefronts that hold correspondences in the rotated pass
+    const int waves = (N < FP_THREADS) ? (N + WAVE - 1) / WAVE : FP_WAVES;   // wavefronts that hold correspondences in the rotated pass
     double objFunc = 0.0;                                                    // v0' v0, v0 = x0 - x   (:45-46)
-    for (int i = tid; i < N; i += GH_WG_THREADS) {
+    for (int i = tid; i < N; i += FP_THREADS) {
         const Pt6 x = premap(load_pt(pts, i), s.nrm);
 #pragma unroll
         for (int k = 0; k < 6; ++k) { const double d = xi[FP_XI * (long)i + k] - x.v[k]; objFunc += d * d; }
     }
-    objFunc = block_sum(objFunc, s.red);
+    objFunc = block_sum_w<FP_WAVES>(objFunc, s.red);
     int it = 0;
 #pragma unroll 1
     for (it = 1; it <= GH_IT_MAX; ++it) {
@@ -396,7 +401,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
         load_uniform27(s.p, T);
         // ---- W_i = B_i B_i' + 1e-12 I (:52), finite check (:53-55), pinv tolerance ----
         double fro2 = 0.0;
-        for (int i = tid; i < N; i += GH_WG_THREADS) {
+        for (int i = tid; i < N; i += FP_THREADS) {
             double o[6], f[4], B[4][6], W[4][4];
 #pragma unroll
             for (int k = 0; k < 6; ++k) o[k] = xi[FP_XI * (long)i + k];
@@ -410,12 +415,12 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             if (!(fabs(chk) <= 1.79e308) || !(f2 <= 1.79e308)) f2 = 1e300 * 1e300;
             fro2 = (f2 > fro2) ? f2 : fro2;
         }
-        const double f2max = block_max(fro2, s.red);                         // (also orders the owner's constraint rows before the sums reuse Mx)
+        const double f2max = block_max_w<FP_WAVES>(fro2, s.red);                         // (also orders the owner's constraint rows before the sums reuse Mx)
         if (!(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }
         double tolW = 0.0;
         if (!(4.0 * (double)N * eps_of(sqrt(f2max)) < 0.9e-12)) {            // the tolerance 4N eps(max lambda_max) can truncate: it is needed
             double up = 0.0, lo = 0.0;
-            for (int i = tid; i < N; i += GH_WG_THREADS) {
+            for (int i = tid; i < N; i += FP_THREADS) {
                 double o[6], f[4], B[4][6], W[4][4], u1, l1;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) o[k] = xi[FP_XI * (long)i + k];
@@ -425,12 +430,12 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
                 up = (u1 > up) ? u1 : up;
                 lo = (l1 > lo) ? l1 : lo;
             }
-            up = block_max(up, s.red);
-            lo = block_max(lo, s.red);
+            up = block_max_w<FP_WAVES>(up, s.red);
+            lo = block_max_w<FP_WAVES>(lo, s.red);
             double smax = up;
             if (eps_of(lo) != eps_of(up)) {
                 smax = 0.0;
-                for (int i = tid; i < N; i += GH_WG_THREADS) {
+                for (int i = tid; i < N; i += FP_THREADS) {
                     double o[6], f[4], B[4][6], W[4][4], V[4][4];
 #pragma unroll
                     for (int k = 0; k < 6; ++k) o[k] = xi[FP_XI * (long)i + k];
@@ -440,14 +445,14 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
 #pragma unroll
                     for (int a = 0; a < 4; ++a) smax = (fabs(W[a][a]) > smax) ? fabs(W[a][a]) : smax;
                 }
-                smax = block_max(smax, s.red);
+                smax = block_max_w<FP_WAVES>(smax, s.red);
             }
             tolW = 4.0 * (double)N * eps_of(smax);
         }
         phase_stamp(sdbg, 18);
         // ---- weights in the deflated, factored form -> pp: regular part of W+ (with the second + 1e-12 I of :57), n, cs, n'w ----
         bool bad = false;
-        for (int i = tid; i < N; i += GH_WG_THREADS) {
+        for (int i = tid; i < N; i += FP_THREADS) {
             double o[6], f[4], B[4][6], W[4][4], Wp[10], nn[4], cs = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) o[k] = xi[FP_XI * (long)i + k];
@@ -467,28 +472,26 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             for (int k = 0; k < 4; ++k) rec[10 + k] = nn[k];
             rec[14] = cs; rec[15] = om;
         }
-        if (block_any(bad, s.red)) { *st = ST_RETRY; break; }                // (barrier: the records of every correspondence are in place)
+        if (block_any_w<FP_WAVES>(bad, s.red)) { *st = ST_RETRY; break; }                // (barrier: the records of every correspondence are in place)
         phase_stamp(sdbg, 19);
         // ---- the structured sums: ten sweeps for R / ghat, ten for Hs / sum cs (n'w) a, dealt to the four wavefronts ----
         {
             double* Hr = s.Mx; double* Hq = s.Mx + 300;
-            if (wave == 0) {
+            if (wave == 0) {                                                 // (two wavefronts: ten sweeps each)
                 fp_sweep<false, 0, SP>(s, xi, pp, pts, N, T, Hr); fp_sweep<false, 4, SP>(s, xi, pp, pts, N, T, Hr); fp_sweep<false, 8, SP>(s, xi, pp, pts, N, T, Hr);
                 fp_sweep<true, 2, SP>(s, xi, pp, pts, N, T, Hq); fp_sweep<true, 6, SP>(s, xi, pp, pts, N, T, Hq);
-            } else if (wave == 1) {
-                fp_sweep<false, 1, SP>(s, xi, pp, pts, N, T, Hr); fp_sweep<false, 5, SP>(s, xi, pp, pts, N, T, Hr); fp_sweep<false, 9, SP>(s, xi, pp, pts, N, T, Hr);
-                fp_sweep<true, 3, SP>(s, xi, pp, pts, N, T, Hq); fp_sweep<true, 7, SP>(s, xi, pp, pts, N, T, Hq);
-            } else if (wave == 2) {
                 fp_sweep<false, 2, SP>(s, xi, pp, pts, N, T, Hr); fp_sweep<false, 6, SP>(s, xi, pp, pts, N, T, Hr);
                 fp_sweep<true, 0, SP>(s, xi, pp, pts, N, T, Hq); fp_sweep<true, 4, SP>(s, xi, pp, pts, N, T, Hq); fp_sweep<true, 8, SP>(s, xi, pp, pts, N, T, Hq);
             } else {
+                fp_sweep<false, 1, SP>(s, xi, pp, pts, N, T, Hr); fp_sweep<false, 5, SP>(s, xi, pp, pts, N, T, Hr); fp_sweep<false, 9, SP>(s, xi, pp, pts, N, T, Hr);
+                fp_sweep<true, 3, SP>(s, xi, pp, pts, N, T, Hq); fp_sweep<true, 7, SP>(s, xi, pp, pts, N, T, Hq);
                 fp_sweep<false, 3, SP>(s, xi, pp, pts, N, T, Hr); fp_sweep<false, 7, SP>(s, xi, pp, pts, N, T, Hr);
                 fp_sweep<true, 1, SP>(s, xi, pp, pts, N, T, Hq); fp_sweep<true, 5, SP>(s, xi, pp, pts, N, T, Hq); fp_sweep<true, 9, SP>(s, xi, pp, pts, N, T, Hq);
             }
         }
         __syncthreads();
         phase_stamp(sdbg, 20);
-        for (int e = tid; e < 729 + 27; e += GH_WG_THREADS) {                // Ghat[(q,i1),(q',i1')] = H[6 tri(q,q') + hht(i1,i1')], both families
+        for (int e = tid; e < 729 + 27; e += FP_THREADS) {                // Ghat[(q,i1),(q',i1')] = H[6 tri(q,q') + hht(i1,i1')], both families
             if (e < 729) {
                 const int r = e / 27, cc = e % 27;
                 const int q = r % 9, i1 = r / 9, qq = cc % 9, i1p = cc / 9;
@@ -517,7 +520,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
         // ---- rotated strong sums (one correspondence per thread); Y = R Q ----
         if (wave < waves) fp_rotated_sums<0, SP>(s, xi, pp, N, s.Mx + wave * 416);
         __syncthreads();
-        for (int e = tid; e < 729; e += GH_WG_THREADS) {                     // Y = R Q -> A2 (Hs is dead now)
+        for (int e = tid; e < 729; e += FP_THREADS) {                     // Y = R Q -> A2 (Hs is dead now)
             const int r = e / 27, c = e % 27;
             double acc = 0.0;
             for (int k = 0; k < 27; ++k) acc += s.A1[r * 27 + k] * s.Q[k * 27 + c];
@@ -527,7 +530,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
         phase_stamp(sdbg, 23);
         {
             const int nsum = 405, stride = 416;
-            for (int e = tid; e < 729 + 405; e += GH_WG_THREADS) {
+            for (int e = tid; e < 729 + 405; e += FP_THREADS) {
                 if (e < 729) {                                               // Q' (R Q) -> A1
                     const int r = e / 27, c = e % 27;
                     double acc = 0.0;
@@ -544,7 +547,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
         phase_stamp(sdbg, 24);
         // ---- M' (39 x 40, augmented) ----
         double chkM = 0.0;
-        for (int e = tid; e < 39 * 40; e += GH_WG_THREADS) {
+        for (int e = tid; e < 39 * 40; e += FP_THREADS) {
             const int r = e / 40, c = e % 40;
             double v;
             if (r < 27 && c < 27) {
@@ -567,7 +570,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
             chkM += v;
             s.Mx[e] = v;                                                     // (the slots that lived here were last read before the barrier above)
         }
-        if (!(fabs(block_sum(chkM, s.red)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
+        if (!(fabs(block_sum_w<FP_WAVES>(chkM, s.red)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
         phase_stamp(sdbg, 25);
         // ---- block elimination of the strong ns x ns block ----
         if (owner) {
@@ -579,7 +582,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
         phase_stamp(sdbg, 26);
         {
             const int n2 = 39 - ns, w2 = 40 - ns;
-            for (int e = tid; e < n2 * w2; e += GH_WG_THREADS) {             // Schur complement, right-hand side included
+            for (int e = tid; e < n2 * w2; e += FP_THREADS) {             // Schur complement, right-hand side included
                 const int r = ns + e / w2, c = ns + e % w2;
                 double acc = 0.0;
                 for (int k = 0; k < ns; ++k) acc += s.Mx[k * 40 + r] * s.Mx[k * 40 + c];
@@ -646,7 +649,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
         load_uniform27(s.dt, dTr);
         // ---- v = -B' W+ (A dt - w)   (:69); v overwrites the record's W+ slots (dead until the next weight pass) ----
         double obj = 0.0, diff = 0.0;
-        for (int i = tid; i < N; i += GH_WG_THREADS) {
+        for (int i = tid; i < N; i += FP_THREADS) {
             double o[6], f[4], B[4][6], Ad[4], wv[4], r[4], Wp[10], nn[4];
             const SP rec = pp + FP_PP * (long)i;
 #pragma unroll
@@ -692,7 +695,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
         if (sqrt(ndt2) < GH_TOL && sqrt(diff) < GH_TOL) break;               // :71-73 (dy is empty)
         if (obj > objFunc) break;                                            // :75-76, factor = 1
         objFunc = obj;                                                       // :78
-        for (int i = tid; i < N; i += GH_WG_THREADS) {                       // xi = x + v; ti = ti + dt   (:80)
+        for (int i = tid; i < N; i += FP_THREADS) {                       // xi = x + v; ti = ti + dt   (:80)
             const Pt6 x = premap(load_pt(pts, i), s.nrm);
 #pragma unroll
             for (int k = 0; k < 6; ++k) xi[FP_XI * (long)i + k] = x.v[k] + pp[FP_PP * (long)i + k];
@@ -705,7 +708,7 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
 }
 
 template <bool STATE_IN_LDS>
-__global__ void __launch_bounds__(GH_WG_THREADS, FP_WG_PER_CU) k_fp_block(const GhWgArgs a) {
+__global__ void __launch_bounds__(FP_THREADS, FP_WG_PER_CU * FP_WAVES / 4) k_fp_block(const GhWgArgs a) {   // (second argument: wavefronts per SIMD)
     typedef typename FpState<STATE_IN_LDS>::ptr SP;
     TFF_DYNAMIC_LDS(double, smem);
     FpLds& s = *reinterpret_cast<FpLds*>(smem);
@@ -719,7 +722,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, FP_WG_PER_CU) k_fp_block(const 
         if constexpr (STATE_IN_LDS) xi = to_lds(smem + FP_LDS_DOUBLES);
         else xi = a.spill + blockIdx.x * a.spill_stride;
         pp = xi + FP_XI * (long)N;
-        const int own = pick_serial_wave(s.red);
+        const int own = pick_serial_wave_w<FP_WAVES>(s.red);
         const double* r = a.rec + b * GH_REC_DOUBLES;                        // t 27 | pa 18 | epi 6 | nrm 9   (k_gh_linear)
         if (tid < 27) s.p[tid] = r[tid];                                     // param0 = T(:)   (FaugPapaTFT...m:65)
         if (tid < 9) s.nrm[tid] = r[51 + tid];
@@ -737,7 +740,7 @@ __global__ void __launch_bounds__(GH_WG_THREADS, FP_WG_PER_CU) k_fp_block(const 
             load_uniform12(s.cam[1], PB);
             load_uniform12(s.cam[2], PC);
 #pragma unroll 1
-            for (int i = tid; i < N; i += GH_WG_THREADS) {
+            for (int i = tid; i < N; i += FP_THREADS) {
                 const Pt6 p = premap(load_pt(pts, i), s.nrm);
                 double X[4];
                 dlt_point<true>(PA, PB, PC, s.cam[0], s.cam[1], s.cam[2], true, p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], p.v[5], X);
