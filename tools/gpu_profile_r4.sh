@@ -27,10 +27,10 @@ for T in ${@:-headline headline1 ressl nordberg faugpapa pi picol linearf optimf
     headline)   run_one headline "python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 3" "k_linear_tft_pose_rows" 10000 $ALG 2;;          # bench.py as the driver runs it: two streams, consecutive batches overlap
     headline1)  run_one headline1 "python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 3 --streams 1" "k_linear_tft_pose_rows" 10000 $ALG 2;;   # one stream: a launch has the GPU to itself
     ressl)      run_one ressl "python3 $R/tools/bench_one.py ResslTFTPoseEstimation 8" "k_gh_block" 10000 $ALG 2;;
-    nordberg)   run_one nordberg "python3 $R/tools/bench_one.py NordbergTFTPoseEstimation 8" "k_gh_block" 10000 $ALG 3;;
-    faugpapa)   run_one faugpapa "python3 $R/tools/bench_one.py FaugPapaTFTPoseEstimation 6" "k_fp_block" 10000 $ALG 3;;
+    nordberg)   run_one nordberg "python3 $R/tools/bench_one.py NordbergTFTPoseEstimation 8" "k_gh_block" 10000 $ALG 2;;
+    faugpapa)   run_one faugpapa "python3 $R/tools/bench_one.py FaugPapaTFTPoseEstimation 6" "k_fp_block" 10000 $ALG 2;;
     pi)         run_one pi "python3 $R/tools/bench_one.py PiPoseEstimation 8" "k_pi_block" 10000 $ALG 2;;
-    picol)      run_one picol "python3 $R/tools/bench_one.py PiColPoseEstimation 6" "k_pi_block" 10000 $ALG 4;;
+    picol)      run_one picol "python3 $R/tools/bench_one.py PiColPoseEstimation 6" "k_pi_block" 10000 $ALG 2;;
     linearf)    run_one linearf "python3 $R/tools/bench_one.py LinearFPoseEstimation 20" "k_linear_f_pose_rows" 10000 $ALG 2;;
     optimf)     run_one optimf "python3 $R/tools/bench_one.py OptimFPoseEstimation 10" "k_optimf_refine" 10000 $ALG 2;;
     config4tft) run_one config4tft "python3 $R/tools/config4_split.py 1000000" "k_linear_tft_pose_rows_exact" 1000000 $((1000000 * 440)) 2;;
