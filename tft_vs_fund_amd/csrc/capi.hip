@@ -300,7 +300,7 @@ int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_
 template <class KBlock, class LdsFn>
 int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg, bool fp_first = false,
-              bool rows_linear = true, bool nordberg_pre = false, int block_threads = tff::GH_WG_THREADS) {
+              bool rows_linear = true, bool nordberg_pre = false, int block_threads = tff::GH_WG_THREADS, size_t xi_bytes_per_n = 0) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     TFF_LOCK(c);
     if (B == 0) return 0;
@@ -360,6 +360,10 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
         if (fp_first) m.flags |= tff::FLAG_ONLY_RETRY;
         size_t lds;
         if (int r = plan_spill(c, wg_lds(N), wg_lds(0), &grid, &m.spill, &m.spill_stride, &lds, occupancy_cap)) return r;
+        if (m.spill && xi_bytes_per_n) {                                     // the state went to global slices for occupancy: does xi alone still fit in LDS?
+            const size_t partial = wg_lds(0) + xi_bytes_per_n * (size_t)N;
+            if (partial <= LDS_LIMIT && LDS_LIMIT / (partial + 512) >= (size_t)occupancy_cap) { lds = partial; m.flags |= tff::FLAG_XI_IN_LDS; }
+        }
         if (int r = ensure_lds(kblock, lds)) return r;
         hipLaunchKernelGGL(kblock, dim3(grid), dim3(block_threads), lds, c->stream, m);
         TFF_HIP(hipGetLastError());
@@ -395,7 +399,7 @@ int launch_gh(tff_ctx* c, KFused kfused, KFusedJac kfused_jac, const double* cor
     // (round 4: Ressl and Nordberg run two wavefronts per workgroup, four workgroups per CU at 256 registers -- gh_wg_kernel.h::gh_wg_waves)
     const int occupancy_cap = tff::gh_wg_per_cu<Model>::value;
     return launch_wg(c, tff::k_gh_block<Model>, wg_lds, occupancy_cap, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg, fp_first, true,
-                     std::is_same<Model, tff::NordbergModel>::value, tff::gh_wg_waves<Model>::value * tff::WAVE);
+                     std::is_same<Model, tff::NordbergModel>::value, tff::gh_wg_waves<Model>::value * tff::WAVE, tff::GH_XI * sizeof(double));
 }
 template <class Model>
 int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,

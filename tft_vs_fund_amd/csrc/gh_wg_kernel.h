@@ -613,7 +613,13 @@ __global__ void __launch_bounds__(gh_wg_waves<Model>::value * WAVE, gh_wg_per_cu
         const double* pts = a.corresp + b * 6 * (long)N;
         double* red;
         GhWork g = gh_wg_carve(ghbase, w, Model::U, Model::C, a.spill ? 0 : N, Model::REDUNDANT_CONSTRAINTS, &red);
-        if (a.spill) { g.xi = a.spill + blockIdx.x * a.spill_stride; g.pp = g.xi + GH_XI * (long)N; }
+        if (a.spill) {
+            double* slice = a.spill + blockIdx.x * a.spill_stride;
+            // FLAG_XI_IN_LDS: xi (read by every pass) behind the fixed part in LDS, W+ (10 N, the bigger half) in the slice -- when that still fits
+            // the workgroups per CU the launcher wants (Ressl at N = 200: 38.5 KB, four per CU)
+            g.xi = (a.flags & FLAG_XI_IN_LDS) ? ghbase + gh_wg_lds_doubles(Model::U, Model::C, 0, Model::REDUNDANT_CONSTRAINTS) : slice;
+            g.pp = slice + GH_XI * (long)N;
+        }
         const int own = pick_serial_wave_w<WV>(red);
         const double* r = a.rec + b * GH_REC_DOUBLES;
         if (tid < 27) w->t[tid] = r[tid];

@@ -18,6 +18,7 @@ constexpr int FLAG_STAGE_LDS = 4;     // correspondences are staged once in LDS 
 constexpr int FLAG_ONLY_RETRY = 8;    // fix-up pass: process only triplets whose status is ST_RETRY
 constexpr int FLAG_DBG_FP_HANDOVER = 64; // FaugPapa block kernel, test hook (TFF_OPT_DEBUG_FP_HANDOVER): hand every third triplet back to the generic kernel as if its pseudo-inverse had failed
 constexpr int FLAG_DBG_ADAPTIVE = 32; // rows kernel, debug entry points only: keep the adaptive cheirality votes (the default under debug is all four scores)
+constexpr int FLAG_XI_IN_LDS = 128;   // workgroup Gauss-Helmert kernels with the per-correspondence state in global slices: xi (6 N) stays in LDS after all, only W+ goes out
 constexpr int FLAG_GH_EXACT = 16;     // Gauss-Helmert: always take the eigen-decomposition path for pinv(W) (A/B against the Cholesky path)
 
 // ---- status codes (per triplet), mirroring the reference's failure modes --
