@@ -707,7 +707,8 @@ def test_iterative_methods_at_large_n_use_the_global_workspace(gpu_ctx):
 
 @pytest.mark.parametrize("method,N", [("OptimFPoseEstimation", 500), ("ResslTFTPoseEstimation", 500), ("NordbergTFTPoseEstimation", 400),
                                       ("FaugPapaTFTPoseEstimation", 200), ("PiPoseEstimation", 300), ("PiColPoseEstimation", 200),
-                                      ("PiPoseEstimation", 64), ("OptimFPoseEstimation", 1500)])
+                                      ("PiPoseEstimation", 64), ("OptimFPoseEstimation", 1500),
+                                      ("ResslTFTPoseEstimation", 200), ("NordbergTFTPoseEstimation", 200)])   # (N = 200: xi in LDS, W+ in the slices -- FLAG_XI_IN_LDS)
 def test_spilled_batches_are_bit_identical_to_single_triplets(gpu_ctx, method, N):
     """Configurations whose per-correspondence state lives in global spill slices (for occupancy, or because it exceeds the LDS):
     every triplet of a batch -- neighbouring blocks running concurrently on adjacent slices -- must come out bit-identical to the same
