@@ -575,7 +575,9 @@ struct VoteCam { double PB[12], R3[4]; };
 // what vote_one knows about the 4 x 4 system when it is done: the Cholesky factor of S + delta I short of its last pivot (d4, unfloored) and the
 // inhomogeneous point z -- exactly the state of spd_min_eigvec<4> before its first iteration (dlt_from_vote goes on from there)
 struct VoteFactor { double L[4][3], inv[3], d4, z[3], pfloor; };
-template <bool KEEP = false>
+// CERT = false (with KEEP): factor and z only -- the caller takes the two signs from the converged point dlt_from_vote gives it anyway (the exact
+// tier of the vote by definition), so the certificate of the fast tier is not needed; score / all_certain are left alone.
+template <bool KEEP = false, bool CERT = true>
 __device__ __forceinline__ void vote_one(const double (&SA)[6], const VoteCam& cam, const double x2, const double y2, int& score, bool& all_certain,
                                          VoteFactor* keep = nullptr) {
     double b0[4], b1[4];
@@ -618,18 +620,20 @@ __device__ __forceinline__ void vote_one(const double (&SA)[6], const VoteCam& c
         for (int k = r + 1; k < 3; ++k) sum -= L[k][r] * z[k];
         z[r] = sum * inv[r];
     }
-    const double d1 = z[2], d2 = cam.R3[0] * z[0] + cam.R3[1] * z[1] + cam.R3[2] * z[2] + cam.R3[3];
     const double d4 = S33 + delta - (L[3][0] * L[3][0] + L[3][1] * L[3][1] + L[3][2] * L[3][2]);
-    const double zz = z[0] * z[0] + z[1] * z[1] + z[2] * z[2];
-    const double idet = (inv[0] * inv[1]) * (inv[0] * inv[1]) * (inv[2] * inv[2]);
-    const double trs = tr3 + 3.0 * delta;
-    const double e = trs * trs * idet;
-    const double Gp = 4.0 * (1.0 + zz) - d4 * e;
-    const double rhs = 2.0 * d4 * e + 2.5e-14 * trs * e * Gp;
-    const double dmin2 = fmin(d1 * d1, d2 * d2);
-    const bool certain = Gp > 0.0 && dmin2 * Gp * Gp > rhs * rhs * zz;      // false for NaN / inf
-    all_certain = all_certain && certain;
-    score += (int)sgn(d1) + (int)sgn(d2);
+    if constexpr (CERT) {
+        const double d1 = z[2], d2 = cam.R3[0] * z[0] + cam.R3[1] * z[1] + cam.R3[2] * z[2] + cam.R3[3];
+        const double zz = z[0] * z[0] + z[1] * z[1] + z[2] * z[2];
+        const double idet = (inv[0] * inv[1]) * (inv[0] * inv[1]) * (inv[2] * inv[2]);
+        const double trs = tr3 + 3.0 * delta;
+        const double e = trs * trs * idet;
+        const double Gp = 4.0 * (1.0 + zz) - d4 * e;
+        const double rhs = 2.0 * d4 * e + 2.5e-14 * trs * e * Gp;
+        const double dmin2 = fmin(d1 * d1, d2 * d2);
+        const bool certain = Gp > 0.0 && dmin2 * Gp * Gp > rhs * rhs * zz;  // false for NaN / inf
+        all_certain = all_certain && certain;
+        score += (int)sgn(d1) + (int)sgn(d2);
+    }
     if constexpr (KEEP) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)

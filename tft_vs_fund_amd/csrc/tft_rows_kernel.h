@@ -109,7 +109,7 @@ __device__ __forceinline__ void rows_centroids(const RowSrc& s, const int N, dou
 //     scales afterwards (a monomial of degree d1 in view 1, d2 in view 2, d3 in view 3 scales by s1^d1 s2^d2 s3^d3: no cancellation);
 //   * two lanes share a correspondence: the even lane accumulates the 48 sums of the p1-monomials {x1^2, x1 y1, x1}, the odd lane those of
 //     {y1^2, y1, 1} (96 accumulators per lane would not fit the register file; 48 each do, and the pair's loads coalesce into one request);
-//   * the pair also splits the distance sums: even lane view 1, odd lane view 3, both view 2 (halved afterwards: exact).
+//   * the pair also splits the distance sums: even lane view 1, odd lane view 3, view 2 alternately (two correspondences per loop iteration).
 // Leaves nrm[0..8] (LDS, and nr[] on every lane) and mom[0..95] (LDS).
 __device__ __forceinline__ void rows_distances_moments(const RowSrc& s, const int N, const double (&c)[6], double* nrm, double (&nr)[9], double* mom) {
     const int p = rows_p();
@@ -121,13 +121,15 @@ __device__ __forceinline__ void rows_distances_moments(const RowSrc& s, const in
     double dA = 0.0, dB = 0.0;
     // (the loads of trips t + 1 and t + 2 are in flight while trip t is consumed: a trip issues ~80 fp64 instructions, an L2 / MALL round trip
     // lasts five times that, and the other wavefront of the SIMD is in the same pass more often than not)
-    auto body = [&](const Pt6& q) {
+    // (view 2's distance is needed once per correspondence and the pair holds two of them per loop iteration: the even lane takes the first one's
+    // square root, the odd lane the second one's -- three square roots per lane and two trips instead of four)
+    auto body = [&](const Pt6& q, double& r2_out) {
         const double x1 = q.v[0] - c[0], y1 = q.v[1] - c[1];
         const double x2 = q.v[2] - c[2], y2 = q.v[3] - c[3];
         const double x3 = q.v[4] - c[4], y3 = q.v[5] - c[5];
         const double r1 = x1 * x1 + y1 * y1, r2 = x2 * x2 + y2 * y2, r3 = x3 * x3 + y3 * y3;
         dA += sqrt(odd ? r3 : r1);                                           // Normalize2Ddata.m:35
-        dB += sqrt(r2);
+        r2_out = r2;
         const double q2[4] = {1.0, x2, y2, r2};
         const double q3[4] = {1.0, x3, y3, r3};
         const double pa = odd ? y1 * y1 : x1 * x1, pb = odd ? y1 : x1 * y1, pc = odd ? 1.0 : x1;
@@ -148,15 +150,17 @@ __device__ __forceinline__ void rows_distances_moments(const RowSrc& s, const in
     for (int i = slot; i < N; i += 2 * STEP) {
         const Pt6 q = pe;
         if (i + 2 * STEP < N) pe = rows_load(s, i + 2 * STEP);
-        body(q);
+        double r2a, r2b = 0.0;
+        body(q, r2a);
         if (i + STEP < N) {
             const Pt6 r = po;
             if (i + 3 * STEP < N) po = rows_load(s, i + 3 * STEP);
-            body(r);
+            body(r, r2b);
         }
+        dB += sqrt(odd ? r2b : r2a);
     }
     // mean distances -> scales and offsets (every lane of the row)
-    const double d1 = row_sum16(odd ? 0.0 : dA), d3 = row_sum16(odd ? dA : 0.0), d2 = 0.5 * row_sum16(dB);
+    const double d1 = row_sum16(odd ? 0.0 : dA), d3 = row_sum16(odd ? dA : 0.0), d2 = row_sum16(dB);
     const double r2c = sqrt(2.0);
     const double dd[3] = {d1, d2, d3};
 #pragma unroll
@@ -602,7 +606,9 @@ __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const R
                     for (int c = 0; c < 4; ++c) cam.R3[c] = pr[8 + c];
                     int term = 0;
                     bool cert = true;
-                    if (SPEC && call == 0) vote_one<true>(SA, cam, x2, y2, term, cert, &fA);
+                    // (view 2's main candidate past the first trip: its two signs come from the converged point of the scale sums below)
+                    if (SPEC && call == 0 && !first) vote_one<true, false>(SA, cam, x2, y2, term, cert, &fA);
+                    else if (SPEC && call == 0) vote_one<true>(SA, cam, x2, y2, term, cert, &fA);
                     else vote_one(SA, cam, x2, y2, term, cert);
                     scA[call] += have ? term : 0;
                     certA[call] = certA[call] && (cert || !have);
@@ -644,6 +650,13 @@ __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const R
                     double X[4];
                     const bool conv = dlt_from_vote(fA, X);
                     sconv = sconv && (conv || !have);
+                    if (!first) {                                            // the vote's exact tier (pose_common.h::tri_vote_exact): signs of the converged point
+                        const double* pr = rt->candRt[0] + opaque_lane_int(offA[0]);
+                        const double s4 = sgn(X[3]);                         // X1 = X ./ X(4)
+                        const double d1 = X[2] * s4, d2 = (pr[8] * X[0] + pr[9] * X[1] + pr[10] * X[2] + pr[11] * X[3]) * s4;
+                        scA[0] += have ? (int)sgn(d1) + (int)sgn(d2) : 0;
+                        certA[0] = certA[0] && (conv || !have);
+                    }
                     const double iw = 1.0 / X[3];
                     const double X0 = X[0] * iw, X1 = X[1] * iw, X2 = X[2] * iw;
                     const double* ax = rt->P[0] + opaque_lane_int(offA[1]);  // K3 [R3 | t3] of view 3's main candidate
