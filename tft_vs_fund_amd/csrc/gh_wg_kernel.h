@@ -469,24 +469,71 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
             // (Summing over the <= 9 non-zeros per column of Ressl's D instead -- 5 k multiply-adds for the two products, not 25 k -- was
             // measured SLOWER, 14.2 k -> 23.8 k cycles: the index arithmetic and the irregular LDS addresses cost more than the dense,
             // perfectly regular loops save.)
-            for (int e = tid; e < 27 * u; e += THREADS) {              // Y = Ghat D
-                const int r = e / u, pcol = e % u;
-                double acc = 0.0;
-                for (int k = 0; k < 27; ++k) acc += g.G[r * 27 + k] * g.D[k * u + pcol];
-                g.Y[e] = acc;
-            }
-            __syncthreads();
-            for (int e = tid; e < u * u + u; e += THREADS) {           // M = [D'Y + 1e-12 I ...], b = [D' ghat; -g]
-                const int pr = e / u, pc = e % u;
-                double acc = 0.0;
-                if (e < u * u) {
-                    for (int k = 0; k < 27; ++k) acc += g.D[k * u + pr] * g.Y[k * u + pc];
-                    if (factored) acc += g.S[(pr >= pc) ? tri_index(pr, pc) : tri_index(pc, pr)];
-                    g.M[pr * ld + pc] = acc + ((pr == pc) ? 1e-12 : 0.0);
-                } else {
-                    for (int k = 0; k < 27; ++k) acc += g.D[k * u + pc] * g.H[270 + k];
-                    if (factored) acc += g.S[u * (u + 1) / 2 + pc];
-                    g.M[pc * ld + n] = acc;
+            if constexpr (u % 4 == 0) {                                      // (Ressl, u = 20; Nordberg's u = 19 loses the 16-byte alignment: measured 2.5 % slower)
+                // Four adjacent columns per thread: one read of Ghat(r,k) (D(k,pr)) and two 16-byte reads of D (Y) feed four multiply-adds, where a
+                // thread per entry made two LDS reads per multiply-add -- these two products were 14 % (N = 200) to 22 % (N = 60) of an iteration,
+                // LDS-issue-bound.  Every entry is still the same 27-term sum in the same order.
+                constexpr int UQ = (u + 3) / 4;
+                for (int e = tid; e < 27 * UQ; e += THREADS) {             // Y = Ghat D
+                    const int r = e / UQ, c0 = 4 * (e % UQ);
+                    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    #pragma unroll 3
+                    for (int k = 0; k < 27; ++k) {                         // (fully unrolled the 135 loads are hoisted and spill 80 registers)
+                        const double gv = g.G[r * 27 + k];
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] += gv * g.D[k * u + ((c0 + j < u) ? c0 + j : 0)];
+                    }
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) if (c0 + j < u) g.Y[r * u + c0 + j] = acc[j];
+                }
+                __syncthreads();
+                for (int e = tid; e < u * UQ + u; e += THREADS) {          // M = [D'Y + 1e-12 I ...], b = [D' ghat; -g]
+                    if (e < u * UQ) {
+                        const int pr = e / UQ, c0 = 4 * (e % UQ);
+                        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    #pragma unroll 3
+                        for (int k = 0; k < 27; ++k) {
+                            const double dv = g.D[k * u + pr];
+    #pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[j] += dv * g.Y[k * u + ((c0 + j < u) ? c0 + j : 0)];
+                        }
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int pc = c0 + j;
+                            if (pc < u) {
+                                double v = acc[j];
+                                if (factored) v += g.S[(pr >= pc) ? tri_index(pr, pc) : tri_index(pc, pr)];
+                                g.M[pr * ld + pc] = v + ((pr == pc) ? 1e-12 : 0.0);
+                            }
+                        }
+                    } else {
+                        const int pc = e - u * UQ;
+                        double acc = 0.0;
+                        for (int k = 0; k < 27; ++k) acc += g.D[k * u + pc] * g.H[270 + k];
+                        if (factored) acc += g.S[u * (u + 1) / 2 + pc];
+                        g.M[pc * ld + n] = acc;
+                    }
+                }
+            } else {
+                for (int e = tid; e < 27 * u; e += THREADS) {              // Y = Ghat D
+                    const int r = e / u, pcol = e % u;
+                    double acc = 0.0;
+                    for (int k = 0; k < 27; ++k) acc += g.G[r * 27 + k] * g.D[k * u + pcol];
+                    g.Y[e] = acc;
+                }
+                __syncthreads();
+                for (int e = tid; e < u * u + u; e += THREADS) {           // M = [D'Y + 1e-12 I ...], b = [D' ghat; -g]
+                    const int pr = e / u, pc = e % u;
+                    double acc = 0.0;
+                    if (e < u * u) {
+                        for (int k = 0; k < 27; ++k) acc += g.D[k * u + pr] * g.Y[k * u + pc];
+                        if (factored) acc += g.S[(pr >= pc) ? tri_index(pr, pc) : tri_index(pc, pr)];
+                        g.M[pr * ld + pc] = acc + ((pr == pc) ? 1e-12 : 0.0);
+                    } else {
+                        for (int k = 0; k < 27; ++k) acc += g.D[k * u + pc] * g.H[270 + k];
+                        if (factored) acc += g.S[u * (u + 1) / 2 + pc];
+                        g.M[pc * ld + n] = acc;
+                    }
                 }
             }
         }
