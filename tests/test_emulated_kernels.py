@@ -60,7 +60,7 @@ def test_linear_tft_kernel_matches_oracle(emu, N, sigma, flags):
 @pytest.mark.parametrize("entry,N", [("emu_linear_tft_pose", 9), ("emu_linear_f_pose", 9), ("emu_optim_f_pose", 10), ("emu_ressl_tft_pose", 9)])
 def test_grid_stride_loop_leaves_no_state_between_triplets(emu, entry, N):
     """One block taking several triplets through the same LDS (grid capped at 1) gives bit-identical results to one block per triplet."""
-    B = 3
+    B = 2
     C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=40 + N)
     ref = run_linear_tft(emu, C, CalM, entry=entry)
     emu.emu_set_grid_cap(1)
@@ -127,9 +127,9 @@ def test_optim_f_kernel_matches_golden(emu, golden_dir, entry):
 
 
 def test_optim_f_staged_matches_fused_and_oracle(emu):
-    """Seven triplets (a ragged last wavefront in the two row-layout stages), N = 40: the staged route against the fused kernel and the oracle --
+    """Five triplets (a ragged last wavefront in the two row-layout stages), N = 40: the staged route against the fused kernel and the oracle --
     same iteration counts, results within the Gauss-Helmert loop's amplification of the start's rounding."""
-    B, N = 7, 40
+    B, N = 5, 40
     C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=21)
     st = run_linear_tft(emu, C, CalM, entry="emu_optim_f_pose_staged", debug=False)
     fu = run_linear_tft(emu, C, CalM, entry="emu_optim_f_pose", debug=False)
@@ -575,11 +575,12 @@ def test_rows_kernel_matches_oracle(emu, B, N, sigma):
     assert np.abs(prod["debug"][:, 68] / out["debug"][:, 68] - 1.0).max() < 1e-12
     if B >= 5:
         assert set(out["debug"][:, 95].tolist()) == {0.0, 1.0}
-    wave = run_linear_tft(emu, C, CalM)
+    nw = min(B, 2)                                           # (the one-triplet kernel as the reference: a wavefront per triplet, two are enough here)
+    wave = run_linear_tft(emu, C[:nw], CalM)
     # the four cheirality scores of both essential matrices, up to the candidate order (the signs svd(E) gives U(:,3), V(:,3) permute the list)
-    so, sw = out["debug"][:, 60:68].reshape(B, 2, 4), wave["debug"][:, 60:68].reshape(B, 2, 4)
+    so, sw = out["debug"][:nw, 60:68].reshape(nw, 2, 4), wave["debug"][:, 60:68].reshape(nw, 2, 4)
     assert np.array_equal(np.sort(so, axis=2), np.sort(sw, axis=2))
-    assert np.abs(out["debug"][:, 33:60] - wave["debug"][:, 33:60]).max() < 1e-12     # linearTFT's constrained tensor (normalised frame)
+    assert np.abs(out["debug"][:nw, 33:60] - wave["debug"][:, 33:60]).max() < 1e-12     # linearTFT's constrained tensor (normalised frame)
 
 
 def test_rows_kernel_grid_stride_and_too_few(emu):
