@@ -387,12 +387,12 @@ def test_pinv_shortcut_equals_jacobi_branch_on_graded_blocks(emu):
 @pytest.mark.parametrize("model,fixture", [("ressl", "gh_mp.npz"), ("nordberg", "gh_mp_nordberg.npz"), ("pi", "gh_mp_pi.npz")])
 def test_emulated_workgroup_kernels_reproduce_the_50_digit_iteration(emu, model, fixture):
     """The GPU-less twin of tests/test_gpu_gh_noise.py: the workgroup Gauss-Helmert kernels (factored weights), compiled against the
-    lane emulator, on the first three N = 12 scenes of the extended-precision fixtures -- T, R_t_2, R_t_3 within 1e-9 of the 50-digit
+    lane emulator, on the first two N = 12 scenes of the extended-precision fixtures -- T, R_t_2, R_t_3 within 1e-9 of the 50-digit
     evaluation (observed <= 6e-11) and the same iteration count; Nordberg under one of the eight sign conventions of linearTFT's
     singular vectors (tests/helpers.py::oracle_under_epipole_conventions)."""
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
     pre = "c0_"
-    C = np.ascontiguousarray(g[pre + "Corresp"][:3]); CalM = g[pre + "CalM"]
+    C = np.ascontiguousarray(g[pre + "Corresp"][:2]); CalM = g[pre + "CalM"]
     B, N, _ = C.shape
     calm = calm_colmajor(CalM)
     Rt2 = np.zeros((B, 12)); Rt3 = np.zeros((B, 12)); T = np.zeros((B, 27)); it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32)
@@ -459,7 +459,7 @@ def test_emulated_tridiagonal_pinv_solver_reports_clustered_eigenvalues(emu, var
     The solver must either still be right or say so (fail = 1: the caller takes the orthogonalising eigen-decomposition) -- never silently
     wrong.  Well separated spectra (the test above) must not trip the guard."""
     rng = np.random.default_rng(11 + variant)
-    n, B = 24, 4
+    n, B = 24, 3
     Ms, tols, refs = [], [], []
     for b in range(B):
         Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
