@@ -17,10 +17,18 @@ Steps are independent batches, so they are issued round-robin on `--streams`
 HIP streams (default 2, one library context per stream, result records
 double-buffered): 10 000 triplets are 2 500 wavefronts of four triplets on
 2 048 wavefront slots, and the next batch's wavefronts fill the slots the
-previous batch's 452-wavefront tail leaves idle.  Every step still runs whole
-inside the timed region; `roofline.kernel_ms` is the launches' own HIP-event
-duration on their streams (longer than ms_per_step when two overlap), and the
-one-stream, nothing-overlapped figure is reported beside it (`single_stream`).
+previous batch's tail leaves idle.  Every step still runs whole inside the
+timed region.  What the line reports, so that it closes on itself:
+  * `value`, `ms_per_step`: K steps between barrier + synchronize, repeated
+    `--reps` times, the MEDIAN repetition (all of them listed);
+  * `in_flight`: batches that may be resident at once (= streams);
+  * `roofline.kernel_ms` / `achieved` / `frac`: one call's launches with the
+    GPU TO ITSELF (one stream, HIP events on that stream around every call,
+    nothing else queued) -- the figure `rocprofv3 --kernel-trace --stats` of
+    `bench.py --streams 1` reproduces (profiles/);
+  * `overlap_factor` = kernel_ms / ms_per_step (<= in_flight): how much of a
+    launch is hidden behind its neighbour; kernel_ms * steps / in_flight <=
+    ms_per_step * steps can be checked from the line alone.
 
 Rank 0 prints ONE JSON line (metric, value, roofline, cpu_baseline, ...).
 """
@@ -110,6 +118,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary blocks (other methods, N sweep, config 4; 1 GPU, rank 0)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the steps alternate between (1 = strictly one batch at a time)")
+    ap.add_argument("--reps", type=int, default=7, help="repetitions of the timed K-step region; the median repetition is reported")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="TEST SEAM (tests/test_gpu_process_group.py): at WORLD_SIZE = 1 still create the nccl (= RCCL) process group, a clique of one, and "
+                         "run the overlapped all-gather of every step through it; the line then carries `process_group_check`")
     ap.add_argument("--stub-compute", action="store_true",
                     help="TEST SEAM (tests/test_bench_flow_gloo.py): CPU tensors + gloo, the HIP launch replaced by a tagged fill -- everything around it "
                          "(rendezvous, rank-0 build + barrier, step / gather pipeline, weak-scaling accounting, the JSON line) runs as on the GPUs")
@@ -122,7 +134,8 @@ def main():
     from tft_vs_fund_amd.scenes import generate_scene_batch
 
     stub = args.stub_compute
-    rank, world, local = tdist.init_from_env("cpu" if stub else "cuda")
+    rank, world, local = tdist.init_from_env("cpu" if stub else "cuda", force_group=args.force_process_group)
+    use_pg = world > 1 or args.force_process_group
     if world != args.gpus:
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
@@ -178,16 +191,18 @@ def main():
         # gather that last read this buffer blocks this stream, the new gather waits for this stream's launch -- the other stream is not involved
         j = k % S
         ev = timing["events"][k] if timing["events"] is not None else None
-        if ev is not None and not os.environ.get("TFF_BENCH_NOEV"):
+        if args.force_process_group:       # test seam: a gather that ran ahead of this step's launch would deliver zeros, not the previous step's (equal) records
+            r.zero_()
+        if ev is not None:
             ev[0].record(side[j])
         rc = lib.tff_linear_tft_pose_batch_dev(ctxs[j].handle, p(d_C), p(d_calm), 0, B, N, p(r, 0), p(r, 12 * B), p(r, 24 * B),
                                                None, None, ctypes.c_void_p(statuses[j].data_ptr()))
-        if ev is not None and not os.environ.get("TFF_BENCH_NOEV"):
+        if ev is not None:
             ev[1].record(side[j])
         if rc != 0:
             raise RuntimeError("tff_linear_tft_pose_batch_dev failed: %s" % lib.tff_last_error().decode())
 
-    pipe = tdist.OverlappedGather(world, tdist.RECORD_DOUBLES * B, dev, compute_stub if stub else compute, nbuf=max(2, S))
+    pipe = tdist.OverlappedGather(world, tdist.RECORD_DOUBLES * B, dev, compute_stub if stub else compute, nbuf=max(2, S), collective=use_pg)
     drain = pipe.drain
     if stub or S == 1:
         step = pipe.step
@@ -205,11 +220,33 @@ def main():
         step(k)
     drain()
     sync_all()
-    if world > 1:
-        dist.barrier()
-    dsync()
+
+    def timed_region():
+        """EXACTLY --steps steps between barrier + synchronize on both sides; returns the seconds (max over ranks)."""
+        if use_pg:
+            dist.barrier()
+        dsync()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        drain()
+        sync_all()
+        if use_pg:
+            dist.barrier()
+        dsync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # the region is a few milliseconds of wall clock: it is repeated and the MEDIAN repetition is the one reported (every repetition listed)
+    reps = max(1, args.reps)
+    rep_s = [timed_region() for _ in range(reps)]
+    elapsed = float(np.median(rep_s))
+    # per-launch HIP events of one more, UNTIMED repetition of the same loop: how long a launch lasts while its neighbour shares the GPU
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if not stub else [None] * args.steps
-    t0 = time.perf_counter()
     timing["events"] = events
     for k in range(args.steps):
         step(k)
@@ -219,19 +256,16 @@ def main():
     if world > 1:
         dist.barrier()
     dsync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     n_bad = sum(int((st_ != 0).sum().item()) for st_ in statuses)
+    pg_last, pg_check = None, None
+    if use_pg and not stub and rank == 0:                   # rank 0's own records as the last step's all-gather delivered them
+        pg_last = pipe.gathered[(args.steps - 1) % pipe.nbuf][rank].clone()
     for c in ctxs:                                          # the secondary blocks below run on the main stream, one call at a time
         c.set_stream(stream.cuda_stream)
     if stub:
-        step_ms = np.array(stub_ms) if stub_ms else np.array([float("nan")])
+        inflight_ms = np.array(stub_ms) if stub_ms else np.array([float("nan")])
     else:
-        step_ms = np.array([a.elapsed_time(b) for a, b in events]) if events and not os.environ.get("TFF_BENCH_NOEV") else np.array([float("nan")])
-    kern_ms = float(step_ms.mean())
+        inflight_ms = np.array([a.elapsed_time(b) for a, b in events]) if events else np.array([float("nan")])
     gather_check = None
     if stub and world > 1:                                  # every rank's records of the last step arrived complete and in rank order
         kl = args.steps - 1
@@ -255,15 +289,32 @@ def main():
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) / reps
 
-    single = None
+    single, iso_ms = None, None
     if rank == 0 and not stub:
-        # the same launch, strictly one batch at a time on one stream (no overlap between consecutive batches)
+        # the same call with the GPU to itself: one stream, nothing else queued, HIP events on that stream around every call (both launches of a
+        # call inside the pair)
         r0 = pipe.recs[0]
         call = lambda: lib.tff_linear_tft_pose_batch_dev(ctx.handle, p(d_C), p(d_calm), 0, B, N, p(r0, 0), p(r0, 12 * B), p(r0, 24 * B), None, None,
                                                          ctypes.c_void_p(status.data_ptr()))
-        ms1 = time_calls(call, max(10, args.steps))
+        n_iso = max(20, args.steps)
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize(dev)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_iso)]
+        for e0, e1 in evs:
+            e0.record(stream)
+            call()
+            e1.record(stream)
+            torch.cuda.synchronize(dev)                                      # the next call starts on an idle device
+        iso_ms = np.array([e0.elapsed_time(e1) for e0, e1 in evs])
+        # ... and back to back on that one stream (no host synchronisation between the calls): the one-batch-at-a-time throughput
+        ms1 = time_calls(call, max(20, args.steps))
         single = {"ms_per_batch": ms1, "value": B / (ms1 * 1e-3), "unit": "triplet-hypotheses/s",
                   "achieved_GBs": algorithmic_bytes_per_triplet(N) * B / (ms1 * 1e-3) / 1e9}
+        if pg_last is not None:          # --force-process-group: what the last step's overlapped gather delivered == this one-stream result, bit for bit
+            torch.cuda.synchronize(dev)
+            pg_check = {"forced": args.force_process_group, "backend": dist.get_backend(), "world": world, "streams": S,
+                        "gathered_equals_single_stream": bool(torch.equal(pg_last, r0)), "records": int(r0.numel())}
     if rank == 0 and world == 1 and not args.no_secondary and not stub:
         it32 = torch.zeros(B, dtype=torch.int32, device=dev)
         r = pipe.recs[0]
@@ -317,7 +368,9 @@ def main():
     if rank == 0:
         total = world * B * args.steps
         value = total / elapsed
+        ms_per_step = 1e3 * elapsed / args.steps
         alg = algorithmic_bytes_per_triplet(N) * B
+        kern_ms = float(iso_ms.mean()) if iso_ms is not None else float(inflight_ms.mean())
         achieved = alg / (kern_ms * 1e-3) / 1e9
         traffic, valu = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -326,37 +379,45 @@ def main():
                 pj = json.load(open(pmc))
                 traffic = pj.get("hbm_bytes_per_launch")
                 # the bound that actually binds: fp64 vector issue.  Counters from the committed rocprofv3 PMC passes;
-                # the issue-limited rate = SIMDs x clock / (4 cycles per wave64 VALU instruction) / instructions per triplet.
+                # the issue-limited rate = SIMDs x clock / (cycles per wave64 fp64 VALU instruction, profiles/r5_dpp_fmac.txt) / instructions per triplet.
                 ipt = pj.get("valu_instructions_per_triplet")
                 if ipt:
                     simds, clock_hz = 256 * 4, 2.4e9
                     valu = {"instructions_per_triplet": ipt, "busy_fraction": pj.get("valu_busy_fraction"),
                             "issue_limited_triplets_per_s": simds * clock_hz / 4.0 / ipt, "source": "profiles/pmc_latest.json (rocprofv3 --pmc, same command)"}
                     valu["frac_of_issue_limit"] = (value / world) / valu["issue_limited_triplets_per_s"]       # of the per-GPU rate actually delivered
+                    if single:
+                        valu["frac_of_issue_limit_one_batch_at_a_time"] = single["value"] / valu["issue_limited_triplets_per_s"]
             except Exception:
                 traffic, valu = None, None
         out = {
             "metric": "triplet-hypotheses/sec (linearTFT+R,t) at N=200 corresp.",
             "value": value, "unit": "triplet-hypotheses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            # batches that may be resident on a GPU at once (consecutive steps alternate between that many streams), and how much of a launch
+            # is hidden behind its neighbour: kernel_ms (GPU to itself) / ms_per_step; kernel_ms * steps / in_flight <= ms_per_step * steps
+            "in_flight": S, "overlap_factor": kern_ms / ms_per_step,
+            "repetitions": {"n": reps, "reported": "median", "ms_per_step_each": [1e3 * t_ / args.steps for t_ in rep_s],
+                            "timed_region_ms_each": [1e3 * t_ for t_ in rep_s]},
             "config": {"workload": "configs[1]: batch of %d synthetic triplets x %d correspondences, sigma=1px, "
                                    "linearTFT + R_t_from_TFT (LinearTFTPoseEstimation without Reconst), one batch per GPU" % (B, N),
                        "batch_per_gpu": B, "correspondences": N,
                        "streams": "%d (consecutive batches alternate between streams and may overlap)" % S if S > 1 else "1",
                        "gather": ("%s all_gather of 408-B result records, overlapped" % ("gloo (stub)" if stub else "RCCL")) if world > 1 else "none (1 GPU)",
                        "failed_triplets": n_bad},
+            # ONE launch, ONE duration: the call with the GPU to itself (see the docstring); `in_flight_launch_ms` is the same call's HIP-event
+            # duration while its neighbour on the other stream shares the GPU (longer: not the kernel's own time, reported for the record only)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_linear_tft_pose_rows", "kernel_ms": kern_ms,
-                         # kernel_ms: HIP events around each step's launches on the step's own stream, mean over the timed region (with two
-                         # streams a launch shares the GPU with its neighbour, so it is LONGER than ms_per_step); minimum and median beside it
-                         "kernel_ms_min": float(step_ms.min()), "kernel_ms_median": float(np.median(step_ms)),
-                         "value_at_median_step": (world * B / (float(np.median(step_ms)) * 1e-3)) if S == 1 else None,
+                         "kernel_ms_how": "HIP events on the launch stream around every call (k_linear_tft_pose_rows + the exact kernel's status scan), "
+                                          "one stream, device idle before every call, mean of %d calls" % (len(iso_ms) if iso_ms is not None else 0),
+                         "kernel_ms_min": float(iso_ms.min()) if iso_ms is not None else None,
+                         "kernel_ms_median": float(np.median(iso_ms)) if iso_ms is not None else None,
+                         "in_flight_launch_ms": float(inflight_ms.mean()),
                          "algorithmic_bytes_per_launch": alg,
-                         # with two streams a launch shares the GPU with its neighbour: `achieved` above prices ONE launch over its own (longer)
-                         # duration; the rate the device delivers is the algorithmic bytes of a step over ms_per_step
-                         "delivered": {"achieved": alg * world / (1e3 * elapsed / args.steps * 1e-3) / 1e9 / world,
-                                       "frac": alg / (1e3 * elapsed / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s per GPU"}},
+                         # the rate the device delivers with `in_flight` batches resident: algorithmic bytes of a step over ms_per_step
+                         "delivered": {"achieved": alg / (ms_per_step * 1e-3) / 1e9, "frac": alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s per GPU"}},
         }
         if single:
             out["single_stream"] = single
@@ -368,6 +429,8 @@ def main():
             out["n_sweep"] = n_sweep
         if config4:
             out["config4"] = config4
+        if pg_check:
+            out["process_group_check"] = pg_check
         if stub:
             out["stub"] = {"compute": "tagged fill on CPU tensors (test seam, not a measurement)", "gather_check": gather_check}
         if world == 1 and not args.no_cpu_baseline and not stub:
@@ -378,7 +441,7 @@ def main():
             if ref_t:
                 out["cpu_baseline_reference"] = ref_t
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

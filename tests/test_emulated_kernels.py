@@ -736,3 +736,41 @@ def test_rows_exact_linear_f_kernel_matches_oracle(emu, B, N, sigma):
         assert rel_err_T(out["T"][b], T) < 1e-9 and rel_err(out["R_t_2"][b], R2) < 1e-9 and rel_err(out["R_t_3"][b], R3) < 1e-9
         assert rel_err(out["Reconst"][b], Rec) < 1e-9
         assert rel_err_T(out["T"][b], ref["T"][b]) < 1e-10 and rel_err(out["R_t_3"][b], ref["R_t_3"][b]) < 1e-10
+
+
+def _run_gh_wg(emu, model, C, CalM, reconst=True):
+    B, N, _ = C.shape
+    calm = calm_colmajor(CalM)
+    Rt2 = np.zeros((B, 12)); Rt3 = np.zeros((B, 12)); T = np.zeros((B, 27)); Rec = np.zeros((B, N, 3)) if reconst else None
+    it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32)
+    emu.emu_gh_wg_pose(ctypes.c_int(model), _p(C), _p(calm), ctypes.c_long(0), ctypes.c_long(B), ctypes.c_int(N), ctypes.c_int(0),
+                       _p(Rt2), _p(Rt3), _p(T), _p(Rec), _p(it), _p(st))
+    return dict(Rt2=Rt2, Rt3=Rt3, T=T, Rec=Rec, iter=it, status=st)
+
+
+@pytest.mark.parametrize("neighbour", ["nan", "collinear"])
+def test_gh_finish_rows_keeps_the_rows_of_a_wavefront_independent(emu, neighbour):
+    """k_gh_finish_rows (gh_rows_kernel.h) with Reconst requested: a failed triplet (status > 0) keeps its all-NaN outputs -- the pose tail that
+    its row still runs on a dummy tensor must not store -- and what a triplet gets does not depend on what the other rows of its wavefront hold:
+    neither on a dead row nor on a row the exact tiers have to redo (collinear camera centres: the fast null vectors report, the whole
+    wavefront goes through the tail a second time and only that row may store)."""
+    B, N = 3, 12
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=77)
+    ref = _run_gh_wg(emu, 0, C, CalM)
+    assert np.all(ref["status"] == 0)
+    Cx = C.copy()
+    if neighbour == "nan":
+        Cx[1, 5, 2] = np.nan
+    else:
+        Cc, _, _, _ = generate_scene_batch(1, N, noise=1.0, seed=312, angle=180)
+        Cx[1] = Cc[0]
+    out = _run_gh_wg(emu, 0, Cx, CalM)
+    if neighbour == "nan":
+        assert out["status"][1] == 2
+        assert np.all(np.isnan(out["Rec"][1])) and np.all(np.isnan(out["T"][1])) and np.all(np.isnan(out["Rt2"][1])) and np.all(np.isnan(out["Rt3"][1]))
+    else:
+        assert out["status"][1] == 0 and np.all(np.isfinite(out["Rec"][1]))
+    for b in (0, 2):
+        assert out["status"][b] == 0 and out["iter"][b] == ref["iter"][b]
+        for k in ("Rec", "T", "Rt2", "Rt3"):
+            assert np.array_equal(out[k][b], ref[k][b]), (neighbour, b, k)

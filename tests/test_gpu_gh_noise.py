@@ -25,11 +25,14 @@ from helpers import rel_err_T, rel_err, golden_cases   # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def gpu_ctx():
+@pytest.fixture(scope="module", params=[pytest.param(1, id="rows"), pytest.param(0, id="wave")])
+def gpu_ctx(request):
+    """Both kernel routes (tests/conftest.py::ROUTES): 1 = the linear stage and pose tail four triplets per wavefront (large batches), 0 = one triplet
+    per wavefront -- what the library's default picks for the small batches of the MEX drop-in.  Every 50-digit gate below runs on both."""
     from tft_vs_fund_amd import api
     ctx = api.Context(0)
-    ctx.set_rows(1)                                                          # (the linear stage of the large-batch route: tests/conftest.py)
+    ctx.set_rows(request.param)
+    ctx.route = request.param
     return ctx
 
 

@@ -4,7 +4,7 @@ batches of 1024 triplets and more) on the MI355X
 against the one-triplet-per-wavefront kernels (TFF_OPT_ROWS = 0) and the oracle: same arithmetic per matrix entry and correspondence, sums taken in
 a different order, so the two routes must agree to rounding on every batch shape -- full and ragged last wavefronts, one to many trips
 per data pass, well-posed and outlier-ridden data (adaptive cheirality votes: second sweep), sampled hypotheses (config 4).
-The oracle comparisons of tests/test_gpu_parity.py run through the rows kernels as well (tests/conftest.py forces TFF_OPT_ROWS = 1).
+The oracle comparisons of tests/test_gpu_parity.py run through both routes as well (tests/conftest.py::ROUTES).
 """
 import numpy as np
 import pytest
@@ -14,6 +14,17 @@ pytestmark = pytest.mark.gpu
 from helpers import rel_err_T, rel_err   # noqa: E402
 
 TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def gpu_ctx():
+    """(not the route-parametrised context of conftest.py: every test here switches between the routes itself and leaves TFF_OPT_ROWS = 1 behind)"""
+    from tft_vs_fund_amd import api
+    from tft_vs_fund_amd.build import build_library
+    build_library()
+    ctx = api.Context(0)
+    ctx.set_rows(1)
+    return ctx
 
 
 def _both_routes(ctx, *args, **kw):
@@ -182,3 +193,27 @@ def test_default_route_goes_by_batch_size(method):
         assert not torch.equal(a["T"], o["T"])                               # (the two routes differ in the last bits, so the check above says which one ran)
         with pytest.raises(Exception):
             auto.set_rows(3)
+
+
+@pytest.mark.parametrize("method", ["ResslTFTPoseEstimation", "PiPoseEstimation", "LinearTFTPoseEstimation", "LinearFPoseEstimation", "OptimFPoseEstimation"])
+def test_a_failed_triplet_has_all_nan_outputs_and_its_neighbours_do_not_notice(gpu_ctx, method):
+    """Rows route with Reconst requested: a triplet with a NaN coordinate (status != 0) gets NaN in EVERY output, Reconst included -- its row still
+    walks through the pose tail on a dummy tensor and must not store -- and the three triplets that share its wavefront are bit-identical to a
+    run in which the failed one is replaced by a healthy triplet (rows_pose_tail: per-row Reconst store)."""
+    import torch
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    B, N = 8, 24
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=515)
+    calm = torch.from_numpy(CalM).cuda()
+    ref = gpu_ctx.pose_batch(method, torch.from_numpy(C).cuda(), calm, reconst=True)
+    Cb = C.copy()
+    Cb[5, 7, 2] = np.nan
+    out = gpu_ctx.pose_batch(method, torch.from_numpy(Cb).cuda(), calm, reconst=True)
+    st = out["status"].cpu().numpy() if hasattr(out["status"], "cpu") else np.asarray(out["status"])
+    assert st[5] != 0
+    for k in ("T", "R_t_2", "R_t_3", "Reconst"):
+        v = out[k].cpu().numpy() if hasattr(out[k], "cpu") else np.asarray(out[k])
+        r = ref[k].cpu().numpy() if hasattr(ref[k], "cpu") else np.asarray(ref[k])
+        assert np.all(np.isnan(v[5])), (method, k, v[5].ravel()[:6])
+        for b in (0, 1, 2, 3, 4, 6, 7):
+            assert np.array_equal(v[b], r[b]), (method, k, b)

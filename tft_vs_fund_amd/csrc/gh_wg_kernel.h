@@ -733,12 +733,18 @@ __global__ void __launch_bounds__(64, 2) k_gh_finish(const GhWgArgs a) {
         int status = rt_from_tft_wave<false>(w, pts, N, nullptr, &fine);
         if (!fine) status = rt_from_tft_wave<true>(w, pts, N, nullptr);
         if (s0 < 0) status = -s0;
-        write_poses(w, a.Rt2 + b * 12, a.Rt3 + b * 12);
-        if (lane < 27) a.T[b * 27 + lane] = w->T1[lane];
-        if (a.reconst) final_reconst(w, pts, N, a.reconst + b * 3 * (long)N);
         double chk = (lane < 12) ? w->Rt[0][lane] : ((lane < 24) ? w->Rt[1][lane - 12] : ((lane < 51) ? w->T1[lane - 24] : 0.0));
         const bool bad = !(fabs(chk) <= 1.79e308);
-        if (wave_any(bad) && status == ST_OK) status = ST_NONFINITE;
+        if (wave_any(bad)) {                                                 // non-finite outputs: status 2 (unless the iteration reported first), ALL outputs NaN
+            if (status == ST_OK) status = ST_NONFINITE;
+            if (lane < 12) { a.Rt2[b * 12 + lane] = qnan; a.Rt3[b * 12 + lane] = qnan; }
+            if (lane < 27) a.T[b * 27 + lane] = qnan;
+            if (a.reconst) for (int i = lane; i < 3 * N; i += WAVE) a.reconst[b * 3 * (long)N + i] = qnan;
+        } else {
+            write_poses(w, a.Rt2 + b * 12, a.Rt3 + b * 12);
+            if (lane < 27) a.T[b * 27 + lane] = w->T1[lane];
+            if (a.reconst) final_reconst(w, pts, N, a.reconst + b * 3 * (long)N);
+        }
         if (lane == 0) a.status[b] = status;
     }
 }

@@ -713,7 +713,8 @@ __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const R
 
 // One pass over the row's correspondences with the fast DLT tier (pose_common.h::tri_pass_fast): MODE TRI_SCALE -> num / den of
 // R_t_from_TFT.m:72-73 (every lane of the row), TRI_RECONST -> dehomogenised points to out (3 x N).  Returns false (per row) when some
-// correspondence's inverse iteration hit its cap.
+// correspondence's inverse iteration hit its cap.  out is per ROW: nullptr for a row that stores nothing (a tail row, a failed triplet whose
+// outputs are already NaN, a row the caller only carries along) -- its lanes still make the pass, the trip count is the wavefront's.
 template <int MODE, bool EXACT = false>
 __device__ __forceinline__ bool rows_tri_pass(const RowSrc& s, const int N, const double* camA, const double* camB, const double* aux,
                                               double* out, double& num_out, double& den_out) {
@@ -752,7 +753,7 @@ __device__ __forceinline__ bool rows_tri_pass(const RowSrc& s, const int N, cons
             cross3(p3, u3, c2);
             num += c1[0] * c2[0] + c1[1] * c2[1] + c1[2] * c2[2];
             den += c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2];
-        } else {
+        } else if (out) {                                                    // (per row: a row that must not store passes nullptr)
             out[3 * (long)i + 0] = X0;
             out[3 * (long)i + 1] = X1;
             out[3 * (long)i + 2] = X2;
@@ -907,12 +908,6 @@ __device__ __forceinline__ int rows_pose_tail(const LinearTftArgs& a, RowLds* w,
         if (p == 0) compose_camera_from_pose(load_K(w->calm, 2), rt->Rt[1], rt->Pfin[2]);           // K3 [R3 | lam t3]
         wave_sync();
     }
-    if (a.reconst) {                                                         // LinearTFTPoseEstimation.m:59-60
-        double n0, d0;
-        // (a tail row repeats triplet B - 1 and stores the same values to the same places)
-        const bool conv = rows_tri_pass<TRI_RECONST, EXACT>(j.src, N, rt->Pfin[0], rt->Pfin[1], rt->Pfin[2], a.reconst + b * 3 * (long)N, n0, d0);
-        ok = ok && conv;
-    }
     if constexpr (T_FROM_CAMERAS) {                                          // TFT_from_P.m:25-33 (f_kernel.h::tft_from_cameras): 27 determinants, positions p and 16 + p
         double val[2];
 #pragma unroll
@@ -935,35 +930,44 @@ __device__ __forceinline__ int rows_pose_tail(const LinearTftArgs& a, RowLds* w,
         if (p < 11) rt->T1[16 + p] = val[1] * rs;
         wave_sync();
     }
-    if (j.bad_index) {
-        status = ST_TOO_FEW;
-        rows_store_nan(a, j, N);
-    } else if (!ok) {
-        status = ST_RETRY;                                                   // redone by the exact kernel
-    }
-    {
-        const bool store = j.valid && ok && !j.bad_index;                    // per row
-        bool bad = false;
+    // poses (row-major in LDS) -> MATLAB column-major 3x4 arrays; a non-finite entry anywhere makes the triplet ST_NONFINITE with ALL-NaN outputs
+    double vRt[2], vT[2];
+    bool bad = false;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {                                        // poses (row-major in LDS) -> MATLAB column-major 3x4 arrays
-            const int e24 = 16 * h + p;
-            if (e24 < 24) {
-                const int which = e24 / 12, e = e24 % 12, c = e / 3, r = e % 3;
-                const double v = rt->Rt[which][4 * r + c];
-                bad = bad || !(fabs(v) <= 1.79e308);
-                if (store) (which ? a.Rt3 : a.Rt2)[b * 12 + e] = v;
-            }
-            const int e27 = 16 * h + p;
-            if (e27 < 27) {
-                const double v = rt->T1[e27];
-                bad = bad || !(fabs(v) <= 1.79e308);
-                if (store) a.T[b * 27 + e27] = v;
-            }
+    for (int h = 0; h < 2; ++h) {
+        const int e24 = 16 * h + p;
+        vRt[h] = 0.0; vT[h] = 0.0;
+        if (e24 < 24) {
+            const int which = e24 / 12, e = e24 % 12, c = e / 3, r = e % 3;
+            vRt[h] = rt->Rt[which][4 * r + c];
         }
-        rows_stamp(dbg, 13);
-        const bool nonfinite = row_any(bad);                                 // (the ballot is the whole wavefront's: outside every per-row branch)
-        if (nonfinite && status == ST_OK) status = ST_NONFINITE;             // non-finite outputs -> status 2
+        if (e24 < 27) vT[h] = rt->T1[e24];
+        bad = bad || !(fabs(vRt[h]) <= 1.79e308) || !(fabs(vT[h]) <= 1.79e308);
     }
+    const bool nonfinite = row_any(bad);                                     // (the ballot is the whole wavefront's: outside every per-row branch)
+    if (a.reconst) {                                                         // LinearTFTPoseEstimation.m:59-60
+        double n0, d0;
+        // only a row that owns a live triplet stores: a tail row, a failed triplet (its Reconst is NaN) and a row that is merely carried
+        // along by a neighbour's exact-tier redo (k_gh_finish_rows) leave Reconst alone -- a triplet's bits never depend on its neighbours
+        double* rec = (j.valid && !j.bad_index && !nonfinite) ? a.reconst + b * 3 * (long)N : nullptr;
+        const bool conv = rows_tri_pass<TRI_RECONST, EXACT>(j.src, N, rt->Pfin[0], rt->Pfin[1], rt->Pfin[2], rec, n0, d0);
+        ok = ok && conv;
+    }
+    if (j.bad_index) status = ST_TOO_FEW;
+    else if (!ok) status = ST_RETRY;                                         // redone by the exact kernel
+    else if (nonfinite && status == ST_OK) status = ST_NONFINITE;            // non-finite outputs -> status 2
+    if (j.bad_index || (ok && nonfinite)) {
+        rows_store_nan(a, j, N);                                             // (stores only for a row that owns a triplet)
+    } else {
+        const bool store = j.valid && ok;                                    // per row
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e24 = 16 * h + p;
+            if (e24 < 24 && store) ((e24 >= 12) ? a.Rt3 : a.Rt2)[b * 12 + e24 % 12] = vRt[h];
+            if (e24 < 27 && store) a.T[b * 27 + e24] = vT[h];
+        }
+    }
+    rows_stamp(dbg, 13);
     return status;
 }
 

@@ -20,13 +20,14 @@ def shard_bounds(B, world, rank):
     return (rank * B) // world, ((rank + 1) * B) // world
 
 
-def init_from_env(device_type=None):
+def init_from_env(device_type=None, force_group=False):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (set by torch.distributed.run).
-    Returns (rank, world, local_rank).  Single process: (0, 1, 0) without a process group."""
+    Returns (rank, world, local_rank).  Single process: (0, 1, 0) without a process group -- unless force_group asks for a
+    clique-of-one group (a test seam: the collective path then executes against RCCL on one GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if device_type is None:
@@ -117,10 +118,11 @@ class OverlappedGather:
     `ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)` first (bench.py does), or the gather reads half-written records
     and the buffer reuse is unprotected.  The gloo CPU test cannot see a violation of this."""
 
-    def __init__(self, world, numel, device, compute, nbuf=2, dtype=torch.float64):
+    def __init__(self, world, numel, device, compute, nbuf=2, dtype=torch.float64, collective=None):
         self.world, self.nbuf, self.compute = world, nbuf, compute
+        self.collective = (world > 1) if collective is None else bool(collective)      # (True at world 1: a clique-of-one group, test seam)
         self.recs = [torch.empty(numel, dtype=dtype, device=device) for _ in range(nbuf)]
-        self.gathered = [torch.empty((world, numel), dtype=dtype, device=device) for _ in range(nbuf)] if world > 1 else None
+        self.gathered = [torch.empty((world, numel), dtype=dtype, device=device) for _ in range(nbuf)] if self.collective else None
         self.pending = [None] * nbuf
 
     def step(self, k):
@@ -130,7 +132,7 @@ class OverlappedGather:
             self.pending[buf] = None
         r = self.recs[buf]
         self.compute(r, k)
-        if self.world > 1:
+        if self.collective:
             self.pending[buf] = dist.all_gather_into_tensor(self.gathered[buf].reshape(-1), r, async_op=True)
         return buf
 
