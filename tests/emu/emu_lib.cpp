@@ -46,7 +46,20 @@ extern "C" int emu_linear_tft_pose_rows(const double* corresp, const double* cal
                                         double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
     tff::LinearTftArgs a{corresp, calm, calm_stride, B, N, flags & ~tff::FLAG_JACOBI, Rt2, Rt3, T, reconst, iter, status, dbg, nullptr, nullptr, nullptr};
     if (reconst) a.flags |= tff::FLAG_RECONST;
-    emu::launch(tff::k_linear_tft_pose_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);
+    std::vector<double> pre;
+    if (flags & 8192) {                                                      // test switch: moments + normalisations from k_tft_moments (as the C ABI does from N >= 48)
+        pre.assign((size_t)B * tff::PRE_DOUBLES, 0.0);
+        tff::MomentArgs m{corresp, B, N, pre.data()};
+        const bool stage = !(flags & 16384);                                 // (16384: second pass from global memory, the large-N variant)
+        if (stage) emu::launch(tff::k_tft_moments<true>, emu_grid(B), 64, tff::moments_lds_bytes(N, true), m);
+        else emu::launch(tff::k_tft_moments<false>, emu_grid(B), 64, tff::moments_lds_bytes(N, false), m);
+        a.pre = pre.data();
+        a.flags &= ~(8192 | 16384);
+        emu::launch(tff::k_linear_tft_pose_rows<true>, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);
+        a.pre = nullptr;
+    } else {
+        emu::launch(tff::k_linear_tft_pose_rows<false>, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);
+    }
     bool any = false;
     for (long b = 0; b < B; ++b) any = any || status[b] == tff::ST_RETRY;
     if (!any) return 0;

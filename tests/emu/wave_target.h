@@ -14,6 +14,7 @@ inline uint64_t emu_bits(double v) { uint64_t u; std::memcpy(&u, &v, 8); return 
 inline double emu_dbl(uint64_t u) { double v; std::memcpy(&v, &u, 8); return v; }
 
 inline void wave_sync() { emu::wave_barrier(); }
+inline void store_fence() { emu::wave_barrier(); }
 inline double wave_shfl_xor(double v, int mask) { return emu_dbl(emu::exchange(emu_bits(v), emu_lane() ^ mask)); }
 inline int wave_shfl_xor_i(int v, int mask) { return (int)emu::exchange((uint64_t)(uint32_t)v, emu_lane() ^ mask); }
 inline double wave_bcast(double v, int src) { return emu_dbl(emu::exchange(emu_bits(v), src)); }

@@ -774,3 +774,32 @@ def test_gh_finish_rows_keeps_the_rows_of_a_wavefront_independent(emu, neighbour
         assert out["status"][b] == 0 and out["iter"][b] == ref["iter"][b]
         for k in ("Rec", "T", "Rt2", "Rt3"):
             assert np.array_equal(out[k][b], ref[k][b]), (neighbour, b, k)
+
+
+FLAG_PRE, FLAG_PRE_GLOBAL = 8192, 16384
+
+
+@pytest.mark.parametrize("B,N,sigma,extra", [(5, 12, 1.0, 0), (3, 70, 0.0, 0), (2, 130, 1.0, FLAG_PRE_GLOBAL), (6, 200, 1.0, 0), (1, 333, 2.0, FLAG_PRE_GLOBAL), (2, 64, 1.0, 0)])
+def test_moments_kernel_feeds_the_rows_kernel(emu, B, N, sigma, extra):
+    """k_tft_moments (tft_moments_kernel.h: one triplet per wavefront, correspondences parked in LDS -- or, extra = FLAG_PRE_GLOBAL, re-read from
+    global memory as for N beyond the LDS budget) + k_linear_tft_pose_rows<true> against the oracle at 1e-9 and against the fused rows kernel,
+    whose two data passes it replaces, to rounding (same arithmetic per correspondence, sums in a different order); the normalisations and the
+    linear tensor of the debug record to 1e-12.  Also one block taking all triplets through the same LDS copy (grid capped at 1)."""
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=sigma, seed=900 + N)
+    fused = run_linear_tft(emu, C, CalM, entry="emu_linear_tft_pose_rows", debug=True)
+    out = run_linear_tft(emu, C, CalM, flags=FLAG_PRE | extra, entry="emu_linear_tft_pose_rows", debug=True)
+    assert np.all(out["status"] == 0) and np.all(out["iter"] == 0)
+    assert np.abs(out["debug"][:, 71:80] / fused["debug"][:, 71:80] - 1.0).max() < 1e-13        # Normalize2Ddata: s, -s cx, -s cy per view
+    assert np.abs(out["debug"][:, 33:60] - fused["debug"][:, 33:60]).max() < 1e-11              # linearTFT's constrained tensor
+    for b in range(B):
+        R2, R3, Rec, T, _ = O.LinearTFTPoseEstimation(C[b].T.copy(), CalM)
+        assert rel_err_T(out["T"][b], T) < 1e-9 and rel_err(out["R_t_2"][b], R2) < 1e-9 and rel_err(out["R_t_3"][b], R3) < 1e-9
+        assert rel_err(out["Reconst"][b], Rec) < 1e-9
+        assert rel_err_T(out["T"][b], fused["T"][b]) < 1e-11 and rel_err(out["R_t_3"][b], fused["R_t_3"][b]) < 1e-11
+    emu.emu_set_grid_cap(1)
+    try:
+        one = run_linear_tft(emu, C, CalM, flags=FLAG_PRE | extra, entry="emu_linear_tft_pose_rows", debug=False)
+    finally:
+        emu.emu_set_grid_cap(0)
+    for k in ("T", "R_t_2", "R_t_3", "Reconst", "status"):
+        assert np.array_equal(one[k], out[k], equal_nan=True), k

@@ -38,6 +38,7 @@ TFF_OPT_SPILL = 6
 TFF_OPT_ROWS = 7
 TFF_OPT_DEBUG_FP_HANDOVER = 8
 TFF_OPT_DEBUG_ADAPTIVE = 9
+TFF_OPT_PRE = 10
 DEBUG_STRIDE = 128
 
 ST_OK, ST_TOO_FEW, ST_NONFINITE, ST_NO_POSE, ST_RANK, ST_NO_PARAM = 0, 1, 2, 3, 4, 5
@@ -192,6 +193,12 @@ class Context:
         the device in one go; one per wavefront below); True / 1 = the row kernels always; False / 0 = never."""
         v = 2 if on == "auto" else (int(on) if isinstance(on, int) and not isinstance(on, bool) else int(bool(on)))
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_ROWS, v), "set_option")
+
+    def set_pre(self, on):
+        """TFF_OPT_PRE: "auto" or 2 (default) = normalisations + moment sums of the trifocal row kernels in a kernel of their own (one triplet per
+        wavefront, correspondences read once) from N >= 48; True / 1 = always; False / 0 = inside the row kernels."""
+        v = 2 if on == "auto" else (int(on) if isinstance(on, int) and not isinstance(on, bool) else int(bool(on)))
+        _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_PRE, v), "set_option")
 
     def set_debug_adaptive(self, on):
         """TFF_OPT_DEBUG_ADAPTIVE (profiling hook): debug entry points keep the production cheirality-vote logic."""

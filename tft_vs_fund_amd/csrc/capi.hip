@@ -55,7 +55,7 @@ struct tff_ctx {
     int solver = 0;
     int exact_below = tff::EXACT_BELOW_N;   // TFF_OPT_EXACT_BELOW
     int stage = -1;
-    DevBuf in, calm, out, idx, scratch_status, gh_rec, gh_topt, gh_init, spill;
+    DevBuf in, calm, out, idx, scratch_status, gh_rec, gh_topt, gh_init, spill, pre;
     const int32_t* sample_idx = nullptr;   // set around a *_sampled_dev call
     int32_t sample_ns = 0;                 //   size of the scene the indices refer to
     double* init_p = nullptr; double* init_x = nullptr;   // set around tff_pi_pose_batch_debug_dev
@@ -63,6 +63,7 @@ struct tff_ctx {
     int gh_exact = 0;                      // TFF_OPT_GH_EXACT
     int spill_only_if_needed = 0;          // TFF_OPT_SPILL
     int rows = 2;                          // TFF_OPT_ROWS: 0 never, 1 always, 2 by batch size (rows_for)
+    int pre = 2;                           // TFF_OPT_PRE: 0 never, 1 always, 2 by N (pre_for)
     int dbg_fp_handover = 0;               // TFF_OPT_DEBUG_FP_HANDOVER
     int dbg_adaptive = 0;                  // TFF_OPT_DEBUG_ADAPTIVE
 };
@@ -76,6 +77,27 @@ namespace {
 bool rows_for(const tff_ctx* c, int64_t B, int32_t N) {
     if (c->rows != 2) return c->rows != 0;
     return B >= (N <= 256 ? 1024 : 2048 + 1);
+}
+
+// The normalisations and moment sums of the trifocal row kernels as a kernel of their own (tft_moments_kernel.h: one triplet per wavefront,
+// correspondences read once, three wavefronts per SIMD)?  A wavefront per triplet idles on a handful of correspondences, so small N keeps the
+// fused passes (tools/ab_pre.py).  TFF_OPT_PRE = 0 / 1 force a route; sampled hypotheses (config 4) never take it.
+bool pre_for(const tff_ctx* c, int32_t N) {
+    if (c->sample_idx) return false;
+    if (c->pre != 2) return c->pre != 0;
+    return N >= 48;
+}
+// launches k_tft_moments on the context's stream; *pre_out = the B x PRE_DOUBLES records the row kernels' <true> variants read
+int launch_moments(tff_ctx* c, const double* corresp, int64_t B, int32_t N, const double** pre_out) {
+    if (int r = c->pre.reserve((size_t)B * tff::PRE_DOUBLES * sizeof(double))) return r;
+    tff::MomentArgs m{corresp, (long)B, N, (double*)c->pre.p};
+    const bool stage = N <= tff::PRE_STAGE_MAX_N;
+    const size_t lds = tff::moments_lds_bytes(N, stage);
+    if (stage) hipLaunchKernelGGL(tff::k_tft_moments<true>, dim3(tff::moments_grid(B)), dim3(64), lds, c->stream, m);
+    else hipLaunchKernelGGL(tff::k_tft_moments<false>, dim3(tff::moments_grid(B)), dim3(64), lds, c->stream, m);
+    TFF_HIP(hipGetLastError());
+    *pre_out = (const double*)c->pre.p;
+    return 0;
 }
 
 int base_flags(const tff_ctx* c, bool reconst) {
@@ -188,9 +210,11 @@ int launch_pose(tff_ctx* c, KMain kmain, KJac kjac, lds_fn ldsfn, int stage_max_
 
 // LinearTFTPoseEstimation / LinearFPoseEstimation, default route: four triplets per wavefront (tft_rows_kernel.h / f_rows_kernel.h, fast
 // tiers), then the exact kernel (one wavefront per triplet) over what they could not finish or certify.
+// krows_pre (may be null): the variant of krows that starts from k_tft_moments' records; taken when pre_for() says so.
 template <class KRows, class KExact>
 int launch_pose_rows(tff_ctx* c, KRows krows, KExact kexact, lds_fn exact_lds, int stage_max_n, const double* corresp, const double* calm, int64_t calm_stride,
-                     int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
+                     int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg,
+                     KRows krows_pre = nullptr) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     TFF_LOCK(c);
     if (B == 0) return 0;
@@ -202,7 +226,13 @@ int launch_pose_rows(tff_ctx* c, KRows krows, KExact kexact, lds_fn exact_lds, i
     }
     tff::LinearTftArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr),
                          Rt2, Rt3, T, reconst, iter, status, dbg, c->sample_idx, c->init_p, c->init_x, nullptr, 0, c->sample_ns};
-    hipLaunchKernelGGL(krows, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, a);
+    if (krows_pre && N >= 7 && pre_for(c, N)) {
+        if (int r = launch_moments(c, corresp, B, N, &a.pre)) return r;
+        hipLaunchKernelGGL(krows_pre, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, a);
+        a.pre = nullptr;
+    } else {
+        hipLaunchKernelGGL(krows, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, a);
+    }
     TFF_HIP(hipGetLastError());
     a.flags |= tff::FLAG_ONLY_RETRY;
     if (c->sample_idx) a.flags |= tff::FLAG_STAGE_LDS;   // the exact kernel gathers samples into LDS
@@ -227,8 +257,8 @@ int launch_linear_tft(tff_ctx* c, const double* corresp, const double* calm, int
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
     const bool rows = c && rows_for(c, B, N);
     if (rows && c->solver == 0 && N >= c->exact_below)
-        return launch_pose_rows(c, tff::k_linear_tft_pose_rows, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, corresp, calm, calm_stride,
-                                B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+        return launch_pose_rows(c, tff::k_linear_tft_pose_rows<false>, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, corresp, calm, calm_stride,
+                                B, N, Rt2, Rt3, T, reconst, iter, status, dbg, tff::k_linear_tft_pose_rows<true>);
     if (rows)             // whole batches for the exact tiers (minimal samples, TFF_OPT_SOLVER = 1): four triplets per wavefront there too (tft_rows_exact_kernel.h)
         return launch_pose_rows(c, tff::k_linear_tft_pose_rows_exact, tff::k_linear_tft_pose<true>, tff::pose_lds_bytes, tff::STAGE_MAX_N_TFT, corresp, calm,
                                 calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
@@ -511,7 +541,7 @@ void tff_ctx_destroy(tff_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->own) { (void)hipStreamSynchronize(c->own); (void)hipStreamDestroy(c->own); }
     if (c->handover) (void)hipEventDestroy(c->handover);
-    c->in.release(); c->calm.release(); c->out.release(); c->idx.release(); c->scratch_status.release(); c->gh_rec.release(); c->gh_topt.release(); c->gh_init.release(); c->spill.release();
+    c->in.release(); c->calm.release(); c->out.release(); c->idx.release(); c->scratch_status.release(); c->gh_rec.release(); c->gh_topt.release(); c->gh_init.release(); c->spill.release(); c->pre.release();
     delete c;
 }
 
@@ -561,6 +591,7 @@ int tff_ctx_set_option(tff_ctx* c, int option, long value) {
         case TFF_OPT_GH_EXACT: c->gh_exact = value != 0; return 0;
         case TFF_OPT_SPILL: c->spill_only_if_needed = value != 0; return 0;
         case TFF_OPT_ROWS: if (value < 0 || value > 2) return fail(TFF_E_INVALID, "rows must be 0, 1 or 2"); c->rows = (int)value; return 0;
+        case TFF_OPT_PRE: if (value < 0 || value > 2) return fail(TFF_E_INVALID, "pre must be 0, 1 or 2"); c->pre = (int)value; return 0;
         case TFF_OPT_DEBUG_FP_HANDOVER: c->dbg_fp_handover = value != 0; return 0;
         case TFF_OPT_DEBUG_ADAPTIVE: c->dbg_adaptive = value != 0; return 0;
         case TFF_OPT_KERNEL: if (value < 0 || value > 2) return fail(TFF_E_INVALID, "kernel must be 0, 1 or 2"); c->kernel_variant = (int)value; return 0;

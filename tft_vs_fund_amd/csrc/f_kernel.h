@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(64, (METHOD == 1 && !JAC) ? 3 : 2) k_f_pose(co
                     if (lane < 27) a.T[b * 27 + lane] = w->T1[lane];
                     double chk = (lane < 12) ? w->Rt[0][lane] : ((lane < 24) ? w->Rt[1][lane - 12] : ((lane < 51) ? w->T1[lane - 24] : 0.0));
                     const bool bad = !(fabs(chk) <= 1.79e308);
-                    if (wave_any(bad) && status == ST_OK) status = ST_NONFINITE;
+                    if (wave_any(bad)) { if (status == ST_OK) status = ST_NONFINITE; wave_nan_outputs(a.Rt2, a.Rt3, a.T, a.reconst, b, N); }
                 }
             }
         }

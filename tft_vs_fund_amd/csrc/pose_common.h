@@ -30,6 +30,17 @@ constexpr int ST_RETRY = 100;         // internal: a fast tier could not finish 
 
 constexpr int DBG_STRIDE = 128;       // doubles per triplet in the optional debug buffer
 
+// A triplet whose outputs hold a NaN / Inf anywhere reports it in its status and gets NaN in EVERY output (T, R_t_2, R_t_3, Reconst): the
+// one-triplet kernels call this after their stores (whole wavefront; the fence puts the rewrite behind the stores other lanes made).
+__device__ __forceinline__ void wave_nan_outputs(double* Rt2, double* Rt3, double* T, double* reconst, const long b, const int N) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    store_fence();
+    if (lane < 12) { Rt2[b * 12 + lane] = qnan; Rt3[b * 12 + lane] = qnan; }
+    if (lane < 27) T[b * 27 + lane] = qnan;
+    if (reconst) for (int i = lane; i < 3 * N; i += 64) reconst[b * 3 * (long)N + i] = qnan;
+}
+
 // ---- per-wave LDS workspace ------------------------------------------------
 struct PoseLds {
     double mom[96];        // 6 x 4 x 4 moment sums of the normalised correspondences: mom[16*h + 4*i3 + i2]

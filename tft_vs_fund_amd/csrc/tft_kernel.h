@@ -64,6 +64,7 @@ struct LinearTftArgs {
     double* spill;           // null, or global workspace for the per-correspondence state of the iterative methods when it does not
     long spill_stride;       //   fit the 160 KB of LDS (large N): gridDim.x blocks of spill_stride doubles
     int sample_ns;           // with sample_idx: number of correspondences in the shared scene (indices outside [0, sample_ns) -> ST_TOO_FEW)
+    const double* pre;       // null, or B x PRE_DOUBLES: moment sums and normalisations from k_tft_moments (tft_moments_kernel.h; the row kernels' <true> variants)
 };
 
 // Inverse-iteration cap before a triplet is handed to the Jacobi fix-up pass: 300 iterations (~0.13 M
@@ -496,7 +497,7 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose(const LinearTftArgs a
                 // non-finite outputs -> status 2
                 double chk = (lane < 12) ? w->Rt[0][lane] : ((lane < 24) ? w->Rt[1][lane - 12] : ((lane < 51) ? w->T1[lane - 24] : 0.0));
                 const bool bad = !(fabs(chk) <= 1.79e308);
-                if (wave_any(bad) && status == ST_OK) status = ST_NONFINITE;
+                if (wave_any(bad)) { if (status == ST_OK) status = ST_NONFINITE; wave_nan_outputs(a.Rt2, a.Rt3, a.T, a.reconst, b, N); }
             }
         }
         if (lane == 0) {

@@ -19,6 +19,7 @@
 // auxiliar_functions/Normalize2Ddata.m:33-39, triangulation3D.m:51-63.
 #pragma once
 #include "tft_kernel.h"
+#include "tft_moments_kernel.h"
 
 namespace tff {
 
@@ -971,6 +972,9 @@ __device__ __forceinline__ int rows_pose_tail(const LinearTftArgs& a, RowLds* w,
     return status;
 }
 
+// PRE: the normalisations and moment sums come from k_tft_moments (a.pre) instead of the two data passes: the kernel starts at linearTFT's solve
+// and touches the correspondences in the vote pass only (and for Reconst).
+template <bool PRE>
 __global__ void __launch_bounds__(64, 2) k_linear_tft_pose_rows(const LinearTftArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
     const int p = lane_id() & 15, row = lane_id() >> 4;
@@ -986,7 +990,12 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose_rows(const LinearTftA
             status = ST_TOO_FEW;
             rows_store_nan(a, j, N);
         } else {
-            {
+            if constexpr (PRE) {
+                rows_load_pre(a.pre, j.b, w->mom, w->nrm);
+                rows_stamp(dbg, 1);
+                wave_sync();
+                if (dbg && p < 9) dbg[71 + p] = w->nrm[p];
+            } else {
                 double cen[6], nr[9];
                 rows_centroids(j.src, N, cen);                               // LinearTFTPoseEstimation.m:45-47
                 rows_stamp(dbg, 1);

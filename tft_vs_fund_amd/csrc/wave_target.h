@@ -14,6 +14,8 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// every global store this wavefront has issued is complete before a later one (rare clean-up paths that rewrite outputs other lanes stored)
+__device__ __forceinline__ void store_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
 __device__ __forceinline__ double wave_shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ int wave_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
 // src must be wave-uniform: lowers to v_readlane_b32 pairs (no LDS crossbar).
