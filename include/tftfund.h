@@ -86,9 +86,10 @@ typedef struct tff_ctx tff_ctx;
                              * kernels (shorter latency) below.  The two routes agree to rounding (1e-14), so a triplet's last bits may depend on
                              * the size of the batch it arrives in; set 0 or 1 where that matters */
 #define TFF_OPT_PRE 10      /* trifocal row kernels (TFF_OPT_ROWS route): where the three Normalize2Ddata calls and the 96 moment sums of linearTFT's system are
-                             * computed.  1 = in a kernel of their own, one triplet per wavefront, the correspondences read from HBM once and parked in LDS
-                             * (csrc/tft_moments_kernel.h), the row kernels starting from its 112-double record; 0 = inside the row kernels (two more passes
-                             * over correspondences they cannot stage); 2 (default) = the separate kernel from N >= 48.  Results agree to rounding */
+                             * computed.  0 (default) = inside the row kernels (two passes over the correspondences); 1 = in a kernel of their own, one triplet
+                             * per wavefront, the correspondences read from HBM once and parked in LDS (csrc/tft_moments_kernel.h), the row kernels starting
+                             * from its 112-double record; 2 = that kernel from N >= 48.  An A/B switch: measured slower than the fused passes on MI355X
+                             * (profiles/r5_ab_pre.txt) -- the path is bound by fp64 issue, not by those passes' memory waits.  Results agree to rounding */
 #define TFF_OPT_DEBUG_FP_HANDOVER 8 /* test hook: 1 = FaugPapa's block kernel hands every third triplet back to the generic workgroup kernel, as it does when its
                              * pseudo-inverse reports a failure (exercises that production fall-back; results must not depend on it beyond the
                              * generic kernel's LAPACK-level noise) */

@@ -210,7 +210,7 @@ static int emu_wg_run(KBlock kblock, int block_threads, size_t lds_block, const 
     std::vector<double> rec((size_t)B * tff::GH_REC_DOUBLES), topt((size_t)B * 27);
     tff::GhWgArgs a{corresp, calm, calm_stride, B, N, (flags & ~tff::FLAG_JACOBI) | (reconst ? tff::FLAG_RECONST : 0), rec.data(), topt.data(),
                     Rt2, Rt3, T, reconst, iter, status, nullptr, nullptr, 0};
-    emu::launch(tff::k_gh_linear_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);     // (as the C ABI: four triplets per wavefront)
+    emu::launch(tff::k_gh_linear_rows<false>, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);     // (as the C ABI: four triplets per wavefront)
     tff::GhWgArgs m = a;
     m.flags |= tff::FLAG_ONLY_RETRY;
     emu::launch(tff::k_gh_linear<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
@@ -235,7 +235,7 @@ static int emu_gh_wg_impl(const double* corresp, const double* calm, long calm_s
     std::vector<double> rec((size_t)B * tff::GH_REC_DOUBLES), topt((size_t)B * 27);
     tff::GhWgArgs a{corresp, calm, calm_stride, B, N, (flags & ~tff::FLAG_JACOBI) | (reconst ? tff::FLAG_RECONST : 0), rec.data(), topt.data(),
                     Rt2, Rt3, T, reconst, iter, status, nullptr, nullptr, 0};
-    emu::launch(tff::k_gh_linear_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);     // (as the C ABI: four triplets per wavefront)
+    emu::launch(tff::k_gh_linear_rows<false>, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);     // (as the C ABI: four triplets per wavefront)
     tff::GhWgArgs m = a;
     m.flags |= tff::FLAG_ONLY_RETRY;
     emu::launch(tff::k_gh_linear<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);
@@ -257,7 +257,7 @@ extern "C" int emu_fp_pose(const double* corresp, const double* calm, long calm_
     std::vector<double> rec((size_t)B * tff::GH_REC_DOUBLES), topt((size_t)B * 27);
     tff::GhWgArgs a{corresp, calm, calm_stride, B, N, (flags & ~tff::FLAG_JACOBI) | (reconst ? tff::FLAG_RECONST : 0), rec.data(), topt.data(),
                     Rt2, Rt3, T, reconst, iter, status, nullptr, nullptr, 0};
-    emu::launch(tff::k_gh_linear_rows, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);     // (as the C ABI: four triplets per wavefront)
+    emu::launch(tff::k_gh_linear_rows<false>, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);     // (as the C ABI: four triplets per wavefront)
     tff::GhWgArgs m = a;
     m.flags |= tff::FLAG_ONLY_RETRY;
     emu::launch(tff::k_gh_linear<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, m.flags, true), m);

@@ -169,10 +169,10 @@ def test_exact_rows_kernel_against_the_one_triplet_exact_kernel(gpu_ctx, method,
     assert np.quantile(eT, 0.999) < 1e-7 and (e3 > 1e-6).mean() < 3e-3, (np.quantile(eT, 0.999), (e3 > 1e-6).mean())
 
 
-@pytest.mark.parametrize("method", ["LinearTFTPoseEstimation", "LinearFPoseEstimation", "ResslTFTPoseEstimation", "OptimFPoseEstimation"])
+@pytest.mark.parametrize("method", ["LinearTFTPoseEstimation", "LinearFPoseEstimation"])
 def test_default_route_goes_by_batch_size(method):
-    """TFF_OPT_ROWS = 2 (the default of a new context): bit-identical to the one-triplet kernels on a batch that fits the device in one go, to the
-    row kernels on a large one (include/tftfund.h; the crossover is measured: tools/ab_rows_sweep.py)."""
+    """TFF_OPT_ROWS = 2 (the default of a new context), the two LINEAR methods: bit-identical to the one-triplet kernels on a batch that fits the
+    device in one go, to the row kernels on a large one (include/tftfund.h; the crossover is measured: tools/ab_rows_sweep.py)."""
     import torch
     from tft_vs_fund_amd import api
     from tft_vs_fund_amd.scenes import generate_scene_batch
@@ -193,6 +193,31 @@ def test_default_route_goes_by_batch_size(method):
         assert not torch.equal(a["T"], o["T"])                               # (the two routes differ in the last bits, so the check above says which one ran)
         with pytest.raises(Exception):
             auto.set_rows(3)
+
+
+@pytest.mark.parametrize("method", ["ResslTFTPoseEstimation", "NordbergTFTPoseEstimation", "FaugPapaTFTPoseEstimation", "PiPoseEstimation", "PiColPoseEstimation",
+                                    "OptimFPoseEstimation"])
+def test_iterative_methods_do_not_depend_on_the_batch_a_triplet_arrives_in(method):
+    """The iterative methods amplify a last-bit difference of their start (the exit test of Gauss_Helmert.m:71-82 can flip on it), so the library's
+    DEFAULT route for them must not depend on the batch size (capi.hip::rows_for_iterative): the same 40 triplets alone, at the head of a batch
+    of 1023 and scattered through a batch of 1024 / 2500 give bit-identical T, R_t_2, R_t_3 and the same `iter` and status."""
+    import torch
+    from tft_vs_fund_amd import api
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    N = 60
+    C, CalM, _, _ = generate_scene_batch(2500, N, noise=1.0, seed=4242)
+    calm = torch.from_numpy(CalM).cuda()
+    ctx = api.Context(0)                                                     # library defaults
+    pick = np.arange(0, 2500, 63)[:40]
+    small = ctx.pose_batch(method, torch.from_numpy(np.ascontiguousarray(C[pick])).cuda(), calm, reconst=False)
+    for B in (1023, 1024, 2500):
+        idx = np.arange(B)
+        pos = pick[pick < B] if B == 2500 else np.arange(len(pick)) * (B // len(pick))
+        Cb = C[:B].copy()
+        Cb[pos] = C[pick[:len(pos)]]
+        big = ctx.pose_batch(method, torch.from_numpy(Cb).cuda(), calm, reconst=False)
+        for k in ("T", "R_t_2", "R_t_3", "iter", "status"):
+            assert torch.equal(big[k][torch.from_numpy(pos).cuda()] if big[k].is_cuda else big[k][pos], small[k][:len(pos)]), (method, B, k)
 
 
 @pytest.mark.parametrize("method", ["ResslTFTPoseEstimation", "PiPoseEstimation", "LinearTFTPoseEstimation", "LinearFPoseEstimation", "OptimFPoseEstimation"])
@@ -217,3 +242,35 @@ def test_a_failed_triplet_has_all_nan_outputs_and_its_neighbours_do_not_notice(g
         assert np.all(np.isnan(v[5])), (method, k, v[5].ravel()[:6])
         for b in (0, 1, 2, 3, 4, 6, 7):
             assert np.array_equal(v[b], r[b]), (method, k, b)
+
+
+@pytest.mark.parametrize("B,N", [(4099, 200), (1025, 60), (300, 500)])
+def test_moments_pre_kernel_agrees_with_the_fused_passes(B, N):
+    """TFF_OPT_PRE = 1 (k_tft_moments + k_linear_tft_pose_rows<true>, csrc/tft_moments_kernel.h; N = 500: the variant that re-reads global memory)
+    against the default (the two passes inside the row kernel): same arithmetic per correspondence, sums in a different order -- 1e-12 -- and
+    against the oracle at 1e-9; Ressl through k_gh_linear_rows<true>: same iteration counts."""
+    import torch
+    from tft_vs_fund_amd import api
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    from oracle import tft_oracle as O
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=B + N)
+    d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
+    ctx = api.Context(0)
+    ctx.set_rows(1)
+    ref = ctx.pose_batch("LinearTFTPoseEstimation", d, calm, reconst=True)
+    ctx.set_pre(1)
+    out = ctx.pose_batch("LinearTFTPoseEstimation", d, calm, reconst=True)
+    assert torch.equal(out["status"], ref["status"]) and int((out["status"] != 0).sum()) == 0
+    r, o = {k: v.cpu().numpy() for k, v in ref.items() if k in ("T", "R_t_2", "R_t_3", "Reconst")}, {k: v.cpu().numpy() for k, v in out.items() if k in ("T", "R_t_2", "R_t_3", "Reconst")}
+    sg = np.sign(np.sum(r["T"] * o["T"], axis=(1, 2, 3)))[:, None, None, None]
+    assert np.abs(o["T"] * sg - r["T"]).max() < 1e-12 and np.abs(o["R_t_2"] - r["R_t_2"]).max() < 1e-12
+    assert np.abs(o["R_t_3"] - r["R_t_3"]).max() < 1e-12 * max(1.0, np.abs(r["R_t_3"]).max())
+    assert np.abs(o["Reconst"] - r["Reconst"]).max() < 1e-10 * np.abs(r["Reconst"]).max()
+    for b in (0, B // 3, B - 1):
+        R2, R3, Rec, T, _ = O.LinearTFTPoseEstimation(C[b].T.copy(), CalM)
+        assert rel_err_T(o["T"][b], T) < TOL and rel_err(o["R_t_2"][b], R2) < TOL and rel_err(o["R_t_3"][b], R3) < TOL and rel_err(o["Reconst"][b], Rec) < TOL
+    if N <= 200:
+        g1 = ctx.pose_batch("ResslTFTPoseEstimation", d[:512].contiguous(), calm, reconst=False)
+        ctx.set_pre(0)
+        g0 = ctx.pose_batch("ResslTFTPoseEstimation", d[:512].contiguous(), calm, reconst=False)
+        assert int((g1["status"] != 0).sum()) == 0 and float((g1["iter"] != g0["iter"]).double().mean()) < 0.01

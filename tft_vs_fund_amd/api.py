@@ -195,8 +195,8 @@ class Context:
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_ROWS, v), "set_option")
 
     def set_pre(self, on):
-        """TFF_OPT_PRE: "auto" or 2 (default) = normalisations + moment sums of the trifocal row kernels in a kernel of their own (one triplet per
-        wavefront, correspondences read once) from N >= 48; True / 1 = always; False / 0 = inside the row kernels."""
+        """TFF_OPT_PRE (A/B switch): False / 0 (default) = normalisations + moment sums inside the trifocal row kernels; True / 1 = in a kernel of
+        their own (one triplet per wavefront, correspondences read once; measured slower: profiles/r5_ab_pre.txt); "auto" / 2 = that kernel from N >= 48."""
         v = 2 if on == "auto" else (int(on) if isinstance(on, int) and not isinstance(on, bool) else int(bool(on)))
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_PRE, v), "set_option")
 

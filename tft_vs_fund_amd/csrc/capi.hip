@@ -55,7 +55,7 @@ struct tff_ctx {
     int solver = 0;
     int exact_below = tff::EXACT_BELOW_N;   // TFF_OPT_EXACT_BELOW
     int stage = -1;
-    DevBuf in, calm, out, idx, scratch_status, gh_rec, gh_topt, gh_init, spill, pre;
+    DevBuf in, calm, out, idx, scratch_status, gh_rec, gh_topt, gh_init, spill, pre_rec;
     const int32_t* sample_idx = nullptr;   // set around a *_sampled_dev call
     int32_t sample_ns = 0;                 //   size of the scene the indices refer to
     double* init_p = nullptr; double* init_x = nullptr;   // set around tff_pi_pose_batch_debug_dev
@@ -63,7 +63,7 @@ struct tff_ctx {
     int gh_exact = 0;                      // TFF_OPT_GH_EXACT
     int spill_only_if_needed = 0;          // TFF_OPT_SPILL
     int rows = 2;                          // TFF_OPT_ROWS: 0 never, 1 always, 2 by batch size (rows_for)
-    int pre = 2;                           // TFF_OPT_PRE: 0 never, 1 always, 2 by N (pre_for)
+    int pre = 0;                           // TFF_OPT_PRE: 0 never (default: measured slower, see pre_for), 1 always, 2 from N >= 48
     int dbg_fp_handover = 0;               // TFF_OPT_DEBUG_FP_HANDOVER
     int dbg_adaptive = 0;                  // TFF_OPT_DEBUG_ADAPTIVE
 };
@@ -79,9 +79,17 @@ bool rows_for(const tff_ctx* c, int64_t B, int32_t N) {
     return B >= (N <= 256 ? 1024 : 2048 + 1);
 }
 
+// The iterative methods (Gauss-Helmert on T / F / the Pi matrices) amplify a last-bit difference of their start, so for them the route must not
+// depend on the batch size: whatever B, the linear stage and the pose tail run four triplets per wavefront unless TFF_OPT_ROWS = 0 forces the
+// one-triplet kernels (a few tens of microseconds of latency on a millisecond iteration).  Same triplet, same bits, same `iter` in any batch.
+bool rows_for_iterative(const tff_ctx* c) { return c->rows != 0; }
 // The normalisations and moment sums of the trifocal row kernels as a kernel of their own (tft_moments_kernel.h: one triplet per wavefront,
-// correspondences read once, three wavefronts per SIMD)?  A wavefront per triplet idles on a handful of correspondences, so small N keeps the
-// fused passes (tools/ab_pre.py).  TFF_OPT_PRE = 0 / 1 force a route; sampled hypotheses (config 4) never take it.
+// correspondences read from HBM once, three wavefronts per SIMD)?  Built and measured in round 5 (profiles/r5_ab_pre.txt, tools/ab_pre.py,
+// 10 000 triplets): N = 200 one batch at a time 0.179 -> 0.173 ms, two batches in flight 0.1225 -> 0.1284 ms; slower at every other N
+// (N = 100: 0.136 -> 0.139 / 0.092 -> 0.103; N = 500: 0.312 -> 0.322 / 0.204 -> 0.252).  The two passes it removes from the row kernel were
+// 31 % of a wavefront's CYCLES but memory waits that the SIMD's other wavefront filled with its compute-bound middle: the path is bound by fp64
+// issue, and the pre-kernel only moves ~900 instructions per triplet to a launch of its own.  Hence OFF by default (TFF_OPT_PRE = 1 enables it,
+// 2 = from N >= 48); sampled hypotheses (config 4) never take it.
 bool pre_for(const tff_ctx* c, int32_t N) {
     if (c->sample_idx) return false;
     if (c->pre != 2) return c->pre != 0;
@@ -89,14 +97,14 @@ bool pre_for(const tff_ctx* c, int32_t N) {
 }
 // launches k_tft_moments on the context's stream; *pre_out = the B x PRE_DOUBLES records the row kernels' <true> variants read
 int launch_moments(tff_ctx* c, const double* corresp, int64_t B, int32_t N, const double** pre_out) {
-    if (int r = c->pre.reserve((size_t)B * tff::PRE_DOUBLES * sizeof(double))) return r;
-    tff::MomentArgs m{corresp, (long)B, N, (double*)c->pre.p};
+    if (int r = c->pre_rec.reserve((size_t)B * tff::PRE_DOUBLES * sizeof(double))) return r;
+    tff::MomentArgs m{corresp, (long)B, N, (double*)c->pre_rec.p};
     const bool stage = N <= tff::PRE_STAGE_MAX_N;
     const size_t lds = tff::moments_lds_bytes(N, stage);
     if (stage) hipLaunchKernelGGL(tff::k_tft_moments<true>, dim3(tff::moments_grid(B)), dim3(64), lds, c->stream, m);
     else hipLaunchKernelGGL(tff::k_tft_moments<false>, dim3(tff::moments_grid(B)), dim3(64), lds, c->stream, m);
     TFF_HIP(hipGetLastError());
-    *pre_out = (const double*)c->pre.p;
+    *pre_out = (const double*)c->pre_rec.p;
     return 0;
 }
 
@@ -281,7 +289,7 @@ int launch_linear_f(tff_ctx* c, const double* corresp, const double* calm, int64
 // samples, TFF_OPT_SOLVER = 1, debug records: the fused one-triplet kernel.
 int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                    double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
-    if (c && B > 0 && rows_for(c, B, N) && c->solver == 0 && N >= c->exact_below && N >= 8 && !dbg && !c->sample_idx && c->kernel_variant != 1) {
+    if (c && B > 0 && rows_for_iterative(c) && c->solver == 0 && N >= c->exact_below && N >= 8 && !dbg && !c->sample_idx && c->kernel_variant != 1) {
         if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
         TFF_LOCK(c);
         if (!Rt2 || !Rt3 || !T) return fail(TFF_E_INVALID, "null output pointer");
@@ -330,7 +338,7 @@ int launch_optim_f(tff_ctx* c, const double* corresp, const double* calm, int64_
 template <class KBlock, class LdsFn>
 int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
               double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg, bool fp_first = false,
-              bool rows_linear = true, bool nordberg_pre = false, int block_threads = tff::GH_WG_THREADS, size_t xi_bytes_per_n = 0) {
+              bool rows_linear = true, bool nordberg_pre = false, int block_threads = tff::GH_WG_THREADS, size_t xi_bytes_per_n = 0, bool rows_finish = true) {
     if (int r = check_common(c, corresp, calm, calm_stride, B, N)) return r;
     TFF_LOCK(c);
     if (B == 0) return 0;
@@ -348,8 +356,14 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
         const bool all_exact = c->solver != 0 || N < c->exact_below;
         tff::GhWgArgs m = a;
         size_t lds;
-        if (!all_exact && rows_linear && rows_for(c, B, N)) {                          // four triplets per wavefront (gh_rows_kernel.h)
-            hipLaunchKernelGGL(tff::k_gh_linear_rows, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, m);
+        if (!all_exact && rows_linear && rows_for_iterative(c)) {                      // four triplets per wavefront (gh_rows_kernel.h), whatever the batch size
+            if (N >= 7 && pre_for(c, N)) {                                             // normalisations + moment sums in their own kernel (tft_moments_kernel.h)
+                if (int r = launch_moments(c, corresp, B, N, &m.pre)) return r;
+                hipLaunchKernelGGL(tff::k_gh_linear_rows<true>, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, m);
+                m.pre = nullptr;
+            } else {
+                hipLaunchKernelGGL(tff::k_gh_linear_rows<false>, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, m);
+            }
             TFF_HIP(hipGetLastError());
         } else if (!all_exact) {
             m.flags = staged_flags(c, N, a.flags, false);
@@ -398,7 +412,7 @@ int launch_wg(tff_ctx* c, KBlock kblock, LdsFn wg_lds, int occupancy_cap, const 
         hipLaunchKernelGGL(kblock, dim3(grid), dim3(block_threads), lds, c->stream, m);
         TFF_HIP(hipGetLastError());
     }
-    if (rows_linear && N >= 12 && rows_for(c, B, N)) {                                 // four triplets per wavefront (gh_rows_kernel.h); minimal samples: the one-triplet kernel's ladder
+    if (rows_finish && N >= 12 && rows_for_iterative(c)) {                             // four triplets per wavefront (gh_rows_kernel.h); minimal samples: the one-triplet kernel's ladder
         hipLaunchKernelGGL(tff::k_gh_finish_rows, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, a);
         TFF_HIP(hipGetLastError());
     } else {
@@ -443,11 +457,13 @@ int launch_pi_model(tff_ctx* c, const double* corresp, const double* calm, int64
         return launch_pose(c, tff::k_pi_tft_pose<Model, false>, tff::k_pi_tft_pose<Model, true>, tff::pi_lds_bytes<Model>, 0, 4,
                            corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
     auto wg_lds = [](int n) { return (size_t)(((tff::POSE_LDS_DOUBLES + 1) & ~1) + tff::pi_wg_lds_doubles(Model::E, Model::C, n)) * sizeof(double); };
-    // PiCol keeps the one-triplet-per-wavefront linear stage: its scenes that take seven Gauss-Helmert iterations amplify a last-bit difference
+    // PiCol keeps the one-triplet-per-wavefront LINEAR stage: its scenes that take seven Gauss-Helmert iterations amplify a last-bit difference
     // of the start a million times (tools/diag_gh_noise_picol.py: 3.3e-10 from the 50-digit iteration with this start, 2.5e-9 with the rows
-    // kernel's on the same N = 60 scene -- both draws of the same rounding noise, one of them over the 1e-9 gate of tests/test_gpu_gh_noise.py)
+    // kernel's on the same N = 60 scene -- both draws of the same rounding noise, one of them over the 1e-9 gate of tests/test_gpu_gh_noise.py).
+    // Its POSE TAIL (transform_TFT, R_t_from_TFT of the optimised tensor) is a fixed, well-conditioned function of that tensor and nothing
+    // amplifies its rounding: it runs four triplets per wavefront like everyone else's since round 5 (k_gh_finish was 0.56 of PiCol's 5.4 ms).
     return launch_wg(c, tff::k_pi_block<Model>, wg_lds, 4, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg,
-                     false, !Model::PINV_KKT, false, tff::pi_wg_waves<Model>::value * tff::WAVE);
+                     false, !Model::PINV_KKT, false, tff::pi_wg_waves<Model>::value * tff::WAVE, 0, true);
 }
 int launch_ressl_tft(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B, int32_t N,
                       double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter, int32_t* status, double* dbg) {
@@ -541,7 +557,7 @@ void tff_ctx_destroy(tff_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->own) { (void)hipStreamSynchronize(c->own); (void)hipStreamDestroy(c->own); }
     if (c->handover) (void)hipEventDestroy(c->handover);
-    c->in.release(); c->calm.release(); c->out.release(); c->idx.release(); c->scratch_status.release(); c->gh_rec.release(); c->gh_topt.release(); c->gh_init.release(); c->spill.release(); c->pre.release();
+    c->in.release(); c->calm.release(); c->out.release(); c->idx.release(); c->scratch_status.release(); c->gh_rec.release(); c->gh_topt.release(); c->gh_init.release(); c->spill.release(); c->pre_rec.release();
     delete c;
 }
 

@@ -336,12 +336,16 @@ __device__ __forceinline__ void fp_eliminate_strong(double* M_, const int ns, do
 
 // The rotated strong sums: every thread takes correspondences tid, tid + 256, ...; g = sqrt(cs) Q(:, C0:27)' a, U = 27 - C0 components,
 // U (U + 1) / 2 + U sums (the last U: g * sqrt(cs) n'w) in halving butterflies -> the calling wavefront's slot (zeroed here).
+// Round 5: the sums are taken on the matrix core (gh_kernel.h::StrongGram, v_mfma_f64_16x16x4_f64; tiles in registers across the trips) -- the
+// thirteen butterflies per trip were a tenth of an iteration.  scratch: StrongGram<U, 16>::SCRATCH doubles of this wavefront's own.
 template <int C0, class SP>
-__device__ inline void fp_rotated_sums(const FpLds& s, const SP xi, const SP pp, const int N, double* slot) {
+__device__ inline void fp_rotated_sums(const FpLds& s, const SP xi, const SP pp, const int N, double* slot, double* scratch) {
     constexpr int U = 27 - C0;
     constexpr int total = U * (U + 1) / 2 + U;
     const int tid = thread_in_block(), lane = lane_id(), wave = wave_in_block();
     for (int e = lane; e < ((total + 1) & ~1); e += WAVE) slot[e] = 0.0;
+    StrongGram<U, 16> gram;
+    gram.clear();
     wave_sync();
 #pragma unroll 1
     for (int base = 0; base < N; base += FP_THREADS) {
@@ -364,8 +368,10 @@ __device__ inline void fp_rotated_sums(const FpLds& s, const SP xi, const SP pp,
             static_assert(C0 == 0, "two variants");
             fp_rotate_chunk<0, 9, 0, U>(s.Q, o, sq, bv); fp_rotate_chunk<9, 9, 9, U>(s.Q, o, sq, bv); fp_rotate_chunk<18, 9, 18, U>(s.Q, o, sq, bv);
         }
-        strong_accumulate<U>(bv, sc * om, slot);
+        gram.add(bv, sc * om, scratch);
     }
+    wave_sync();
+    gram.store(slot);
 }
 
 // Gauss_Helmert.m:38-83 with FaugPapaTFTPoseEstimation.m:87-153 as the callback, one workgroup per problem; xi holds x0 on entry.
@@ -518,7 +524,9 @@ __device__ inline int gauss_helmert_fp(FpLds& s, const int own, const double* pt
         // small against THAT.  All 378 + 27 sums come from the rotated factors.)
         phase_stamp(sdbg, 22);
         // ---- rotated strong sums (one correspondence per thread); Y = R Q ----
-        if (wave < waves) fp_rotated_sums<0, SP>(s, xi, pp, N, s.Mx + wave * 416);
+        // (transposition scratch of the Gram sums: Hs in A2 is dead since the basis was built, so is the upper half of Mx)
+        static_assert(FP_WAVES == 2 && StrongGram<27, 16>::SCRATCH <= 729 && 2 * 416 + StrongGram<27, 16>::SCRATCH <= 1664, "scratch of the rotated sums");
+        if (wave < waves) fp_rotated_sums<0, SP>(s, xi, pp, N, s.Mx + wave * 416, (wave == 0) ? const_cast<double*>(s.A2) : const_cast<double*>(s.Mx) + 2 * 416);
         __syncthreads();
         for (int e = tid; e < 729; e += FP_THREADS) {                     // Y = R Q -> A2 (Hs is dead now)
             const int r = e / 27, c = e % 27;

@@ -1012,6 +1012,66 @@ __device__ inline void strong_accumulate(const double (&b)[U], const double t, d
     strong_sweep<U, 8>(b, t, slot); strong_sweep<U, 9>(b, t, slot); strong_sweep<U, 10>(b, t, slot); strong_sweep<U, 11>(b, t, slot);
     strong_sweep<U, 12>(b, t, slot);
 }
+// The same sums on the matrix core (round 5).  They are a genuine dense contraction: with e_i = [b_i; t_i] (U + 1 entries per correspondence)
+//   [N_s  r_s; r_s'  .] = sum_i e_i e_i' = E' E,   E = [e_1' ; ... ; e_N']   (N x (U + 1))
+// -- the Gram matrix of a tall matrix, K = N.  The butterflies above cost 32 products + 93 exchange / add instructions per 32 sums and
+// correspondence trip (8 sweeps for U = 20, 13 for U = 27: 1.0 k / 1.7 k VALU instructions per trip and wavefront, a fifth to a third of a
+// Gauss-Helmert iteration); v_mfma_f64_16x16x4_f64 takes four correspondences and a 16 x 16 tile per instruction: three tiles ((0,0), (1,0), (1,1):
+// U + 1 <= 32) x 16 k-steps = 48 instructions per trip of 64 correspondences, accumulators in registers across the trips.
+// The operands want the TRANSPOSED layout (lane = component, k = correspondence), so the wavefront passes its vectors through a scratch area of
+// its own in LDS, CH correspondences at a time (CH x LDE doubles, LDE odd: rows of 16 lanes read consecutive doubles, the four k-rows land on
+// different banks).  Summation order differs from the butterflies' (k order inside the matrix core, then over the steps): same accuracy, other
+// rounding.  add(): every lane of the wavefront calls it (a lane without a correspondence passes zeros); store(): tiles -> the slot layout of
+// strong_accumulate (lower triangle, then the U entries of r_s).
+template <int U, int CH>
+struct StrongGram {
+    static_assert(U + 1 > 16 && U + 1 <= 32 && (CH == 16 || CH == 32 || CH == 64), "two blocks of 16 components");
+    static constexpr int UE = U + 1, LDE = UE | 1, SCRATCH = CH * LDE;
+    double t00[4], t10[4], t11[4];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { t00[v] = 0.0; t10[v] = 0.0; t11[v] = 0.0; }
+    }
+    __device__ __forceinline__ void add(const double (&b)[U], const double t, double* scratch) {
+        const int lane = lane_id();
+#pragma unroll 1
+        for (int c0 = 0; c0 < WAVE; c0 += CH) {
+            wave_sync();                                                     // (the previous chunk's reads are done)
+            if (lane >= c0 && lane < c0 + CH) {
+                double* row = scratch + (lane - c0) * LDE;
+#pragma unroll
+                for (int k = 0; k < U; ++k) row[k] = b[k];
+                row[U] = t;
+            }
+            wave_sync();
+            const double* src = scratch + (lane >> 4) * LDE + (lane & 15);
+            const bool hi = 16 + (lane & 15) < UE;
+#pragma unroll 1
+            for (int s = 0; s < CH / 4; ++s) {                               // k-step s: correspondences 4 s .. 4 s + 3 of the chunk
+                const double a0 = src[4 * s * LDE];
+                const double a1 = hi ? src[4 * s * LDE + 16] : 0.0;
+                mfma_f64_16x16x4(a0, a0, t00);
+                mfma_f64_16x16x4(a1, a0, t10);
+                mfma_f64_16x16x4(a1, a1, t11);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(double* slot) const {
+        constexpr int ntri = U * (U + 1) / 2;
+        const int lane = lane_id(), col = lane & 15, rg = lane >> 4;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = rg + 4 * v;
+            if (col <= row) slot[tri_index(row, col)] = t00[v];              // rows / columns 0 .. 15
+            const int r1 = 16 + row, c1 = 16 + col;
+            if (r1 < U) slot[tri_index(r1, col)] = t10[v];
+            else if (r1 == U) slot[ntri + col] = t10[v];                     // the t row: r_s[col]
+            if (r1 < U && c1 <= r1) slot[tri_index(r1, c1)] = t11[v];
+            else if (r1 == U && c1 < U) slot[ntri + c1] = t11[v];
+        }
+    }
+};
+
 // a = D' q for q = h1 (x) vec(gm) (27): through the model's sparse form when it has one, else the dense 27 x U matrix in LDS
 template <class M, class = void> struct gh_has_kronecker_dt { static constexpr bool value = false; };
 template <class M> struct gh_has_kronecker_dt<M, decltype((void)M::KRONECKER_DT)> { static constexpr bool value = M::KRONECKER_DT; };

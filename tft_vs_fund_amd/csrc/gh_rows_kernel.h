@@ -9,6 +9,8 @@
 
 namespace tff {
 
+// PRE: normalisations and moment sums from k_tft_moments (a.pre) instead of the two data passes.
+template <bool PRE>
 __global__ void __launch_bounds__(64, 2) k_gh_linear_rows(const GhWgArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
     const int lane = lane_id();
@@ -26,7 +28,9 @@ __global__ void __launch_bounds__(64, 2) k_gh_linear_rows(const GhWgArgs a) {
         if (N < 7) {                                                         // wave-uniform
             status = ST_TOO_FEW;
         } else {
-            {
+            if constexpr (PRE) {
+                rows_load_pre(a.pre, b, w->mom, w->nrm);
+            } else {
                 double cen[6], nr[9];
                 rows_centroids(src, N, cen);
                 rows_distances_moments(src, N, cen, w->nrm, nr, w->mom);

@@ -85,6 +85,7 @@ struct GhWgArgs {
     double* Rt2; double* Rt3; double* T; double* reconst; int* iter; int* status; double* dbg;
     double* spill; long spill_stride;   // see LinearTftArgs
     double* init_rec;        // B x Model::PRE_DOUBLES (k_nordberg_init out, k_gh_block<NordbergModel> in) or null
+    const double* pre;       // null, or B x tff::PRE_DOUBLES from k_tft_moments (tft_moments_kernel.h): what k_gh_linear_rows<true> starts from
 };
 
 template <bool JAC>
@@ -175,6 +176,24 @@ __device__ __forceinline__ double block_max_w(double v, double* red) {
     return r;
 }
 template <int WV> __device__ __forceinline__ bool block_any_w(bool p, double* red) { return block_sum_w<WV>(p ? 1.0 : 0.0, red) != 0.0; }
+// three maxima and one "any" in ONE barrier pair (two-wavefront workgroups: red[0 .. 7]; four wavefronts: the single reductions)
+template <int WV>
+__device__ __forceinline__ void block_max3_any_w(double& a, double& b, double& c, bool& flag, double* red) {
+    if constexpr (WV == 2) {
+        a = wave_max(a); b = wave_max(b); c = wave_max(c);
+        const double f = wave_any(flag) ? 1.0 : 0.0;
+        if (lane_id() == 0) { const int w = wave_in_block(); red[w] = a; red[2 + w] = b; red[4 + w] = c; red[6 + w] = f; }
+        __syncthreads();
+        a = (red[0] > red[1]) ? red[0] : red[1];
+        b = (red[2] > red[3]) ? red[2] : red[3];
+        c = (red[4] > red[5]) ? red[4] : red[5];
+        flag = (red[6] + red[7]) != 0.0;
+        __syncthreads();
+    } else {
+        a = block_max_w<WV>(a, red); b = block_max_w<WV>(b, red); c = block_max_w<WV>(c, red);
+        flag = block_any_w<WV>(flag, red);
+    }
+}
 __device__ __forceinline__ double block_sum(double v, double* red) { return block_sum_w<GH_WG_WAVES>(v, red); }
 __device__ __forceinline__ double block_max(double v, double* red) { return block_max_w<GH_WG_WAVES>(v, red); }
 __device__ __forceinline__ bool block_any(bool p, double* red) { return block_any_w<GH_WG_WAVES>(p, red); }
@@ -271,6 +290,16 @@ __device__ inline void gh_block_reproject(PoseLds* w, const double* pts, int N, 
 }
 
 // Gauss_Helmert.m:38-83, one workgroup per problem.  `own`: the wavefront that runs the wave-serial steps.
+// Round 5 measured four changes to THIS iteration against the round-4 build on the same box (tools/ab_libs.py, profiles/r5_ab_libs.txt; Ressl /
+// Nordberg, ms per 10 000 x 200) and kept none of them -- the iteration below is round 4's:
+//   * finite check riding on a speculative weight pass (+ the strong direction n, cs kept in a 16-double W+ record for the v pass): 2.371 -> 2.365 /
+//     2.659 -> 2.669; the v pass fell from 19 k to 12 k cycles but the 128-byte record stride cost the ten sweeps as much (W+ is in global slices);
+//   * check and tolerance bounds in one pass: 2.369 -> 2.430 / 2.672 -> 2.719 (the blocks stay under the truncation limit here, so round 4 never ran
+//     the bounds pass: this only added work);
+//   * the strong-direction sums on the matrix core (gh_kernel.h::StrongGram; kept for the Pi kernels, U = 27: -12 %): 2.449 -> 2.432 / 2.742 -> 2.769;
+//   * Ghat D and D'Y on the matrix core (14 matrix instructions per wavefront and product): 2.364 -> 2.412 / 2.657 -> 2.711 with the speculative pass.
+// What the phase stamps attribute to a phase is mostly the wait for the SIMD shared with three other workgroups' wavefronts: shortening one
+// phase of one workgroup moves the wait, not the kernel's 0.74 VALU-busy total.
 template <class Model, int WV>
 __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Model& model, int own, const double* pts, int N,
                                           int* st, bool exact_pinv, double* dbg) {

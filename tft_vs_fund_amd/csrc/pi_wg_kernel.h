@@ -90,25 +90,11 @@ __device__ __forceinline__ bool pinv_block_deflated2(const double (&B)[E][6], co
 
 // pinv's tolerance E N eps(max_i lambda_max(W_i)) for the block-diagonal weight matrix (Gauss_Helmert.m:57).  Only the binade of the
 // maximum enters: the eigenvalue pass is skipped when cheap upper / lower bounds agree on it.  Block-wide (contains barriers).
+// pi_tolerance_from_bounds: umax / lmax are the block-wide bounds (taken along with the finite check since round 5).
 template <class Model, int WV>
-__device__ inline double pi_block_tolerance(const PiWork& g, const double (&pi)[27], const int N, const int tid, double* red) {
+__device__ inline double pi_tolerance_from_bounds(const PiWork& g, const double (&pi)[27], const int N, const int tid, double* red, const double umax, const double lmax) {
     constexpr int THREADS = WV * WAVE;
     constexpr int E = Model::E;
-    double umax = 0.0, lmax = 0.0;                                           // upper / lower bound on max_i lambda_max(W_i)
-    for (int i = tid; i < N; i += THREADS) {
-        double o[6], W[E][E];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
-        PiPoint<E> pt;
-        pi_eval<Model, true>(pi, o, pt);
-        pi_block_W<E>(pt.B, W);
-        double up, lo;
-        psd_lambda_max_bounds(W, up, lo);
-        umax = (up > umax) ? up : umax;
-        lmax = (lo > lmax) ? lo : lmax;
-    }
-    umax = block_max_w<WV>(umax, red);
-    lmax = block_max_w<WV>(lmax, red);
     double smax = umax;
     if (eps_of(lmax) != eps_of(umax)) {
         smax = 0.0;
@@ -146,40 +132,61 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
     for (it = 1; it <= GH_IT_MAX; ++it) {
         double pi[27];
         load_uniform27(g.p, pi);
-        double f2max = 0.0;                                                  // max_i |W_i|_F^2
-        bool finite = true;
-        for (int i = tid; i < N; i += THREADS) {
-            double o[6], W[E][E];
+        // ---- W = B B' (:52), its finite check (:53-55) and pinv(W + 1e-12 I) (:57).
+        // Round 5: the finite check, max_i |W_i|_F and the cheap bounds on max_i lambda_max(W_i) behind pinv's tolerance are ONE pass and one
+        // barrier pair (the bounds were a pass of their own: pi_eval + pi_block_W per correspondence again, two more reductions).  Same blocks,
+        // same arithmetic.  (A speculative weight pass without the tolerance was measured first and lost: on normalised image data at
+        // N = 200 the tolerance E N eps(lambda_max) exceeds the 1e-12 shift, so the pass was repeated on every problem -- profiles/r5_ab_libs.txt.)
+        double f2max = 0.0, umax = 0.0, lmax = 0.0;                          // max_i |W_i|_F^2; bounds on max_i lambda_max(W_i)
+        {
+            bool finite = true;
+            for (int i = tid; i < N; i += THREADS) {
+                double o[6], W[E][E];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
-            PiPoint<E> pt;
-            pi_eval<Model, true>(pi, o, pt);
-            pi_block_W<E>(pt.B, W);
-            double chk = 0.0, fro2 = 0.0;
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[6 * i + k];
+                PiPoint<E> pt;
+                pi_eval<Model, true>(pi, o, pt);
+                pi_block_W<E>(pt.B, W);
+                double chk = 0.0, fro2 = 0.0;
 #pragma unroll
-            for (int a = 0; a < E; ++a) {
+                for (int a = 0; a < E; ++a) {
 #pragma unroll
-                for (int b = 0; b < E; ++b) { chk += W[a][b]; fro2 += W[a][b] * W[a][b]; }
+                    for (int b = 0; b < E; ++b) { chk += W[a][b]; fro2 += W[a][b] * W[a][b]; }
+                }
+                finite = finite && (fabs(chk) <= 1.79e308);
+                f2max = (fro2 > f2max) ? fro2 : f2max;
+                double up, lo;
+                psd_lambda_max_bounds(W, up, lo);
+                umax = (up > umax) ? up : umax;
+                lmax = (lo > lmax) ? lo : lmax;
             }
-            finite = finite && (fabs(chk) <= 1.79e308);
-            f2max = (fro2 > f2max) ? fro2 : f2max;
+            bool bad_entry = !finite;
+            block_max3_any_w<WV>(f2max, umax, lmax, bad_entry, red);
+            if (bad_entry || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
         }
-        f2max = block_max_w<WV>(f2max, red);
-        if (block_any_w<WV>(!finite, red) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
         // ---- Pi (4 x 4 blocks, non-singular KKT): weights at the accuracy of the formulas, as in gh_wg_kernel.h -- the block
         //      pseudo-inverse deflated by its one small eigenvalue (pinv_block_deflated<true>: regular part only in pp), the strong
         //      direction kept apart as (n, cs, n'w) and its contributions cs a a', cs a n'w formed from a = A_i' n FIRST (a is the
-        //      inconsistency of the correspondence: tiny, while cs ~ 1e12).  Sums: 27 * 28 / 2 + 27 = 405, thirteen butterflies per
-        //      wavefront into partial slots (V, H: both dead here), combined into S = V[0 .. 405).
+        //      inconsistency of the correspondence: tiny, while cs ~ 1e12).  Sums: 27 * 28 / 2 + 27 = 405 (PiCol: two families), on the matrix
+        //      core into per-wavefront slots (V, H: both dead here), combined into S = V[0 .. 405).
         bool factored = false;
         constexpr int SN = pi_sn(E);
-        {
-            if (!exact_pinv && g.sn != nullptr) {
-                const double tolW = pi_block_tolerance<Model, WV>(g, pi, N, tid, red);
+        if (!exact_pinv && g.sn != nullptr) {
+            {
+                const double tolW = pi_tolerance_from_bounds<Model, WV>(g, pi, N, tid, red, umax, lmax);
                 constexpr int SLOT = 406;
                 double* slot = (wave < WV - 1) ? g.V + wave * SLOT : g.H;
                 for (int e = lane; e < SLOT; e += WAVE) slot[e] = 0.0;
                 bool bad = false;
+                // the strong-direction sums on the matrix core (gh_kernel.h::StrongGram): tiles in registers across the trips; the wavefront's
+                // transposition scratch lives in M (dead until the KKT matrix is assembled).  PiCol's two families keep their own accumulators
+                // and meet in the slot, as their butterfly sums did.
+                typedef StrongGram<27, 16> Gram;
+                static_assert(WV * Gram::SCRATCH <= (27 + C) * (28 + C), "transposition scratch of the strong-direction Gram must fit M");
+                Gram gram, gram2;
+                gram.clear();
+                if constexpr (E == 5) gram2.clear();
+                double* gscratch = g.M + wave * Gram::SCRATCH;
 #pragma unroll 1
                 for (int base = 0; base < N; base += THREADS) {        // block-uniform trip count (the butterflies need whole wavefronts)
                     const int i = base + tid;
@@ -239,9 +246,15 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
                             tv = sc * nw; tv2 = sc2 * nw2;
                         }
                     }
-                    strong_accumulate<27>(bv, tv, slot);
-                    if constexpr (E == 5) strong_accumulate<27>(bv2, tv2, slot);   // kept apart from the first: adding the products before the butterflies saves 4 % and moves the worst fixture scene from 7e-10 to 1.7e-9
+                    gram.add(bv, tv, gscratch);
+                    if constexpr (E == 5) gram2.add(bv2, tv2, gscratch);          // kept apart from the first: one accumulator for both families (more k-steps of the same tiles) moved a fixture scene over the 1e-9 gate, as adding the products before the butterflies did in round 3 (7e-10 -> 1.7e-9)
                 }
+                wave_sync();
+                if constexpr (E == 5) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { gram.t00[v] += gram2.t00[v]; gram.t10[v] += gram2.t10[v]; gram.t11[v] += gram2.t11[v]; }
+                }
+                gram.store(slot);
                 __syncthreads();
                 for (int e = tid; e < 405; e += THREADS) g.V[e] = (WV == 4) ? (g.V[e] + g.V[SLOT + e]) + (g.V[2 * SLOT + e] + g.H[e]) : g.V[e] + g.H[e];
                 factored = !block_any_w<WV>(bad, red);                             // a block without the structure: the unfactored paths below for all
@@ -266,7 +279,7 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
             if (block_any_w<WV>(bad, red)) fast = false;
         }
         if (!fast && !factored) {
-            const double tolW = pi_block_tolerance<Model, WV>(g, pi, N, tid, red);
+            const double tolW = pi_tolerance_from_bounds<Model, WV>(g, pi, N, tid, red, umax, lmax);
             for (int i = tid; i < N; i += THREADS) {
                 double o[6], W[E][E], V[E][E];
 #pragma unroll

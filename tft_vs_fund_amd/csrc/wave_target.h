@@ -134,4 +134,15 @@ __device__ __forceinline__ double swap_sum(double a, double b) {
     }
 }
 
+// The matrix core, fp64: D = A B + C with A 16 x 4, B 4 x 16, C / D 16 x 16 (v_mfma_f64_16x16x4_f64: 32 cycles of the matrix pipe per SIMD, one
+// VALU issue slot).  Lane l holds A[l & 15][l >> 4] in `a`, B[l >> 4][l & 15] in `b`, and C / D[(l >> 4) + 4 v][l & 15] in c[v], v = 0 .. 3
+// (cdna_hip_programming.md: the f64 form has its own C / D row map).  Used where the path HAS a dense contraction: Gram matrices of per-
+// correspondence vectors, sum_i e_i e_i' (gh_kernel.h::StrongGram).
+typedef double tff_f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma_f64_16x16x4(const double a, const double b, double (&c)[4]) {
+    tff_f64x4 v = {c[0], c[1], c[2], c[3]};
+    v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, v, 0, 0, 0);
+    c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3];
+}
+
 }  // namespace tff
