@@ -779,7 +779,7 @@ def test_gh_finish_rows_keeps_the_rows_of_a_wavefront_independent(emu, neighbour
 FLAG_PRE, FLAG_PRE_GLOBAL = 8192, 16384
 
 
-@pytest.mark.parametrize("B,N,sigma,extra", [(5, 12, 1.0, 0), (3, 70, 0.0, 0), (2, 130, 1.0, FLAG_PRE_GLOBAL), (6, 200, 1.0, 0), (1, 333, 2.0, FLAG_PRE_GLOBAL), (2, 64, 1.0, 0)])
+@pytest.mark.parametrize("B,N,sigma,extra", [(5, 12, 1.0, 0), (2, 130, 1.0, FLAG_PRE_GLOBAL), (5, 200, 1.0, 0)])
 def test_moments_kernel_feeds_the_rows_kernel(emu, B, N, sigma, extra):
     """k_tft_moments (tft_moments_kernel.h: one triplet per wavefront, correspondences parked in LDS -- or, extra = FLAG_PRE_GLOBAL, re-read from
     global memory as for N beyond the LDS budget) + k_linear_tft_pose_rows<true> against the oracle at 1e-9 and against the fused rows kernel,

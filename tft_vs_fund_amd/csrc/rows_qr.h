@@ -146,7 +146,7 @@ __device__ __forceinline__ void rows_invit_from_R(const double* Rp, double* dinv
             ++it;
             if (r2 <= 1e-26) { res = 0.0; done = true; }
             else if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) { res = 0.0; done = true; }
-            else if (!(r2 == r2) || it >= maxit || invit_hopeless(it, maxit, r2, rprev2)) { res = (r2 == r2) ? r2 : 1.0; done = true; }
+            else if (!(r2 == r2) || it >= maxit) { res = (r2 == r2) ? r2 : 1.0; done = true; }
             rprev2 = r2;
         }
         if (!wave_any(!done)) break;                        // the four rows iterate on four different systems

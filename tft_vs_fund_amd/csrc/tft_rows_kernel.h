@@ -280,7 +280,7 @@ __device__ __forceinline__ void rows_min_eigvec(double (&g0)[RowEigDims<n>::N0],
             ++it;
             if (r2 <= 1e-26) { res = 0.0; done = true; }
             else if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) { res = 0.0; done = true; }
-            else if (!(r2 == r2) || it >= maxit || invit_hopeless(it, maxit, r2, rprev2)) { res = (r2 == r2) ? r2 : 1.0; done = true; }
+            else if (!(r2 == r2) || it >= maxit) { res = (r2 == r2) ? r2 : 1.0; done = true; }
             if (it >= 2 && r2 > 1e-30) { rk_r2 = r2; rk_rp = rprev2; rk_nn = nn; }
             rprev2 = r2;
         }

@@ -24,17 +24,10 @@
 
 namespace tff {
 
-// Inverse iteration that cannot reach its stopping threshold before the cap: stop now.  The observed rate q = |step|^2 / |previous step|^2 only
-// gets slower as the iteration settles on its slowest mode, so "at this rate |step|^2 is still above 1e-26 at iteration `maxit`" means the cap
-// would be hit anyway -- with the same verdict (not converged: the caller's next tier takes over) some 280 iterations later.  Nearly coincident
-// smallest singular values are the rule for minimal samples of outlier-ridden scenes (config 4: ~2 % of seven-point samples), where a wavefront of
-// four triplets used to run 300 iterations for its one hopeless row.  Checked every eighth iteration from the sixteenth on, never near the
-// rounding floor (|step|^2 <= 1e-20 converges or stagnates within a few iterations, and there the rate is noise).
-__device__ __forceinline__ bool invit_hopeless(const int it, const int maxit, const double r2, const double rprev2) {
-    if (it < 16 || (it & 7) != 0 || !(r2 > 1e-20)) return false;
-    if (!(r2 < rprev2)) return true;
-    return log(r2 * 1e26) > (double)(maxit - it) * log(rprev2 / r2);
-}
+// (Round 5, measured and dropped: leaving an inverse iteration early when its observed rate says the cap will be hit anyway -- config 4's seven-point
+// samples, where ~0.3 % of the rows run into the cap and hold their wavefront for 300 iterations.  Same-box A/B, tools/ab_libs_config4.py: 26.94 ->
+// 30.41 ms per million hypotheses, and hypotheses that used to converge in-row after 100 - 250 iterations changed hands: the rate is not monotone
+// on these clustered spectra, and the one-triplet exact kernel that takes the hand-over costs more than the iterations saved.)
 
 
 __device__ __forceinline__ int tri_index(int r, int c) { return (r * (r + 1)) / 2 + c; }   // packed lower, c <= r
@@ -99,7 +92,7 @@ __device__ inline double wave_invit_unit(const double* Lp, const double myinv, c
             // |step|^2 = r2; the error of the new iterate is ~ rho |step| / (1 - rho) with rho ~ |step| / |previous step|
             if (r2 <= 1e-26) { res = 0.0; done = true; }                                     // converged: stopped moving
             else if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) { res = 0.0; done = true; }   // predicted error < 1e-13
-            else if (!(r2 == r2) || it >= maxit || invit_hopeless(it, maxit, r2, rprev2)) { res = (r2 == r2) ? r2 : 1.0; done = true; }             // NaN / iteration cap: not converged
+            else if (!(r2 == r2) || it >= maxit) { res = (r2 == r2) ? r2 : 1.0; done = true; }             // NaN / iteration cap: not converged
             if (it >= 2 && r2 > 1e-30) { rk_r2 = r2; rk_rp = rprev2; rk_nn = nn; }            // last observable pair of steps
             rprev2 = r2;
         }
