@@ -388,6 +388,16 @@ def main():
                     valu["frac_of_issue_limit"] = (value / world) / valu["issue_limited_triplets_per_s"]       # of the per-GPU rate actually delivered
                     if single:
                         valu["frac_of_issue_limit_one_batch_at_a_time"] = single["value"] / valu["issue_limited_triplets_per_s"]
+                    # ... and against the MEASURED issue rate (tools/micro/fp64_issue.hip, profiles/r5_fp64_issue.txt: independent v_fma_f64 /
+                    # v_fmac_f64_dpp streams at two wavefronts per SIMD; the shader clock settles near 2.0 - 2.35 GHz under fp64 load, so the
+                    # nominal 2.4 GHz / 4 cycles above is 10 - 25 % optimistic)
+                    mr = pj.get("measured_fp64_issue_inst_per_ns_per_simd_at_2_waves") or {}
+                    lo, hi = mr.get("v_fma_f64"), mr.get("v_fmac_f64_dpp row_newbcast")
+                    if lo and hi:
+                        lim = [simds * r * 1e9 / ipt for r in (lo, hi)]
+                        valu["measured_issue_rate_inst_per_ns_per_simd"] = [lo, hi]
+                        valu["measured_issue_limited_triplets_per_s"] = lim
+                        valu["frac_of_measured_issue_limit"] = [(value / world) / lim[1], (value / world) / lim[0]]
             except Exception:
                 traffic, valu = None, None
         out = {

@@ -79,12 +79,17 @@ typedef struct tff_ctx tff_ctx;
                              * for Ressl / Nordberg / Pi / PiCol, four for FaugPapa -- at every N since round 4);
                              * 1 the fused single-wavefront kernels (one wavefront per triplet from start to end);
                              * 2 workgroup kernels always (the same as 0 now) */
-#define TFF_OPT_ROWS 7      /* LinearTFT / LinearF pose kernels and the linear stage of the iterative TFT methods: 1 four triplets per wavefront,
-                             * one per row of 16 lanes (csrc/tft_rows_kernel.h, f_rows_kernel.h, gh_rows_kernel.h); 0 one triplet per wavefront
-                             * (csrc/tft_kernel.h, f_kernel.h); 2 (default) by batch size: the row kernels (2.5x fewer instructions per triplet) once
-                             * the batch no longer fits the device's wavefront slots in one go (B >= 1024, or > 2048 when N > 256), the one-triplet
-                             * kernels (shorter latency) below.  The two routes agree to rounding (1e-14), so a triplet's last bits may depend on
-                             * the size of the batch it arrives in; set 0 or 1 where that matters */
+#define TFF_OPT_ROWS 7      /* LinearTFT / LinearF pose kernels, and the linear stage + pose tail of the iterative methods: 1 four triplets per wavefront,
+                             * one per row of 16 lanes (csrc/tft_rows_kernel.h, f_rows_kernel.h, gh_rows_kernel.h, optimf_rows_kernel.h); 0 one triplet
+                             * per wavefront (csrc/tft_kernel.h, f_kernel.h); 2 (default):
+                             *   - the two LINEAR methods go by batch size: the row kernels (2.5x fewer instructions per triplet) once the batch no
+                             *     longer fits the device's wavefront slots in one go (B >= 1024, or > 2048 when N > 256), the one-triplet kernels
+                             *     (shorter latency) below.  The two routes agree to rounding (1e-14), so a linear result's last bits may depend on
+                             *     the size of the batch it arrives in; set 0 or 1 where that matters;
+                             *   - the ITERATIVE methods (OptimF, Ressl, Nordberg, FaugPapa, Pi, PiCol) always take the row kernels (round 5): their
+                             *     iteration amplifies a last bit of its start, so their route must not depend on the batch size -- the same triplet
+                             *     gives the same bits and the same `iter` in any batch.
+                             * Whatever the route: a triplet with status != 0 has NaN in every output (T, R_t_2, R_t_3, Reconst) */
 #define TFF_OPT_PRE 10      /* trifocal row kernels (TFF_OPT_ROWS route): where the three Normalize2Ddata calls and the 96 moment sums of linearTFT's system are
                              * computed.  0 (default) = inside the row kernels (two passes over the correspondences); 1 = in a kernel of their own, one triplet
                              * per wavefront, the correspondences read from HBM once and parked in LDS (csrc/tft_moments_kernel.h), the row kernels starting

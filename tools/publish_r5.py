@@ -25,5 +25,15 @@ pmc = {
     "valu_instructions_per_triplet": s["valu_instructions_per_unit"], "salu_instructions_per_triplet": s["salu_instructions_per_unit"],
     "valu_busy_fraction": s["valu_busy_fraction"], "lane_utilisation": s["lane_utilisation"], "waiting_fraction": s["waiting_fraction"],
 }
+# the measured fp64 issue rate (tools/micro/fp64_issue.hip -> profiles/r5_fp64_issue.txt): instructions per ns and SIMD at two wavefronts per SIMD
+rates = {}
+fi = os.path.join(ROOT, "profiles", "r5_fp64_issue.txt")
+if os.path.exists(fi):
+    import re
+    for line in open(fi):
+        m = re.match(r"(\S+(?: \S+)*?)\s+2 wave\(s\)/SIMD:\s+[\d.]+ ms, ([\d.]+) inst/ns/SIMD", line)
+        if m:
+            rates[m.group(1)] = float(m.group(2))
+pmc["measured_fp64_issue_inst_per_ns_per_simd_at_2_waves"] = rates
 json.dump(pmc, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
 print(json.dumps(pmc, indent=1))
