@@ -274,3 +274,24 @@ def test_moments_pre_kernel_agrees_with_the_fused_passes(B, N):
         ctx.set_pre(0)
         g0 = ctx.pose_batch("ResslTFTPoseEstimation", d[:512].contiguous(), calm, reconst=False)
         assert int((g1["status"] != 0).sum()) == 0 and float((g1["iter"] != g0["iter"]).double().mean()) < 0.01
+
+
+@pytest.mark.parametrize("method", ["ResslTFTPoseEstimation", "LinearTFTPoseEstimation"])
+def test_a_row_the_exact_tiers_redo_does_not_touch_its_neighbours(gpu_ctx, method):
+    """Rows route with Reconst: one triplet with collinear camera centres (the fast null vectors report, its row is redone on the exact tiers --
+    in k_gh_finish_rows the whole wavefront walks through the pose tail a second time and only that row may store) among generic ones: every
+    other triplet, the three that share its wavefront included, is bit-identical to a run in which it is replaced by a generic triplet."""
+    import torch
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    B, N = 12, 60
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=808)
+    Cc, _, _, _ = generate_scene_batch(1, N, noise=1.0, seed=360, angle=180)
+    calm = torch.from_numpy(CalM).cuda()
+    ref = gpu_ctx.pose_batch(method, torch.from_numpy(C).cuda(), calm, reconst=True)
+    Cx = C.copy(); Cx[6] = Cc[0]
+    out = gpu_ctx.pose_batch(method, torch.from_numpy(Cx).cuda(), calm, reconst=True)
+    assert int((out["status"] != 0).sum()) == 0 and int((ref["status"] != 0).sum()) == 0
+    keep = torch.tensor([b for b in range(B) if b != 6]).cuda()
+    for k in ("T", "R_t_2", "R_t_3", "Reconst", "iter"):
+        assert torch.equal(out[k][keep], ref[k][keep]), (method, k)
+    assert not torch.equal(out["T"][6], ref["T"][6])
