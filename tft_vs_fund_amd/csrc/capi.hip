@@ -55,7 +55,7 @@ struct tff_ctx {
     int solver = 0;
     int exact_below = tff::EXACT_BELOW_N;   // TFF_OPT_EXACT_BELOW
     int stage = -1;
-    DevBuf in, calm, out, idx, scratch_status, gh_rec, gh_topt, gh_init, spill, pre_rec;
+    DevBuf in, calm, out, idx, scratch_status, gh_rec, gh_topt, gh_init, spill, pre_rec, retry;
     const int32_t* sample_idx = nullptr;   // set around a *_sampled_dev call
     int32_t sample_ns = 0;                 //   size of the scene the indices refer to
     double* init_p = nullptr; double* init_x = nullptr;   // set around tff_pi_pose_batch_debug_dev
@@ -234,6 +234,9 @@ int launch_pose_rows(tff_ctx* c, KRows krows, KExact kexact, lds_fn exact_lds, i
     }
     tff::LinearTftArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr),
                          Rt2, Rt3, T, reconst, iter, status, dbg, c->sample_idx, c->init_p, c->init_x, nullptr, 0, c->sample_ns};
+    // the triplets the row kernel flags go to the exact kernel as a compact list: [count | B indices] (the row kernel zeroes the count)
+    if (int r = c->retry.reserve(((size_t)B + 1) * sizeof(int32_t))) return r;
+    a.retry_count = (int*)c->retry.p;
     if (krows_pre && N >= 7 && pre_for(c, N)) {
         if (int r = launch_moments(c, corresp, B, N, &a.pre)) return r;
         hipLaunchKernelGGL(krows_pre, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, a);
@@ -251,10 +254,13 @@ int launch_pose_rows(tff_ctx* c, KRows krows, KExact kexact, lds_fn exact_lds, i
     }
     const size_t lds = exact_lds(N, a.flags, true);
     if (int r = ensure_lds(kexact, lds)) return r;
-    // the fix-up grid: 1024 wavefronts scan the status array (resident in one go; almost always nothing to redo).  Whole batches of minimal
-    // samples hand ~2 % on when the scene has gross outliers (config 4): a block then redoes its share one after the other, a lone wavefront at
-    // ~0.4 ms each -- a grid that grows with the batch (one block per 64 triplets) keeps that share at one or two
-    const long fix = (B / 64 > FIXUP_GRID) ? ((B / 64 < 65536) ? B / 64 : 65536) : FIXUP_GRID;
+    // the fix-up: k_collect_retry compacts the flagged triplets (almost always none; ~0.3 % of a million seven-point samples of an outlier-ridden
+    // scene, config 4), then one resident round of wavefronts walks the list -- one triplet per wavefront and round, where until round 5 every
+    // block scanned a fixed share of the status array and redid what it found there one after the other (5 of 27 ms in config 4)
+    hipLaunchKernelGGL(tff::k_collect_retry, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, c->stream, status, (long)B, (int*)c->retry.p + 1, (int*)c->retry.p);
+    TFF_HIP(hipGetLastError());
+    a.retry_list = (const int*)c->retry.p + 1;
+    const long fix = 2 * FIXUP_GRID;
     hipLaunchKernelGGL(kexact, dim3((unsigned)(B < fix ? B : fix)), dim3(64), lds, c->stream, a);
     TFF_HIP(hipGetLastError());
     return 0;
@@ -557,7 +563,7 @@ void tff_ctx_destroy(tff_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->own) { (void)hipStreamSynchronize(c->own); (void)hipStreamDestroy(c->own); }
     if (c->handover) (void)hipEventDestroy(c->handover);
-    c->in.release(); c->calm.release(); c->out.release(); c->idx.release(); c->scratch_status.release(); c->gh_rec.release(); c->gh_topt.release(); c->gh_init.release(); c->spill.release(); c->pre_rec.release();
+    c->in.release(); c->calm.release(); c->out.release(); c->idx.release(); c->scratch_status.release(); c->gh_rec.release(); c->gh_topt.release(); c->gh_init.release(); c->spill.release(); c->pre_rec.release(); c->retry.release();
     delete c;
 }
 

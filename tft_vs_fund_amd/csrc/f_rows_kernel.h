@@ -154,6 +154,7 @@ __device__ __forceinline__ bool rows_linear_f_middle(RowLds* w, RowRt* rt, doubl
 
 __global__ void __launch_bounds__(64, 2) k_linear_f_pose_rows(const LinearTftArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
+    if (a.retry_count && blockIdx.x == 0 && threadIdx.x == 0) *a.retry_count = 0;   // (the list the exact kernel will walk: k_collect_retry fills it after this kernel)
     const int p = lane_id() & 15, row = lane_id() >> 4;
     RowLds* w = reinterpret_cast<RowLds*>(smem) + row;
     RowRt* rt = reinterpret_cast<RowRt*>(w->ov);
@@ -279,6 +280,7 @@ __device__ __forceinline__ bool rows_linear_f_middle_exact(RowLds* w, RowRt* rt,
 
 __global__ void __launch_bounds__(64, 2) k_linear_f_pose_rows_exact(const LinearTftArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
+    if (a.retry_count && blockIdx.x == 0 && threadIdx.x == 0) *a.retry_count = 0;   // (the list the exact kernel will walk: k_collect_retry fills it after this kernel)
     const int p = lane_id() & 15, row = lane_id() >> 4;
     RowLds* w = reinterpret_cast<RowLds*>(smem) + row;
     RowRt* rt = reinterpret_cast<RowRt*>(w->ov);
