@@ -60,9 +60,12 @@ extern "C" int emu_linear_tft_pose_rows(const double* corresp, const double* cal
     } else {
         emu::launch(tff::k_linear_tft_pose_rows<false>, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);
     }
-    bool any = false;
-    for (long b = 0; b < B; ++b) any = any || status[b] == tff::ST_RETRY;
-    if (!any) return 0;
+    // (as the C ABI: the flagged triplets reach the exact kernel as the compact list of k_collect_retry)
+    std::vector<int> retry((size_t)B + 1, 0);
+    emu::launch(tff::k_collect_retry, (unsigned)((B + 255) / 256), 256, 0, (const int*)status, B, retry.data() + 1, retry.data());
+    if (retry[0] == 0) return 0;
+    a.retry_list = retry.data() + 1;
+    a.retry_count = retry.data();
     a.flags |= tff::FLAG_ONLY_RETRY;
     a.flags = tff::pose_auto_flags(N, a.flags, true);
     emu::launch(tff::k_linear_tft_pose<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, a.flags, true), a);

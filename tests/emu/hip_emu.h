@@ -90,5 +90,6 @@ void launch(F kernel, unsigned grid, unsigned block, size_t smem, A... args) {
 struct double2 { double x, y; };
 inline void __syncthreads() { emu::block_barrier(); }
 inline double __longlong_as_double(long long v) { double d; std::memcpy(&d, &v, 8); return d; }
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }   // (k_collect_retry: lanes are threads here)
 inline long long __double_as_longlong(double d) { long long v; std::memcpy(&v, &d, 8); return v; }
 inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }

@@ -31,7 +31,7 @@ constexpr int GH_REC_DOUBLES = 64;        // t 27 | pa 18 | epi 6 | nrm 9 | pad
 // A component-major layout (xi[k * N + i]: conflict-free ds_read_b64) was measured slower too -- the ten sweeps 17.3 k -> 22.5 k cycles,
 // twice the LDS instructions and 20 more spilled registers: the SQ_LDS_BANK_CONFLICT share of profiles/r2_ressl_* (0.75 of the LDS
 // instruction cycles) is not what bounds these passes, LDS instruction issue is.
-constexpr int GH_XI = 6, GH_PP = 10;
+constexpr int GH_XI = 6, GH_PP = 10, GH_SN = 6;         // GH_SN: per correspondence n (4), cs, pad -- N records behind the N W+ records (pp + GH_PP N)
 
 // LDS of k_gh_block after the PoseLds header: p, dt, Tc, dT, D, H, Y, M, V (112 doubles of scratch), xi (6N), W+ (10N), reduction slots.
 // `pinv` (FaugPapa: D is the identity and never stored): the eigenvectors + scratch of the pseudo-inverse (n^2 + 2n) overlay D | H | Y,
@@ -42,7 +42,7 @@ constexpr int GH_XI = 6, GH_PP = 10;
 __host__ __device__ inline int gh_wg_lds_doubles(int u, int c, int N, bool pinv) {
     const int n = u + c;
     const int strong = pinv ? 0 : ((u * (u + 1) / 2 + u + 1) & ~1);          // sums of the factored strong-direction terms (minimal parameterisations)
-    return 2 * ((u + 1) & ~1) + 2 * c + 28 + 28 + 27 * u + 298 + ((27 * u > 298) ? 27 * u : 298) + n * (n + 1) + 112 + strong + GH_XI * N + GH_PP * N + 16 + 8;
+    return 2 * ((u + 1) & ~1) + 2 * c + 28 + 28 + 27 * u + 298 + ((27 * u > 298) ? 27 * u : 298) + n * (n + 1) + 112 + strong + GH_XI * N + (GH_PP + GH_SN) * N + 16 + 8;
 }
 __device__ inline GhWork gh_wg_carve(double* base, PoseLds* w, int u, int c, int N, bool pinv, double** red) {
     GhWork g;
@@ -60,7 +60,7 @@ __device__ inline GhWork gh_wg_carve(double* base, PoseLds* w, int u, int c, int
     g.V = pinv ? g.D : q; q += 112;                                                // 108 doubles of scratch (Nordberg's rotations)
     g.S = pinv ? nullptr : q; q += pinv ? 0 : ((u * (u + 1) / 2 + u + 1) & ~1);
     g.xi = q; q += GH_XI * N;
-    g.pp = q; q += GH_PP * N;
+    g.pp = q; q += (GH_PP + GH_SN) * N;
     *red = q;
     g.u = u; g.c = c;
     return g;
@@ -290,8 +290,10 @@ __device__ inline void gh_block_reproject(PoseLds* w, const double* pts, int N, 
 }
 
 // Gauss_Helmert.m:38-83, one workgroup per problem.  `own`: the wavefront that runs the wave-serial steps.
-// Round 5 measured four changes to THIS iteration against the round-4 build on the same box (tools/ab_libs.py, profiles/r5_ab_libs.txt; Ressl /
-// Nordberg, ms per 10 000 x 200) and kept none of them -- the iteration below is round 4's:
+// Round 5 measured six changes to THIS iteration against the round-4 build on the same box (tools/ab_libs.py, profiles/r5_ab_libs.txt; Ressl /
+// Nordberg, ms per 10 000 x 200).  KEPT (run 5): the finite check riding on a speculative weight pass + the strong direction (n, cs) kept in a
+// record of its own BEHIND the packed W+ records, so that the v pass does not deflate every block a second time: 2.367 -> 2.268 / 2.673 -> 2.579
+// (the speculation alone: 2.340 / 2.669).  NOT kept:
 //   * finite check riding on a speculative weight pass (+ the strong direction n, cs kept in a 16-double W+ record for the v pass): 2.371 -> 2.365 /
 //     2.659 -> 2.669; the v pass fell from 19 k to 12 k cycles but the 128-byte record stride cost the ten sweeps as much (W+ is in global slices);
 //   * check and tolerance bounds in one pass: 2.369 -> 2.430 / 2.672 -> 2.719 (the blocks stay under the truncation limit here, so round 4 never ran
@@ -316,6 +318,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
     }
     objFunc = block_sum_w<WV>(objFunc, red);
     int it = 0;
+    bool expect_truncate = false;                                            // what the previous iteration found (the blocks change little between iterations)
 #pragma unroll 1
     for (it = 1; it <= GH_IT_MAX; ++it) {
         if (it == 1) phase_stamp(sdbg, 40);
@@ -326,26 +329,34 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         load_uniform27(g.Tc, T);
         // ---- W = B B' (:52): finite check, bound on the largest eigenvalue; see gh_kernel.h for the two pinv paths ----
         double f2max = 0.0;                                                  // max_i |W_i|_F^2
-        bool finite = true;
-        for (int i = tid; i < N; i += THREADS) {
-            double o[6], f[4], B[4][6], W[4][4];
+        // Round 5: pinv's tolerance matters only when it can reach the 1e-12 shift, and whether it can is known from max_i |W_i|_F -- a by-product of
+        // the blocks the weight pass builds anyway.  So the deflated weight pass runs first, without tolerance, and takes the finite check and the
+        // Frobenius maximum along (`spec`); it is repeated with the tolerance only if the maximum says pinv could truncate, and a problem whose
+        // previous iteration found that keeps the old order.  The trifocal blocks of normalised image data at N = 200 stay under the limit.
+        bool spec = !exact_pinv && !expect_truncate;                         // the check rides on the weight pass
+        bool nonfinite = false;
+        if (!spec) {
+            bool finite = true;
+            for (int i = tid; i < N; i += THREADS) {
+                double o[6], f[4], B[4][6], W[4][4];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) o[k] = g.xi[GH_XI * i + k];
-            tril_block(T, o, f, B);
-            block_W(B, W);
-            double chk = 0.0, fro2 = 0.0;
+                for (int k = 0; k < 6; ++k) o[k] = g.xi[GH_XI * i + k];
+                tril_block(T, o, f, B);
+                block_W(B, W);
+                double chk = 0.0, fro2 = 0.0;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
+                for (int a = 0; a < 4; ++a) {
 #pragma unroll
-                for (int b = 0; b < 4; ++b) { chk += W[a][b]; fro2 += W[a][b] * W[a][b]; }
+                    for (int b = 0; b < 4; ++b) { chk += W[a][b]; fro2 += W[a][b] * W[a][b]; }
+                }
+                finite = finite && (fabs(chk) <= 1.79e308);
+                f2max = (fro2 > f2max) ? fro2 : f2max;
             }
-            finite = finite && (fabs(chk) <= 1.79e308);
-            f2max = (fro2 > f2max) ? fro2 : f2max;
+            f2max = block_max_w<WV>(f2max, red);
+            if (block_any_w<WV>(!finite, red) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
         }
-        f2max = block_max_w<WV>(f2max, red);
-        if (block_any_w<WV>(!finite, red) || !(f2max <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :53-55
         // blocks in the deflated form (gh_kernel.h, pinv_block_deflated); pinv's tolerance is needed only when it can truncate
-        const bool may_truncate = !(4.0 * (double)N * eps_of(sqrt(f2max)) < 0.9e-12);
+        bool may_truncate = spec ? false : !(4.0 * (double)N * eps_of(sqrt(f2max)) < 0.9e-12);
         if (it == 1) phase_stamp(sdbg, 42);
         double tolW = 0.0;
         bool have_tol = false, jacobi = exact_pinv;
@@ -353,7 +364,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
         const bool want_factored = !Model::IDENTITY_D && g.S != nullptr;
         bool factored = false;
 #pragma unroll 1
-        for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int attempt = 0; attempt < 3; ++attempt) {
             if ((may_truncate || jacobi) && !have_tol) {
                 // pinv's tolerance 4N eps(max_i lambda_max(W_i)) needs only the binade of that maximum: when cheap bounds agree on it,
                 // the eigenvalue pass that would find the maximum is skipped
@@ -390,7 +401,7 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
                 have_tol = true;
             }
             if (!jacobi) {
-                bool bad = false;
+                bool bad = false, finite = true;
                 constexpr int SLOT = (Model::U * (Model::U + 1) / 2 + Model::U + 1) & ~1;
                 double* slot = nullptr;
                 if (want_factored) {                                         // per-wavefront partial sums of the strong-direction terms
@@ -409,6 +420,16 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
                         for (int k = 0; k < 6; ++k) o[k] = g.xi[GH_XI * i + k];
                         tril_block(T, o, f, B);
                         block_W(B, W);
+                        if (spec) {
+                            double chk = 0.0, fro2 = 0.0;
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) { chk += W[a][b]; fro2 += W[a][b] * W[a][b]; }
+                            }
+                            finite = finite && (fabs(chk) <= 1.79e308);
+                            f2max = (fro2 > f2max) ? fro2 : f2max;
+                        }
                         double nn[4], cs = 0.0;
                         const bool ok = want_factored ? pinv_block_deflated<true>(B, W, tolW, Wp, nn, &cs) : pinv_block_deflated<false>(B, W, tolW, Wp, nn, &cs);
                         bad = !ok || bad;
@@ -417,6 +438,10 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
 #pragma unroll
                         for (int k = 0; k < 10; ++k) g.pp[GH_PP * i + k] = Wp[k];
                         if constexpr (!Model::IDENTITY_D) if (want_factored && ok) {
+                            double* sn = g.pp + GH_PP * (long)N + GH_SN * (long)i;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) sn[k] = nn[k];
+                            sn[4] = cs;
                             // b = sqrt(cs) D' (Ap' n),  t = sqrt(cs) n'w,  n'w = -n'f - (B'n) . (x - xi)
                             double gm[3][3];
                             tril_grad_n(o, nn, gm);
@@ -439,6 +464,13 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
                     constexpr int total = Model::U * (Model::U + 1) / 2 + Model::U;
                     for (int e = tid; e < total; e += THREADS)
                         g.S[e] = (WV == 4) ? (g.G[e] + g.G[SLOT + e]) + (g.G[2 * SLOT + e] + g.S[e]) : g.G[e] + g.S[e];
+                }
+                if (spec) {
+                    f2max = block_max_w<WV>(f2max, red);
+                    if (block_any_w<WV>(!finite, red) || !(f2max <= 1.79e308)) { nonfinite = true; break; }   // :53-55
+                    spec = false;
+                    may_truncate = !(4.0 * (double)N * eps_of(sqrt(f2max)) < 0.9e-12);
+                    if (may_truncate) continue;
                 }
                 if (!block_any_w<WV>(bad, red)) { factored = want_factored; break; }
                 jacobi = true;                                               // a block without the structure: eigen-decompositions for all
@@ -466,6 +498,8 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
             }
             break;
         }
+        if (nonfinite) { *st = ST_NONFINITE; break; }
+        expect_truncate = may_truncate;
         if (it == 1) phase_stamp(sdbg, 43);
         // ---- Ghat, ghat: the ten sweeps are dealt to the four wavefronts, each sweep runs over ALL correspondences on one wavefront
         //      (4 per lane at N = 200) and ends in one reduce-scatter: a quarter of the reductions of the per-wavefront-partial layout
@@ -630,9 +664,9 @@ __device__ inline int gauss_helmert_block(PoseLds* w, GhWork& g, double* red, Mo
                 r[a] = wp_at(Wp, a, 0) * wv[0] + wp_at(Wp, a, 1) * wv[1] + wp_at(Wp, a, 2) * wv[2] + wp_at(Wp, a, 3) * wv[3];
             double bn[6] = {0, 0, 0, 0, 0, 0}, sterm = 0.0;                  // strong direction: -cs (B'n) n'(A dt - w)
             if (factored) {
-                double W[4][4], Wq[10], nn[4], cs = 0.0;
-                block_W(B, W);
-                pinv_block_deflated<true>(B, W, tolW, Wq, nn, &cs);
+                const double* sn = g.pp + GH_PP * (long)N + GH_SN * (long)i;
+                const double nn[4] = {sn[0], sn[1], sn[2], sn[3]};
+                const double cs = sn[4];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) bn[k] = B[0][k] * nn[0] + B[1][k] * nn[1] + B[2][k] * nn[2] + B[3][k] * nn[3];
                 sterm = cs * (nn[0] * wv[0] + nn[1] * wv[1] + nn[2] * wv[2] + nn[3] * wv[3]);
