@@ -46,6 +46,8 @@ extern "C" int emu_linear_tft_pose_rows(const double* corresp, const double* cal
                                         double* Rt2, double* Rt3, double* T, double* reconst, int* iter, int* status, double* dbg) {
     tff::LinearTftArgs a{corresp, calm, calm_stride, B, N, flags & ~tff::FLAG_JACOBI, Rt2, Rt3, T, reconst, iter, status, dbg, nullptr, nullptr, nullptr};
     if (reconst) a.flags |= tff::FLAG_RECONST;
+    std::vector<int> retry((size_t)B + 2, 0);                // [count | next call's count | indices]
+    a.retry_count = retry.data(); a.retry_zero = retry.data() + 1; a.retry_list = retry.data() + 2;
     std::vector<double> pre;
     if (flags & 8192) {                                                      // test switch: moments + normalisations from k_tft_moments (as the C ABI does from N >= 48)
         pre.assign((size_t)B * tff::PRE_DOUBLES, 0.0);
@@ -60,12 +62,7 @@ extern "C" int emu_linear_tft_pose_rows(const double* corresp, const double* cal
     } else {
         emu::launch(tff::k_linear_tft_pose_rows<false>, emu_rows_grid(B), 64, tff::rows_lds_bytes(), a);
     }
-    // (as the C ABI: the flagged triplets reach the exact kernel as the compact list of k_collect_retry)
-    std::vector<int> retry((size_t)B + 1, 0);
-    emu::launch(tff::k_collect_retry, (unsigned)((B + 255) / 256), 256, 0, (const int*)status, B, retry.data() + 1, retry.data());
-    if (retry[0] == 0) return 0;
-    a.retry_list = retry.data() + 1;
-    a.retry_count = retry.data();
+    if (retry[0] == 0) return 0;                             // (as the C ABI: the row kernel has put the flagged triplets on the list)
     a.flags |= tff::FLAG_ONLY_RETRY;
     a.flags = tff::pose_auto_flags(N, a.flags, true);
     emu::launch(tff::k_linear_tft_pose<true>, emu_grid(B), 64, tff::pose_lds_bytes(N, a.flags, true), a);

@@ -346,12 +346,4 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft(const LinearTftOnlyArgs a)
     }
 }
 
-// The triplets a row kernel flagged ST_RETRY as a compact list for the exact kernel (order irrelevant: every triplet is redone on its own).
-// Until round 5 the exact kernel scanned the status array itself, each block a fixed share: on a batch with many retries (config 4: 0.3 % of a
-// million seven-point samples) the blocks that found two or three ran them one after the other, 0.4 ms each, while most of the grid was idle.
-__global__ void __launch_bounds__(256) k_collect_retry(const int* __restrict__ status, const long B, int* __restrict__ list, int* __restrict__ count) {
-    const long b = (long)blockIdx.x * 256 + threadIdx.x;
-    if (b < B && status[b] == ST_RETRY) list[atomicAdd(count, 1)] = (int)b;
-}
-
 }  // namespace tff

@@ -63,6 +63,7 @@ struct tff_ctx {
     int gh_exact = 0;                      // TFF_OPT_GH_EXACT
     int spill_only_if_needed = 0;          // TFF_OPT_SPILL
     int rows = 2;                          // TFF_OPT_ROWS: 0 never, 1 always, 2 by batch size (rows_for)
+    int retry_parity = 0;                  // which of the two retry counters this call uses (launch_pose_rows)
     int pre = 0;                           // TFF_OPT_PRE: 0 never (default: measured slower, see pre_for), 1 always, 2 from N >= 48
     int dbg_fp_handover = 0;               // TFF_OPT_DEBUG_FP_HANDOVER
     int dbg_adaptive = 0;                  // TFF_OPT_DEBUG_ADAPTIVE
@@ -234,9 +235,18 @@ int launch_pose_rows(tff_ctx* c, KRows krows, KExact kexact, lds_fn exact_lds, i
     }
     tff::LinearTftArgs a{corresp, calm, (long)calm_stride, (long)B, N, base_flags(c, reconst != nullptr),
                          Rt2, Rt3, T, reconst, iter, status, dbg, c->sample_idx, c->init_p, c->init_x, nullptr, 0, c->sample_ns};
-    // the triplets the row kernel flags go to the exact kernel as a compact list: [count | B indices] (the row kernel zeroes the count)
-    if (int r = c->retry.reserve(((size_t)B + 1) * sizeof(int32_t))) return r;
-    a.retry_count = (int*)c->retry.p;
+    // the triplets the row kernel flags go to the exact kernel as a compact list: [count 0 | count 1 | B indices].  The row kernel appends to the
+    // list itself (one atomic per flagged triplet) and zeroes the OTHER counter for the context's next call; this call's counter was zeroed
+    // during the previous call (both at allocation).  No scan of the status array, no launch in between.
+    {
+        void* before = c->retry.p;
+        if (int r = c->retry.reserve(((size_t)B + 2) * sizeof(int32_t))) return r;
+        if (c->retry.p != before) { TFF_HIP(hipMemsetAsync(c->retry.p, 0, 2 * sizeof(int32_t), c->stream)); c->retry_parity = 0; }
+    }
+    a.retry_count = (int*)c->retry.p + c->retry_parity;
+    a.retry_zero = (int*)c->retry.p + (1 - c->retry_parity);
+    a.retry_list = (int*)c->retry.p + 2;
+    c->retry_parity ^= 1;
     if (krows_pre && N >= 7 && pre_for(c, N)) {
         if (int r = launch_moments(c, corresp, B, N, &a.pre)) return r;
         hipLaunchKernelGGL(krows_pre, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, a);
@@ -254,12 +264,9 @@ int launch_pose_rows(tff_ctx* c, KRows krows, KExact kexact, lds_fn exact_lds, i
     }
     const size_t lds = exact_lds(N, a.flags, true);
     if (int r = ensure_lds(kexact, lds)) return r;
-    // the fix-up: k_collect_retry compacts the flagged triplets (almost always none; ~0.3 % of a million seven-point samples of an outlier-ridden
-    // scene, config 4), then one resident round of wavefronts walks the list -- one triplet per wavefront and round, where until round 5 every
-    // block scanned a fixed share of the status array and redid what it found there one after the other (5 of 27 ms in config 4)
-    hipLaunchKernelGGL(tff::k_collect_retry, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, c->stream, status, (long)B, (int*)c->retry.p + 1, (int*)c->retry.p);
-    TFF_HIP(hipGetLastError());
-    a.retry_list = (const int*)c->retry.p + 1;
+    // the fix-up: one resident round of wavefronts walks the list the row kernel has filled (almost always empty; ~0.3 % of a million seven-point
+    // samples of an outlier-ridden scene, config 4) -- one triplet per wavefront and round, where until round 5 every block scanned a fixed share
+    // of the status array and redid what it found there one after the other (5 of 27 ms in config 4)
     const long fix = 2 * FIXUP_GRID;
     hipLaunchKernelGGL(kexact, dim3((unsigned)(B < fix ? B : fix)), dim3(64), lds, c->stream, a);
     TFF_HIP(hipGetLastError());

@@ -447,9 +447,9 @@ __global__ void __launch_bounds__(64, (METHOD == 1 && !JAC) ? 3 : 2) k_f_pose(co
     double* oxi = a.spill ? a.spill + blockIdx.x * a.spill_stride : extra + ((OPTIMF_FIXED_DOUBLES + 1) & ~1);   // METHOD 1: xi (4N); large N: global
     double* lds_pts = (METHOD == 1) ? oxi + 4 * a.N + 2 : extra;             // staged correspondences (METHOD 0, or sampled)
     const int lane = lane_id();
-    const long nwork = a.retry_list ? (long)*a.retry_count : a.B;            // (fix-up of a row kernel: the compact list of k_collect_retry)
+    const long nwork = (a.retry_list && (a.flags & FLAG_ONLY_RETRY)) ? (long)*a.retry_count : a.B;            // (fix-up of a row kernel: the compact list of k_collect_retry)
     for (long wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-        const long b = a.retry_list ? (long)a.retry_list[wi] : wi;
+        const long b = (a.retry_list && (a.flags & FLAG_ONLY_RETRY)) ? (long)a.retry_list[wi] : wi;
         if ((a.flags & FLAG_ONLY_RETRY) && a.status[b] != ST_RETRY) continue;      // wave-uniform
         const int N = opaque_int(a.N);                                       // (not hoisted out of the one-trip triplet loop: tft_kernel.h)
         double* dbg = a.dbg ? a.dbg + b * DBG_STRIDE : nullptr;

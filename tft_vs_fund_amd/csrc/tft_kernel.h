@@ -65,10 +65,12 @@ struct LinearTftArgs {
     long spill_stride;       //   fit the 160 KB of LDS (large N): gridDim.x blocks of spill_stride doubles
     int sample_ns;           // with sample_idx: number of correspondences in the shared scene (indices outside [0, sample_ns) -> ST_TOO_FEW)
     const double* pre;       // null, or B x PRE_DOUBLES: moment sums and normalisations from k_tft_moments (tft_moments_kernel.h; the row kernels' <true> variants)
-    // The exact kernels as the fix-up of a row kernel: the triplets to redo as a compact list (k_collect_retry, blocks_kernel.h) instead of a scan of
-    // the status array -- retry_list[0 .. *retry_count).  The row kernels only zero *retry_count (they run first on the stream).
-    const int* retry_list;
+    // The exact kernels as the fix-up of a row kernel: the triplets to redo arrive as a compact list instead of a scan of the status array --
+    // retry_list[0 .. *retry_count).  The ROW kernels append to it themselves (one atomic per flagged triplet, rows_publish_status) and zero
+    // *retry_zero, the counter of the context's NEXT call (two counters alternate: the one in use was zeroed during the previous call).
+    int* retry_list;
     int* retry_count;
+    int* retry_zero;
 };
 
 // Inverse-iteration cap before a triplet is handed to the Jacobi fix-up pass: 300 iterations (~0.13 M
@@ -455,9 +457,9 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose(const LinearTftArgs a
     JacobiLds* jw = JAC ? reinterpret_cast<JacobiLds*>(smem + base) : nullptr;
     double* lds_pts = smem + base + (JAC ? ((JACOBI_LDS_DOUBLES + 1) & ~1) : 0);
     const int lane = lane_id();
-    const long nwork = a.retry_list ? (long)*a.retry_count : a.B;
+    const long nwork = (a.retry_list && (a.flags & FLAG_ONLY_RETRY)) ? (long)*a.retry_count : a.B;
     for (long wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-        const long b = a.retry_list ? (long)a.retry_list[wi] : wi;
+        const long b = (a.retry_list && (a.flags & FLAG_ONLY_RETRY)) ? (long)a.retry_list[wi] : wi;
         // (opaque: the loop makes one trip per workgroup; what the optimiser derives from N and the flags ahead of it -- N * 6, N < 7,
         // flag tests as scalar masks, ... -- would be computed in the pre-header and spilled across the whole body, see wave.h::lane_id)
         const int N = opaque_int(a.N), flags = opaque_int(a.flags);

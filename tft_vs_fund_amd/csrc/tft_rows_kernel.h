@@ -977,7 +977,7 @@ __device__ __forceinline__ int rows_pose_tail(const LinearTftArgs& a, RowLds* w,
 template <bool PRE>
 __global__ void __launch_bounds__(64, 2) k_linear_tft_pose_rows(const LinearTftArgs a) {
     TFF_DYNAMIC_LDS(double, smem);
-    if (a.retry_count && blockIdx.x == 0 && threadIdx.x == 0) *a.retry_count = 0;   // (the list the exact kernel will walk: k_collect_retry fills it after this kernel)
+    if (a.retry_zero && blockIdx.x == 0 && threadIdx.x == 0) *a.retry_zero = 0;   // (the counter of the context's next call; this call's was zeroed during the previous one)
     const int p = lane_id() & 15, row = lane_id() >> 4;
     RowLds* w = reinterpret_cast<RowLds*>(smem) + row;
     RowRt* rt = reinterpret_cast<RowRt*>(w->ov);
@@ -1015,6 +1015,7 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose_rows(const LinearTftA
         if (p == 0 && j.valid) {
             if (a.iter) a.iter[j.b] = 0;                                     // :62
             a.status[j.b] = status;
+            if (status == ST_RETRY && a.retry_list) a.retry_list[atomicAdd(a.retry_count, 1)] = (int)j.b;   // the list the exact kernel walks
         }
     }
 }
