@@ -27,6 +27,7 @@ typedef double* lds_ptr;
 inline lds_ptr to_lds(double* p) { return p; }
 inline double fast_rcp(double v) { return 1.0 / v; }
 inline double rsqrt_pos(double v) { return rsqrt(v); }
+inline double sqrt_nonneg(double v) { return std::sqrt(v); }
 inline int opaque_int(int v) { return v; }
 inline int opaque_lane_int(int v) { return v; }
 inline int hw_simd_id() { return (int)((threadIdx.x >> 6) & 3u); }

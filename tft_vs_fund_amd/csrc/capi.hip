@@ -246,7 +246,6 @@ int launch_pose_rows(tff_ctx* c, KRows krows, KExact kexact, lds_fn exact_lds, i
     a.retry_count = (int*)c->retry.p + c->retry_parity;
     a.retry_zero = (int*)c->retry.p + (1 - c->retry_parity);
     a.retry_list = (int*)c->retry.p + 2;
-    c->retry_parity ^= 1;
     if (krows_pre && N >= 7 && pre_for(c, N)) {
         if (int r = launch_moments(c, corresp, B, N, &a.pre)) return r;
         hipLaunchKernelGGL(krows_pre, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, a);
@@ -255,6 +254,7 @@ int launch_pose_rows(tff_ctx* c, KRows krows, KExact kexact, lds_fn exact_lds, i
         hipLaunchKernelGGL(krows, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, a);
     }
     TFF_HIP(hipGetLastError());
+    c->retry_parity ^= 1;                  // (only now: the row kernel that zeroes the next call's counter is on the stream)
     a.flags |= tff::FLAG_ONLY_RETRY;
     if (c->sample_idx) a.flags |= tff::FLAG_STAGE_LDS;   // the exact kernel gathers samples into LDS
     else a.flags = staged_flags(c, N, a.flags, true, stage_max_n);

@@ -38,7 +38,7 @@ __device__ __forceinline__ void rows_distances_moments_f(const RowSrc& s, const 
         const double m1[6] = {x1 * x1, x1 * y1, x1, y1 * y1, y1, 1.0};
         const double m2[6] = {x2 * x2, x2 * y2, x2, y2 * y2, y2, 1.0};
         const double m3[6] = {x3 * x3, x3 * y3, x3, y3 * y3, y3, 1.0};
-        d[0] += sqrt(m1[0] + m1[3]); d[1] += sqrt(m2[0] + m2[3]); d[2] += sqrt(m3[0] + m3[3]);
+        d[0] += sqrt_nonneg(m1[0] + m1[3]); d[1] += sqrt_nonneg(m2[0] + m2[3]); d[2] += sqrt_nonneg(m3[0] + m3[3]);
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll

@@ -129,7 +129,7 @@ __device__ __forceinline__ void rows_distances_moments(const RowSrc& s, const in
         const double x2 = q.v[2] - c[2], y2 = q.v[3] - c[3];
         const double x3 = q.v[4] - c[4], y3 = q.v[5] - c[5];
         const double r1 = x1 * x1 + y1 * y1, r2 = x2 * x2 + y2 * y2, r3 = x3 * x3 + y3 * y3;
-        dA += sqrt(odd ? r3 : r1);                                           // Normalize2Ddata.m:35
+        dA += sqrt_nonneg(odd ? r3 : r1);                                    // Normalize2Ddata.m:35
         r2_out = r2;
         const double q2[4] = {1.0, x2, y2, r2};
         const double q3[4] = {1.0, x3, y3, r3};
@@ -158,7 +158,7 @@ __device__ __forceinline__ void rows_distances_moments(const RowSrc& s, const in
             if (i + 3 * STEP < N) po = rows_load(s, i + 3 * STEP);
             body(r, r2b);
         }
-        dB += sqrt(odd ? r2b : r2a);
+        dB += sqrt_nonneg(odd ? r2b : r2a);
     }
     // mean distances -> scales and offsets (every lane of the row)
     const double d1 = row_sum16(odd ? 0.0 : dA), d3 = row_sum16(odd ? dA : 0.0), d2 = row_sum16(dB);

@@ -51,6 +51,13 @@ __device__ __forceinline__ double rsqrt_pos(double x) {
     const double e = fma(y0 * -x, y0, 1.0);
     return fma(y0 * e, fma(e, 0.375, 0.5), y0);
 }
+// sqrt(x) for x >= 0 as x * rsqrt_pos(x): 9 VALU instructions where sqrt() takes 20 (its exponent scaling for subnormal / huge arguments and the
+// class test at the end), within 2 ulp of the correctly rounded root; 0 -> 0, NaN -> NaN, +inf -> NaN.  For SUMS of hundreds of distances
+// (Normalize2Ddata.m:35 in the row kernels: three roots per two correspondences), where the ulp disappears in the sum's own rounding.
+__device__ __forceinline__ double sqrt_nonneg(double x) {
+    const double s = x * rsqrt_pos(x);
+    return (x == 0.0) ? 0.0 : s;
+}
 // approximate reciprocal (v_rcp_f64: ~1e-7 relative), for sign / margin tests only
 __device__ __forceinline__ double fast_rcp(double v) { return __builtin_amdgcn_rcp(v); }
 // a wave-uniform integer the optimiser cannot see through (keeps a loop with a small constant trip count rolled)
