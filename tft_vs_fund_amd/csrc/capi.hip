@@ -245,7 +245,7 @@ int launch_pose_rows(tff_ctx* c, KRows krows, KExact kexact, lds_fn exact_lds, i
     }
     a.retry_count = (int*)c->retry.p + c->retry_parity;
     a.retry_zero = (int*)c->retry.p + (1 - c->retry_parity);
-    a.retry_list = (int*)c->retry.p + 2;
+    a.retry_list = (B < (1L << tff::RETRY_HINT_SHIFT)) ? (int*)c->retry.p + 2 : nullptr;   // (an entry is index | hints << 28; beyond, the exact kernel scans the status array as before)
     if (krows_pre && N >= 7 && pre_for(c, N)) {
         if (int r = launch_moments(c, corresp, B, N, &a.pre)) return r;
         hipLaunchKernelGGL(krows_pre, dim3(tff::rows_grid(B)), dim3(64), tff::rows_lds_bytes(), c->stream, a);

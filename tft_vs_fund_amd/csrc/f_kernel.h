@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(64, (METHOD == 1 && !JAC) ? 3 : 2) k_f_pose(co
     const int lane = lane_id();
     const long nwork = (a.retry_list && (a.flags & FLAG_ONLY_RETRY)) ? (long)*a.retry_count : a.B;            // (fix-up of a row kernel: the compact list of k_collect_retry)
     for (long wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-        const long b = (a.retry_list && (a.flags & FLAG_ONLY_RETRY)) ? (long)a.retry_list[wi] : wi;
+        const long b = (a.retry_list && (a.flags & FLAG_ONLY_RETRY)) ? (long)(a.retry_list[wi] & RETRY_INDEX_MASK) : wi;
         if ((a.flags & FLAG_ONLY_RETRY) && a.status[b] != ST_RETRY) continue;      // wave-uniform
         const int N = opaque_int(a.N);                                       // (not hoisted out of the one-trip triplet loop: tft_kernel.h)
         double* dbg = a.dbg ? a.dbg + b * DBG_STRIDE : nullptr;

@@ -77,6 +77,10 @@ struct LinearTftArgs {
 // instructions) are still ~10x cheaper than the LDS Jacobi, and cover spectral-gap ratios up to ~0.9
 // (minimal 7-point samples, samples with outliers); typical well-posed triplets use 4.
 constexpr int EIG_MAXIT = 300;
+// entries of the retry list a row kernel hands to the exact kernel: index | hints << 28 (bit 0: the 27-column inverse iteration hit its cap,
+// bit 1: the 15-column one did); batches of 2^28 triplets and more go without the list (capi.hip)
+constexpr int RETRY_HINT_SHIFT = 28;
+constexpr int RETRY_INDEX_MASK = (1 << RETRY_HINT_SHIFT) - 1;
 
 // c-vector of a pair of 3-vectors (see header): bilinear weights of the q-monomials
 __device__ __forceinline__ void cvec(const double* a, const double* b, double (&c)[4]) {
@@ -218,7 +222,7 @@ __device__ inline void tft_system_qr(const double* pts, const int N, const doubl
 // |G| / (lambda_(n-1) - lambda_n) beyond which the Gram eigenvector is not trusted: 1e7 (error ~ 1e-16 x this), the default limit of
 // wave_min_eigvec_reg's gram_risk flag
 template <bool JAC, int G>
-__device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double* pts, int N, bool want_P, double* dbg) {
+__device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double* pts, int N, bool want_P, double* dbg, const int hint = 0) {
     static_assert(!JAC || G == 64, "the exact solver works on whole wavefronts");
     using Grp = Group<G>;
     const int lane = Grp::lane();
@@ -232,7 +236,9 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double
             phase_stamp(dbg, 3, wl);
             double g[27];
             wave_qr_rows_from_lds<27>(jw->A, g);
-            x = wave_qr_min_rsv<27>(g, jw->A, w->Lp, w->Lp, EIG_MAXIT, &it1);
+            // (hint bit 0: the row kernel that handed this triplet on has run THIS inverse iteration into its cap already -- tft_rows_exact_kernel.h:
+            // same matrix, same rate -- so the one-sided Jacobi takes over after a single step instead of 300)
+            x = wave_qr_min_rsv<27>(g, jw->A, w->Lp, w->Lp, (hint & 1) ? 0 : EIG_MAXIT, &it1);
             if (it1 >= 1000) {                                               // the fall-back rotated R away: factor again (rare)
                 if (lane < 27) w->t[lane] = x;
                 wave_sync();
@@ -304,7 +310,7 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double
         phase_stamp(dbg, 6, wl);
         double h[15];
         wave_qr_rows_from_lds<15>(R2, h);
-        const double x = wave_qr_min_rsv<15>(h, jw->A, jw->A + 256, w->Lp, EIG_MAXIT, &it2);
+        const double x = wave_qr_min_rsv<15>(h, jw->A, jw->A + 256, w->Lp, (hint & 2) ? 0 : EIG_MAXIT, &it2);
         it2 += 10000;
         if (lane < 15) w->tp[lane] = x;
         wave_sync();
@@ -392,10 +398,10 @@ __device__ inline bool linear_tft_middle(PoseLds* w, JacobiLds* jw, const double
 
 // linearTFT.m:33-91 on the normalised correspondences (data pass + the rest), whole wavefront.
 template <bool JAC>
-__device__ __forceinline__ bool linear_tft_wave(PoseLds* w, JacobiLds* jw, const double* pts, int N, bool want_P, double* dbg) {
+__device__ __forceinline__ bool linear_tft_wave(PoseLds* w, JacobiLds* jw, const double* pts, int N, bool want_P, double* dbg, const int hint = 0) {
     if (!JAC) accumulate_moments(w, pts, N);
     phase_stamp(dbg, 2);
-    return linear_tft_middle<JAC, 64>(w, jw, pts, N, want_P, dbg);
+    return linear_tft_middle<JAC, 64>(w, jw, pts, N, want_P, dbg, hint);
 }
 
 // R_t_from_TFT.m:44-58 and the decomposition of E21, E31 (:85-88): the lane-sparse part of
@@ -459,7 +465,10 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose(const LinearTftArgs a
     const int lane = lane_id();
     const long nwork = (a.retry_list && (a.flags & FLAG_ONLY_RETRY)) ? (long)*a.retry_count : a.B;
     for (long wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-        const long b = (a.retry_list && (a.flags & FLAG_ONLY_RETRY)) ? (long)a.retry_list[wi] : wi;
+        // a list entry: triplet index in bits 0 .. 27, what the row kernel knows about its failure in bits 28 .. 29 (RETRY_HINT_*)
+        const int entry = (a.retry_list && (a.flags & FLAG_ONLY_RETRY)) ? a.retry_list[wi] : 0;
+        const long b = (a.retry_list && (a.flags & FLAG_ONLY_RETRY)) ? (long)(entry & RETRY_INDEX_MASK) : wi;
+        const int hint = JAC ? (int)((unsigned)entry >> RETRY_HINT_SHIFT) : 0;
         // (opaque: the loop makes one trip per workgroup; what the optimiser derives from N and the flags ahead of it -- N * 6, N < 7,
         // flag tests as scalar masks, ... -- would be computed in the pre-header and spilled across the whole body, see wave.h::lane_id)
         const int N = opaque_int(a.N), flags = opaque_int(a.flags);
@@ -489,7 +498,7 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose(const LinearTftArgs a
             normalise3(pts, N, w->nrm);                                      // LinearTFTPoseEstimation.m:45-47
             if (dbg && lane < 9) dbg[71 + lane] = w->nrm[lane];
             phase_stamp(dbg, 1);
-            bool ok = linear_tft_wave<JAC>(w, jw, pts, N, false, dbg);       // :50
+            bool ok = linear_tft_wave<JAC>(w, jw, pts, N, false, dbg, hint);  // :50
             phase_stamp(dbg, 8);
             if (ok) {
                 transform_tft_inverse(w->t, w->T1, w->Lp, [w](int v) { return normal_matrix(w->nrm, v); });   // :53

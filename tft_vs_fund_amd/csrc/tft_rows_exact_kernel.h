@@ -75,7 +75,8 @@ __device__ __forceinline__ void rows_tft_system_qr(const RowSrc& s, const int N,
 // linearTFT.m:64-91 at the accuracy of the reference's svd() calls (tft_kernel.h::linear_tft_middle<true, 64>), one triplet per row.
 // Rp: the row's packed R workspace (w->ov), xch / dinv: 28 + 27 doubles of the row's LDS (w->mom).  Returns false (per row) when one of the
 // two inverse iterations hit its cap.
-__device__ __forceinline__ bool rows_linear_tft_middle_exact(RowLds* w, const RowSrc& s, const int N, double* dbg) {
+// *capped (per row): bit 0 / bit 1 set when the 27- / 15-column inverse iteration hit its cap (the hints of the retry list, tft_kernel.h).
+__device__ __forceinline__ bool rows_linear_tft_middle_exact(RowLds* w, const RowSrc& s, const int N, double* dbg, int* capped) {
     const int p = opaque_lane_int(rows_p());
     double* Rp = w->ov;
     double* xch = w->mom;
@@ -87,6 +88,7 @@ __device__ __forceinline__ bool rows_linear_tft_middle_exact(RowLds* w, const Ro
         double x0, x1, r2;
         rows_invit_from_R<27>(Rp, dinv, EIG_MAXIT, &it1, &r2, x0, x1);
         ok = ok && eig_converged(r2);
+        *capped = eig_converged(r2) ? 0 : 1;
         wave_sync();
         w->t[p] = x0;
         if (p < 11) w->t[16 + p] = x1;
@@ -132,6 +134,7 @@ __device__ __forceinline__ bool rows_linear_tft_middle_exact(RowLds* w, const Ro
         double x0, x1, r2;
         rows_invit_from_R<15>(Rp, dinv, EIG_MAXIT, &it2, &r2, x0, x1);
         ok = ok && eig_converged(r2);
+        *capped |= eig_converged(r2) ? 0 : 2;
         if (have) w->tp[p] = x0;
         wave_sync();
     }
@@ -172,7 +175,7 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose_rows_exact(const Line
         const int N = opaque_int(a.N);
         const RowJob j = rows_begin(a, w, blk, N);
         double* dbg = j.dbg;
-        int status;
+        int status, hint = 0;
         if (N < 7) {                                                         // experiments.m:99 (wave-uniform: N is the batch's)
             status = ST_TOO_FEW;
             rows_store_nan(a, j, N);
@@ -183,7 +186,9 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose_rows_exact(const Line
                 rows_distances(j.src, N, cen, w->nrm);
                 if (dbg && p < 9) dbg[71 + p] = w->nrm[p];
             }
-            bool ok = rows_linear_tft_middle_exact(w, j.src, N, dbg);        // :50
+            int capped = 0;
+            bool ok = rows_linear_tft_middle_exact(w, j.src, N, dbg, &capped);   // :50
+            hint = capped;
             rows_transform_tft_inverse(w->t, rt->T1, rt->mats, [w](int v) { return normal_matrix(w->nrm, v); });   // :53
             ok = rows_rt_prepare<true>(w, rt, dbg) && ok;                    // :56
             status = rows_pose_tail<false, true>(a, w, rt, j, N, ok);
@@ -191,7 +196,7 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose_rows_exact(const Line
         if (p == 0 && j.valid) {
             if (a.iter) a.iter[j.b] = 0;                                     // :62
             a.status[j.b] = status;
-            if (status == ST_RETRY && a.retry_list) a.retry_list[atomicAdd(a.retry_count, 1)] = (int)j.b;   // the list the exact kernel walks
+            if (status == ST_RETRY && a.retry_list) a.retry_list[atomicAdd(a.retry_count, 1)] = (int)j.b | (hint << RETRY_HINT_SHIFT);   // the list the exact kernel walks, with what is known about the failure
         }
     }
 }
