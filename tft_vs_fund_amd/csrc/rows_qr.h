@@ -128,6 +128,13 @@ __device__ __forceinline__ void rows_invit_from_R(const double* Rp, double* dinv
     double rprev2 = 1.0, res = 1.0;
     int it = 0;
     bool done = false;
+    // Extrapolation of the slow mode (round 5).  Minimal samples of outlier-ridden scenes often have TWO small singular values close together
+    // (sigma_n / sigma_(n-1) ~ 0.9 .. 0.99): the iteration then crawls along one direction, step_(k+1) ~ q step_k with q = (sigma_n / sigma_(n-1))^2
+    // -- 100 to 250 iterations, and the three other rows of the wavefront wait.  Once consecutive steps are aligned (cos^2 >= 0.97) and shrink
+    // slowly (q > 0.5), the geometric tail is summed in one go: x += step q / (1 - q), q = <step_(k+1), step_k> / |step_k|^2.  The iterate is still
+    // only ever ACCEPTED by the tests below (it stopped moving under the plain iteration), so what converges is the same fixed point.
+    double pd0 = 0.0, pd1 = 0.0;                            // the previous step
+    int since = 0;                                          // iterations since the start / the last extrapolation
 #pragma unroll 1
     while (true) {
         double y0 = x0 * myinv0, y1 = x1 * myinv1;
@@ -141,13 +148,30 @@ __device__ __forceinline__ void rows_invit_from_R(const double* Rp, double* dinv
         const double yn0 = y0 * sc, yn1 = y1 * sc;
         const double dd0 = yn0 - x0, dd1 = yn1 - x1;
         const double r2 = row_sum16(dd0 * dd0 + dd1 * dd1);
-        if (!done) {                                        // the same tests as wave_invit_unit
+        const double cross = row_sum16(dd0 * pd0 + dd1 * pd1);
+        const bool live = !done;                            // (a row that has stopped keeps its iterate and its counters)
+        bool jumped = false;
+        double q = 0.0;
+        if (live) {                                         // the same tests as wave_invit_unit
             x0 = yn0; x1 = yn1;
-            ++it;
+            ++it; ++since;
             if (r2 <= 1e-26) { res = 0.0; done = true; }
             else if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) { res = 0.0; done = true; }
             else if (!(r2 == r2) || it >= maxit) { res = (r2 == r2) ? r2 : 1.0; done = true; }
-            rprev2 = r2;
+            jumped = !done && since >= 3 && r2 > 1e-24 && r2 > 0.25 * rprev2 && cross > 0.0 && cross * cross >= 0.97 * r2 * rprev2;
+            q = jumped ? cross / rprev2 : 0.0;
+            jumped = jumped && q > 0.5 && q < 0.9995;
+        }
+        if (wave_any(jumped)) {                             // (outside every per-row branch: the ballot and the row reduction are the whole wavefront's)
+            const double f = jumped ? q / (1.0 - q) : 0.0;
+            const double e0 = x0 + f * dd0, e1 = x1 + f * dd1;
+            const double nr = rsqrt(row_sum16(e0 * e0 + e1 * e1));
+            x0 = jumped ? e0 * nr : x0; x1 = jumped ? e1 * nr : x1;
+        }
+        if (live) {
+            pd0 = jumped ? 0.0 : dd0; pd1 = jumped ? 0.0 : dd1;
+            since = jumped ? 0 : since;
+            rprev2 = jumped ? 0.0 : r2;                     // (0: the step after a jump says nothing about the rate -- the predictive test sits out one iteration)
         }
         if (!wave_any(!done)) break;                        // the four rows iterate on four different systems
     }

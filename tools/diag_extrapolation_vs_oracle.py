@@ -1,0 +1,58 @@
+"""Seven-point samples of the config-4 scene on which two library builds disagree: which one is the oracle's (svd) answer?
+python tools/diag_extrapolation_vs_oracle.py [H] libA.so libB.so"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from tft_vs_fund_amd.scenes import generate_scene_batch
+from oracle import tft_oracle as O
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import pose_err_any_convention
+
+H = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+libs = sys.argv[2:4]
+Ns = 400
+dev = torch.device("cuda", 0)
+C, CalM, _, _ = generate_scene_batch(1, Ns, noise=0.5, seed=7)
+scene = C[0].copy()
+rng = np.random.default_rng(1)
+bad = rng.choice(Ns, Ns // 4, replace=False)
+scene[bad, 2:6] += rng.uniform(20, 80, size=(bad.size, 4))
+d_scene = torch.from_numpy(scene).to(dev); calm = torch.from_numpy(np.ascontiguousarray(CalM.T).reshape(27)).to(dev)
+stream = torch.cuda.current_stream(dev)
+p = lambda t: ctypes.c_void_p(t.data_ptr())
+g = torch.Generator(device=dev); g.manual_seed(1234)
+idx = torch.rand((H, Ns), device=dev, generator=g).argsort(dim=1)[:, :7].to(torch.int32).contiguous()
+res = []
+for path in libs:
+    lib = ctypes.CDLL(path)
+    lib.tff_ctx_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+    lib.tff_ctx_set_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    h = ctypes.c_void_p(); assert lib.tff_ctx_create(ctypes.byref(h), 0) == 0
+    lib.tff_ctx_set_stream(h, ctypes.c_void_p(stream.cuda_stream))
+    Rt2 = torch.empty((H, 12), dtype=torch.float64, device=dev); Rt3 = torch.empty_like(Rt2); T = torch.empty((H, 27), dtype=torch.float64, device=dev)
+    st = torch.zeros(H, dtype=torch.int32, device=dev)
+    assert lib.tff_linear_tft_pose_sampled_dev(h, p(d_scene), ctypes.c_int(Ns), p(calm), p(idx), ctypes.c_long(H), ctypes.c_int(7), p(Rt2), p(Rt3), p(T), p(st)) == 0
+    torch.cuda.synchronize()
+    res.append((Rt2.cpu().numpy().reshape(H, 4, 3).transpose(0, 2, 1), Rt3.cpu().numpy().reshape(H, 4, 3).transpose(0, 2, 1), st.cpu().numpy(),
+                T.cpu().numpy().reshape(H, 3, 3, 3).transpose(0, 3, 2, 1)))
+d = np.abs(res[0][1] - res[1][1]).reshape(H, -1).max(axis=1)
+differ = np.nonzero(d > 1e-6)[0]
+print("%d of %d hypotheses differ by more than 1e-6 in R_t_3 (max %.2g); status nonzero: %d / %d" % (differ.size, H, d.max(), (res[0][2] != 0).sum(), (res[1][2] != 0).sum()))
+idx_h = idx.cpu().numpy()
+wins = [0, 0, 0]
+for b in differ[:60]:
+    Cs = scene[idx_h[b]]
+    # (a cheirality-vote tie between the two rotations has no unique reference answer: the best of the sign conventions svd(E) leaves open)
+    e = []
+    for r in res:
+        out_b = {"R_t_2": r[0][b], "R_t_3": r[1][b], "T": r[3][b]}
+        try:
+            e0, eb = pose_err_any_convention(out_b, O.LinearTFTPoseEstimation, Cs.T.copy(), CalM)
+        except Exception as ex:
+            e0, eb = float("nan"), float("nan")
+        e.append((e0, eb))
+    wins[0 if e[0][1] < e[1][1] else 1] += 1
+    if e[0][1] > 1e-6 and e[1][1] > 1e-6: wins[2] += 1
+    print("hypothesis %7d: first build vs oracle %.2e (best convention %.2e)   second build %.2e (best convention %.2e)" % (b, e[0][0], e[0][1], e[1][0], e[1][1]))
+print("closer to the oracle under its best convention: first build %d, second build %d (both farther than 1e-6: %d)" % tuple(wins))
