@@ -131,7 +131,8 @@ __device__ __forceinline__ void rows_invit_from_R(const double* Rp, double* dinv
     // Extrapolation of the slow mode (round 5).  Minimal samples of outlier-ridden scenes often have TWO small singular values close together
     // (sigma_n / sigma_(n-1) ~ 0.9 .. 0.99): the iteration then crawls along one direction, step_(k+1) ~ q step_k with q = (sigma_n / sigma_(n-1))^2
     // -- 100 to 250 iterations, and the three other rows of the wavefront wait.  Once consecutive steps are aligned (cos^2 >= 0.97) and shrink
-    // slowly (q > 0.5), the geometric tail is summed in one go: x += step q / (1 - q), q = <step_(k+1), step_k> / |step_k|^2.  The iterate is still
+    // slowly (q > 0.15; measured on config 4: q > 0.5 gives 22.8 ms per million samples, q > 0.15 21.4, q > 0.08 with cos^2 >= 0.95 21.3 and the first
+    // hand-overs), the geometric tail is summed in one go: x += step q / (1 - q), q = <step_(k+1), step_k> / |step_k|^2.  The iterate is still
     // only ever ACCEPTED by the tests below (it stopped moving under the plain iteration), so what converges is the same fixed point.
     double pd0 = 0.0, pd1 = 0.0;                            // the previous step
     int since = 0;                                          // iterations since the start / the last extrapolation
@@ -158,9 +159,9 @@ __device__ __forceinline__ void rows_invit_from_R(const double* Rp, double* dinv
             if (r2 <= 1e-26) { res = 0.0; done = true; }
             else if (it >= 2 && r2 < 0.25 * rprev2 && r2 * r2 < 1e-26 * rprev2) { res = 0.0; done = true; }
             else if (!(r2 == r2) || it >= maxit) { res = (r2 == r2) ? r2 : 1.0; done = true; }
-            jumped = !done && since >= 3 && r2 > 1e-24 && r2 > 0.25 * rprev2 && cross > 0.0 && cross * cross >= 0.97 * r2 * rprev2;
+            jumped = !done && since >= 2 && r2 > 1e-24 && r2 > 0.0225 * rprev2 && cross > 0.0 && cross * cross >= 0.97 * r2 * rprev2;
             q = jumped ? cross / rprev2 : 0.0;
-            jumped = jumped && q > 0.5 && q < 0.9995;
+            jumped = jumped && q > 0.15 && q < 0.9995;
         }
         if (wave_any(jumped)) {                             // (outside every per-row branch: the ballot and the row reduction are the whole wavefront's)
             const double f = jumped ? q / (1.0 - q) : 0.0;
