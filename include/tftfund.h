@@ -264,6 +264,23 @@ int tff_bundle_adjust_batch_host(tff_ctx* ctx, const double* calm, int64_t calm_
                                  const double* Rt3_in, const double* corresp, int64_t B, int32_t N, const double* reconst0,
                                  double* Rt2, double* Rt3, double* reconst, int32_t* iter, double* repr_err, int32_t* status);
 
+/* BundleAdjustment (Optimization/BundleAdjustment.m:49-216) as the reference writes it, for M = 2 .. 6 views, in MATLAB's own
+ * array layouts so that a gateway passes its arguments through: calm = CalM (3M x 3, column-major; calm_stride 0 = shared, 9M =
+ * one per item), Rt_in = R_t_0 (3M x 4 column-major per item, camera 1 included and NOT required to be [I|0]: the change of
+ * coordinates of :80-86 is done on the device, after the optional initial triangulation of :59-77 in the given frame),
+ * corresp = Corresp (2M x N column-major per item), reconst0 = Reconst0 (3 x N per item) or NULL.  Outputs: Rt = R_t (3M x 4
+ * column-major per item, R_t(1:3,:) = eye(3,4), |t2| = 1), reconst (3 x N per item, or NULL), iter, repr_err, status.
+ * Missing observations (:28-29, :165): a NaN entry is handled as the reference's code handles it -- Normalize2Ddata.m:34-37 turns
+ * every point of that VIEW into NaN, :165 then skips the whole view: its camera keeps the initial angles and translation, the
+ * other views are adjusted.  Without reconst0, fewer than two complete views: status TFF_ST_TOO_FEW and NaN outputs (the
+ * reference stops with an error at :73-74).  Same Levenberg-Marquardt loop as tff_bundle_adjust_batch_dev. */
+int tff_bundle_adjust_views_batch_dev(tff_ctx* ctx, int32_t M, const double* calm, int64_t calm_stride, const double* Rt_in,
+                                      const double* corresp, int64_t B, int32_t N, const double* reconst0, double* Rt,
+                                      double* reconst, int32_t* iter, double* repr_err, int32_t* status);
+int tff_bundle_adjust_views_batch_host(tff_ctx* ctx, int32_t M, const double* calm, int64_t calm_stride, const double* Rt_in,
+                                       const double* corresp, int64_t B, int32_t N, const double* reconst0, double* Rt,
+                                       double* reconst, int32_t* iter, double* repr_err, int32_t* status);
+
 /* Minimal-sample hypotheses (BASELINE.json config 4): hypothesis b = the n correspondences
  * sample_idx[b*n .. b*n+n) of one shared scene (6 x Ns); n >= 7 (TFT) / 8 (F); shared CalM (27). */
 int tff_linear_tft_pose_sampled_dev(tff_ctx* ctx, const double* scene, int32_t Ns, const double* calm,

@@ -41,37 +41,32 @@ static void cleanup(void) {
 typedef int (*pose_host_fn)(tff_ctx*, const double*, const double*, int64_t, int64_t, int32_t, double*, double*, double*,
                             double*, int32_t*, int32_t*);
 
-/* [R_t, Reconst, iter, repr_err] = tftfund_mex('bundle_adjustment', Corresp (6xN), CalM (9x3), R_t_0 (9x4) [, Reconst0 (3xN)]) */
+/* [R_t, Reconst, iter, repr_err] = tftfund_mex('bundle_adjustment', Corresp (2M x N), CalM (3M x 3), R_t_0 (3M x 4) [, Reconst0 (3 x N)]),
+ * M = 2 .. 6: the arrays go to tff_bundle_adjust_views_batch_host as they are (it takes MATLAB's own layouts). */
 static void bundle_adjustment(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
-    double Rt2_in[12], Rt3_in[12], Rt2[12], Rt3[12], err = 0;
-    const double* R0;
+    double err = 0;
     int32_t it = 0, st = 0;
-    mwSize N, r, c;
+    mwSize N, M;
+    mxArray* rec;
     if (nrhs < 4 || nrhs > 5 || nlhs > 4) mexErrMsgIdAndTxt("tftfund:nargin", "usage: tftfund_mex('bundle_adjustment', Corresp, CalM, R_t_0 [, Reconst0])");
-    if (!mxIsDouble(prhs[1]) || mxGetM(prhs[1]) != 6) mexErrMsgIdAndTxt("tftfund:shape", "Corresp must be 6 x N (three views)");
-    if (!mxIsDouble(prhs[2]) || mxGetM(prhs[2]) != 9 || mxGetN(prhs[2]) != 3) mexErrMsgIdAndTxt("tftfund:shape", "CalM must be 9 x 3");
-    if (!mxIsDouble(prhs[3]) || mxGetM(prhs[3]) != 9 || mxGetN(prhs[3]) != 4) mexErrMsgIdAndTxt("tftfund:shape", "R_t_0 must be 9 x 4");
+    if (!mxIsDouble(prhs[1]) || mxGetM(prhs[1]) % 2 || mxGetM(prhs[1]) < 4 || mxGetM(prhs[1]) > 12) mexErrMsgIdAndTxt("tftfund:shape", "Corresp must be 2M x N, M = 2 .. 6 views");
+    M = mxGetM(prhs[1]) / 2;
     N = mxGetN(prhs[1]);
+    if (!mxIsDouble(prhs[2]) || mxGetM(prhs[2]) != 3 * M || mxGetN(prhs[2]) != 3) mexErrMsgIdAndTxt("tftfund:shape", "CalM must be 3M x 3");
+    if (!mxIsDouble(prhs[3]) || mxGetM(prhs[3]) != 3 * M || mxGetN(prhs[3]) != 4) mexErrMsgIdAndTxt("tftfund:shape", "R_t_0 must be 3M x 4");
     if (nrhs == 5 && (!mxIsDouble(prhs[4]) || mxGetM(prhs[4]) != 3 || mxGetN(prhs[4]) != N)) mexErrMsgIdAndTxt("tftfund:shape", "Reconst0 must be 3 x N");
-    R0 = mxGetPr(prhs[3]);                                         /* 9 x 4 column-major: R_t_0(3j+r, c) = R0[3j + r + 9c] */
-    for (r = 0; r < 3; ++r) for (c = 0; c < 4; ++c) {
-        if (R0[r + 9 * c] != ((r == c) ? 1.0 : 0.0)) mexErrMsgIdAndTxt("tftfund:frame", "R_t_0(1:3,:) must be eye(3,4)");
-        Rt2_in[r + 3 * c] = R0[3 + r + 9 * c]; Rt3_in[r + 3 * c] = R0[6 + r + 9 * c];
-    }
     if (!g_ctx) {
         if (tff_ctx_create(&g_ctx, 0) != 0) mexErrMsgIdAndTxt("tftfund:hip", "tff_ctx_create: %s", tff_last_error());
         mexAtExit(cleanup);
     }
-    plhs[0] = mxCreateDoubleMatrix(9, 4, mxREAL);
-    {
-        mxArray* rec = mxCreateDoubleMatrix(3, N, mxREAL);
-        double* out = mxGetPr(plhs[0]);
-        if (tff_bundle_adjust_batch_host(g_ctx, mxGetPr(prhs[2]), 0, Rt2_in, Rt3_in, mxGetPr(prhs[1]), 1, (int32_t)N,
-                                         nrhs == 5 ? mxGetPr(prhs[4]) : NULL, Rt2, Rt3, mxGetPr(rec), &it, &err, &st) != 0)
-            mexErrMsgIdAndTxt("tftfund:hip", "bundle_adjustment: %s", tff_last_error());
-        for (r = 0; r < 3; ++r) for (c = 0; c < 4; ++c) { out[r + 9 * c] = (r == c) ? 1.0 : 0.0; out[3 + r + 9 * c] = Rt2[r + 3 * c]; out[6 + r + 9 * c] = Rt3[r + 3 * c]; }
-        if (nlhs >= 2) plhs[1] = rec; else mxDestroyArray(rec);
-    }
+    plhs[0] = mxCreateDoubleMatrix(3 * M, 4, mxREAL);
+    rec = mxCreateDoubleMatrix(3, N, mxREAL);
+    if (tff_bundle_adjust_views_batch_host(g_ctx, (int32_t)M, mxGetPr(prhs[2]), 0, mxGetPr(prhs[3]), mxGetPr(prhs[1]), 1, (int32_t)N,
+                                           nrhs == 5 ? mxGetPr(prhs[4]) : NULL, mxGetPr(plhs[0]), mxGetPr(rec), &it, &err, &st) != 0)
+        mexErrMsgIdAndTxt("tftfund:hip", "bundle_adjustment: %s", tff_last_error());
+    if (st == TFF_ST_TOO_FEW)                                    /* the reference stops here too: triangulation3D.m:36-38 returns nothing, BundleAdjustment.m:73-74 */
+        mexErrMsgIdAndTxt("tftfund:views", "fewer than two complete views to triangulate from");
+    if (nlhs >= 2) plhs[1] = rec; else mxDestroyArray(rec);
     if (nlhs >= 3) plhs[2] = mxCreateDoubleScalar((double)it);
     if (nlhs >= 4) plhs[3] = mxCreateDoubleScalar(err);
 }

@@ -4,8 +4,10 @@ TEST INFRASTRUCTURE ONLY -- CPU restatement of Optimization/BundleAdjustment.m (
 PARITY UNPINNED, twice over: the reference cannot run here (MATLAB), and its optimiser is MATLAB's closed-source
 `lsqnonlin(..., 'Algorithm','levenberg-marquardt')` (BundleAdjustment.m:101-103).  What IS restated literally:
 
-  * the pre-processing: per-view Normalize2Ddata folded into the calibration (:52-56), optional initial
-    triangulation (:59-77), change of coordinates to camera 1 (:80-86), the three Euler angles of each rotation
+  * the pre-processing: per-view Normalize2Ddata folded into the calibration (:52-56) -- NOTE what it does to a view with a
+    missing observation: `mean` over the view's points (Normalize2Ddata.m:34-35) is NaN, so EVERY point of that view and its
+    calibration become NaN, and the callback's `isnan` test (:165) then skips the whole view --, optional initial
+    triangulation over the views that see the point (:59-77), change of coordinates to camera 1 (:80-86), the three Euler angles of each rotation
     (:89-96), the variable vector [angles(:,2:M), translations(:,2:M), Reconst] (:100);
   * the residual / Jacobian callback `bundleadjustment_LM` (:128-204): observed minus projected point, analytic
     derivatives through Gamma and the Rx*Ry*Rz parameterisation;
@@ -38,7 +40,7 @@ def _rot_parts(a):
 
 
 def bundleadjustment_LM(variables, Corresp, CalM, want_jacobian=True):
-    """BundleAdjustment.m:128-204 (all points visible in all views; the NaN branch of :165 is not restated)."""
+    """BundleAdjustment.m:128-204, with the `isnan` branch of :165-167 (the rows of a skipped observation stay zero)."""
     N = Corresp.shape[1]
     M = Corresp.shape[0] // 2
     v = variables.reshape(3, N + 2 * (M - 1), order='F')
@@ -57,6 +59,8 @@ def bundleadjustment_LM(variables, Corresp, CalM, want_jacobian=True):
     for i in range(N):
         X = pts[:, i]
         for j in range(M):
+            if np.isnan(Corresp[2 * j, i]):                                              # :165-167
+                continue
             K, P, parts = cams[j]
             ind = 2 * M * i + 2 * j
             vv = P @ np.append(X, 1.0)
@@ -122,8 +126,17 @@ def BundleAdjustment(CalM, R_t_0, Corresp, Reconst0=None, return_debug=False):
         Corresp[2 * j:2 * j + 2] = new_Corr
         CalM[3 * j:3 * j + 3] = Normal @ CalM[3 * j:3 * j + 3]
     if Reconst0 is None:                                                                 # :59-77
-        X = O.triangulation3D([CalM[3 * j:3 * j + 3] @ R_t_0[3 * j:3 * j + 3] for j in range(M)], Corresp)
-        Reconst0 = X[0:3] / X[3:4]
+        if not np.isnan(Corresp).any():
+            X = O.triangulation3D([CalM[3 * j:3 * j + 3] @ R_t_0[3 * j:3 * j + 3] for j in range(M)], Corresp)
+            Reconst0 = X[0:3] / X[3:4]
+        else:                                                                            # per point, the views that see it (:63-72)
+            Reconst0 = np.zeros((3, N))
+            for i in range(N):
+                js = [j for j in range(M) if not np.isnan(Corresp[2 * j, i])]
+                if len(js) < 2:
+                    raise ValueError("triangulation3D.m:36-38 returns nothing for fewer than two cameras: BundleAdjustment.m:73-74 stops with an error")
+                X = O.triangulation3D([CalM[3 * j:3 * j + 3] @ R_t_0[3 * j:3 * j + 3] for j in js], np.concatenate([Corresp[2 * j:2 * j + 2, i:i + 1] for j in js]))
+                Reconst0[:, i] = X[0:3, 0] / X[3, 0]
     cc = R_t_0[0:3].copy()                                                               # :80-86
     R_t_0[0:3] = np.eye(3, 4)
     for j in range(1, M):

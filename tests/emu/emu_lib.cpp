@@ -285,6 +285,20 @@ extern "C" int emu_bundle_adjust(const double* calm, long calm_stride, const dou
     emu::launch(tff::k_bundle_adjust, emu_grid(B), 64, tff::ba_lds_bytes(N), a);
     return 0;
 }
+template <int M> static void emu_bav(const tff::BavArgs& a) { emu::launch(tff::k_bundle_adjust_views<M>, emu_grid(a.B), 64, tff::bav_lds_bytes<M>(a.N), a); }
+extern "C" int emu_bundle_adjust_views(int M, const double* calm, long calm_stride, const double* Rt_in, const double* corresp, long B, int N,
+                                       const double* reconst0, double* Rt, double* reconst, int* iter, double* repr_err, int* status) {
+    const tff::BavArgs a{calm, calm_stride, Rt_in, corresp, B, N, reconst0, Rt, reconst, iter, repr_err, status};
+    switch (M) {
+        case 2: emu_bav<2>(a); break;
+        case 3: emu_bav<3>(a); break;
+        case 4: emu_bav<4>(a); break;
+        case 5: emu_bav<5>(a); break;
+        case 6: emu_bav<6>(a); break;
+        default: return -1;
+    }
+    return 0;
+}
 // building block: linearF / optimF per view pair (tff_linear_f_batch_dev)
 extern "C" int emu_linear_f(const double* corresp, long B, int N, int refine, double* F21, double* F31, int* iter, int* status) {
     tff::LinearFOnlyArgs a{corresp, B, N, 0, F21, F31, iter, status};

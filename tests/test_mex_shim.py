@@ -22,7 +22,7 @@ def test_mex_gateway_compiles_cleanly():
 
 
 def test_mex_gateway_binds_every_host_entry_point_it_names():
-    """the eight `tff_<method>_pose_batch_host` symbols, `tff_pose_batch_host_multi` and `tff_bundle_adjust_batch_host` it calls are declared in
+    """the eight `tff_<method>_pose_batch_host` symbols, `tff_pose_batch_host_multi` and `tff_bundle_adjust_views_batch_host` it calls are declared in
     include/tftfund.h with the argument lists it uses (the compile above) and exported by the library (tests/test_capi_symbols.py)"""
     src = open(MEX).read()
     hdr = open(os.path.join(ROOT, "include", "tftfund.h")).read()

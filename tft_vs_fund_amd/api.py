@@ -100,6 +100,8 @@ def load_library(path=None):
             "tff_linear_f_batch_dev": [V, V, I64, I32, I32, V, V, V, V],
             "tff_bundle_adjust_batch_dev": [V, V, I64, V, V, V, I64, I32, V, V, V, V, V, V, V],
             "tff_bundle_adjust_batch_host": [V, V, I64, V, V, V, I64, I32, V, V, V, V, V, V, V],
+            "tff_bundle_adjust_views_batch_dev": [V, I32, V, I64, V, V, I64, I32, V, V, V, V, V, V],
+            "tff_bundle_adjust_views_batch_host": [V, I32, V, I64, V, V, I64, I32, V, V, V, V, V, V],
             "tff_pi_pose_batch_debug_dev": [V, I32, V, V, I64, I64, I32, V, V, V, V, V, V, V, V],
             "tff_linear_tft_pose_sampled_dev": [V, V, I32, V, V, I64, I32, V, V, V, V],
             "tff_linear_f_pose_sampled_dev": [V, V, I32, V, V, I64, I32, V, V, V, V],
@@ -145,7 +147,7 @@ EXPORTED_SYMBOLS = [
     "tff_pi_pose_batch_dev", "tff_pi_pose_batch_host", "tff_picol_pose_batch_dev", "tff_picol_pose_batch_host",
     "tff_pi_pose_batch_debug_dev",
     "tff_triangulate_batch_dev", "tff_repr_error_batch_dev", "tff_inlier_count_batch_dev", "tff_transform_tft_batch_dev",
-    "tff_rt_from_tft_batch_dev", "tff_linear_tft_batch_dev", "tff_linear_f_batch_dev", "tff_bundle_adjust_batch_dev", "tff_bundle_adjust_batch_host", "tff_linear_tft_pose_sampled_dev", "tff_linear_f_pose_sampled_dev",
+    "tff_rt_from_tft_batch_dev", "tff_linear_tft_batch_dev", "tff_linear_f_batch_dev", "tff_bundle_adjust_batch_dev", "tff_bundle_adjust_batch_host", "tff_bundle_adjust_views_batch_dev", "tff_bundle_adjust_views_batch_host", "tff_linear_tft_pose_sampled_dev", "tff_linear_f_pose_sampled_dev",
     "tff_multi_create", "tff_multi_destroy", "tff_multi_size", "tff_multi_ctx", "tff_multi_shard", "tff_pose_batch_host_multi", "tff_pose_batch_dev_multi",
 ]
 
@@ -453,6 +455,33 @@ class Context:
         return dict(R_t_2=o2.reshape(B, 4, 3).transpose(1, 2), R_t_3=o3.reshape(B, 4, 3).transpose(1, 2), Reconst=rec.transpose(1, 2),
                     iter=it, repr_err=err, status=st)
 
+    def bundle_adjust_views(self, calm, R_t_0, corresp, reconst0=None):
+        """BundleAdjustment for B problems of M = 2 .. 6 views (tff_bundle_adjust_views_batch_dev): calm (3M,3) or (B,3M,3); R_t_0 (B,3M,4),
+        first camera included and free; corresp (B,N,2M), NaN = not seen (drops the whole view, as the reference's code does); reconst0 (B,3,N) or
+        None.  -> dict(R_t (B,3M,4), Reconst (B,3,N), iter, repr_err, status)."""
+        self._begin()
+        corresp = self._t(corresp); B, N, M2 = corresp.shape
+        M = M2 // 2
+        dev = corresp.device
+        calm = self._t(calm)
+        if calm.dim() == 2:
+            calm_cm, stride = calm.t().contiguous().reshape(9 * M), 0
+        else:
+            calm_cm, stride = calm.transpose(1, 2).contiguous().reshape(B * 9 * M), 9 * M
+        rt = self._t(R_t_0)
+        if M2 != 2 * M or tuple(rt.shape) != (B, 3 * M, 4) or calm_cm.numel() != (9 * M if stride == 0 else B * 9 * M):
+            raise ValueError("M views: corresp (B,N,2M), R_t_0 (B,3M,4), calm (3M,3) or (B,3M,3)")
+        rt_cm = rt.transpose(1, 2).contiguous()
+        x0 = self._t(reconst0).transpose(1, 2).contiguous() if reconst0 is not None else None
+        out = torch.empty((B, 4, 3 * M), dtype=torch.float64, device=dev)
+        rec = torch.empty((B, N, 3), dtype=torch.float64, device=dev)
+        it = torch.zeros(B, dtype=torch.int32, device=dev); st = torch.zeros_like(it)
+        err = torch.empty(B, dtype=torch.float64, device=dev)
+        _check(self.lib, self.lib.tff_bundle_adjust_views_batch_dev(self.handle, M, self._p(calm_cm), stride, self._p(rt_cm), self._p(corresp), B, N,
+                                                                    self._p(x0), self._p(out), self._p(rec), self._p(it), self._p(err), self._p(st)),
+               "tff_bundle_adjust_views_batch_dev")
+        return dict(R_t=out.transpose(1, 2), Reconst=rec.transpose(1, 2), iter=it, repr_err=err, status=st)
+
     def pose_sampled(self, method, scene, calm, sample_idx):
         """Minimal-sample hypotheses (config 4): scene (Ns, 6), sample_idx (B, n) int32 -> R_t_2, R_t_3 (B,3,4), T, status."""
         self._begin()
@@ -630,26 +659,18 @@ def PiColPoseEstimation(Corresp, CalM):
 
 
 def BundleAdjustment(CalM, R_t_0, Corresp, Reconst0=None):
-    """Drop-in for Optimization/BundleAdjustment.m with M = 3 views: CalM 9x3, R_t_0 9x4, Corresp 6xN, Reconst0 3xN or None
-    -> R_t (9x4, first camera [I|0], |t2| = 1), Reconst (3xN), iter, repr_err.  A first camera other than [I|0] is handled as the
-    reference does (BundleAdjustment.m:80-86): change of coordinates to camera 1 on the host, then the batched kernel."""
-    CalM = np.asarray(CalM, dtype=np.float64); R_t_0 = np.array(R_t_0, dtype=np.float64); Corresp = np.asarray(Corresp, dtype=np.float64)
-    if R_t_0.shape != (9, 4) or Corresp.ndim != 2 or Corresp.shape[0] != 6:
-        raise ValueError("three views: R_t_0 must be 9x4 and Corresp 6xN")
-    if np.isnan(Corresp).any():
-        raise ValueError("correspondences missing in some view (NaN) are not supported")
-    X0 = None if Reconst0 is None else np.array(Reconst0, dtype=np.float64)
-    cc = R_t_0[0:3].copy()
-    if not np.array_equal(cc, np.eye(3, 4)):                                  # :80-86
-        for j in (1, 2):
-            R_t_0[3 * j:3 * j + 3, 3] = R_t_0[3 * j:3 * j + 3, 3] - R_t_0[3 * j:3 * j + 3, 0:3] @ cc[:, 0:3].T @ cc[:, 3]
-            R_t_0[3 * j:3 * j + 3, 0:3] = R_t_0[3 * j:3 * j + 3, 0:3] @ cc[:, 0:3].T
-        if X0 is not None:
-            X0 = cc[:, 0:3] @ X0 + cc[:, 3:4]
-        # without Reconst0 the kernel triangulates with the transformed cameras: the same DLT systems up to the rigid motion of the
-        # frame (the homogeneous minimiser is taken in a rotated/translated basis), i.e. the same points to rounding for noise-free
-        # data and an equally valid start otherwise
-    out = default_context().bundle_adjust(CalM, R_t_0[3:6][None], R_t_0[6:9][None], np.ascontiguousarray(Corresp.T)[None],
-                                          None if X0 is None else X0[None])
-    R_t = np.vstack([np.eye(3, 4), out["R_t_2"][0].cpu().numpy(), out["R_t_3"][0].cpu().numpy()])
-    return R_t, out["Reconst"][0].cpu().numpy(), int(out["iter"][0]), float(out["repr_err"][0])
+    """Drop-in for Optimization/BundleAdjustment.m, M = 2 .. 6 views: CalM 3Mx3, R_t_0 3Mx4, Corresp 2MxN (NaN = not seen), Reconst0 3xN or None
+    -> R_t (3Mx4, first camera [I|0], |t2| = 1), Reconst (3xN), iter, repr_err.  The initial triangulation (:59-77), the change of coordinates to
+    camera 1 (:80-86) and the `isnan` branch (:165 -- it drops a whole VIEW, see csrc/ba_views_kernel.h) run on the device as the reference orders them.
+    Raises ValueError where the reference stops with an error (fewer than two complete views to triangulate from, :73-74)."""
+    CalM = np.asarray(CalM, dtype=np.float64); R_t_0 = np.asarray(R_t_0, dtype=np.float64); Corresp = np.asarray(Corresp, dtype=np.float64)
+    if Corresp.ndim != 2 or Corresp.shape[0] % 2 or not 2 <= Corresp.shape[0] // 2 <= 6:
+        raise ValueError("Corresp must be 2M x N with M = 2 .. 6 views")
+    M = Corresp.shape[0] // 2
+    if R_t_0.shape != (3 * M, 4) or CalM.shape != (3 * M, 3):
+        raise ValueError("%d views: R_t_0 must be %dx4 and CalM %dx3" % (M, 3 * M, 3 * M))
+    X0 = None if Reconst0 is None else np.asarray(Reconst0, dtype=np.float64)[None]
+    out = default_context().bundle_adjust_views(CalM, R_t_0[None], np.ascontiguousarray(Corresp.T)[None], X0)
+    if int(out["status"][0]) == 1:
+        raise ValueError("fewer than two complete views: triangulation3D returns nothing (triangulation3D.m:36-38) and BundleAdjustment.m:73-74 stops")
+    return out["R_t"][0].cpu().numpy(), out["Reconst"][0].cpu().numpy(), int(out["iter"][0]), float(out["repr_err"][0])

@@ -543,6 +543,25 @@ int pose_batch_host(pose_launcher launch, tff_ctx* c, const double* corresp, con
 
 }  // namespace
 
+// BundleAdjustment as the reference writes it, M = 2 .. 6 views, MATLAB's own array layouts (csrc/ba_views_kernel.h)
+template <int M>
+static int launch_bundle_adjust_views(tff_ctx* c, const tff::BavArgs& a) {
+    const size_t lds = tff::bav_lds_bytes<M>(a.N);
+    if (int r = ensure_lds(tff::k_bundle_adjust_views<M>, lds)) return r;
+    hipLaunchKernelGGL(tff::k_bundle_adjust_views<M>, dim3(tff::pose_grid(a.B)), dim3(64), lds, c->stream, a);
+    TFF_HIP(hipGetLastError());
+    return 0;
+}
+static int check_views(const tff_ctx* c, int32_t M, const void* calm, int64_t calm_stride, const void* Rt_in, const void* corresp, int64_t B, int32_t N, const void* Rt) {
+    if (!c) return fail(TFF_E_INVALID, "null context");
+    if (M < tff::BAV_MIN_VIEWS || M > tff::BAV_MAX_VIEWS) return fail(TFF_E_INVALID, "bundle adjustment takes 2 .. 6 views");
+    if (B < 0 || N < 0) return fail(TFF_E_INVALID, "negative batch or correspondence count");
+    if (B > 0 && (!corresp || !calm || !Rt_in || !Rt)) return fail(TFF_E_INVALID, "null pointer");
+    if (calm_stride != 0 && calm_stride != 9 * (int64_t)M) return fail(TFF_E_INVALID, "calm_stride must be 0 (shared CalM) or 9 M");
+    if (B > 0 && N < 1) return fail(TFF_E_INVALID, "bundle adjustment needs at least one correspondence");
+    return 0;
+}
+
 extern "C" {
 
 int tff_version(void) { return 100; }
@@ -908,6 +927,55 @@ int tff_bundle_adjust_batch_host(tff_ctx* c, const double* calm, int64_t calm_st
     if (int r = tff_bundle_adjust_batch_dev(c, (double*)c->calm.p, calm_stride, d_r2, d_r3, d_C, B, N, reconst0 ? d_X0 : nullptr, d_o2, d_o3, d_rec, d_it, d_err, d_st)) return r;
     TFF_HIP(hipMemcpyAsync(Rt2, d_o2, npose, hipMemcpyDeviceToHost, c->stream));
     TFF_HIP(hipMemcpyAsync(Rt3, d_o3, npose, hipMemcpyDeviceToHost, c->stream));
+    if (reconst) TFF_HIP(hipMemcpyAsync(reconst, d_rec, npt, hipMemcpyDeviceToHost, c->stream));
+    if (iter) TFF_HIP(hipMemcpyAsync(iter, d_it, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (repr_err) TFF_HIP(hipMemcpyAsync(repr_err, d_err, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (status) TFF_HIP(hipMemcpyAsync(status, d_st, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    TFF_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// BundleAdjustment as the reference writes it, M = 2 .. 6 views (launch_bundle_adjust_views above)
+int tff_bundle_adjust_views_batch_dev(tff_ctx* c, int32_t M, const double* calm, int64_t calm_stride, const double* Rt_in, const double* corresp,
+                                      int64_t B, int32_t N, const double* reconst0, double* Rt, double* reconst, int32_t* iter, double* repr_err,
+                                      int32_t* status) {
+    if (int r = check_views(c, M, calm, calm_stride, Rt_in, corresp, B, N, Rt)) return r;
+    TFF_LOCK(c);
+    if (B == 0) return 0;
+    TFF_HIP(hipSetDevice(c->device));
+    const tff::BavArgs a{calm, (long)calm_stride, Rt_in, corresp, (long)B, N, reconst0, Rt, reconst, iter, repr_err, status};
+    switch (M) {
+        case 2: return launch_bundle_adjust_views<2>(c, a);
+        case 3: return launch_bundle_adjust_views<3>(c, a);
+        case 4: return launch_bundle_adjust_views<4>(c, a);
+        case 5: return launch_bundle_adjust_views<5>(c, a);
+        default: return launch_bundle_adjust_views<6>(c, a);
+    }
+}
+int tff_bundle_adjust_views_batch_host(tff_ctx* c, int32_t M, const double* calm, int64_t calm_stride, const double* Rt_in, const double* corresp,
+                                       int64_t B, int32_t N, const double* reconst0, double* Rt, double* reconst, int32_t* iter, double* repr_err,
+                                       int32_t* status) {
+    if (int r = check_views(c, M, calm, calm_stride, Rt_in, corresp, B, N, Rt)) return r;
+    TFF_LOCK(c);
+    if (B == 0) return 0;
+    TFF_HIP(hipSetDevice(c->device));
+    const size_t nin = (size_t)B * 2 * M * (size_t)N * sizeof(double), npt = (size_t)B * 3 * (size_t)N * sizeof(double);
+    const size_t ncal = (calm_stride ? (size_t)B : 1) * 9 * M * sizeof(double), npose = (size_t)B * 12 * M * sizeof(double);
+    if (int r = c->in.reserve(nin + npt + npose)) return r;
+    if (int r = c->calm.reserve(ncal)) return r;
+    if (int r = c->out.reserve(npose + npt + (size_t)B * sizeof(double))) return r;
+    if (int r = c->idx.reserve((size_t)B * 2 * sizeof(int32_t))) return r;
+    char* din = (char*)c->in.p;
+    double* d_C = (double*)din; double* d_X0 = (double*)(din + nin); double* d_r = (double*)(din + nin + npt);
+    char* dout = (char*)c->out.p;
+    double* d_o = (double*)dout; double* d_rec = (double*)(dout + npose); double* d_err = (double*)(dout + npose + npt);
+    int32_t* d_it = (int32_t*)c->idx.p; int32_t* d_st = d_it + B;
+    TFF_HIP(hipMemcpyAsync(d_C, corresp, nin, hipMemcpyHostToDevice, c->stream));
+    if (reconst0) TFF_HIP(hipMemcpyAsync(d_X0, reconst0, npt, hipMemcpyHostToDevice, c->stream));
+    TFF_HIP(hipMemcpyAsync(d_r, Rt_in, npose, hipMemcpyHostToDevice, c->stream));
+    TFF_HIP(hipMemcpyAsync(c->calm.p, calm, ncal, hipMemcpyHostToDevice, c->stream));
+    if (int r = tff_bundle_adjust_views_batch_dev(c, M, (double*)c->calm.p, calm_stride, d_r, d_C, B, N, reconst0 ? d_X0 : nullptr, d_o, d_rec, d_it, d_err, d_st)) return r;
+    TFF_HIP(hipMemcpyAsync(Rt, d_o, npose, hipMemcpyDeviceToHost, c->stream));
     if (reconst) TFF_HIP(hipMemcpyAsync(reconst, d_rec, npt, hipMemcpyDeviceToHost, c->stream));
     if (iter) TFF_HIP(hipMemcpyAsync(iter, d_it, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     if (repr_err) TFF_HIP(hipMemcpyAsync(repr_err, d_err, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -15,6 +15,7 @@
 #include "gh_fp_kernel.h"
 #include "pi_wg_kernel.h"
 #include "ba_kernel.h"
+#include "ba_views_kernel.h"
 
 namespace tff {
 

@@ -96,3 +96,31 @@ def generate_scene_batch(B, N, noise=1.0, seed=0, focalL=50.0, angle=None):
 def calm_colmajor(CalM):
     """9x3 numpy CalM -> the 27 doubles of a MATLAB column-major 9x3 array."""
     return np.ascontiguousarray(np.asarray(CalM, dtype=np.float64).T).reshape(27)
+
+
+def generate_multiview_scene(M, N, noise=1.0, seed=0, focalL=50.0):
+    """One scene of N points seen by M cameras (BundleAdjustment.m takes any number of views): the three cameras of
+    generateSyntheticScene.m:52-60 first, further centres on the same side of the point cube, every camera looking at the origin.
+    Returns Corresp (2M x N), CalM (3M x 3), R_t (3M x 4 ground truth, first pose [I|0]), points3D (3 x N)."""
+    k = focalL / 50.0
+    pix = 50.0
+    K = np.array([[50 * k * pix, 0, 18 * pix], [0, 50 * k * pix, 12 * pix], [0, 0, 1]])
+    centres = [np.array([0., -1400, 400]), np.array([-400., -1000, 0]), np.array([600., -800, -200]), np.array([300., -1200, 500]),
+               np.array([-700., -900, -300]), np.array([100., -1500, -100])]
+    if not 2 <= M <= len(centres):
+        raise ValueError("2 .. %d views" % len(centres))
+    down = np.array([0., 0, -1])
+    Cs = [k * c for c in centres[:M]]
+    Rs = [_rotation(c, down) for c in Cs]
+    Ps = [K @ R @ np.hstack([np.eye(3), -c.reshape(3, 1)]) for R, c in zip(Rs, Cs)]
+    rng = np.random.Generator(np.random.Philox(key=int(seed)))
+    X = np.empty((3, 0)); x = np.empty((2 * M, 0))
+    while X.shape[1] < N:
+        Xn = 400 * rng.random((3, 2 * N)) - 200
+        xh = [P @ np.vstack([Xn, np.ones(2 * N)]) for P in Ps]
+        xn = np.vstack([h[0:2] / h[2:3] for h in xh]) + noise * rng.standard_normal((2 * M, 2 * N))
+        inside = np.all((xn[0::2] <= 36 * pix) & (xn[0::2] >= 0) & (xn[1::2] <= 24 * pix) & (xn[1::2] >= 0), axis=0)
+        X = np.hstack([X, Xn[:, inside]]); x = np.hstack([x, xn[:, inside]])
+    R_t = np.vstack([R @ np.hstack([Rs[0].T, (Cs[0] - c).reshape(3, 1)]) for R, c in zip(Rs, Cs)])
+    R_t[0:3] = np.eye(3, 4)
+    return x[:, :N].copy(), np.vstack([K] * M), R_t, (Rs[0] @ (X[:, :N] - Cs[0].reshape(3, 1)))
