@@ -128,6 +128,11 @@ int tff_linear_tft_pose_batch_debug_dev(tff_ctx* ctx, const double* corresp, con
                                         int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
                                         int32_t* iter, int32_t* status, double* dbg);
 
+/* the same record for LinearFPoseEstimation (phase stamps at dbg[80 ..], iteration counts of the two view pairs at dbg[69], dbg[70]) */
+int tff_linear_f_pose_batch_debug_dev(tff_ctx* ctx, const double* corresp, const double* calm, int64_t calm_stride,
+                                      int64_t B, int32_t N, double* Rt2, double* Rt3, double* T, double* reconst,
+                                      int32_t* iter, int32_t* status, double* dbg);
+
 /* ResslTFTPoseEstimation (TFT_methods/ResslTFTPoseEstimation.m:47-177): linearTFT, Ressl's 20-parameter /
  * 2-constraint minimal parameterisation, Gauss-Helmert refinement (Optimization/Gauss_Helmert.m:38-83),
  * then transform_TFT -> R_t_from_TFT -> (Reconst).  iter = Gauss-Helmert iterations.  Any N (the per-correspondence state spills to a

@@ -804,3 +804,25 @@ def test_moments_kernel_feeds_the_rows_kernel(emu, B, N, sigma, extra):
         emu.emu_set_grid_cap(0)
     for k in ("T", "R_t_2", "R_t_3", "Reconst", "status"):
         assert np.array_equal(one[k], prod[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("entry,ref_entry,n", [("emu_linear_tft_pose_rows_exact", "emu_linear_tft_pose", 7), ("emu_linear_f_pose_rows_exact", "emu_linear_f_pose", 8)])
+def test_rows_exact_kernels_score_contaminated_minimal_samples_like_the_one_triplet_kernel(emu, entry, ref_entry, n):
+    """Minimal samples of a scene with gross outliers (config 4): most fast votes are not certified, so the exact re-score runs -- for N <= 8 with the two
+    candidates of an essential matrix side by side in a row's sixteen positions (rows_vote_exact_pair).  All eight scores equal the one-triplet exact
+    kernel's, and so do the poses."""
+    Ns, B = 60, 8
+    Cs, CalM, _, _ = generate_scene_batch(1, Ns, noise=0.5, seed=77)
+    scene = Cs[0].copy()
+    rng = np.random.default_rng(5)
+    bad = rng.choice(Ns, Ns // 4, replace=False)
+    scene[bad, 2:6] += rng.uniform(20, 80, size=(bad.size, 4))
+    C = np.ascontiguousarray(np.stack([scene[rng.choice(Ns, n, replace=False)] for _ in range(B)]))
+    out = run_linear_tft(emu, C, CalM, entry=entry, debug=True)
+    ref = run_linear_tft(emu, C, CalM, flags=FLAG_JACOBI, entry=ref_entry)
+    live = (out["status"] == 0) & (ref["status"] == 0)
+    assert live.sum() >= B - 2 and np.array_equal(out["status"] == 3, ref["status"] == 3)
+    so, sw = out["debug"][:, 60:68].reshape(B, 2, 4), ref["debug"][:, 60:68].reshape(B, 2, 4)
+    assert np.array_equal(so[live], sw[live])
+    for b in np.nonzero(live)[0]:
+        assert rel_err(out["R_t_2"][b], ref["R_t_2"][b]) < 1e-8 and rel_err(out["R_t_3"][b], ref["R_t_3"][b]) < 1e-8

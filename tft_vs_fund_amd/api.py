@@ -138,7 +138,7 @@ POSE_METHODS = {
 EXPORTED_SYMBOLS = [
     "tff_version", "tff_last_error", "tff_ctx_create", "tff_ctx_destroy", "tff_ctx_set_stream",
     "tff_ctx_use_own_stream", "tff_ctx_get_stream", "tff_ctx_set_option", "tff_ctx_synchronize",
-    "tff_linear_tft_pose_batch_dev", "tff_linear_tft_pose_batch_host", "tff_linear_tft_pose_batch_debug_dev",
+    "tff_linear_tft_pose_batch_dev", "tff_linear_tft_pose_batch_host", "tff_linear_tft_pose_batch_debug_dev", "tff_linear_f_pose_batch_debug_dev",
     "tff_linear_f_pose_batch_dev", "tff_linear_f_pose_batch_host",
     "tff_ressl_tft_pose_batch_dev", "tff_ressl_tft_pose_batch_host", "tff_ressl_tft_pose_batch_debug_dev",
     "tff_faugpapa_tft_pose_batch_dev", "tff_faugpapa_tft_pose_batch_host", "tff_faugpapa_tft_pose_batch_debug_dev",

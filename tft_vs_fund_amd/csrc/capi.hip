@@ -764,6 +764,12 @@ int tff_linear_f_pose_batch_dev(tff_ctx* c, const double* corresp, const double*
                                 int32_t* status) {
     return launch_linear_f(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, nullptr);
 }
+int tff_linear_f_pose_batch_debug_dev(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
+                                      int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
+                                      int32_t* status, double* dbg) {
+    if (!dbg) return fail(TFF_E_INVALID, "null debug buffer");
+    return launch_linear_f(c, corresp, calm, calm_stride, B, N, Rt2, Rt3, T, reconst, iter, status, dbg);
+}
 int tff_linear_f_pose_batch_host(tff_ctx* c, const double* corresp, const double* calm, int64_t calm_stride, int64_t B,
                                  int32_t N, double* Rt2, double* Rt3, double* T, double* reconst, int32_t* iter,
                                  int32_t* status) {

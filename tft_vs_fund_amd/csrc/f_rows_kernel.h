@@ -293,15 +293,19 @@ __global__ void __launch_bounds__(64, 2) k_linear_f_pose_rows_exact(const Linear
             status = ST_TOO_FEW;
             rows_store_nan(a, j, N);
         } else {
+            rows_stamp(j.dbg, 0);
             {
                 double cen[6];
                 rows_centroids(j.src, N, cen);                               // LinearFPoseEstimation.m:46-48
                 rows_distances(j.src, N, cen, w->nrm);
             }
+            rows_stamp(j.dbg, 1);
             // (the rank-2 F matrices go to w->t, linearF's inner normalisation to w->pa; the packed R lives in the overlay until E is formed --
             //  rt->Ein overlaps it, so E is written after the last solve)
             bool ok = rows_linear_f_middle_exact(w, rt, j.src, N, w->t, w->pa, j.dbg);
+            rows_stamp(j.dbg, 2);
             rows_recover_prepare(w, rt);
+            rows_stamp(j.dbg, 10);
             status = rows_pose_tail<true, true>(a, w, rt, j, N, ok);
         }
         if (p == 0 && j.valid) {

@@ -180,17 +180,21 @@ __global__ void __launch_bounds__(64, 2) k_linear_tft_pose_rows_exact(const Line
             status = ST_TOO_FEW;
             rows_store_nan(a, j, N);
         } else {
+            rows_stamp(dbg, 0);
             {
                 double cen[6];
                 rows_centroids(j.src, N, cen);                               // LinearTFTPoseEstimation.m:45-47
                 rows_distances(j.src, N, cen, w->nrm);
                 if (dbg && p < 9) dbg[71 + p] = w->nrm[p];
             }
+            rows_stamp(dbg, 1);
             int capped = 0;
             bool ok = rows_linear_tft_middle_exact(w, j.src, N, dbg, &capped);   // :50
             hint = capped;
+            rows_stamp(dbg, 2);
             rows_transform_tft_inverse(w->t, rt->T1, rt->mats, [w](int v) { return normal_matrix(w->nrm, v); });   // :53
             ok = rows_rt_prepare<true>(w, rt, dbg) && ok;                    // :56
+            rows_stamp(dbg, 10);
             status = rows_pose_tail<false, true>(a, w, rt, j, N, ok);
         }
         if (p == 0 && j.valid) {

@@ -834,6 +834,30 @@ __device__ __forceinline__ int rows_vote_exact(const RowSrc& s, const int N, con
     return (int)row_sum16(score);
 }
 
+// Minimal samples (N <= 8: half of a row's sixteen positions would idle above): the two candidates of one essential matrix side by side --
+// positions 0..7 score candidate k, positions 8..15 candidate k + 1, correspondence p & 7.  Per correspondence the same arithmetic as
+// rows_vote_exact, and the scores are sums of +-1: bit-identical results (config 4: exact votes were 30 % / 16 % of the eight- / seven-point kernels).
+__device__ __forceinline__ void rows_vote_exact_pair(const RowSrc& s, const int N, const RowRt* rt, const int k, const int view, int& exA, int& exB) {
+    const int p = rows_p(), half = p >> 3, i = p & 7;
+    const int cand_off = 12 * (k + half);
+    typedef const double (&cam_ref)[12];
+    cam_ref PA = *reinterpret_cast<const double(*)[12]>(rt->Pfin[0]);
+    const double* camB = rt->P[0] + cand_off;
+    cam_ref PB = *reinterpret_cast<const double(*)[12]>(camB);
+    const double* pr = rt->candRt[0] + cand_off;
+    double score = 0.0;
+    if (i < N) {
+        const Pt6 q = rows_load(s, i);
+        double X[4];
+        dlt_point<true, true>(PA, PB, PB, rt->Pfin[0], camB, camB, false, q.v[0], q.v[1], (view == 1) ? q.v[2] : q.v[4], (view == 1) ? q.v[3] : q.v[5], 0.0, 0.0, X);
+        const double s4 = sgn(X[3]);                                         // X1 = X ./ X(4)
+        const double d1 = X[2] * s4, d2 = (pr[8] * X[0] + pr[9] * X[1] + pr[10] * X[2] + pr[11] * X[3]) * s4;
+        score = sgn(d1) + sgn(d2);
+    }
+    exA = (int)row_sum16(half ? 0.0 : score);
+    exB = (int)row_sum16(half ? score : 0.0);
+}
+
 // EXACT: every score is evaluated (all four candidates), an uncertified one is recomputed by rows_vote_exact, the t3 scale and Reconst take the
 // certified DLT ladder -- the row then fails only on what the caller's exact tiers reported.
 template <bool T_FROM_CAMERAS, bool EXACT = false>
@@ -852,12 +876,25 @@ __device__ __forceinline__ int rows_pose_tail(const LinearTftArgs& a, RowLds* w,
         if constexpr (EXACT) {
             bool cert4[4];
             rows_votes(j.src, N, rt, true, sc, &sweeps, cert4);             // all four fast scores and which of them are certified
+            rows_stamp(dbg, 3);
+            if (N <= 8) {                                                    // (wave-uniform: N is the batch's) both candidates of an essential matrix in one pass
 #pragma unroll 1
-            for (int k = 0; k < 4; ++k) {                                    // (wave-uniform loop; a row joins when its candidate k needs the exact tier)
-                const bool need = !((k == 0) ? cert4[0] : (k == 1) ? cert4[1] : (k == 2) ? cert4[2] : cert4[3]);
-                if (!wave_any(need)) continue;
-                const int ex = rows_vote_exact(j.src, N, rt, 12 * k, (k < 2) ? 1 : 2);
-                if (need) { if (k == 0) sc[0][0] = ex; else if (k == 1) sc[0][1] = ex; else if (k == 2) sc[1][0] = ex; else sc[1][1] = ex; }
+                for (int call = 0; call < 2; ++call) {
+                    const bool needA = !(call ? cert4[2] : cert4[0]), needB = !(call ? cert4[3] : cert4[1]);
+                    if (!wave_any(needA || needB)) continue;
+                    int exA, exB;
+                    rows_vote_exact_pair(j.src, N, rt, 2 * call, call + 1, exA, exB);
+                    if (needA) { if (call) sc[1][0] = exA; else sc[0][0] = exA; }
+                    if (needB) { if (call) sc[1][1] = exB; else sc[0][1] = exB; }
+                }
+            } else {
+#pragma unroll 1
+                for (int k = 0; k < 4; ++k) {                                // (wave-uniform loop; a row joins when its candidate k needs the exact tier)
+                    const bool need = !((k == 0) ? cert4[0] : (k == 1) ? cert4[1] : (k == 2) ? cert4[2] : cert4[3]);
+                    if (!wave_any(need)) continue;
+                    const int ex = rows_vote_exact(j.src, N, rt, 12 * k, (k < 2) ? 1 : 2);
+                    if (need) { if (k == 0) sc[0][0] = ex; else if (k == 1) sc[0][1] = ex; else if (k == 2) sc[1][0] = ex; else sc[1][1] = ex; }
+                }
             }
         } else {
             ok = rows_votes<true>(j.src, N, rt, dbg != nullptr && !(a.flags & FLAG_DBG_ADAPTIVE), sc, &sweeps, nullptr, &spec) && ok;   // an uncertified sign: the exact kernel's business
