@@ -184,6 +184,24 @@ __global__ void __launch_bounds__(64, 2) k_linear_f_pose_rows(const LinearTftArg
     }
 }
 
+// M rows (correspondences base .. base + M - 1) of the N x 9 system of one view pair appended to the row's packed R: entry h1 (x) h2 at position 3a + b
+// (linearF.m:48-53), on the points normalised twice (LinearFPoseEstimation.m:46-48, linearF.m:45-46).
+template <int M>
+__device__ __forceinline__ void rows_f_system_chunk(const RowSrc& s, const int N, const int base, const double* nrm, const double* nrm2, const int p, const int ca,
+                                                    const int cb, const int pair, double* Rp, double* xch) {
+    double a0[M], a1[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        const int i = base + r;                                              // row-uniform: every lane of the row reads the same correspondence
+        const Pt6 q = premap(premap(rows_load(s, (i < N) ? i : 0), nrm), nrm2);
+        const double h1 = (ca == 0) ? q.v[0] : (ca == 1) ? q.v[1] : 1.0;
+        const double h2 = (cb == 0) ? (pair ? q.v[4] : q.v[2]) : (cb == 1) ? (pair ? q.v[5] : q.v[3]) : 1.0;
+        a0[r] = (i < N && p < 9) ? h1 * h2 : 0.0;
+        a1[r] = 0.0;
+    }
+    rows_qr_append<9, M>(a0, a1, Rp, xch);
+}
+
 // ---- the exact tiers of LinearFPoseEstimation, four triplets per wavefront (k_f_pose<true, 0> in the row layout; minimal samples / TFF_OPT_SOLVER = 1) ----
 // Streaming Householder QR of the explicit N x 9 system of each view pair (rows_qr.h: position p < 9 owns column p, 16 rows per chunk), inverse
 // iteration with L = R', certified 3 x 3 null vectors, all four votes with the exact re-score behind them, certified DLT ladder for t3 scale and
@@ -230,19 +248,11 @@ __device__ __forceinline__ bool rows_linear_f_middle_exact(RowLds* w, RowRt* rt,
     for (int pair = 0; pair < 2; ++pair) {                                   // linearF(x1,x2), linearF(x1,x3): rows h1 (x) h2, position 3a + b (linearF.m:48-53)
         rows_qr_clear<9>(Rp);
         const int col = (p < 9) ? p : 0, ca = col / 3, cb = col % 3;
+        if (N <= 8) {                                                        // (wave-uniform) an eight-point sample: one chunk of eight rows -- the other eight would be zero rows that
+            rows_f_system_chunk<8>(s, N, 0, w->nrm, nrm2, p, ca, cb, pair, Rp, xch);   // change nothing (fma(0, 0, x) = x) and cost half of the factorisation
+        } else {
 #pragma unroll 1
-        for (int base = 0; base < N; base += 16) {
-            double a0[16], a1[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = base + r;                                      // row-uniform: every lane of the row reads the same correspondence
-                const Pt6 q = premap(premap(rows_load(s, (i < N) ? i : 0), w->nrm), nrm2);
-                const double h1 = (ca == 0) ? q.v[0] : (ca == 1) ? q.v[1] : 1.0;
-                const double h2 = (cb == 0) ? (pair ? q.v[4] : q.v[2]) : (cb == 1) ? (pair ? q.v[5] : q.v[3]) : 1.0;
-                a0[r] = (i < N && p < 9) ? h1 * h2 : 0.0;
-                a1[r] = 0.0;
-            }
-            rows_qr_append<9, 16>(a0, a1, Rp, xch);
+            for (int base = 0; base < N; base += 16) rows_f_system_chunk<16>(s, N, base, w->nrm, nrm2, p, ca, cb, pair, Rp, xch);
         }
         int its = 0;
         double x0, x1, r2;

@@ -85,8 +85,10 @@ __device__ __forceinline__ bool rows_linear_tft_middle_exact(RowLds* w, const Ro
     int it1 = 0, it2 = 0;
     {                                                                        // :64-67
         rows_tft_system_qr(s, N, w->nrm, Rp, xch);
+        rows_stamp(dbg, 4);
         double x0, x1, r2;
         rows_invit_from_R<27>(Rp, dinv, EIG_MAXIT, &it1, &r2, x0, x1);
+        rows_stamp(dbg, 5);
         ok = ok && eig_converged(r2);
         *capped = eig_converged(r2) ? 0 : 1;
         wave_sync();
@@ -102,6 +104,7 @@ __device__ __forceinline__ bool rows_linear_tft_middle_exact(RowLds* w, const Ro
     if (p == 0) frame_of(w->epi, w->Q);                                      // Q2 from e21
     if (p == 1) frame_of(w->epi + 3, w->Q + 9);                              // Q3 from e31
     wave_sync();
+    rows_stamp(dbg, 6);
     {                                                                        // :84 from R: svd(A Up) == svd(R Up), A = Q R
         // column c = 5 i + m of B = R Up (27 x 15) on position c < 15: B[r][c] = sum_{k,j} R[r][j + 3k + 9i] Q2[j][jj] Q3[k][kk]
         double a0[27], a1[27];
@@ -131,6 +134,7 @@ __device__ __forceinline__ bool rows_linear_tft_middle_exact(RowLds* w, const Ro
         wave_sync();                                                         // R is read; the 15 x 15 factor takes its place
         rows_qr_clear<15>(Rp);
         rows_qr_append<15, 27>(a0, a1, Rp, xch);
+        rows_stamp(dbg, 7);
         double x0, x1, r2;
         rows_invit_from_R<15>(Rp, dinv, EIG_MAXIT, &it2, &r2, x0, x1);
         ok = ok && eig_converged(r2);

@@ -1,5 +1,5 @@
-"""Seven-point samples of the config-4 scene on which two library builds disagree: which one is the oracle's (svd) answer?
-python tools/diag_extrapolation_vs_oracle.py [H] libA.so libB.so"""
+"""Minimal samples of the config-4 scene on which two library builds disagree: which one is the oracle's (svd) answer?
+python tools/diag_extrapolation_vs_oracle.py [H] libA.so libB.so [tft|f]      (seven-point LinearTFT samples by default, eight-point LinearF with `f`)"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,6 +11,8 @@ from helpers import pose_err_any_convention
 
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 libs = sys.argv[2:4]
+use_f = len(sys.argv) > 4 and sys.argv[4] == "f"
+n_min = 8 if use_f else 7
 Ns = 400
 dev = torch.device("cuda", 0)
 C, CalM, _, _ = generate_scene_batch(1, Ns, noise=0.5, seed=7)
@@ -22,7 +24,7 @@ d_scene = torch.from_numpy(scene).to(dev); calm = torch.from_numpy(np.ascontiguo
 stream = torch.cuda.current_stream(dev)
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 g = torch.Generator(device=dev); g.manual_seed(1234)
-idx = torch.rand((H, Ns), device=dev, generator=g).argsort(dim=1)[:, :7].to(torch.int32).contiguous()
+idx = torch.rand((H, Ns), device=dev, generator=g).argsort(dim=1)[:, :n_min].to(torch.int32).contiguous()
 res = []
 for path in libs:
     lib = ctypes.CDLL(path)
@@ -32,7 +34,8 @@ for path in libs:
     lib.tff_ctx_set_stream(h, ctypes.c_void_p(stream.cuda_stream))
     Rt2 = torch.empty((H, 12), dtype=torch.float64, device=dev); Rt3 = torch.empty_like(Rt2); T = torch.empty((H, 27), dtype=torch.float64, device=dev)
     st = torch.zeros(H, dtype=torch.int32, device=dev)
-    assert lib.tff_linear_tft_pose_sampled_dev(h, p(d_scene), ctypes.c_int(Ns), p(calm), p(idx), ctypes.c_long(H), ctypes.c_int(7), p(Rt2), p(Rt3), p(T), p(st)) == 0
+    fn = lib.tff_linear_f_pose_sampled_dev if use_f else lib.tff_linear_tft_pose_sampled_dev
+    assert fn(h, p(d_scene), ctypes.c_int(Ns), p(calm), p(idx), ctypes.c_long(H), ctypes.c_int(n_min), p(Rt2), p(Rt3), p(T), p(st)) == 0
     torch.cuda.synchronize()
     res.append((Rt2.cpu().numpy().reshape(H, 4, 3).transpose(0, 2, 1), Rt3.cpu().numpy().reshape(H, 4, 3).transpose(0, 2, 1), st.cpu().numpy(),
                 T.cpu().numpy().reshape(H, 3, 3, 3).transpose(0, 3, 2, 1)))
@@ -48,7 +51,7 @@ for b in differ[:60]:
     for r in res:
         out_b = {"R_t_2": r[0][b], "R_t_3": r[1][b], "T": r[3][b]}
         try:
-            e0, eb = pose_err_any_convention(out_b, O.LinearTFTPoseEstimation, Cs.T.copy(), CalM)
+            e0, eb = pose_err_any_convention(out_b, O.LinearFPoseEstimation if use_f else O.LinearTFTPoseEstimation, Cs.T.copy(), CalM)
         except Exception as ex:
             e0, eb = float("nan"), float("nan")
         e.append((e0, eb))
