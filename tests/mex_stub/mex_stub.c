@@ -59,8 +59,31 @@ int main(int argc, char** argv) {
     mwSize dc[3], dk[2];
     long B, N, b;
     size_t got;
-    if (argc != 4) { fprintf(stderr, "usage: mex_driver method B N\n"); return 2; }
+    if (argc != 4) { fprintf(stderr, "usage: mex_driver method B N   |   mex_driver bundle_adjustment M N\n"); return 2; }
     B = atol(argv[2]); N = atol(argv[3]);
+    if (!strcmp(argv[1], "bundle_adjustment")) {                 /* stdin: Corresp (2M x N), CalM (3M x 3), R_t_0 (3M x 4); stdout: R_t (3M x 4), Reconst (3 x N), iter, repr_err */
+        const long M = B;
+        mxArray *in[4], *out[4] = {0, 0, 0, 0};
+        mwSize d2[2];
+        in[0] = (mxArray*)calloc(1, sizeof(mxArray));
+        in[0]->cls = mxCHAR_CLASS; in[0]->ndim = 2; in[0]->dims[0] = 1; in[0]->dims[1] = strlen(argv[1]);
+        in[0]->str = (char*)malloc(strlen(argv[1]) + 1); strcpy(in[0]->str, argv[1]);
+        d2[0] = (mwSize)(2 * M); d2[1] = (mwSize)N; in[1] = mxCreateNumericArray(2, d2, mxDOUBLE_CLASS, mxREAL);
+        d2[0] = (mwSize)(3 * M); d2[1] = 3; in[2] = mxCreateNumericArray(2, d2, mxDOUBLE_CLASS, mxREAL);
+        d2[0] = (mwSize)(3 * M); d2[1] = 4; in[3] = mxCreateNumericArray(2, d2, mxDOUBLE_CLASS, mxREAL);
+        got = fread(in[1]->pr, sizeof(double), (size_t)(2 * M * N), stdin);
+        got += fread(in[2]->pr, sizeof(double), (size_t)(9 * M), stdin);
+        got += fread(in[3]->pr, sizeof(double), (size_t)(12 * M), stdin);
+        if (got != (size_t)(2 * M * N + 21 * M)) { fprintf(stderr, "short input\n"); return 2; }
+        if (setjmp(g_jmp)) { fprintf(stderr, "MEXERROR %s\n", g_err); if (g_exit) g_exit(); return 3; }
+        mexFunction(4, out, 4, (const mxArray**)in);
+        fwrite(mxGetPr(out[0]), sizeof(double), (size_t)(12 * M), stdout);
+        fwrite(mxGetPr(out[1]), sizeof(double), (size_t)(3 * N), stdout);
+        fwrite(mxGetPr(out[2]), sizeof(double), 1, stdout);
+        fwrite(mxGetPr(out[3]), sizeof(double), 1, stdout);
+        if (g_exit) g_exit();
+        return 0;
+    }
     prhs[0] = (mxArray*)calloc(1, sizeof(mxArray));
     prhs[0]->cls = mxCHAR_CLASS; prhs[0]->ndim = 2; prhs[0]->dims[0] = 1; prhs[0]->dims[1] = strlen(argv[1]);
     prhs[0]->str = (char*)malloc(strlen(argv[1]) + 1); strcpy(prhs[0]->str, argv[1]);

@@ -60,3 +60,34 @@ def test_mex_gateway_runs_end_to_end_through_the_stub(tmp_path):
     C1 = C[:1, :6].copy()                                                          # six correspondences: linearF needs eight
     r = subprocess.run([exe, "linear_f", "1", "6"], input=C1.tobytes() + calm_colmajor(CalM).tobytes(), capture_output=True)
     assert r.returncode == 3 and b"tftfund:tooFew" in r.stderr
+
+
+@pytest.mark.gpu
+def test_mex_gateway_bundle_adjustment_for_four_views(tmp_path):
+    """mexFunction('bundle_adjustment', Corresp 8 x N, CalM 12 x 3, R_t_0 12 x 4) through the stub: MATLAB's arrays go to
+    tff_bundle_adjust_views_batch_host as they are; the result equals the oracle's restatement of BundleAdjustment.m (1e-9, same iter); a problem with
+    fewer than two complete views raises the MATLAB error where the reference stops (BundleAdjustment.m:73-74)."""
+    import warnings
+    from oracle import ba_oracle as BA
+    from tft_vs_fund_amd.build import build_library
+    from tft_vs_fund_amd.scenes import generate_multiview_scene
+    so = build_library()
+    exe = str(tmp_path / "mex_driver")
+    subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + STUB, "-I" + os.path.join(ROOT, "include"), MEX, os.path.join(STUB, "mex_stub.c"),
+                    "-o", exe, "-L" + os.path.dirname(so), "-ltftfund", "-Wl,-rpath," + os.path.dirname(so)], check=True)
+    M, N = 4, 30
+    C, CalM, R_t, X = generate_multiview_scene(M, N, noise=1.0, seed=41)
+    sc = np.linalg.norm(R_t[3:6, 3]); R_t[:, 3] /= sc
+    R0 = R_t.copy(); R0[3:, 3] *= 1.01
+    blob = np.ascontiguousarray(C.T).tobytes() + np.ascontiguousarray(CalM.T).tobytes() + np.ascontiguousarray(R0.T).tobytes()   # column-major, as MATLAB holds them
+    r = subprocess.run([exe, "bundle_adjustment", str(M), str(N)], input=blob, capture_output=True, check=True)
+    got = np.frombuffer(r.stdout, dtype=np.float64)
+    assert got.size == 12 * M + 3 * N + 2
+    Rk = got[:12 * M].reshape(4, 3 * M).T; Xk = got[12 * M:12 * M + 3 * N].reshape(N, 3).T; it, err = int(got[-2]), got[-1]
+    Ro, Xo, ito, erro = BA.BundleAdjustment(CalM, R0, C, None)
+    assert it == ito and abs(err - erro) <= 1e-9 * erro
+    assert np.abs(Rk - Ro).max() < 1e-9 * np.abs(Ro).max() and np.abs(Xk - Xo).max() < 1e-9 * np.abs(Xo).max()
+    C2 = C[:4].copy(); C2[2, 0] = np.nan                                           # two views, one of them incomplete
+    blob = np.ascontiguousarray(C2.T).tobytes() + np.ascontiguousarray(CalM[:6].T).tobytes() + np.ascontiguousarray(R0[:6].T).tobytes()
+    r = subprocess.run([exe, "bundle_adjustment", "2", str(N)], input=blob, capture_output=True)
+    assert r.returncode == 3 and b"tftfund:views" in r.stderr
