@@ -85,7 +85,9 @@ typedef struct tff_ctx tff_ctx;
                              *   - the two LINEAR methods go by batch size: the row kernels (2.5x fewer instructions per triplet) once the batch no
                              *     longer fits the device's wavefront slots in one go (B >= 1024, or > 2048 when N > 256), the one-triplet kernels
                              *     (shorter latency) below.  The two routes agree to rounding (1e-14), so a linear result's last bits may depend on
-                             *     the size of the batch it arrives in; set 0 or 1 where that matters;
+                             *     the size of the batch it arrives in; set 0 or 1 where that matters.  Two kinds of call never depend on how a job is
+                             *     cut up: the *_sampled_dev entry points (RANSAC chunks of any size) always take the row kernels, and the shards of a
+                             *     tff_pose_batch_*_multi call are routed by the size of the WHOLE batch;
                              *   - the ITERATIVE methods (OptimF, Ressl, Nordberg, FaugPapa, Pi, PiCol) always take the row kernels (round 5): their
                              *     iteration amplifies a last bit of its start, so their route must not depend on the batch size -- the same triplet
                              *     gives the same bits and the same `iter` in any batch.
@@ -95,6 +97,8 @@ typedef struct tff_ctx tff_ctx;
                              * per wavefront, the correspondences read from HBM once and parked in LDS (csrc/tft_moments_kernel.h), the row kernels starting
                              * from its 112-double record; 2 = that kernel from N >= 48.  An A/B switch: measured slower than the fused passes on MI355X
                              * (profiles/r5_ab_pre.txt) -- the path is bound by fp64 issue, not by those passes' memory waits.  Results agree to rounding */
+#define TFF_OPT_COUNT_ROWS 11 /* tff_inlier_count_batch_dev on many hypotheses of one scene: 1 (default) four hypotheses per wavefront, one per row of 16 lanes
+                             * (the cameras composed once per row, 25 trips of 16 over a 400-correspondence scene); 0 one hypothesis per wavefront.  Identical counts */
 #define TFF_OPT_DEBUG_FP_HANDOVER 8 /* test hook: 1 = FaugPapa's block kernel hands every third triplet back to the generic workgroup kernel, as it does when its
                              * pseudo-inverse reports a failure (exercises that production fall-back; results must not depend on it beyond the
                              * generic kernel's LAPACK-level noise) */

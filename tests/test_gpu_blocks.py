@@ -192,6 +192,12 @@ def test_config4_at_one_million_hypotheses(gpu_ctx):
         cnt = gpu_ctx.inlier_count(d_scene, d_calm, hyp["R_t_2"], hyp["R_t_3"], 1.0)
         torch.cuda.synchronize()
         assert int((hyp["status"] != 0).sum()) == 0
+        gpu_ctx.set_count_rows(False)                                           # one hypothesis per wavefront instead of four (TFF_OPT_COUNT_ROWS): the same counts
+        try:
+            cnt_w = gpu_ctx.inlier_count(d_scene, d_calm, hyp["R_t_2"], hyp["R_t_3"], 1.0)
+        finally:
+            gpu_ctx.set_count_rows(True)
+        assert torch.equal(cnt_w, cnt), int((cnt_w != cnt).sum())
         clean = ~is_bad[idx.long()].any(dim=1)
         assert int(clean.sum()) > 1000
         assert int(cnt.max()) == Ns - bad.size

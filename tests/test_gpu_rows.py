@@ -295,3 +295,29 @@ def test_a_row_the_exact_tiers_redo_does_not_touch_its_neighbours(gpu_ctx, metho
     for k in ("T", "R_t_2", "R_t_3", "Reconst", "iter"):
         assert torch.equal(out[k][keep], ref[k][keep]), (method, k)
     assert not torch.equal(out["T"][6], ref["T"][6])
+
+
+@pytest.mark.parametrize("method,n", [("LinearTFTPoseEstimation", 7), ("LinearFPoseEstimation", 8), ("LinearTFTPoseEstimation", 14)])
+def test_sampled_hypotheses_do_not_depend_on_the_chunk_they_arrive_in(method, n):
+    """A RANSAC loop may evaluate its hypotheses in chunks of any size: on a DEFAULT context (route by batch size for the linear methods) the *_sampled
+    entry points always take the row kernels, so a hypothesis gets the same bits alone in a chunk of 37, of 1 500 or in one call of 3 000."""
+    import torch
+    from tft_vs_fund_amd import api
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    Ns, H = 200, 3000
+    Cs, CalM, _, _ = generate_scene_batch(1, Ns, noise=0.5, seed=21)
+    scene = Cs[0].copy()
+    rng = np.random.default_rng(3)
+    bad = rng.choice(Ns, Ns // 5, replace=False)
+    scene[bad, 2:6] += rng.uniform(20, 80, size=(bad.size, 4))
+    d_scene = torch.from_numpy(scene).cuda(); calm = torch.from_numpy(CalM).cuda()
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    idx = torch.rand((H, Ns), device="cuda", generator=g).argsort(dim=1)[:, :n].to(torch.int32).contiguous()
+    ctx = api.Context(0)                                                      # default options
+    whole = ctx.pose_sampled(method, d_scene, calm, idx)
+    for chunk in (37, 1500):
+        parts = [ctx.pose_sampled(method, d_scene, calm, idx[s:s + chunk].contiguous()) for s in range(0, H, chunk)]
+        for key in ("R_t_2", "R_t_3", "T"):
+            got = torch.cat([p[key] for p in parts]).cpu().numpy(); ref = whole[key].cpu().numpy()
+            assert np.array_equal(got, ref, equal_nan=True), (key, chunk)
+        assert torch.equal(torch.cat([p["status"] for p in parts]), whole["status"])

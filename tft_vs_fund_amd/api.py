@@ -190,6 +190,10 @@ class Context:
         HBM traffic near the algorithmic bytes); False (default) = it goes to global slices when that raises the occupancy."""
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_SPILL, int(bool(on))), "set_option")
 
+    def set_count_rows(self, on):
+        """TFF_OPT_COUNT_ROWS: inlier counts with four hypotheses per wavefront (default) or one."""
+        _check(self.lib, self.lib.tff_ctx_set_option(self.handle, 11, int(bool(on))), "set_option")
+
     def set_rows(self, on):
         """TFF_OPT_ROWS: "auto" or 2 (default) = by batch size (four triplets per wavefront, one per row of 16 lanes, once the batch no longer fits
         the device in one go; one per wavefront below); True / 1 = the row kernels always; False / 0 = never."""

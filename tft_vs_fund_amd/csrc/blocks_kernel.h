@@ -236,6 +236,75 @@ __global__ void __launch_bounds__(64 * INLIER_WG_WAVES, 4) k_inlier_count_staged
     }
 }
 
+// The same counts with FOUR hypotheses per wavefront, one per row of 16 lanes (round 5): a wavefront per hypothesis spends a fifth of its instructions on
+// work that is the same for all its lanes -- composing three cameras on three lanes, pinning 36 camera entries and the ten entries of Z to scalar
+// registers -- and its seventh trip over a 400-correspondence scene runs 16 lanes of 64.  Here a row composes its hypothesis's cameras once into its own
+// 36 doubles of LDS, every position keeps them in vector registers, and 25 trips of 16 cover the scene exactly.  Per correspondence the same expressions
+// as above (certain-outlier pivot test, then the certified DLT ladder): identical counts (tests/test_gpu_blocks.py).
+__global__ void __launch_bounds__(64 * INLIER_WG_WAVES, 2) k_inlier_count_rows(const ReprErrorArgs a) {
+    TFF_DYNAMIC_LDS(double, smem);
+    double* scene = smem;                                                    // 6 N doubles
+    const int lane = lane_id(), p = lane & 15, row = lane >> 4;
+    double* camw = smem + 6 * (size_t)a.N + 36 * (4 * wave_in_block() + row);   // the row's three cameras (row-major 3 x 4)
+    {
+        const double2* s2 = reinterpret_cast<const double2*>(a.corresp);
+        double2* d2 = reinterpret_cast<double2*>(scene);
+        for (int i = thread_in_block(); i < 3 * a.N; i += 64 * INLIER_WG_WAVES) d2[i] = s2[i];
+    }
+    __syncthreads();
+    for (long b0 = ((long)blockIdx.x * INLIER_WG_WAVES + wave_in_block()) * 4; b0 < a.B; b0 += (long)gridDim.x * INLIER_WG_WAVES * 4) {
+        const bool valid = b0 + row < a.B;
+        const long b = valid ? b0 + row : a.B - 1;                           // (a tail row repeats the last hypothesis and does not store)
+        wave_sync();
+        if (p < 3) {
+            const Mat3 K = load_K(a.calm, p);
+            double Rt[12];                                                   // row-major pose of view p
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                const int r = e >> 2, c = e & 3;
+                Rt[e] = (p == 0) ? ((r == c) ? 1.0 : 0.0) : ((p == 1) ? a.Rt2[b * 12 + r + 3 * c] : a.Rt3[b * 12 + r + 3 * c]);
+            }
+            compose_camera_from_pose(K, Rt, camw + 12 * p);
+        }
+        wave_sync();
+        double P[3][12];
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int c = 0; c < 12; ++c) P[v][c] = camw[12 * v + c];
+        double Zt[4][4];
+        const double k2 = 2.0 * a.thr * a.thr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) Zt[i][j] = k2 * (P[0][8 + i] * P[0][8 + j] + P[1][8 + i] * P[1][8 + j] + P[2][8 + i] * P[2][8 + j]);
+        int cnt = 0;
+#pragma unroll 1
+        for (int i = p; i < a.N; i += 16) {
+            const Pt6 q = load_pt(scene, i);
+            double S[4][4], X[4];
+            tri_zero(S);
+            tri_accum(S, P[0], q.v[0], q.v[1]);
+            tri_accum(S, P[1], q.v[2], q.v[3]);
+            tri_accum(S, P[2], q.v[4], q.v[5]);
+            if (certainly_positive_definite(S, Zt)) continue;
+            dlt_point_solve<true, true>(S, camw, camw + 12, camw + 24, true, q.v[0], q.v[1], q.v[2], q.v[3], q.v[4], q.v[5], X);
+            bool in = true;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const double u = P[v][0] * X[0] + P[v][1] * X[1] + P[v][2] * X[2] + P[v][3] * X[3];
+                const double w2 = P[v][4] * X[0] + P[v][5] * X[1] + P[v][6] * X[2] + P[v][7] * X[3];
+                const double z = P[v][8] * X[0] + P[v][9] * X[1] + P[v][10] * X[2] + P[v][11] * X[3];
+                const double dx = u / z - q.v[2 * v], dy = w2 / z - q.v[2 * v + 1];
+                in = in && (fabs(dx) <= a.thr) && (fabs(dy) <= a.thr);     // sum(abs(residuals) > th, 1) == 0
+            }
+            cnt += in ? 1 : 0;
+        }
+        const double tot = row_sum16((double)cnt);
+        if (p == 0 && valid) a.inliers[b] = (int)tot;
+    }
+}
+
 // ---- transform_TFT ----------------------------------------------------------------------------
 struct TransformArgs {
     const double* T;         // B x 27

@@ -67,6 +67,8 @@ struct tff_ctx {
     int pre = 0;                           // TFF_OPT_PRE: 0 never (default: measured slower, see pre_for), 1 always, 2 from N >= 48
     int dbg_fp_handover = 0;               // TFF_OPT_DEBUG_FP_HANDOVER
     int dbg_adaptive = 0;                  // TFF_OPT_DEBUG_ADAPTIVE
+    int count_rows = 1;                    // TFF_OPT_COUNT_ROWS: inlier counts four hypotheses per wavefront (default) or one
+    int64_t route_B = 0;                   // > 0: the batch size rows_for() decides by (multi-GPU shards: the whole batch), else the call's own B
 };
 
 namespace {
@@ -75,8 +77,12 @@ namespace {
 // to 1.7x (N = 500) as long as a one-triplet wavefront, and a batch that fits the device's 2048 wavefront slots in one go pays that latency
 // for nothing.  Measured (tools/ab_rows_sweep.py, ms per batch, rows / one-triplet): N = 200: B = 256 0.075 / 0.059, 1024 0.077 / 0.079,
 // 3072 0.085 / 0.125; N = 500: B = 1024 0.125 / 0.103, 2048 0.138 / 0.118, 3072 0.140 / 0.178; LinearF alike.  TFF_OPT_ROWS = 0 / 1 force a route.
+// The route decides a triplet's last bits (1e-14), so it must not depend on how a job is cut up: sampled hypotheses (RANSAC chunks of any size) always
+// take the row kernels, and the shards of a multi-GPU call are routed by the size of the WHOLE batch (route_B, set by tff_pose_batch_*_multi).
 bool rows_for(const tff_ctx* c, int64_t B, int32_t N) {
     if (c->rows != 2) return c->rows != 0;
+    if (c->sample_idx) return true;
+    if (c->route_B > 0) B = c->route_B;
     return B >= (N <= 256 ? 1024 : 2048 + 1);
 }
 
@@ -640,6 +646,7 @@ int tff_ctx_set_option(tff_ctx* c, int option, long value) {
         case TFF_OPT_SPILL: c->spill_only_if_needed = value != 0; return 0;
         case TFF_OPT_ROWS: if (value < 0 || value > 2) return fail(TFF_E_INVALID, "rows must be 0, 1 or 2"); c->rows = (int)value; return 0;
         case TFF_OPT_PRE: if (value < 0 || value > 2) return fail(TFF_E_INVALID, "pre must be 0, 1 or 2"); c->pre = (int)value; return 0;
+        case TFF_OPT_COUNT_ROWS: c->count_rows = value != 0; return 0;
         case TFF_OPT_DEBUG_FP_HANDOVER: c->dbg_fp_handover = value != 0; return 0;
         case TFF_OPT_DEBUG_ADAPTIVE: c->dbg_adaptive = value != 0; return 0;
         case TFF_OPT_KERNEL: if (value < 0 || value > 2) return fail(TFF_E_INVALID, "kernel must be 0, 1 or 2"); c->kernel_variant = (int)value; return 0;
@@ -826,7 +833,16 @@ int tff_inlier_count_batch_dev(tff_ctx* c, const double* scene, int32_t Ns, cons
         const int per_cu = (int)((LDS_LIMIT / (staged + 512) < 4) ? LDS_LIMIT / (staged + 512) : 4);
         long grid = 256L * per_cu;
         if (grid * tff::INLIER_WG_WAVES > B) grid = (B + tff::INLIER_WG_WAVES - 1) / tff::INLIER_WG_WAVES;
-        hipLaunchKernelGGL(tff::k_inlier_count_staged, dim3((unsigned)grid), dim3(64 * tff::INLIER_WG_WAVES), staged, c->stream, a);
+        if (c->count_rows) {                                                 // four hypotheses per wavefront (blocks_kernel.h::k_inlier_count_rows): two workgroups per CU
+            const size_t staged_rows = ((size_t)6 * Ns + 36 * 4 * tff::INLIER_WG_WAVES) * sizeof(double);
+            long grid_rows = 256L * 2;
+            const long per_wg = 4L * tff::INLIER_WG_WAVES;
+            if (grid_rows * per_wg > B) grid_rows = (B + per_wg - 1) / per_wg;
+            if (int r = ensure_lds(tff::k_inlier_count_rows, staged_rows)) return r;
+            hipLaunchKernelGGL(tff::k_inlier_count_rows, dim3((unsigned)grid_rows), dim3(64 * tff::INLIER_WG_WAVES), staged_rows, c->stream, a);
+        } else {
+            hipLaunchKernelGGL(tff::k_inlier_count_staged, dim3((unsigned)grid), dim3(64 * tff::INLIER_WG_WAVES), staged, c->stream, a);
+        }
     } else {
         hipLaunchKernelGGL(tff::k_repr_error, dim3(tff::pose_grid(B)), dim3(64), 0, c->stream, a);
     }
@@ -1190,9 +1206,11 @@ int tff_pose_batch_host_multi(tff_multi* m, int32_t method, const double* corres
             int64_t b0, b1;
             tff_multi_shard(m, B, g, &b0, &b1);
             if (b1 <= b0) return;
+            m->ctx[g]->route_B = B;                                          // every shard takes the route of the whole batch
             rc[g] = pose_batch_host(launch, m->ctx[g], corresp + b0 * 6 * (int64_t)N, calm + b0 * calm_stride, calm_stride, b1 - b0, N,
                                     Rt2 + b0 * 12, Rt3 + b0 * 12, T + b0 * 27, reconst ? reconst + b0 * 3 * (int64_t)N : nullptr,
                                     iter ? iter + b0 : nullptr, status ? status + b0 : nullptr);
+            m->ctx[g]->route_B = 0;
             if (rc[g] != 0) msg[g] = g_err;                                  // tff_last_error() is thread-local: carry it over
         });
     }
@@ -1238,8 +1256,10 @@ int tff_pose_batch_dev_multi(tff_multi* m, int32_t method, const double* const* 
                 if (e != hipSuccess) { rc[g] = hip_fail(e, "hipMemsetAsync(record block)"); msg[g] = g_err; return; }
             }
             if (b1 <= b0) return;
+            m->ctx[g]->route_B = B;                                          // every shard takes the route of the whole batch
             rc[g] = launch(m->ctx[g], corresp[g], calm[g], calm_stride, b1 - b0, N, blk, blk + chunk * 12, blk + chunk * 24, nullptr, nullptr,
                            sblk, nullptr);
+            m->ctx[g]->route_B = 0;
             if (rc[g] != 0) msg[g] = g_err;
         });
     }

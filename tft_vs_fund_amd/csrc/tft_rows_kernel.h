@@ -569,6 +569,7 @@ __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const R
     bool main1[2] = {false, false};                                          // the row's main candidate is Rp
     bool evalA = true, evalB[2] = {true, true};                              // wave-uniform: what the running sweep evaluates
     bool fullB[2] = {true, true};                                            // wave-uniform: B covers every trip
+    bool rowB[2] = {true, true};                                             // per ROW: this row's pick needs B's score (what a neighbour needs must not reach this row's result)
     int sweeps = 0;
     double snum = 0.0, sden = 0.0;
     bool sconv = true;
@@ -644,6 +645,7 @@ __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const R
                         offA[call] = 12 + 24 * call; offB[call] = 24 * call;
                         if (SPEC && call == 0) fA = fB;
                     }
+                    rowB[call] = !single;
                     evalB[call] = wave_any(!single);                         // some row of the wavefront needs both candidates of this pair
                     fullB[call] = evalB[call];
                 }
@@ -679,6 +681,8 @@ __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const R
 #pragma unroll
         for (int call = 0; call < 2; ++call) {
             const int tA = (int)row_sum16((double)scA[call]);                // |score| <= 2 N: exact
+            const bool mine = !rowB[call] && tA != 2 * N && tA != -2 * N;    // this row's main candidate fell short: its partner's score decides
+            rowB[call] = rowB[call] || mine;
             const bool need = wave_any(!fullB[call] && tA != 2 * N && tA != -2 * N);
             evalB[call] = need;
             fullB[call] = fullB[call] || need;
@@ -691,9 +695,12 @@ __device__ __forceinline__ bool rows_votes(const RowSrc& s, const int N, const R
 #pragma unroll
     for (int call = 0; call < 2; ++call) {
         const int tA = (int)row_sum16((double)scA[call]);
-        const int tB = fullB[call] ? (int)row_sum16((double)scB[call]) : 0;
+        // B's score and certificate count for a row only when the ROW needs them -- B may have been evaluated in full because a neighbour did: a
+        // triplet's result (and whether it is handed to the exact kernel) never depends on the wavefront it travels in
+        const int tBsum = (int)row_sum16((double)scB[call]);
+        const int tB = (fullB[call] && rowB[call]) ? tBsum : 0;
         const bool badA = row_any(!certA[call]), badB = row_any(!certB[call]);
-        ok = ok && !badA && (!fullB[call] || !badB);
+        ok = ok && !badA && (!(fullB[call] && rowB[call]) || !badB);
         if (cert_out) {                                                      // (with all4: A = (R,t), B = (Rp,t), both evaluated over every trip)
             cert_out[2 * call] = main1[call] ? !badB : !badA;
             cert_out[2 * call + 1] = main1[call] ? !badA : !badB;
