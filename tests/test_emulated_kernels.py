@@ -811,7 +811,7 @@ def test_rows_exact_kernels_score_contaminated_minimal_samples_like_the_one_trip
     """Minimal samples of a scene with gross outliers (config 4): most fast votes are not certified, so the exact re-score runs -- for N <= 8 with the two
     candidates of an essential matrix side by side in a row's sixteen positions (rows_vote_exact_pair).  All eight scores equal the one-triplet exact
     kernel's, and so do the poses."""
-    Ns, B = 60, 8
+    Ns, B = 60, 4
     Cs, CalM, _, _ = generate_scene_batch(1, Ns, noise=0.5, seed=77)
     scene = Cs[0].copy()
     rng = np.random.default_rng(5)
@@ -821,7 +821,7 @@ def test_rows_exact_kernels_score_contaminated_minimal_samples_like_the_one_trip
     out = run_linear_tft(emu, C, CalM, entry=entry, debug=True)
     ref = run_linear_tft(emu, C, CalM, flags=FLAG_JACOBI, entry=ref_entry)
     live = (out["status"] == 0) & (ref["status"] == 0)
-    assert live.sum() >= B - 2 and np.array_equal(out["status"] == 3, ref["status"] == 3)
+    assert live.sum() >= B - 1 and np.array_equal(out["status"] == 3, ref["status"] == 3)
     so, sw = out["debug"][:, 60:68].reshape(B, 2, 4), ref["debug"][:, 60:68].reshape(B, 2, 4)
     assert np.array_equal(so[live], sw[live])
     for b in np.nonzero(live)[0]:
