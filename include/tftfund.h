@@ -81,16 +81,11 @@ typedef struct tff_ctx tff_ctx;
                              * 2 workgroup kernels always (the same as 0 now) */
 #define TFF_OPT_ROWS 7      /* LinearTFT / LinearF pose kernels, and the linear stage + pose tail of the iterative methods: 1 four triplets per wavefront,
                              * one per row of 16 lanes (csrc/tft_rows_kernel.h, f_rows_kernel.h, gh_rows_kernel.h, optimf_rows_kernel.h); 0 one triplet
-                             * per wavefront (csrc/tft_kernel.h, f_kernel.h); 2 (default):
-                             *   - the two LINEAR methods go by batch size: the row kernels (2.5x fewer instructions per triplet) once the batch no
-                             *     longer fits the device's wavefront slots in one go (B >= 1024, or > 2048 when N > 256), the one-triplet kernels
-                             *     (shorter latency) below.  The two routes agree to rounding (1e-14), so a linear result's last bits may depend on
-                             *     the size of the batch it arrives in; set 0 or 1 where that matters.  Two kinds of call never depend on how a job is
-                             *     cut up: the *_sampled_dev entry points (RANSAC chunks of any size) always take the row kernels, and the shards of a
-                             *     tff_pose_batch_*_multi call are routed by the size of the WHOLE batch;
-                             *   - the ITERATIVE methods (OptimF, Ressl, Nordberg, FaugPapa, Pi, PiCol) always take the row kernels (round 5): their
-                             *     iteration amplifies a last bit of its start, so their route must not depend on the batch size -- the same triplet
-                             *     gives the same bits and the same `iter` in any batch.
+                             * per wavefront (csrc/tft_kernel.h, f_kernel.h: the lowest latency for batches under ~1 000 triplets, ~16 us less per call); 2 (default)
+                             * = 1 for every method and every batch size since the end of round 5.  (Before, the two linear methods went by batch size;
+                             * the two routes agree to 1e-14 but not bit for bit, so a triplet's last bits depended on the batch it arrived in.)  With the
+                             * default the same triplet gives the same bits -- and, for the iterative methods, the same `iter` -- in a batch of one, of 1 023
+                             * or of a million, through the *_sampled_dev entry points in chunks of any size, and in any shard of a multi-GPU call.
                              * Whatever the route: a triplet with status != 0 has NaN in every output (T, R_t_2, R_t_3, Reconst) */
 #define TFF_OPT_PRE 10      /* trifocal row kernels (TFF_OPT_ROWS route): where the three Normalize2Ddata calls and the 96 moment sums of linearTFT's system are
                              * computed.  0 (default) = inside the row kernels (two passes over the correspondences); 1 = in a kernel of their own, one triplet

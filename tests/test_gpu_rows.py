@@ -170,35 +170,36 @@ def test_exact_rows_kernel_against_the_one_triplet_exact_kernel(gpu_ctx, method,
 
 
 @pytest.mark.parametrize("method", ["LinearTFTPoseEstimation", "LinearFPoseEstimation"])
-def test_default_route_goes_by_batch_size(method):
-    """TFF_OPT_ROWS = 2 (the default of a new context), the two LINEAR methods: bit-identical to the one-triplet kernels on a batch that fits the
-    device in one go, to the row kernels on a large one (include/tftfund.h; the crossover is measured: tools/ab_rows_sweep.py)."""
+def test_default_route_is_the_row_kernels_at_any_batch_size(method):
+    """TFF_OPT_ROWS = 2 (the default of a new context) is the row kernels whatever the batch size since the end of round 5 (include/tftfund.h): bit-identical
+    to TFF_OPT_ROWS = 1 from one triplet to 6 000, minimal samples included, and NOT to the one-triplet kernels (the two routes differ in the last bits,
+    which is why the route must not depend on the batch)."""
     import torch
     from tft_vs_fund_amd import api
     from tft_vs_fund_amd.scenes import generate_scene_batch
-    calm = None
-    for B, N, expect in [(300, 100, 0), (1023, 200, 0), (1024, 200, 1), (2048, 300, 0), (2049, 300, 1), (6000, 100, 1)]:
+    for B, N in [(1, 100), (7, 9), (300, 100), (1023, 200), (1024, 200), (2049, 300), (6000, 100)]:
         C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=B)
         d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
         auto = api.Context(0)
         forced = api.Context(0)
-        forced.set_rows(expect)
+        forced.set_rows(1)
         other = api.Context(0)
-        other.set_rows(1 - expect)
+        other.set_rows(0)
         a = auto.pose_batch(method, d, calm, reconst=False)
         f = forced.pose_batch(method, d, calm, reconst=False)
         o = other.pose_batch(method, d, calm, reconst=False)
         for k in ("T", "R_t_2", "R_t_3", "iter", "status"):
             assert torch.equal(a[k], f[k]), (B, N, k)
-        assert not torch.equal(a["T"], o["T"])                               # (the two routes differ in the last bits, so the check above says which one ran)
+        if B >= 300:
+            assert not torch.equal(a["T"], o["T"])                           # (so the check above says which route ran)
         with pytest.raises(Exception):
             auto.set_rows(3)
 
 
 @pytest.mark.parametrize("method", ["ResslTFTPoseEstimation", "NordbergTFTPoseEstimation", "FaugPapaTFTPoseEstimation", "PiPoseEstimation", "PiColPoseEstimation",
-                                    "OptimFPoseEstimation"])
+                                    "OptimFPoseEstimation", "LinearTFTPoseEstimation", "LinearFPoseEstimation"])
 def test_iterative_methods_do_not_depend_on_the_batch_a_triplet_arrives_in(method):
-    """The iterative methods amplify a last-bit difference of their start (the exit test of Gauss_Helmert.m:71-82 can flip on it), so the library's
+    """(All eight methods since the end of round 5: the linear ones no longer pick their kernel by batch size either.)  The iterative methods amplify a last-bit difference of their start (the exit test of Gauss_Helmert.m:71-82 can flip on it), so the library's
     DEFAULT route for them must not depend on the batch size (capi.hip::rows_for_iterative): the same 40 triplets alone, at the head of a batch
     of 1023 and scattered through a batch of 1024 / 2500 give bit-identical T, R_t_2, R_t_3 and the same `iter` and status."""
     import torch

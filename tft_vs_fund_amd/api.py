@@ -195,8 +195,8 @@ class Context:
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, 11, int(bool(on))), "set_option")
 
     def set_rows(self, on):
-        """TFF_OPT_ROWS: "auto" or 2 (default) = by batch size (four triplets per wavefront, one per row of 16 lanes, once the batch no longer fits
-        the device in one go; one per wavefront below); True / 1 = the row kernels always; False / 0 = never."""
+        """TFF_OPT_ROWS: "auto" / 2 (default) and True / 1 = the row kernels (four triplets per wavefront, one per row of 16 lanes) at any batch size:
+        a triplet's bits do not depend on the batch it arrives in; False / 0 = one triplet per wavefront (lowest latency for small batches)."""
         v = 2 if on == "auto" else (int(on) if isinstance(on, int) and not isinstance(on, bool) else int(bool(on)))
         _check(self.lib, self.lib.tff_ctx_set_option(self.handle, TFF_OPT_ROWS, v), "set_option")
 

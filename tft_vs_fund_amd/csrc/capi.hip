@@ -68,7 +68,6 @@ struct tff_ctx {
     int dbg_fp_handover = 0;               // TFF_OPT_DEBUG_FP_HANDOVER
     int dbg_adaptive = 0;                  // TFF_OPT_DEBUG_ADAPTIVE
     int count_rows = 1;                    // TFF_OPT_COUNT_ROWS: inlier counts four hypotheses per wavefront (default) or one
-    int64_t route_B = 0;                   // > 0: the batch size rows_for() decides by (multi-GPU shards: the whole batch), else the call's own B
 };
 
 namespace {
@@ -76,15 +75,13 @@ namespace {
 // Four triplets per wavefront or one?  The row kernels issue ~2.5x fewer instructions per triplet, but a wavefront of theirs lives ~1.3x (N = 200)
 // to 1.7x (N = 500) as long as a one-triplet wavefront, and a batch that fits the device's 2048 wavefront slots in one go pays that latency
 // for nothing.  Measured (tools/ab_rows_sweep.py, ms per batch, rows / one-triplet): N = 200: B = 256 0.075 / 0.059, 1024 0.077 / 0.079,
-// 3072 0.085 / 0.125; N = 500: B = 1024 0.125 / 0.103, 2048 0.138 / 0.118, 3072 0.140 / 0.178; LinearF alike.  TFF_OPT_ROWS = 0 / 1 force a route.
-// The route decides a triplet's last bits (1e-14), so it must not depend on how a job is cut up: sampled hypotheses (RANSAC chunks of any size) always
-// take the row kernels, and the shards of a multi-GPU call are routed by the size of the WHOLE batch (route_B, set by tff_pose_batch_*_multi).
-bool rows_for(const tff_ctx* c, int64_t B, int32_t N) {
-    if (c->rows != 2) return c->rows != 0;
-    if (c->sample_idx) return true;
-    if (c->route_B > 0) B = c->route_B;
-    return B >= (N <= 256 ? 1024 : 2048 + 1);
-}
+// 3072 0.085 / 0.125; N = 500: B = 1024 0.125 / 0.103, 2048 0.138 / 0.118, 3072 0.140 / 0.178; LinearF alike.
+// Until the end of round 5 the default (TFF_OPT_ROWS = 2) went by batch size for the two linear methods.  The two routes agree to 1e-14 but not bit for
+// bit, so a triplet's last bits depended on the batch it arrived in -- a hazard the reference (one deterministic call per triplet) does not have, for
+// ~16 microseconds of latency on calls whose launch + transfer overhead is ten times that.  The default now is the row kernels at ANY batch size, for
+// every method: same triplet, same bits, in a batch of one, of 1 023 or of a million, sampled or not, sharded or not.  TFF_OPT_ROWS = 0 still forces the
+// one-triplet kernels (lowest latency for batches under ~1 000 triplets), 1 is the same as the default.
+bool rows_for(const tff_ctx* c, int64_t /*B*/, int32_t /*N*/) { return c->rows != 0; }
 
 // The iterative methods (Gauss-Helmert on T / F / the Pi matrices) amplify a last-bit difference of their start, so for them the route must not
 // depend on the batch size: whatever B, the linear stage and the pose tail run four triplets per wavefront unless TFF_OPT_ROWS = 0 forces the
@@ -1206,11 +1203,9 @@ int tff_pose_batch_host_multi(tff_multi* m, int32_t method, const double* corres
             int64_t b0, b1;
             tff_multi_shard(m, B, g, &b0, &b1);
             if (b1 <= b0) return;
-            m->ctx[g]->route_B = B;                                          // every shard takes the route of the whole batch
             rc[g] = pose_batch_host(launch, m->ctx[g], corresp + b0 * 6 * (int64_t)N, calm + b0 * calm_stride, calm_stride, b1 - b0, N,
                                     Rt2 + b0 * 12, Rt3 + b0 * 12, T + b0 * 27, reconst ? reconst + b0 * 3 * (int64_t)N : nullptr,
                                     iter ? iter + b0 : nullptr, status ? status + b0 : nullptr);
-            m->ctx[g]->route_B = 0;
             if (rc[g] != 0) msg[g] = g_err;                                  // tff_last_error() is thread-local: carry it over
         });
     }
@@ -1256,10 +1251,8 @@ int tff_pose_batch_dev_multi(tff_multi* m, int32_t method, const double* const* 
                 if (e != hipSuccess) { rc[g] = hip_fail(e, "hipMemsetAsync(record block)"); msg[g] = g_err; return; }
             }
             if (b1 <= b0) return;
-            m->ctx[g]->route_B = B;                                          // every shard takes the route of the whole batch
             rc[g] = launch(m->ctx[g], corresp[g], calm[g], calm_stride, b1 - b0, N, blk, blk + chunk * 12, blk + chunk * 24, nullptr, nullptr,
                            sblk, nullptr);
-            m->ctx[g]->route_B = 0;
             if (rc[g] != 0) msg[g] = g_err;
         });
     }
