@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 rocprofv3 evidence for every method bench.py reports (kernel trace + four separate PMC passes each; program directly after `--`).
-# Usage: bash tools/gpu_profile_r5.sh [tags...]   tags: headline headline1 ressl nordberg faugpapa pi picol linearf optimf config4tft config4f
+# Usage: bash tools/gpu_profile_r5.sh [tags...]   tags: headline headline1 ressl nordberg faugpapa pi picol linearf optimf config4tft config4f config4count
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/r5
 run_one() {   # tag, command, kernel substring, units per launch, algorithmic bytes per launch, waves per SIMD
@@ -34,6 +34,7 @@ for T in ${@:-headline headline1 ressl nordberg faugpapa pi picol linearf optimf
     linearf)    run_one linearf "python3 $R/tools/bench_one.py LinearFPoseEstimation 20" "k_linear_f_pose_rows" 10000 $ALG 2;;
     optimf)     run_one optimf "python3 $R/tools/bench_one.py OptimFPoseEstimation 10" "k_optimf_refine" 10000 $ALG 2;;
     config4tft) run_one config4tft "python3 $R/tools/config4_split.py 1000000" "k_linear_tft_pose_rows_exact" 1000000 $((1000000 * 440)) 2;;
+    config4count) run_one config4count "python3 $R/tools/config4_split.py 1000000" "k_inlier_count_rows" 1000000 $((1000000 * 196)) 2;;   # per hypothesis: two poses in (192 B), one int32 out; the 19 KB scene is staged once per workgroup
     config4f)   run_one config4f "python3 $R/tools/config4_split.py 1000000" "k_linear_f_pose_rows_exact" 1000000 $((1000000 * 444)) 2;;
   esac
 done
