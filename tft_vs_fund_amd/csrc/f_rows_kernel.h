@@ -243,6 +243,7 @@ __device__ __forceinline__ bool rows_linear_f_middle_exact(RowLds* w, RowRt* rt,
         }
         wave_sync();
     }
+    rows_stamp(dbg, 4);
     bool ok = true;
 #pragma unroll 1
     for (int pair = 0; pair < 2; ++pair) {                                   // linearF(x1,x2), linearF(x1,x3): rows h1 (x) h2, position 3a + b (linearF.m:48-53)
@@ -261,6 +262,7 @@ __device__ __forceinline__ bool rows_linear_f_middle_exact(RowLds* w, RowRt* rt,
         if (dbg && p == 0) dbg[69 + pair] = (double)(20000 + its);
         if (p < 9) Fm[9 * pair + 3 * (p % 3) + p / 3] = x0;                  // F = reshape(V(:,9),3,3), row-major
         wave_sync();
+        rows_stamp(dbg, 5 + pair);
     }
     if (p < 2) {
         const int v2 = p + 1;

@@ -39,6 +39,10 @@ for method, n in (("LinearTFTPoseEstimation", 7), ("LinearFPoseEstimation", 8)):
           % (its[:, 0].mean(), its[:, 1].mean(), per_wave[:, 0].mean(), per_wave[:, 1].mean(), np.percentile(its[:, 0], 99), np.percentile(its[:, 1], 99)))
     for k, nme in enumerate(names):
         print("  %-42s %9.0f  %5.1f%%" % (nme, dt[:, k].mean(), 100 * dt[:, k].mean() / tot.mean()))
+    if n == 8:                                                                # inside the eight-point kernel's middle
+        sm = dbg[good][:, [81, 84, 85, 86, 82]]
+        for nme, v in zip(["linearF's own normalisation", "N x 9 system + QR + inverse iteration, pair (1,2)", "the same, pair (1,3)", "de-normalisation, rank 2, E (two positions)"], np.diff(sm, axis=1).T):
+            print("      %-50s %9.0f  %5.1f%%" % (nme, v.mean(), 100 * v.mean() / tot.mean()))
     if n == 7:                                                                # inside the seven-point kernel's middle
         sm = dbg[good][:, [81, 84, 85, 86, 87, 82]]
         for nme, v in zip(["4N x 27 system + Householder QR", "inverse iteration, 27 columns", "epipoles + frames", "R Up + QR, 15 columns", "inverse iteration, 15 columns + t"], np.diff(sm, axis=1).T):
