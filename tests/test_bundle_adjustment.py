@@ -176,6 +176,13 @@ def test_gpu_bundle_adjustment_views(gpu_ctx):
             Ro, Xo, ito, erro = _oracle_ba(*c)
             assert int(out["status"][b]) == 0 and int(out["iter"][b]) == ito and abs(float(out["repr_err"][b]) - erro) <= 1e-9 * erro
             assert rel_err(out["R_t"][b].cpu().numpy(), Ro) < 1e-9 and rel_err(out["Reconst"][b].cpu().numpy(), Xo) < 1e-9
+    # one calibration per problem (calm_stride = 9 M): the same bits as the shared calibration
+    cases = [_views_case(4, 40, sd, False, True, None) for sd in (3, 8, 9)]
+    R0 = np.stack([c[1] for c in cases]); C = np.stack([np.ascontiguousarray(c[2].T) for c in cases])
+    shared = gpu_ctx.bundle_adjust_views(cases[0][0], R0, C, None)
+    per_item = gpu_ctx.bundle_adjust_views(np.stack([cases[0][0]] * 3), R0, C, None)
+    for k in ("R_t", "Reconst", "iter", "repr_err", "status"):
+        assert torch.equal(shared[k], per_item[k]), k
     # host-pointer entry point, MATLAB layouts straight through
     M, N = 4, 40
     CalM, R0, Cm, _ = _views_case(M, N, 3, False, True, None)
