@@ -322,3 +322,28 @@ def test_sampled_hypotheses_do_not_depend_on_the_chunk_they_arrive_in(method, n)
             got = torch.cat([p[key] for p in parts]).cpu().numpy(); ref = whole[key].cpu().numpy()
             assert np.array_equal(got, ref, equal_nan=True), (key, chunk)
         assert torch.equal(torch.cat([p["status"] for p in parts]), whole["status"])
+
+
+@pytest.mark.parametrize("N", [40, 200])
+def test_picol_plain_solve_with_certificate_agrees_with_the_eigen_decomposition(N):
+    """PiColPoseEstimation's 38 x 38 KKT system (Gauss_Helmert.m:67, `pinv(M + 1e-12 I) * b`): the block kernel solves it by elimination when Sturm counts certify
+    that pinv's tolerance truncates nothing (pi_wg_kernel.h::pi_spectrum_clears_tolerance; nearly every scene at N = 40, about half at N = 200) and by the
+    eigen-decomposition otherwise; the fused kernel (TFF_OPT_KERNEL = 1) always takes the eigen-decomposition.  Same iteration counts, same poses."""
+    import torch
+    from tft_vs_fund_amd import api
+    from tft_vs_fund_amd.scenes import generate_scene_batch
+    B = 600
+    C, CalM, _, _ = generate_scene_batch(B, N, noise=1.0, seed=909 + N)
+    d = torch.from_numpy(C).cuda(); calm = torch.from_numpy(CalM).cuda()
+    blk = api.Context(0)
+    fused = api.Context(0); fused.set_kernel_variant(1)
+    a = blk.pose_batch("PiColPoseEstimation", d, calm, reconst=False)
+    f = fused.pose_batch("PiColPoseEstimation", d, calm, reconst=False)
+    ok = (a["status"] == 0) & (f["status"] == 0)
+    assert int(ok.sum()) >= B - 3
+    same_it = (a["iter"] == f["iter"]) & ok
+    assert int(same_it.sum()) >= int(0.99 * B)
+    Ta = a["T"][same_it].reshape(-1, 27); Tf = f["T"][same_it].reshape(-1, 27)
+    s = torch.sign((Ta * Tf).sum(dim=1, keepdim=True))
+    assert float((s * Ta - Tf).abs().max()) < 1e-6
+    assert float((a["R_t_3"][same_it] - f["R_t_3"][same_it]).abs().max()) < 1e-6

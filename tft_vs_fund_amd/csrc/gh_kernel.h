@@ -282,8 +282,10 @@ __device__ inline void gh_sweep(const GhWork& g, int N) {
 // with partial pivoting and no physical row exchange -- the pivot row of column k is the not-yet-used lane with
 // the largest |a[k]|, broadcast by v_readlane; at the end the lane that served as pivot of column k holds x_k.
 // ~n^2 readlanes + n^2/2 FMAs per lane and no LDS traffic inside the loop.
+// min_pivot_rel: a pivot at or below this fraction of the largest entry makes the solve report failure (callers whose fall-back is the truncated
+// pseudo-inverse: 1e-10; PiCol, which certifies the spectrum separately -- pi_wg_kernel.h --: 1e-15).
 template <int n>
-__device__ inline bool wave_solve_gj(const double* M, double* sol) {
+__device__ inline bool wave_solve_gj(const double* M, double* sol, const double min_pivot_rel = 1e-10) {
     constexpr int ld = n + 1;
     const int lane = lane_id();
     const bool valid = lane < n;
@@ -305,7 +307,7 @@ __device__ inline bool wave_solve_gj(const double* M, double* sol) {
     for (int k = 0; k < n; ++k) {
         const double v = active ? fabs(a[k]) : -1.0;
         const double best = (n <= 32) ? wave_max32_finite(v) : wave_max(v);  // rows live in lanes 0..n-1
-        if (!(best > 1e-10 * amax)) ok = false;
+        if (!(best > min_pivot_rel * amax)) ok = false;
         int p = wave_first_lane(active && v == best);                        // wave-uniform
         p = (p < 64) ? p : 0;
         const double ipiv = 1.0 / wave_bcast(a[k], p);

@@ -7,12 +7,48 @@
 #pragma once
 #include "pi_kernel.h"
 #include "gh_wg_kernel.h"
+#include "wave_trid.h"
 
 namespace tff {
 
 // + SN N: the strong direction(s) of every weight block, see the factored weights below -- Pi (4 x 4 blocks, one near-null direction): n (4), cs,
 // n'w; PiCol (5 x 5 blocks, five equations for three independent constraints: TWO near-null directions): n1, n2 (5 each), cs1, cs2, n1'w, n2'w
 __host__ __device__ constexpr int pi_sn(int E) { return (E == 4) ? 6 : 14; }
+// true when the symmetric n x n matrix M (augmented n x (n+1) array, untouched) has NO eigenvalue in [-4 tol, 4 tol), tol = n eps(|M|_2) MATLAB's pinv
+// tolerance: pinv(M) then truncates nothing and equals inv(M).  A copy of M (V: n (n+1) doubles) is reduced to tridiagonal form (wave_trid.h: an orthogonal
+// similarity; its backward error, a few u |M|, is ~0.05 tol -- a direction pinv would truncate shows up well inside the interval, and the factor 4 also covers a
+// largest eigenvalue that sits within rounding of a power of two, where eps(|M|_2) is a coin toss for anyone.  Measured at 10 000 x 200, where the Schur
+// complement of the constraints puts the smallest |eigenvalue| at tol-scale -- it falls like 1 / N, tol grows like N --: 52 % of the scenes are certified
+// (54 % with 2 tol, 38 % with 16 x the Gershgorin-bound tolerance); at N <= 100 nearly all).  Sturm counts do the rest: the binade of
+// |M|_2 from counts at the two powers of two under its Gershgorin bound (which exceeds it by at most 3x), then the counts at -4 tol and 4 tol.
+// H: 192 doubles of scratch.  One wavefront; ~6 k instructions against ~55 k for the eigen-decomposition it makes unnecessary.
+template <int n>
+__device__ inline bool pi_spectrum_clears_tolerance(const double* M, double* V, double* H) {
+    constexpr int ld = n + 1;
+    const int lane = lane_id();
+    for (int e = lane; e < n * ld; e += WAVE) V[e] = M[e];
+    wave_sync();
+    double dreg, ereg;
+    wave_tridiag_burst(to_lds(V), ld, n, dreg, ereg);
+    const lds_ptr dS = to_lds(H), e2S = to_lds(H) + 64, eS = to_lds(H) + 128;
+    if (lane < n) { dS[lane] = dreg; eS[lane] = ereg; e2S[lane] = ereg * ereg; }
+    wave_sync();
+    const int j = (lane < n) ? lane : 0;
+    const double rad = fabs(eS[j]) + ((j > 0) ? fabs(eS[j - 1]) : 0.0);
+    const double bound = wave_max((lane < n) ? fabs(dS[j]) + rad : 0.0);       // |M|_2 <= bound <= 3 |M|_2
+    if (!(bound < 1e300) || !(bound > 1e-300)) return false;                    // (wave-uniform)
+    const double p0 = trid_pow2_floor(bound);                                   // 2^k0 <= bound: |M|_2 lies in binade k0, k0 - 1 or k0 - 2
+    const double pw = (lane < 2) ? p0 : 0.5 * p0;
+    const int cb = trid_count(dS, e2S, n, (lane & 1) ? -pw : pw);              // lanes 0 / 2: eigenvalues below +2^k; lanes 1 / 3: below -2^k
+    const bool any0 = wave_bcast_i(cb, 0) < n || wave_bcast_i(cb, 1) > 0, any1 = wave_bcast_i(cb, 2) < n || wave_bcast_i(cb, 3) > 0;
+    const double tol = (double)n * eps_of(any0 ? p0 : (any1 ? 0.5 * p0 : 0.25 * p0));
+    const double guard = 4.0 * tol;
+    const int c = trid_count(dS, e2S, n, (lane & 1) ? guard : -guard);         // eigenvalues below +guard (odd lanes) / below -guard (even lanes)
+    const int c_lo = wave_bcast_i(c, 0), c_hi = wave_bcast_i(c, 1);
+    wave_sync();
+    return c_lo == c_hi;
+}
+
 __host__ __device__ inline int pi_wg_lds_doubles(int E, int C, int N) { return pi_lds_doubles(E, C, N, true) + pi_sn(E) * N + 16; }
 
 // pinv(B B' + 1e-12 I) of a 5 x 5 block with TWO near-null directions, at the accuracy of the formula (the two-direction form of
@@ -356,9 +392,22 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
         for (int e = tid; e < n * ld; e += THREADS) chkM += g.M[e];
         if (!(fabs(block_sum_w<WV>(chkM, red)) <= 1.79e308)) { *st = ST_NONFINITE; break; }   // :63-65
         // aux = pinv(M + 1e-12 I) b   (:67)
-        bool need_pinv = Model::PINV_KKT;
+        bool need_pinv;
         if (!Model::PINV_KKT) {
             if (owner) { const bool ok = wave_solve_gj<n>(g.M, g.dt); if (lane == 0) red[8] = ok ? 1.0 : 0.0; }
+            __syncthreads();
+            need_pinv = red[8] == 0.0;
+        } else {
+            // PiCol: eleven constraints, redundant on collinear centres -- there pinv truncates and only the eigen-decomposition reproduces it.  On every other
+            // scene the 38 x 38 matrix has no eigenvalue anywhere near pinv's tolerance, pinv(M) IS inv(M), and the eigen-decomposition was 2.9 of the method's
+            // 5.4 ms (profiles/r5_ab_picol_without_pinv.txt).  So: the plain solve first (M stays intact: the elimination runs in registers), then a CERTIFICATE
+            // that nothing would have been truncated (pi_spectrum_clears_tolerance); without it the eigen-decomposition runs on the untouched M as before.
+            if (owner) {
+                const bool solved = wave_solve_gj<n>(g.M, g.dt, 1e-15);
+                bool certified = false;
+                if (wave_uniform_i(solved ? 1 : 0)) certified = pi_spectrum_clears_tolerance<n>(g.M, g.V, g.H);
+                if (lane == 0) red[8] = certified ? 1.0 : 0.0;
+            }
             __syncthreads();
             need_pinv = red[8] == 0.0;
         }
