@@ -400,13 +400,12 @@ __device__ inline int gauss_helmert_pi_block(PoseLds* w, PiWork& g, double* red,
         } else {
             // PiCol: eleven constraints, redundant on collinear centres -- there pinv truncates and only the eigen-decomposition reproduces it.  On every other
             // scene the 38 x 38 matrix has no eigenvalue anywhere near pinv's tolerance, pinv(M) IS inv(M), and the eigen-decomposition was 2.9 of the method's
-            // 5.4 ms (profiles/r5_ab_picol_without_pinv.txt).  So: the plain solve first (M stays intact: the elimination runs in registers), then a CERTIFICATE
-            // that nothing would have been truncated (pi_spectrum_clears_tolerance); without it the eigen-decomposition runs on the untouched M as before.
+            // 5.4 ms (profiles/r5_ab_picol_without_pinv.txt).  So: a CERTIFICATE that nothing would be truncated (pi_spectrum_clears_tolerance, on a copy of M), then the plain
+            // solve (M stays intact: the elimination runs in registers); without the certificate the eigen-decomposition runs on the untouched M as before.
             if (owner) {
-                const bool solved = wave_solve_gj<n>(g.M, g.dt, 1e-15);
-                bool certified = false;
-                if (wave_uniform_i(solved ? 1 : 0)) certified = pi_spectrum_clears_tolerance<n>(g.M, g.V, g.H);
-                if (lane == 0) red[8] = certified ? 1.0 : 0.0;
+                bool settled = false;                                        // the certificate first: half of the N = 200 scenes do not get it, and the elimination would be wasted on them
+                if (wave_uniform_i(pi_spectrum_clears_tolerance<n>(g.M, g.V, g.H) ? 1 : 0)) settled = wave_solve_gj<n>(g.M, g.dt, 1e-15);
+                if (lane == 0) red[8] = settled ? 1.0 : 0.0;
             }
             __syncthreads();
             need_pinv = red[8] == 0.0;
